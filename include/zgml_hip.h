@@ -1,0 +1,356 @@
+/*
+ * zgml_hip.h — C ABI of the MI355X (gfx950) backend for zgml's forward-inference path.
+ *
+ * This header is the drop-in boundary. Every entry point replaces one slot of the
+ * reference's backend plugin surface (all citations relative to the zgml tree):
+ *
+ *   zgml_hip_create / zgml_hip_destroy   <-> Backend.ctx lifetime           src/backend.zig:330-336
+ *   zgml_hip_dense_matmul_f32            <-> VTable.dense_matmul_f32        src/backend.zig:341
+ *   zgml_hip_compile_program             <-> VTable.compile_program         src/backend.zig:343
+ *   zgml_hip_refresh_program             <-> VTable.refresh_program         src/backend.zig:345
+ *   zgml_hip_execute_program             <-> VTable.execute_program         src/backend.zig:347
+ *   zgml_hip_free_program                <-> VTable.free_program            src/backend.zig:349
+ *   zgml_hip_get_runtime_profile         <-> VTable.get_runtime_profile     src/backend.zig:351
+ *   zgml_hip_capabilities                <-> Backend.capabilities           src/backend.zig:14-141
+ *   zgml_hip_program_supported           <-> DeviceProgram.isSupportedBy    src/backend.zig:277-325
+ *
+ * The structs below mirror the Zig types field for field (zgml_device_op <-> DeviceOp
+ * src/backend.zig:179-249, zgml_program_io <-> ProgramIO :252-257, zgml_qweight_upload <->
+ * QuantizedWeightUpload :260-266, zgml_device_program <-> DeviceProgram :270-275). Zig slices
+ * become (pointer, length) pairs and the tagged union becomes `kind` + a C union, so a Zig
+ * adapter can fill them with `extern struct`s (INTEGRATION.md shows it).
+ *
+ * Plain C: no C++ types, no torch types, no HIP types in any signature. Offsets and strides of
+ * device ops are in f32 ELEMENTS; zgml_program_io offsets/sizes are in BYTES; buffer_sizes are
+ * f32 element counts (same units as the reference).
+ *
+ * Extension entry points (zgml_hip_*_ext, zgml_hip_qmatvec_bench_*) have no reference
+ * counterpart; they exist for measurement and for the row-sharded multi-GPU path and are marked
+ * as such below.
+ */
+#ifndef ZGML_HIP_H
+#define ZGML_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZGML_HIP_ABI_VERSION 1
+
+/* ── Op enum ordinals: src/op.zig:11-62 (graph IR `Op`) ─────────────────────────────────── */
+enum {
+    ZGML_OP_NONE = 0,
+    ZGML_OP_VIEW = 1,
+    ZGML_OP_RESHAPE = 2,
+    ZGML_OP_TRANSPOSE = 3,
+    ZGML_OP_PERMUTE = 4,
+    ZGML_OP_AS_STRIDED = 5,
+    ZGML_OP_BROADCAST_TO = 6,
+    ZGML_OP_ADD = 7,
+    ZGML_OP_MUL = 8,
+    ZGML_OP_NEG = 9,
+    ZGML_OP_ABS = 10,
+    ZGML_OP_SGN = 11,
+    ZGML_OP_STEP = 12,
+    ZGML_OP_RELU = 13,
+    ZGML_OP_SQRT = 14,
+    ZGML_OP_RECIP = 15,
+    ZGML_OP_EXP = 16,
+    ZGML_OP_LOG = 17,
+    ZGML_OP_GELU = 18,
+    ZGML_OP_SUM = 19,
+    ZGML_OP_MAX = 20,
+    ZGML_OP_REPEAT = 21
+};
+
+/* ── DeviceOp tags, in the declaration order of the Zig union (src/backend.zig:179-249) ──── */
+enum {
+    ZGML_DOP_ELEMENTWISE = 0,
+    ZGML_DOP_MATMUL = 1,
+    ZGML_DOP_QMATMUL = 2,
+    ZGML_DOP_SOFTMAX = 3,
+    ZGML_DOP_LAYERNORM = 4,
+    ZGML_DOP_RMSNORM = 5,
+    ZGML_DOP_REDUCE = 6,
+    ZGML_DOP_REPEAT = 7,
+    ZGML_DOP_SLICE_ASSIGN = 8,
+    ZGML_DOP_ROPE = 9,
+    ZGML_DOP_ATTENTION = 10,
+    ZGML_DOP_FUSED_ELEMENTWISE = 11,
+    ZGML_DOP_COUNT = 12
+};
+
+/* MatMulGeometry, src/backend.zig:146-158 (usize -> uint64_t). */
+typedef struct zgml_matmul_geom {
+    uint64_t M, N, K;
+    uint64_t a_row_stride, a_col_stride;
+    uint64_t b_row_stride, b_col_stride;
+    uint64_t a_offset, b_offset;
+    uint64_t dst_offset, dst_row_stride;
+} zgml_matmul_geom;
+
+/* FusedEwStep, src/backend.zig:170-175. */
+typedef struct zgml_fused_step {
+    uint32_t op;               /* ZGML_OP_* */
+    uint8_t is_swapped;        /* chain value sits in the src1 position */
+    uint8_t _pad;
+    uint16_t secondary_buf;    /* external operand of a binary step */
+    uint32_t secondary_offset; /* elements */
+} zgml_fused_step;
+
+typedef struct zgml_op_elementwise {
+    uint32_t op;
+    uint16_t dst, src0, src1, _pad;
+    uint32_t n, dst_offset, src0_offset, src1_offset;
+} zgml_op_elementwise;
+
+typedef struct zgml_op_matmul {
+    uint16_t dst, a, b, _pad;
+    zgml_matmul_geom geom;
+} zgml_op_matmul;
+
+typedef struct zgml_op_qmatmul {
+    uint16_t dst, input, weight_idx, _pad;
+    uint32_t M, N, K;
+    uint32_t input_offset, input_row_stride; /* stride 0 => K */
+    uint32_t dst_offset, dst_row_stride;     /* stride 0 => N */
+} zgml_op_qmatmul;
+
+typedef struct zgml_op_rowwise { /* softmax / layernorm / rmsnorm */
+    uint16_t dst, src;
+    uint32_t rows, cols;
+    float eps; /* ignored by softmax */
+    uint32_t src_offset, dst_offset;
+} zgml_op_rowwise;
+
+typedef struct zgml_op_reduce {
+    uint32_t op; /* ZGML_OP_SUM or ZGML_OP_MAX */
+    uint16_t dst, src;
+    uint32_t n_out, reduce_size;
+    uint32_t src_offset, dst_offset;
+} zgml_op_reduce;
+
+typedef struct zgml_op_repeat {
+    uint16_t dst, src;
+    uint32_t n;
+    uint32_t src_ne[4], dst_ne[4], src_strides[4], dst_strides[4];
+    uint32_t src_offset, dst_offset;
+} zgml_op_repeat;
+
+typedef struct zgml_op_slice_assign {
+    uint16_t dst, src;
+    uint32_t rows, cols;
+    uint32_t dst_base_offset;
+    uint32_t dst_offset; /* dynamic: dst_base_offset + pos * patch_stride */
+    uint32_t dst_row_stride, dst_col_stride;
+    uint32_t src_offset, src_row_stride, src_col_stride;
+    uint32_t patch_stride; /* 0 => static */
+} zgml_op_slice_assign;
+
+typedef struct zgml_op_rope {
+    uint16_t dst, src, cos_sin, _pad;
+    uint32_t half_d, seq_len;
+    uint32_t src_off, cs_off, dst_off;
+    uint32_t src_rs, src_cs, cs_cs;
+} zgml_op_rope;
+
+typedef struct zgml_op_attention {
+    uint16_t dst, q, k, v, mask;
+    uint8_t has_mask, _pad;
+    uint32_t d_head, seq_q;
+    uint32_t seq_kv; /* dynamic */
+    float scale;
+    uint32_t q_off, k_off, v_off, mask_off, dst_off;
+    uint32_t q_rs, q_cs, k_rs, k_cs, v_rs, v_cs, mask_rs, mask_cs, dst_rs, dst_cs;
+} zgml_op_attention;
+
+typedef struct zgml_op_fused_elementwise {
+    const zgml_fused_step* steps; /* borrowed: must outlive the compiled program's use of `ops` */
+    uint32_t n_steps;
+    uint32_t n;
+    uint16_t dst, src;
+    uint32_t dst_offset, src_offset;
+} zgml_op_fused_elementwise;
+
+/* DeviceOp, src/backend.zig:179-249. */
+typedef struct zgml_device_op {
+    uint32_t kind; /* ZGML_DOP_* */
+    uint32_t _pad;
+    union {
+        zgml_op_elementwise elementwise;
+        zgml_op_matmul matmul;
+        zgml_op_qmatmul qmatmul;
+        zgml_op_rowwise softmax;
+        zgml_op_rowwise layernorm;
+        zgml_op_rowwise rmsnorm;
+        zgml_op_reduce reduce;
+        zgml_op_repeat repeat;
+        zgml_op_slice_assign slice_assign;
+        zgml_op_rope rope;
+        zgml_op_attention attention;
+        zgml_op_fused_elementwise fused_elementwise;
+    } u;
+} zgml_device_op;
+
+/* ProgramIO, src/backend.zig:252-257. offset/size in bytes. */
+typedef struct zgml_program_io {
+    uint16_t buf_idx;
+    uint16_t _pad;
+    uint32_t offset;
+    void* host_ptr;
+    uint32_t size;
+    uint32_t _pad2;
+} zgml_program_io;
+
+/* QuantizedWeightUpload, src/backend.zig:260-266: int8 data in flat [K,N] row-major order
+ * (index k*N+n), one f32 scale per `block_size` consecutive FLAT elements. */
+typedef struct zgml_qweight_upload {
+    const int8_t* data;
+    uint64_t data_len;
+    const float* scales;
+    uint64_t scales_len;
+    uint64_t rows; /* K */
+    uint64_t cols; /* N */
+    uint64_t block_size;
+} zgml_qweight_upload;
+
+/* DeviceProgram, src/backend.zig:270-275. */
+typedef struct zgml_device_program {
+    const zgml_device_op* ops;
+    uint64_t n_ops;
+    uint16_t n_buffers;
+    const uint64_t* buffer_sizes; /* f32 elements, n_buffers entries */
+    uint64_t n_buffer_sizes;
+    const zgml_program_io* initial_uploads;
+    uint64_t n_initial_uploads;
+    const zgml_qweight_upload* qweights;
+    uint64_t n_qweights;
+} zgml_device_program;
+
+/* Capabilities, src/backend.zig:14-58. Optionals: *_has = 0 means "null" (no limit). */
+typedef struct zgml_capabilities {
+    uint8_t compiled_programs;
+    uint8_t host_visible_program_memory;
+    uint8_t dense_matmul_f32;
+    uint8_t dense_matmul_f16;
+    uint8_t qmatmul;
+    uint8_t fused_elementwise;
+    uint8_t f16_weight_promotion;
+    uint8_t dynamic_program_refresh;
+    uint8_t prefill_attention;
+    uint8_t decode_attention;
+    uint8_t quantized_kv;
+    uint8_t command_buffer_execution;
+    uint8_t max_fused_elementwise_steps_has;
+    uint8_t attention_supported;
+    uint8_t attention_max_seq_kv_has;
+    uint8_t attention_max_d_head_has;
+    uint32_t max_fused_elementwise_steps;
+    uint32_t attention_max_seq_kv;
+    uint32_t attention_max_d_head;
+} zgml_capabilities;
+
+/* Subset of profile.RuntimeProfile (src/profile.zig:820-843) a device backend can fill. */
+typedef struct zgml_runtime_profile {
+    uint64_t time_ns[ZGML_DOP_COUNT]; /* per DeviceOp tag; filled only in profiling mode */
+    uint64_t backend_op_count;
+    uint64_t fallback_op_count; /* always 0: there is no CPU fallback */
+    uint64_t backend_dispatch_count;
+    uint64_t sync_time_ns;
+    uint64_t sync_count;
+    uint32_t call_count;
+    uint32_t _pad;
+} zgml_runtime_profile;
+
+typedef struct zgml_hip_ctx zgml_hip_ctx;         /* Backend.ctx */
+typedef struct zgml_hip_program zgml_hip_program; /* Backend.CompiledHandle */
+
+/* Create a backend context on HIP device `device_ordinal`. NULL on failure (no device, not
+ * gfx950, allocation failure); zgml_hip_last_error(NULL) then describes why. */
+zgml_hip_ctx* zgml_hip_create(int device_ordinal);
+void zgml_hip_destroy(zgml_hip_ctx* ctx);
+
+/* Sticky, human-readable description of the first error recorded on the context (or of the
+ * last failed zgml_hip_create when ctx == NULL). Empty string when there is none. The vtable has
+ * no error channel on execute (src/backend.zig:347 returns void), hence the side channel. */
+const char* zgml_hip_last_error(const zgml_hip_ctx* ctx);
+void zgml_hip_clear_error(zgml_hip_ctx* ctx);
+
+/* Capabilities.hip — what DeviceInference consults when lowering (src/device_inference.zig:108). */
+void zgml_hip_capabilities(zgml_capabilities* out);
+
+/* DeviceProgram.isSupportedBy(Capabilities.hip): 1 if supported, else 0. Pure host logic. */
+int zgml_hip_program_supported(const zgml_device_program* program);
+
+/* VTable.dense_matmul_f32: host slices in, result in dst on return. Returns 1 if handled,
+ * 0 to make the caller fall back (src/tensor/forward.zig:2022-2031). dst_len/a_len/b_len are
+ * element counts of the host slices. */
+int zgml_hip_dense_matmul_f32(zgml_hip_ctx* ctx, float* dst, uint64_t dst_len, const float* a,
+                              uint64_t a_len, const float* b, uint64_t b_len,
+                              const zgml_matmul_geom* geom);
+
+/* VTable.compile_program. All arrays are borrowed for the duration of the call EXCEPT nothing:
+ * the backend copies the op list (including fused steps), so the caller may free everything.
+ * Returns NULL on failure or when the program is unsupported. */
+zgml_hip_program* zgml_hip_compile_program(zgml_hip_ctx* ctx, const zgml_device_program* program);
+
+/* VTable.refresh_program: same-length op list whose dynamic fields changed
+ * (slice_assign.dst_offset, attention.seq_kv). Other fields must be unchanged. */
+void zgml_hip_refresh_program(zgml_hip_ctx* ctx, zgml_hip_program* handle,
+                              const zgml_device_op* ops, uint64_t n_ops);
+
+/* VTable.execute_program: upload inputs, run all ops in order, download outputs; blocking. */
+void zgml_hip_execute_program(zgml_hip_ctx* ctx, zgml_hip_program* handle,
+                              const zgml_program_io* inputs, uint64_t n_inputs,
+                              const zgml_program_io* outputs, uint64_t n_outputs);
+
+void zgml_hip_free_program(zgml_hip_ctx* ctx, zgml_hip_program* handle);
+
+/* VTable.get_runtime_profile: pointer stays valid until free_program. */
+zgml_runtime_profile* zgml_hip_get_runtime_profile(zgml_hip_ctx* ctx, zgml_hip_program* handle);
+
+/* ── Extensions (no reference counterpart) ──────────────────────────────────────────────── */
+
+/* Program options, set before compile on the context. */
+enum {
+    ZGML_HIP_OPT_FUSION = 1,         /* 0/1: pattern-fuse the op stream (default 1) */
+    ZGML_HIP_OPT_GRAPH = 2,          /* 0/1: replay a captured hipGraph per execute (default 1) */
+    ZGML_HIP_OPT_PROFILE = 3,        /* 0/1: per-op hipEvent timing into time_ns (default 0) */
+    ZGML_HIP_OPT_SKIP_DEAD_UPLOADS = 4, /* 0/1: do not allocate/upload buffers no op touches (default 1) */
+    ZGML_HIP_OPT_F16_DENSE_WEIGHTS = 5  /* 0/1: f16 weight promotion for dense matmul B (default 0) */
+};
+int zgml_hip_set_option(zgml_hip_ctx* ctx, int option, int64_t value);
+
+/* Raw device access for harnesses that keep data resident (bench, multi-GPU all-gather glue):
+ * device pointer of program buffer `buf_idx` (NULL if elided). */
+void* zgml_hip_program_buffer_ptr(zgml_hip_program* handle, uint16_t buf_idx);
+/* The HIP stream (hipStream_t as void*) the context launches on. */
+void* zgml_hip_stream(zgml_hip_ctx* ctx);
+/* Execute without host I/O and without blocking: enqueue the program on the context stream. */
+void zgml_hip_enqueue_program(zgml_hip_ctx* ctx, zgml_hip_program* handle);
+/* Enqueue ops [first, first+count) only (multi-GPU harness interleaves collectives). */
+void zgml_hip_enqueue_ops(zgml_hip_ctx* ctx, zgml_hip_program* handle, uint64_t first, uint64_t count);
+void zgml_hip_synchronize(zgml_hip_ctx* ctx);
+/* On-device greedy argmax over f32 elements [offset, offset+n) of a program buffer: first index
+ * of the maximum (strict >), as scripts/generate_llama.zig:101-110 / src/nn.zig:122-138. */
+int64_t zgml_hip_argmax(zgml_hip_ctx* ctx, zgml_hip_program* handle, uint16_t buf_idx,
+                        uint64_t offset, uint64_t n);
+
+/* Mat-vec roofline micro-benchmark: builds `n_matrices` distinct K x N quantized
+ * matrices on the device from the deterministic synthetic generator (q4: nibbles in [-8,7];
+ * otherwise int8), runs `warmup` + `iters` launches round-robin over the ring and returns the
+ * average kernel time in microseconds measured with HIP events on the launch stream (<0 on
+ * error). `bytes_per_launch` receives the algorithmic bytes (K*N/32*{18|34} + 4K + 4N). */
+double zgml_hip_qmatvec_bench(zgml_hip_ctx* ctx, uint32_t K, uint32_t N, int q4, uint32_t n_matrices,
+                              uint32_t warmup, uint32_t iters, uint64_t* bytes_per_launch);
+/* Device-to-device float4 copy of `bytes` bytes, average microseconds per launch (the measured
+ * "achievable HBM" yardstick printed next to the 8 TB/s nominal peak). */
+double zgml_hip_copy_bench(zgml_hip_ctx* ctx, uint64_t bytes, uint32_t warmup, uint32_t iters);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZGML_HIP_H */

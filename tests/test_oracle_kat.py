@@ -1,0 +1,217 @@
+"""Pins the CPU oracle to the reference's own known-answer tests.
+The expected numbers live in tests/golden/kat.json with their reference citations."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from zgml_amd import (Capabilities, DeviceOp, DeviceProgram, FusedEwStep, MatMulGeometry, ProgramIO,
+                      QuantizedWeightUpload)
+from tests.conformance_cases import core_cases
+
+KAT = json.loads((Path(__file__).parent / "golden" / "kat.json").read_text())
+f32 = np.float32
+
+
+def _a(v):
+    return np.array(v, dtype=f32)
+
+
+def test_dense_matmul_kat(oracle):
+    k = KAT["dense_matmul_2x3_3x2"]
+    p = DeviceProgram(ops=[DeviceOp.matmul(2, 0, 1, MatMulGeometry(**k["geom"]))], buffer_sizes=[6, 6, 4],
+                      initial_uploads=[ProgramIO(0, _a(k["a"])), ProgramIO(1, _a(k["b"]))])
+    assert oracle.run_program(p, 2, 4).tolist() == k["expected"]
+
+
+def test_qmatmul_kat(oracle):
+    k = KAT["qmatmul_row_major"]
+    qw = QuantizedWeightUpload(np.array(k["data"], np.int8), _a(k["scales"]), k["K"], k["N"], k["block_size"])
+    p = DeviceProgram(ops=[DeviceOp.qmatmul(1, 0, 0, k["M"], k["N"], k["K"])], buffer_sizes=[6, 6],
+                      initial_uploads=[ProgramIO(0, _a(k["input"]))], qweights=[qw])
+    np.testing.assert_allclose(oracle.run_program(p, 1, 6), k["expected"], atol=k["tol"], rtol=0)
+    k = KAT["qmatmul_offset_stride"]
+    p = DeviceProgram(
+        ops=[DeviceOp.qmatmul(1, 0, 0, k["M"], k["N"], k["K"], k["input_offset"], k["input_row_stride"],
+                              k["dst_offset"], k["dst_row_stride"])],
+        buffer_sizes=[9, 9], initial_uploads=[ProgramIO(0, _a(k["input"])), ProgramIO(1, _a(k["dst_init"]))],
+        qweights=[qw])
+    np.testing.assert_allclose(oracle.run_program(p, 1, 9), k["expected"], atol=k["tol"], rtol=0)
+
+
+def test_elementwise_add_kat(oracle):
+    k = KAT["elementwise_add"]
+    p = DeviceProgram(ops=[DeviceOp.elementwise("add", 2, 0, 1, 4)], buffer_sizes=[4, 4, 4],
+                      initial_uploads=[ProgramIO(0, _a(k["a"])), ProgramIO(1, _a(k["b"]))])
+    assert oracle.run_program(p, 2, 4).tolist() == k["expected"]
+
+
+def test_rope_kat(oracle):
+    k = KAT["rope_half2_seq2"]
+    p = DeviceProgram(
+        ops=[DeviceOp.rope(2, 0, 1, k["half_d"], k["seq_len"], 0, 0, 0, k["src_rs"], k["src_cs"], k["cs_cs"])],
+        buffer_sizes=[8, 8, 8], initial_uploads=[ProgramIO(0, _a(k["src"])), ProgramIO(1, _a(k["cos_sin"]))])
+    assert oracle.run_program(p, 2, 8).tolist() == k["expected"]
+
+
+def slice_assign_refresh_program(k):
+    rows, dst_cols = k["rows"], k["dst_cols"]
+    op = DeviceOp.slice_assign(1, 0, rows, k["cols"], dst_base_offset=0, dst_offset=0, dst_row_stride=1,
+                               dst_col_stride=rows, src_offset=0, src_row_stride=1, src_col_stride=rows,
+                               patch_stride=rows)
+    return DeviceProgram(ops=[op], buffer_sizes=[rows, rows * dst_cols], initial_uploads=[ProgramIO(0, _a(k["src"]))])
+
+
+def run_slice_assign_refresh(be, k):
+    """DeviceInference.patchSliceAssignOffset + execute (src/device_inference.zig:242-263)."""
+    p = slice_assign_refresh_program(k)
+    h = be.compileProgram(p)
+    outs = []
+    try:
+        for pos in k["positions"]:
+            sa = p.ops[0]
+            p.ops[0] = sa.with_(dst_offset=sa.dst_base_offset + pos * sa.patch_stride)
+            be.refreshProgram(h, p.ops)
+            out = np.zeros(k["rows"] * k["dst_cols"], f32)
+            be.executeProgram(h, [], [ProgramIO(1, out)])
+            outs.append(out.tolist())
+    finally:
+        be.freeProgram(h)
+    return outs
+
+
+def test_slice_assign_refresh_kat(oracle):
+    k = KAT["slice_assign_position_refresh"]
+    assert run_slice_assign_refresh(oracle.OracleBackend(), k) == k["expected_after"]
+
+
+def test_slice_assign_strided_kat(oracle):
+    k = KAT["slice_assign_strided"]
+    name, p, idx, n = [c for c in core_cases() if c[0] == "slice_assign"][0]
+    assert oracle.run_program(p, idx, n).tolist() == k["expected"]
+
+
+def test_softmax_all_neg_inf_and_rmsnorm_zero(oracle):
+    k = KAT["softmax_all_neg_inf_is_zero"]
+    p = DeviceProgram(ops=[DeviceOp.softmax(1, 0, 1, k["cols"])], buffer_sizes=[4, 4],
+                      initial_uploads=[ProgramIO(0, np.full(4, -np.inf, f32)), ProgramIO(1, np.full(4, 5, f32))])
+    assert oracle.run_program(p, 1, 4).tolist() == k["expected"]
+    k = KAT["rmsnorm_zero_input_is_zero"]
+    p = DeviceProgram(ops=[DeviceOp.rmsnorm(1, 0, 1, k["cols"], eps=k["eps"])], buffer_sizes=[4, 4],
+                      initial_uploads=[ProgramIO(1, np.full(4, 5, f32))])
+    assert oracle.run_program(p, 1, 4).tolist() == k["expected"]
+
+
+def test_gguf_block_decode_kats(oracle):
+    k = KAT["gguf_q4_0_block"]
+    raw = np.zeros(18, np.uint8)
+    raw[0], raw[1] = k["scale_f16_bits"] & 0xFF, k["scale_f16_bits"] >> 8
+    raw[2] = k["byte0"]
+    deq = oracle.gguf_dequant(raw, k["n_elems"], "q4_0")
+    assert deq[:3].tolist() == k["expected_dequant_first3"]
+    assert np.all(deq[3:] == k["expected_rest"])
+    raw[0], raw[1] = k["import_scale_f16_bits"] & 0xFF, k["import_scale_f16_bits"] >> 8
+    data, scales = oracle.gguf_to_int8(raw, 32, "q4_0")
+    assert data[:3].tolist() == k["expected_int8"] and scales[0] == k["expected_import_scale"]
+    k = KAT["gguf_q8_0_block"]
+    raw = np.zeros(34, np.uint8)
+    raw[0], raw[1] = k["scale_f16_bits"] & 0xFF, k["scale_f16_bits"] >> 8
+    raw[2:5] = np.array(k["q"], np.int8).view(np.uint8)
+    assert oracle.gguf_dequant(raw, 32, "q8_0")[:3].tolist() == k["expected_first3"]
+    data, scales = oracle.gguf_to_int8(raw, 32, "q8_0")
+    assert data[:3].tolist() == k["q"] and scales[0] == 0.5
+
+
+def test_f16_conversion_exhaustive(oracle):
+    lib = oracle.load()
+    bits = np.arange(65536, dtype=np.uint16)
+    ref = bits.view(np.float16).astype(np.float32)
+    got = np.array([lib.zo_f16_to_f32(int(b)) for b in bits[::37]], dtype=np.float32)
+    exp = ref[::37]
+    assert np.array_equal(np.isnan(got), np.isnan(exp))
+    assert np.array_equal(got[~np.isnan(got)], exp[~np.isnan(exp)])
+    vals = np.random.default_rng(0xD3FA).standard_normal(2000).astype(np.float32) * 3
+    back = np.array([lib.zo_f32_to_f16(float(v)) for v in vals], dtype=np.uint16)
+    assert np.array_equal(back, vals.astype(np.float16).view(np.uint16))
+
+
+def test_capability_gating_kat():
+    k = KAT["capability_gating"]
+    one = DeviceProgram(ops=[DeviceOp.fused_elementwise([FusedEwStep("relu")], 1, 1, 0)], buffer_sizes=[1, 1])
+    nine = DeviceProgram(ops=[DeviceOp.fused_elementwise([FusedEwStep("relu")] * 9, 1, 1, 0)], buffer_sizes=[1, 1])
+    for name, want in k["fused_1_step"].items():
+        assert one.isSupportedBy(getattr(Capabilities, name)) is want
+    for name, want in k["fused_9_steps"].items():
+        assert nine.isSupportedBy(getattr(Capabilities, name)) is want
+    qd, sc = np.array([1, 2, 3, 4], np.int8), np.array([1], f32)
+    qops = [DeviceOp.qmatmul(1, 0, 0, 1, 2, 2)]
+    good = DeviceProgram(ops=qops, buffer_sizes=[2, 2], qweights=[QuantizedWeightUpload(qd, sc, 2, 2, 4)])
+    bad = DeviceProgram(ops=qops, buffer_sizes=[2, 2], qweights=[QuantizedWeightUpload(qd, sc, 3, 2, 4)])
+    assert good.isSupportedBy(Capabilities.wgpu) and not bad.isSupportedBy(Capabilities.wgpu)
+    for name, seq_kv, d_head, want in k["attention_limits"]:
+        assert getattr(Capabilities, name).attention.supports(seq_kv, d_head) is want
+
+
+def test_oracle_c_program_supported_matches_python(oracle):
+    import ctypes as C
+    lib = oracle.load()
+    for name, p, _, _ in core_cases():
+        pc, keep = p.to_c()
+        assert lib.zo_program_supported(C.byref(pc), 1, -1, -1, 512) == 1, name
+        assert p.isSupportedBy(Capabilities.reference_cpu)
+
+
+# ── closed-form checks of the conformance cases whose expected values the reference computes at
+#    run time (conformance.zig:133-345): we verify the oracle against explicit float64 formulas.
+
+def test_conformance_cases_vs_closed_forms(oracle):
+    out = {name: oracle.run_program(p, idx, n) for name, p, idx, n in core_cases()}
+    np.testing.assert_array_equal(out["reduce"], [2, 3, 3, 5])
+    np.testing.assert_array_equal(out["repeat"], [7, 8, 7, 8, 7, 8])
+    x = np.array([[1, 2, 3], [-1, 0, 1]], np.float64)
+    sm = np.exp(x - x.max(1, keepdims=True))
+    sm /= sm.sum(1, keepdims=True)
+    np.testing.assert_allclose(out["softmax"], sm.ravel(), atol=1e-6)
+    x = np.array([[1, 2, 3, 4], [-1, 0, 1, 2]], np.float64)
+    ln = (x - x.mean(1, keepdims=True)) / np.sqrt(x.var(1, keepdims=True) + 1e-5)
+    rms = x / np.sqrt((x * x).mean(1, keepdims=True) + 1e-5)
+    np.testing.assert_allclose(out["norms"], np.concatenate([ln.ravel(), rms.ravel()]), atol=1e-6)
+    np.testing.assert_allclose(out["fused_elementwise"], [11, 20, 32, 43], atol=1e-6)
+    # attention: dense softmax(QK^T*scale+mask)V in float64
+    q = np.array([[0.2, 0.1, -0.3, 0.4], [-0.1, 0.5, 0.2, -0.4]])
+    k = np.array([[0.1, 0.2, 0.3, 0.4], [-0.2, 0.3, 0.1, -0.1], [0.5, -0.4, 0.2, 0.1]])
+    v = np.array([[1, 2, 3, 4], [-1, 0.5, 2, -0.5], [0.25, -0.75, 1.5, 2.5]])
+    mask = np.array([[0, 0, -np.inf], [0, -0.25, 0]])
+    s = q @ k.T * 0.5 + mask
+    p = np.exp(s - s.max(1, keepdims=True))
+    p /= p.sum(1, keepdims=True)
+    np.testing.assert_allclose(out["attention"], (p @ v).ravel(), atol=1e-6)
+
+
+def test_attention_fully_masked_row_is_zero(oracle):
+    """seq_kv refresh incl. a fully masked query (src/backend/wgpu.zig:1457-1597)."""
+    rng = np.random.default_rng(0xD3FA)
+    dh, sq, skv = 8, 2, 4
+    q, k, v = (rng.standard_normal(n).astype(f32) for n in (dh * sq, dh * skv, dh * skv))
+    mask = np.zeros(skv * sq, f32)
+    mask[skv:] = -np.inf  # query 1 fully masked
+    op = DeviceOp.attention(4, 0, 1, 2, 3, True, dh, sq, skv, 0.3, 0, 0, 0, 0, 0, 1, dh, 1, dh, 1, dh, 1, skv, 1, dh)
+    p = DeviceProgram(ops=[op], buffer_sizes=[dh * sq, dh * skv, dh * skv, skv * sq, dh * sq],
+                      initial_uploads=[ProgramIO(0, q), ProgramIO(1, k), ProgramIO(2, v), ProgramIO(3, mask)])
+    be = oracle.OracleBackend()
+    h = be.compileProgram(p)
+    out4, out2 = np.zeros(dh * sq, f32), np.zeros(dh * sq, f32)
+    be.executeProgram(h, [], [ProgramIO(4, out4)])
+    p.ops[0] = op.with_(seq_kv=2)
+    be.refreshProgram(h, p.ops)
+    be.executeProgram(h, [], [ProgramIO(4, out2)])
+    be.freeProgram(h)
+    assert np.all(out4[dh:] == 0) and np.all(out2[dh:] == 0)
+
+    def dense(n):
+        s = (q[:dh].astype(np.float64) @ k.reshape(skv, dh)[:n].T.astype(np.float64)) * 0.3
+        w = np.exp(s - s.max())
+        return (w / w.sum()) @ v.reshape(skv, dh)[:n].astype(np.float64)
+    np.testing.assert_allclose(out4[:dh], dense(4), atol=1e-5)
+    np.testing.assert_allclose(out2[:dh], dense(2), atol=1e-5)
