@@ -292,9 +292,10 @@ int zgml_hip_dense_matmul_f32(zgml_hip_ctx* ctx, float* dst, uint64_t dst_len, c
                               uint64_t a_len, const float* b, uint64_t b_len,
                               const zgml_matmul_geom* geom);
 
-/* VTable.compile_program. All arrays are borrowed for the duration of the call EXCEPT nothing:
- * the backend copies the op list (including fused steps), so the caller may free everything.
- * Returns NULL on failure or when the program is unsupported. */
+/* VTable.compile_program. Every array is borrowed for the duration of the call only: the backend
+ * copies the op list (including fused steps), so the caller may free everything afterwards (the
+ * reference's cpu/metal backends keep `ops` borrowed, src/backend/cpu.zig:115; copying is a
+ * superset of that contract). Returns NULL on failure or when the program is unsupported. */
 zgml_hip_program* zgml_hip_compile_program(zgml_hip_ctx* ctx, const zgml_device_program* program);
 
 /* VTable.refresh_program: same-length op list whose dynamic fields changed
@@ -346,6 +347,11 @@ int64_t zgml_hip_argmax(zgml_hip_ctx* ctx, zgml_hip_program* handle, uint16_t bu
  * error). `bytes_per_launch` receives the algorithmic bytes (K*N/32*{18|34} + 4K + 4N). */
 double zgml_hip_qmatvec_bench(zgml_hip_ctx* ctx, uint32_t K, uint32_t N, int q4, uint32_t n_matrices,
                               uint32_t warmup, uint32_t iters, uint64_t* bytes_per_launch);
+/* One mat-vec y = x^T W with synthetic matrix `matrix_id` of the same generator (parity tests
+ * rebuild that matrix on the host in int8 + f32-scale form and check y against the oracle).
+ * Returns 0 on success. */
+int zgml_hip_qmatvec_synth(zgml_hip_ctx* ctx, uint32_t K, uint32_t N, int q4, uint32_t matrix_id,
+                           const float* x_host, float* y_host);
 /* Device-to-device float4 copy of `bytes` bytes, average microseconds per launch (the measured
  * "achievable HBM" yardstick printed next to the 8 TB/s nominal peak). */
 double zgml_hip_copy_bench(zgml_hip_ctx* ctx, uint64_t bytes, uint32_t warmup, uint32_t iters);

@@ -1,0 +1,205 @@
+"""Backend conformance on the MI355X: the reference's core cases (src/backend/conformance.zig)
+run through the HIP C ABI and compared with the oracle, tolerance 1e-5 as for cpu/metal there."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from zgml_amd import DeviceOp, DeviceProgram, FusedEwStep, MatMulGeometry, ProgramIO, DenseMatMulSpecF32, tryDenseMatMul
+from tests.conformance_cases import core_cases
+from tests.test_oracle_kat import run_slice_assign_refresh
+
+pytestmark = pytest.mark.gpu
+KAT = json.loads((Path(__file__).parent / "golden" / "kat.json").read_text())
+f32 = np.float32
+
+
+@pytest.mark.parametrize("graph", [1, 0])
+def test_core_cases_match_reference(hip_backend, oracle, graph):
+    from zgml_amd import capi
+    hip_backend.set_option(capi.OPT_GRAPH, graph)
+    try:
+        for name, prog, idx, n in core_cases():
+            assert hip_backend.supportsProgram(prog), name
+            want = oracle.run_program(prog, idx, n)
+            got = oracle.run_program(prog, idx, n, backend=hip_backend)
+            np.testing.assert_allclose(got, want, atol=1e-5, rtol=0, err_msg=name)
+    finally:
+        hip_backend.set_option(capi.OPT_GRAPH, 1)
+
+
+def test_exact_kats(hip_backend, oracle):
+    out = {name: oracle.run_program(p, idx, n, backend=hip_backend) for name, p, idx, n in core_cases()}
+    assert out["matmul"].tolist() == KAT["dense_matmul_2x3_3x2"]["expected"]
+    np.testing.assert_allclose(out["qmatmul_offsets"], KAT["qmatmul_offset_stride"]["expected"], atol=1e-6, rtol=0)
+    assert out["add"].tolist() == KAT["elementwise_add"]["expected"]
+    assert out["rope"].tolist() == KAT["rope_half2_seq2"]["expected"]
+    assert out["slice_assign"].tolist() == KAT["slice_assign_strided"]["expected"]
+    assert out["repeat"].tolist() == [7, 8, 7, 8, 7, 8]
+    assert out["reduce"].tolist() == [2, 3, 3, 5]
+
+
+def test_slice_assign_position_refresh(hip_backend):
+    k = KAT["slice_assign_position_refresh"]
+    assert run_slice_assign_refresh(hip_backend, k) == k["expected_after"]
+
+
+def test_softmax_all_neg_inf_and_rmsnorm_zero(hip_backend, oracle):
+    p = DeviceProgram(ops=[DeviceOp.softmax(1, 0, 1, 4)], buffer_sizes=[4, 4],
+                      initial_uploads=[ProgramIO(0, np.full(4, -np.inf, f32)), ProgramIO(1, np.full(4, 5, f32))])
+    assert oracle.run_program(p, 1, 4, backend=hip_backend).tolist() == [0, 0, 0, 0]
+    p = DeviceProgram(ops=[DeviceOp.rmsnorm(1, 0, 1, 4)], buffer_sizes=[4, 4], initial_uploads=[ProgramIO(1, np.full(4, 5, f32))])
+    assert oracle.run_program(p, 1, 4, backend=hip_backend).tolist() == [0, 0, 0, 0]
+
+
+def test_attention_seq_kv_refresh_and_masked_row(hip_backend, oracle):
+    rng = np.random.default_rng(0xD3FA)
+    dh, sq, skv = 64, 2, 700  # > 2 key tiles of 256
+    q, k, v = (rng.standard_normal(n).astype(f32) for n in (dh * sq, dh * skv, dh * skv))
+    mask = np.zeros(skv * sq, f32)
+    mask[5] = -np.inf
+    mask[skv:] = -np.inf  # query 1 fully masked -> zeros
+    op = DeviceOp.attention(4, 0, 1, 2, 3, True, dh, sq, skv, 0.125, 0, 0, 0, 0, 0, 1, dh, 1, dh, 1, dh, 1, skv, 1, dh)
+    prog = DeviceProgram(ops=[op], buffer_sizes=[dh * sq, dh * skv, dh * skv, skv * sq, dh * sq],
+                         initial_uploads=[ProgramIO(0, q), ProgramIO(1, k), ProgramIO(2, v), ProgramIO(3, mask)])
+    outs = {}
+    for name, be in (("ref", oracle.OracleBackend()), ("hip", hip_backend)):
+        h = be.compileProgram(prog)
+        res = []
+        for n in (skv, 300, 2, 513):
+            ops = [op.with_(seq_kv=n)]
+            be.refreshProgram(h, ops)
+            o = np.zeros(dh * sq, f32)
+            be.executeProgram(h, [], [ProgramIO(4, o)])
+            res.append(o)
+        be.freeProgram(h)
+        outs[name] = res
+    for r, g in zip(outs["ref"], outs["hip"]):
+        np.testing.assert_allclose(g, r, atol=2e-5, rtol=0)
+        assert np.all(g[dh:] == 0)
+
+
+def test_elementwise_all_ops_and_fused_chain(hip_backend, oracle):
+    rng = np.random.default_rng(1)
+    n = 1000
+    x = (rng.standard_normal(n) * 2).astype(f32)
+    y = rng.standard_normal(n).astype(f32)
+    for op in ("add", "mul", "neg", "abs", "sgn", "step", "relu", "sqrt", "recip", "exp", "log", "gelu"):
+        src = np.abs(x) + 0.1 if op in ("sqrt", "log") else x
+        prog = DeviceProgram(ops=[DeviceOp.elementwise(op, 2, 0, 1, n - 7, dst_offset=3, src0_offset=5, src1_offset=2)],
+                             buffer_sizes=[n, n, n], initial_uploads=[ProgramIO(0, src), ProgramIO(1, y)])
+        want = oracle.run_program(prog, 2, n)
+        got = oracle.run_program(prog, 2, n, backend=hip_backend)
+        np.testing.assert_allclose(got, want, rtol=2e-6, atol=1e-6, err_msg=op)
+    # SiLU chain as the LLaMA lowering emits it: [neg,exp] ; [add(1), recip, mul(x, swapped)]
+    one = np.ones(n, f32)
+    prog = DeviceProgram(
+        ops=[DeviceOp.fused_elementwise([FusedEwStep("neg"), FusedEwStep("exp")], n, 2, 0),
+             DeviceOp.fused_elementwise([FusedEwStep("add", False, 1, 0), FusedEwStep("recip"),
+                                         FusedEwStep("mul", True, 0, 0)], n, 3, 2)],
+        buffer_sizes=[n, n, n, n], initial_uploads=[ProgramIO(0, x), ProgramIO(1, one)])
+    want = oracle.run_program(prog, 3, n)
+    got = oracle.run_program(prog, 3, n, backend=hip_backend)
+    np.testing.assert_allclose(got, want, rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(got, x / (1 + np.exp(-x.astype(np.float64))), rtol=1e-5, atol=1e-6)
+
+
+def test_rowwise_large(hip_backend, oracle):
+    rng = np.random.default_rng(2)
+    rows, cols = 3, 4096 + 5
+    x = rng.standard_normal(rows * cols).astype(f32)
+    for mk in (lambda: DeviceOp.softmax(1, 0, rows, cols), lambda: DeviceOp.layernorm(1, 0, rows, cols, 1e-5),
+               lambda: DeviceOp.rmsnorm(1, 0, rows, cols, 1e-6)):
+        prog = DeviceProgram(ops=[mk()], buffer_sizes=[rows * cols, rows * cols], initial_uploads=[ProgramIO(0, x)])
+        want = oracle.run_program(prog, 1, rows * cols)
+        got = oracle.run_program(prog, 1, rows * cols, backend=hip_backend)
+        np.testing.assert_allclose(got, want, atol=1e-5, rtol=1e-5)
+
+
+def test_repeat_generic_and_rope_strided_bit_exact(hip_backend, oracle):
+    rng = np.random.default_rng(3)
+    # generic repeat: src [3,2] (strided view, row stride 4) -> dst [6,4]
+    src = rng.standard_normal(16).astype(f32)
+    op = DeviceOp.repeat(1, 0, 24, (3, 2, 1, 1), (6, 4, 1, 1), (1, 4, 8, 8), (1, 6, 24, 24), src_offset=1, dst_offset=2)
+    prog = DeviceProgram(ops=[op], buffer_sizes=[16, 30], initial_uploads=[ProgramIO(0, src)])
+    assert np.array_equal(oracle.run_program(prog, 1, 30, backend=hip_backend), oracle.run_program(prog, 1, 30))
+    # rope on a strided row-slice of a projection (src_rs=1, src_cs=kv_dim), as LlamaBlock emits
+    hd, seq, kv_dim = 32, 3, 192
+    x = rng.standard_normal(kv_dim * seq).astype(f32)
+    cs = rng.standard_normal(4 * hd * seq).astype(f32)
+    op = DeviceOp.rope(2, 0, 1, hd, seq, src_off=64, cs_off=0, dst_off=0, src_rs=1, src_cs=kv_dim, cs_cs=4 * hd)
+    prog = DeviceProgram(ops=[op], buffer_sizes=[kv_dim * seq, 4 * hd * seq, 2 * hd * seq],
+                         initial_uploads=[ProgramIO(0, x), ProgramIO(1, cs)])
+    np.testing.assert_allclose(oracle.run_program(prog, 2, 2 * hd * seq, backend=hip_backend),
+                               oracle.run_program(prog, 2, 2 * hd * seq), atol=0, rtol=0)
+
+
+def test_dense_matmul_layouts(hip_backend, oracle):
+    rng = np.random.default_rng(4)
+    M, K, N = 2, 576, 1000
+    a = rng.standard_normal(M * K).astype(f32)
+    b = rng.standard_normal(K * N).astype(f32)
+    bound = (np.abs(a.reshape(M, K)) @ np.abs(b.reshape(K, N))).ravel()
+    # B N-contiguous ([K,N] row-major) and B K-contiguous (tied LM head: trans1)
+    for geom in (MatMulGeometry(M, N, K, K, 1, N, 1, 0, 0, 0, N), MatMulGeometry(M, N, K, K, 1, 1, K, 0, 0, 0, N)):
+        prog = DeviceProgram(ops=[DeviceOp.matmul(2, 0, 1, geom)], buffer_sizes=[M * K, K * N, M * N],
+                             initial_uploads=[ProgramIO(0, a), ProgramIO(1, b)])
+        want = oracle.run_program(prog, 2, M * N)
+        got = oracle.run_program(prog, 2, M * N, backend=hip_backend)
+        if geom.b_col_stride != 1:
+            bound = (np.abs(a.reshape(M, K)) @ np.abs(b.reshape(N, K).T)).ravel()
+        assert np.all(np.abs(got - want) <= 2e-6 * bound + 1e-6)
+
+
+def test_host_dense_matmul_override(hip_backend):
+    k = KAT["dense_matmul_2x3_3x2"]
+    dst = np.zeros(4, f32)
+    ok = tryDenseMatMul(hip_backend, DenseMatMulSpecF32(dst, np.array(k["a"], f32), np.array(k["b"], f32),
+                                                        MatMulGeometry(**k["geom"])))
+    assert ok and dst.tolist() == k["expected"]
+    assert tryDenseMatMul(None, DenseMatMulSpecF32(dst, dst, dst, MatMulGeometry(**k["geom"]))) is False
+    # strided dst keeps the gaps
+    dst = np.full(7, -1, f32)
+    g = MatMulGeometry(2, 2, 3, 3, 1, 2, 1, 0, 0, 1, 3)
+    assert tryDenseMatMul(hip_backend, DenseMatMulSpecF32(dst, np.array(k["a"], f32), np.array(k["b"], f32), g))
+    assert dst.tolist() == [-1, 58, 64, -1, 139, 154, -1]
+
+
+def test_profile_counters_and_no_fallback(hip_backend, oracle):
+    name, prog, idx, n = core_cases()[3]
+    h = hip_backend.compileProgram(prog)
+    out = np.zeros(n, f32)
+    hip_backend.executeProgram(h, [], [ProgramIO(idx, out)])
+    hip_backend.executeProgram(h, [], [ProgramIO(idx, out)])
+    prof = hip_backend.getRuntimeProfile(h)
+    assert prof.call_count == 2 and prof.fallback_op_count == 0 and prof.backend_op_count == 2 * len(prog.ops)
+    assert prof.sync_count == 2
+    hip_backend.freeProgram(h)
+
+
+def test_dead_buffer_elision_and_loud_io_error(hip_backend):
+    # buffer 2 is a dead "f32 master copy": no op references it
+    dead = np.arange(8, dtype=f32)
+    prog = DeviceProgram(ops=[DeviceOp.elementwise("neg", 1, 0, 0, 4)], buffer_sizes=[4, 4, 8],
+                         initial_uploads=[ProgramIO(0, np.arange(4, dtype=f32)), ProgramIO(2, dead)])
+    h = hip_backend.compileProgram(prog)
+    out = np.zeros(4, f32)
+    hip_backend.executeProgram(h, [], [ProgramIO(1, out)])
+    assert out.tolist() == [0, -1, -2, -3]
+    with pytest.raises(RuntimeError, match="elided"):
+        hip_backend.executeProgram(h, [], [ProgramIO(2, np.zeros(8, f32))])
+    hip_backend._lib.zgml_hip_clear_error(hip_backend.ctx)
+    hip_backend.freeProgram(h)
+
+
+def test_argmax_first_max_wins(hip_backend, oracle):
+    rng = np.random.default_rng(5)
+    v = rng.standard_normal(49152).astype(f32)
+    v[[100, 40000]] = 9.0  # tie: first index wins
+    prog = DeviceProgram(ops=[DeviceOp.elementwise("abs", 1, 0, 0, 1)], buffer_sizes=[v.size, 1],
+                         initial_uploads=[ProgramIO(0, v)])
+    h = hip_backend.compileProgram(prog)
+    assert hip_backend.argmax(h, 0, 0, v.size) == oracle.argmax(v) == 100
+    assert hip_backend.argmax(h, 0, 101, v.size - 101) == 40000 - 101
+    hip_backend.freeProgram(h)

@@ -1,0 +1,113 @@
+"""Parity of the HIP quantized mat-vec / matmul with the oracle's exact-dequant path
+(src/quant.zig:475-578 == src/backend/reference.zig:530-565).
+
+Tolerance: |delta| <= 2e-5 * sum_k |x_k * w_kn| — summation order only; the GPU does
+not quantise activations."""
+import numpy as np
+import pytest
+
+from zgml_amd import DeviceOp, DeviceProgram, ProgramIO, QuantizedWeightUpload
+from tests.synth import q4_0_blocks_from_int8, synth_weight, synth_x
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+TOL = 2e-5
+
+
+def bound(data, scales, x, M, N, K, bs):
+    w = np.abs(data.astype(np.float64) * np.repeat(scales.astype(np.float64), bs)[: data.size]).reshape(K, N)
+    return np.abs(x.reshape(M, K).astype(np.float64)) @ w
+
+
+def run_both(hip_backend, oracle, data, scales, x, M, N, K, bs=32, in_off=0, in_rs=0, dst_off=0, dst_rs=0):
+    xin = np.full(in_off + (M - 1) * (in_rs or K) + K + 3, 99, f32)
+    for m in range(M):
+        xin[in_off + m * (in_rs or K):][:K] = x.reshape(M, K)[m]
+    dst_len = dst_off + (M - 1) * (dst_rs or N) + N + 2
+    prog = DeviceProgram(ops=[DeviceOp.qmatmul(1, 0, 0, M, N, K, in_off, in_rs, dst_off, dst_rs)],
+                         buffer_sizes=[xin.size, dst_len],
+                         initial_uploads=[ProgramIO(0, xin), ProgramIO(1, np.full(dst_len, -7, f32))],
+                         qweights=[QuantizedWeightUpload(data, scales, K, N, bs)])
+    want = oracle.run_program(prog, 1, dst_len)
+    got = oracle.run_program(prog, 1, dst_len, backend=hip_backend)
+    return want, got
+
+
+@pytest.mark.parametrize("K,N", [(576, 576), (576, 192), (1536, 576), (576, 1536), (4096, 4096), (100, 64), (33, 32),
+                                 (4096, 11008)])
+@pytest.mark.parametrize("kind", ["q4", "q8"])
+def test_matvec_matches_oracle(hip_backend, oracle, K, N, kind):
+    rng = np.random.default_rng(0xD3FA + K + N)
+    x = rng.standard_normal(K).astype(f32)
+    if kind == "q4":  # GGUF Q4_0-sourced: nibbles + f16 scales through the loader restatement
+        data = rng.integers(-8, 8, K * N).astype(np.int8)
+        scales = (rng.random(K * N // 32 + 1).astype(np.float16) * 0.05 + 0.001).astype(f32)[: (K * N + 31) // 32]
+        raw = q4_0_blocks_from_int8(np.pad(data, (0, (-data.size) % 32)), scales)
+        d2, s2 = oracle.gguf_to_int8(raw, data.size, "q4_0")
+        assert np.array_equal(d2, data) and np.array_equal(s2, scales)
+    else:  # session.quantize() path: fromSlice gives full-range int8 + arbitrary f32 scales
+        w = rng.standard_normal(K * N).astype(f32) * 0.05
+        data, scales = oracle.quantize_from_slice(w, K, N, 32)
+    want, got = run_both(hip_backend, oracle, data, scales, x, 1, N, K)
+    b = bound(data, scales, x, 1, N, K, 32).ravel()
+    assert np.all(np.abs(got[:N] - want[:N]) <= TOL * b + 1e-30), np.max(np.abs(got[:N] - want[:N]) / (b + 1e-30))
+    assert np.all(got[N:] == -7)  # nothing written past N
+
+
+def test_matmul_rows_offsets_strides(hip_backend, oracle):
+    rng = np.random.default_rng(7)
+    M, K, N = 3, 192, 96
+    x = rng.standard_normal(M * K).astype(f32)
+    data = rng.integers(-8, 8, K * N).astype(np.int8)
+    scales = (rng.random(K * N // 32).astype(np.float16) * 0.1).astype(f32)
+    want, got = run_both(hip_backend, oracle, data, scales, x, M, N, K, in_off=5, in_rs=K + 7, dst_off=2, dst_rs=N + 3)
+    np.testing.assert_allclose(got, want, atol=1e-4, rtol=1e-5)
+    assert np.array_equal(got == -7, want == -7)  # sentinels untouched in the same places
+
+
+def test_raw_layout_odd_shapes_bit_exact(hip_backend, oracle):
+    """bs != 32 or N % 32 != 0 uses the k-sequential kernel: same loop order as the reference."""
+    rng = np.random.default_rng(8)
+    for (M, K, N, bs) in [(2, 3, 3, 4), (1, 50, 37, 32), (2, 64, 48, 16)]:
+        x = rng.standard_normal(M * K).astype(f32)
+        data = rng.integers(-127, 128, K * N).astype(np.int8)
+        scales = rng.random((K * N + bs - 1) // bs).astype(f32)
+        want, got = run_both(hip_backend, oracle, data, scales, x, M, N, K, bs=bs)
+        assert np.array_equal(got, want)
+
+
+def test_linearity_and_zero_input_full_size(hip_backend, oracle):
+    """Size-independent properties at the BASELINE shape: y(a*x1 + x2) == a*y(x1) + y(x2) up to
+    rounding, and x = 0 -> y = 0 exactly."""
+    K = N = 4096
+    data, scales = synth_weight(K, N, True, 3)
+    rng = np.random.default_rng(9)
+    x1, x2 = rng.standard_normal(K).astype(f32), rng.standard_normal(K).astype(f32)
+    qw = QuantizedWeightUpload(data, scales, K, N, 32)
+    prog = DeviceProgram(ops=[DeviceOp.qmatmul(1, 0, 0, 1, N, K)], buffer_sizes=[K, N], qweights=[qw])
+    h = hip_backend.compileProgram(prog)
+
+    def y(x):
+        out = np.zeros(N, f32)
+        hip_backend.executeProgram(h, [ProgramIO(0, np.ascontiguousarray(x, f32))], [ProgramIO(1, out)])
+        return out
+    y1, y2, y12, y0 = y(x1), y(x2), y(2.0 * x1 + x2), y(np.zeros(K, f32))
+    hip_backend.freeProgram(h)
+    assert np.all(y0 == 0)
+    b = bound(data, scales, np.abs(2 * x1) + np.abs(x2), 1, N, K, 32).ravel()
+    assert np.all(np.abs(y12 - (2 * y1 + y2)) <= 4 * TOL * b)
+
+
+@pytest.mark.parametrize("q4", [1, 0])
+def test_device_synth_generator_matches_host(hip_backend, oracle, q4):
+    """The roofline ring's on-device generator produces the same matrices as tests/synth.py."""
+    import ctypes as C
+    K, N = 256, 128
+    x = synth_x(K)
+    y = np.zeros(N, f32)
+    rc = hip_backend._lib.zgml_hip_qmatvec_synth(hip_backend.ctx, K, N, q4, 5, x.ctypes.data, y.ctypes.data)
+    assert rc == 0
+    data, scales = synth_weight(K, N, bool(q4), 5)
+    want = oracle.qmatmul_exact(data, scales, x, 1, N, K)
+    b = bound(data, scales, x, 1, N, K, 32).ravel()
+    assert np.all(np.abs(y - want) <= TOL * b)

@@ -166,7 +166,7 @@ HIP_SYMBOLS = [
     "zgml_hip_free_program", "zgml_hip_get_runtime_profile", "zgml_hip_set_option",
     "zgml_hip_program_buffer_ptr", "zgml_hip_stream", "zgml_hip_enqueue_program",
     "zgml_hip_enqueue_ops", "zgml_hip_synchronize", "zgml_hip_argmax", "zgml_hip_qmatvec_bench",
-    "zgml_hip_copy_bench",
+    "zgml_hip_qmatvec_synth", "zgml_hip_copy_bench",
 ]
 
 OPT_FUSION, OPT_GRAPH, OPT_PROFILE, OPT_SKIP_DEAD_UPLOADS, OPT_F16_DENSE_WEIGHTS = 1, 2, 3, 4, 5
@@ -208,6 +208,8 @@ def _bind_hip(lib: C.CDLL) -> None:
     lib.zgml_hip_argmax.argtypes = [vp, vp, C.c_uint16, u64, u64]
     lib.zgml_hip_qmatvec_bench.restype = C.c_double
     lib.zgml_hip_qmatvec_bench.argtypes = [vp, u32, u32, i32, u32, u32, u32, C.POINTER(u64)]
+    lib.zgml_hip_qmatvec_synth.restype = i32
+    lib.zgml_hip_qmatvec_synth.argtypes = [vp, u32, u32, i32, u32, vp, vp]
     lib.zgml_hip_copy_bench.restype = C.c_double
     lib.zgml_hip_copy_bench.argtypes = [vp, u64, u32, u32]
 

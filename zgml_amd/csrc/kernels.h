@@ -1,0 +1,132 @@
+// kernels.h — launch interface between the runtime (runtime.hip) and the gfx950 kernels.
+// All pointers are device pointers; offsets/strides are in f32 elements unless noted.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/zgml_hip.h"
+
+namespace zgml {
+
+constexpr int kMaxFusedSteps = 8; // Capabilities.hip.max_fused_elementwise_steps
+
+struct FusedStepDev {
+    uint32_t op;
+    uint32_t swapped;
+    const float* secondary; // already offset
+};
+
+struct FusedParams {
+    float* dst;
+    const float* src;
+    uint32_t n;
+    uint32_t n_steps;
+    FusedStepDev steps[kMaxFusedSteps];
+};
+
+struct RepeatParams {
+    float* dst;       // base (dst_offset applied in kernel, as the reference indexes)
+    const float* src; // base
+    uint32_t n;
+    uint32_t src_ne[4], src_strides[4], dst_strides[4];
+    uint32_t src_offset, dst_offset;
+    uint32_t mode; // 0 = generic index math, 1 = scalar fill, 2 = flat copy, 3 = tile copy
+    uint32_t src_n;
+};
+
+struct SliceAssignParams {
+    float* dst;
+    const float* src; // src_offset applied
+    uint32_t rows, cols;
+    uint32_t dst_row_stride, dst_col_stride, src_row_stride, src_col_stride;
+    const uint32_t* dyn_dst_offset; // device word holding the current dst_offset
+};
+
+struct RopeParams {
+    float* dst;
+    const float* src;
+    const float* cs;
+    uint32_t half_d, seq_len, src_rs, src_cs, cs_cs;
+};
+
+struct AttentionParams {
+    float* dst;
+    const float* q;
+    const float* k;
+    const float* v;
+    const float* mask; // nullptr when !has_mask
+    uint32_t d_head, seq_q;
+    const uint32_t* dyn_seq_kv; // device word holding the current seq_kv
+    float scale;
+    uint32_t q_rs, q_cs, k_rs, k_cs, v_rs, v_cs, mask_rs, mask_cs, dst_rs, dst_cs;
+};
+
+struct DenseMatmulParams {
+    float* dst;       // dst_offset applied
+    const float* a;   // a_offset applied
+    const void* b;    // b_offset applied; float or __half when b_f16
+    uint32_t M, N, K;
+    uint32_t a_rs, a_cs, b_rs, b_cs, dst_rs;
+    uint32_t b_f16;
+};
+
+// ── quantized weights on the device ──────────────────────────────────────────
+enum QWFormat : uint32_t {
+    QW_RAW = 0, // int8 [K*N] + f32 scale per `bs` flat elements (any bs, any N)
+    QW_Q4 = 1,  // packed nibbles, lane-tiled (see qmatvec.hip)
+    QW_Q8 = 2,  // packed int8, lane-tiled
+};
+
+struct QWeightDev {
+    QWFormat format = QW_RAW;
+    uint32_t K = 0, N = 0, bs = 0;
+    uint32_t KC = 0;       // K chunks of 32 (padded)
+    uint32_t scale_f16 = 0; // packed formats: scales stored as f16 (exact) or f32
+    void* qs = nullptr;     // packed quants or raw int8
+    void* sc = nullptr;     // packed scales or raw f32 scales
+    uint64_t qs_bytes = 0, sc_bytes = 0;
+};
+
+struct QMatmulParams {
+    float* dst;         // dst_offset applied
+    const float* input; // input_offset applied
+    uint32_t M, N, K;
+    uint32_t in_rs, dst_rs;
+};
+
+// generic kernels (kernels_generic.hip)
+void launch_elementwise(hipStream_t s, uint32_t op, float* dst, const float* s0, const float* s1, uint32_t n);
+void launch_fused_elementwise(hipStream_t s, const FusedParams& p);
+void launch_softmax(hipStream_t s, float* dst, const float* src, uint32_t rows, uint32_t cols);
+void launch_layernorm(hipStream_t s, float* dst, const float* src, uint32_t rows, uint32_t cols, float eps);
+void launch_rmsnorm(hipStream_t s, float* dst, const float* src, uint32_t rows, uint32_t cols, float eps);
+void launch_reduce(hipStream_t s, uint32_t op, float* dst, const float* src, uint32_t n_out, uint32_t reduce_size);
+void launch_repeat(hipStream_t s, const RepeatParams& p);
+void launch_slice_assign(hipStream_t s, const SliceAssignParams& p);
+void launch_rope(hipStream_t s, const RopeParams& p);
+void launch_attention(hipStream_t s, const AttentionParams& p);
+void launch_dense_matmul(hipStream_t s, const DenseMatmulParams& p);
+void launch_argmax(hipStream_t s, const float* v, uint64_t n, float* scratch_val, int64_t* scratch_idx, int64_t* out);
+void launch_copy_f4(hipStream_t s, void* dst, const void* src, uint64_t bytes);
+void launch_f32_to_f16(hipStream_t s, void* dst, const float* src, uint64_t n);
+
+// quantized matmul (qmatvec.hip)
+// Device-side repack of a QuantizedWeightUpload (raw int8 + f32 scales already on the device)
+// into the packed layout. `raw_data`/`raw_scales` are device pointers; `out` must have
+// format/K/N/KC/scale_f16 set and qs/sc allocated (packed_bytes() gives the sizes).
+// Classification helpers run on the device too: returns bit0 = all values in [-8,7],
+// bit1 = all scales exactly representable in f16.
+uint32_t classify_qweight(hipStream_t s, const int8_t* raw_data, uint64_t n_elems, const float* raw_scales,
+                          uint64_t n_blocks, uint32_t* flag_scratch /* 2 device words */);
+void packed_bytes(QWFormat format, uint32_t scale_f16, uint64_t K, uint64_t N, uint64_t* qs_bytes,
+                  uint64_t* sc_bytes);
+void launch_pack_qweight(hipStream_t s, const int8_t* raw_data, const float* raw_scales, const QWeightDev& out);
+// Bytes of split-K scratch a qmatmul launch may need (f32 partial slabs).
+uint64_t qmatmul_scratch_bytes(const QWeightDev& w, uint32_t M);
+void launch_qmatmul(hipStream_t s, const QWeightDev& w, const QMatmulParams& p, float* scratch);
+// Deterministic synthetic weights for the roofline micro-benchmark, generated on the device
+// directly in the packed layout (SURVEY §8d generator).
+void launch_synth_packed(hipStream_t s, const QWeightDev& w, uint32_t matrix_id);
+
+} // namespace zgml

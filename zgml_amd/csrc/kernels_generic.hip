@@ -1,0 +1,568 @@
+// kernels_generic.hip — gfx950 kernels for the DeviceOp kinds that are not the quantized
+// mat-vec: elementwise / fused chains / row-wise norms / reduce / repeat / slice_assign / rope /
+// attention / dense matmul / argmax / copy. One launch per op; fused variants live in fused.hip.
+//
+// Semantics follow the reference executor src/backend/reference.zig (cited per kernel). These ops
+// are tiny at decode (d_model..d_ff elements): they are latency-bound, so the kernels favour
+// simple full-wave shapes (64-lane shuffles, one workgroup per row) over tiling.
+#include "kernels.h"
+
+#include <hip/hip_fp16.h>
+#include <math.h>
+
+namespace zgml {
+
+namespace {
+
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// all-threads block reductions over 256 threads (4 waves); `red` has >= 4 floats.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); i++) t += red[i];
+    return t;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = -INFINITY;
+    for (int i = 0; i < (int)(blockDim.x >> 6); i++) t = fmaxf(t, red[i]);
+    return t;
+}
+
+__device__ __forceinline__ float gelu_f(float a) {
+    float kk = 0.7978845608f * (a + 0.044715f * a * a * a);
+    return 0.5f * a * (1.0f + tanhf(kk));
+}
+
+// unary/binary op table: reference.zig:201-273 (+ true sgn/step, forward.zig:959-1007)
+__device__ __forceinline__ float apply_unary(uint32_t op, float a) {
+    switch (op) {
+        case ZGML_OP_NEG: return -a;
+        case ZGML_OP_ABS: return fabsf(a);
+        case ZGML_OP_SGN: return a > 0.f ? 1.f : (a < 0.f ? -1.f : 0.f);
+        case ZGML_OP_STEP: return a > 0.f ? 1.f : 0.f;
+        case ZGML_OP_RELU: return fmaxf(a, 0.f);
+        case ZGML_OP_SQRT: return sqrtf(a);
+        case ZGML_OP_RECIP: return 1.0f / a;
+        case ZGML_OP_EXP: return expf(a);
+        case ZGML_OP_LOG: return logf(a);
+        case ZGML_OP_GELU: return gelu_f(a);
+        default: return a; // reference: unknown tag copies src0 (:271)
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) elementwise_kernel(uint32_t op, float* __restrict__ dst,
+                                                             const float* s0, const float* s1, uint32_t n) {
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    float a = s0[i];
+    float r;
+    if (op == ZGML_OP_ADD)
+        r = a + s1[i];
+    else if (op == ZGML_OP_MUL)
+        r = a * s1[i];
+    else
+        r = apply_unary(op, a);
+    dst[i] = r;
+}
+
+// reference.zig:275-307
+__global__ void __launch_bounds__(kBlock) fused_elementwise_kernel(FusedParams p) {
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= p.n) return;
+    float v = p.src[i];
+#pragma unroll 1
+    for (uint32_t s = 0; s < p.n_steps; s++) {
+        uint32_t op = p.steps[s].op;
+        if (op == ZGML_OP_ADD) {
+            float o = p.steps[s].secondary[i];
+            v = p.steps[s].swapped ? o + v : v + o;
+        } else if (op == ZGML_OP_MUL) {
+            float o = p.steps[s].secondary[i];
+            v = p.steps[s].swapped ? o * v : v * o;
+        } else {
+            v = apply_unary(op, v);
+        }
+    }
+    p.dst[i] = v;
+}
+
+// reference.zig:309-327 with the finite-shift guard of forward.zig:1306-1322 (all -inf -> zeros)
+__global__ void __launch_bounds__(kBlock) softmax_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                                         uint32_t cols) {
+    __shared__ float red[8];
+    const float* s = src + (uint64_t)blockIdx.x * cols;
+    float* d = dst + (uint64_t)blockIdx.x * cols;
+    float m = -INFINITY;
+    for (uint32_t j = threadIdx.x; j < cols; j += kBlock) m = fmaxf(m, s[j]);
+    m = block_max(m, red);
+    float sum = 0;
+    for (uint32_t j = threadIdx.x; j < cols; j += kBlock) {
+        float shifted = s[j] - m;
+        float e = isfinite(shifted) ? expf(shifted) : 0.0f;
+        d[j] = e;
+        sum += e;
+    }
+    sum = block_sum(sum, red);
+    float inv = sum > 0.0f ? 1.0f / sum : 0.0f;
+    for (uint32_t j = threadIdx.x; j < cols; j += kBlock) d[j] *= inv;
+}
+
+// reference.zig:329-347
+__global__ void __launch_bounds__(kBlock) layernorm_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                                           uint32_t cols, float eps) {
+    __shared__ float red[8];
+    const float* s = src + (uint64_t)blockIdx.x * cols;
+    float* d = dst + (uint64_t)blockIdx.x * cols;
+    float mu = 0;
+    for (uint32_t j = threadIdx.x; j < cols; j += kBlock) mu += s[j];
+    mu = block_sum(mu, red) / (float)cols;
+    float v = 0;
+    for (uint32_t j = threadIdx.x; j < cols; j += kBlock) {
+        float diff = s[j] - mu;
+        v += diff * diff;
+    }
+    v = block_sum(v, red);
+    float inv_std = 1.0f / sqrtf(v / (float)cols + eps);
+    for (uint32_t j = threadIdx.x; j < cols; j += kBlock) d[j] = (s[j] - mu) * inv_std;
+}
+
+// reference.zig:349-374: inv = 1/sqrt(ss/cols + eps)
+__global__ void __launch_bounds__(kBlock) rmsnorm_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                                         uint32_t cols, float eps) {
+    __shared__ float red[8];
+    const float* s = src + (uint64_t)blockIdx.x * cols;
+    float* d = dst + (uint64_t)blockIdx.x * cols;
+    float ss = 0;
+    for (uint32_t j = threadIdx.x; j < cols; j += kBlock) ss += s[j] * s[j];
+    ss = block_sum(ss, red);
+    float inv = 1.0f / sqrtf(ss / (float)cols + eps);
+    for (uint32_t j = threadIdx.x; j < cols; j += kBlock) d[j] = s[j] * inv;
+}
+
+// reference.zig:376-389: one wave per output
+__global__ void __launch_bounds__(kBlock) reduce_kernel(uint32_t op, float* __restrict__ dst,
+                                                        const float* __restrict__ src, uint32_t n_out,
+                                                        uint32_t reduce_size) {
+    uint32_t out = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (out >= n_out) return;
+    const float* s = src + (uint64_t)out * reduce_size;
+    uint32_t lane = threadIdx.x & 63;
+    if (op == ZGML_OP_MAX) {
+        float v = -INFINITY;
+        for (uint32_t k = lane; k < reduce_size; k += 64) v = fmaxf(v, s[k]);
+        v = wave_max(v);
+        if (lane == 0) dst[out] = v;
+    } else {
+        float v = 0;
+        for (uint32_t k = lane; k < reduce_size; k += 64) v += s[k];
+        v = wave_sum(v);
+        if (lane == 0) dst[out] = v;
+    }
+}
+
+// reference.zig:391-433 (bit-exact copy semantics; the three fast paths are special cases of the
+// generic index math and are kept only because they avoid the div/mod chain)
+__global__ void __launch_bounds__(kBlock) repeat_kernel(RepeatParams p) {
+    uint32_t gid = blockIdx.x * kBlock + threadIdx.x;
+    if (gid >= p.n) return;
+    float* d = p.dst + p.dst_offset;
+    const float* s = p.src + p.src_offset;
+    if (p.mode == 1) {
+        d[gid] = s[0];
+    } else if (p.mode == 2) {
+        d[gid] = s[gid];
+    } else if (p.mode == 3) {
+        d[gid] = s[gid % p.src_n];
+    } else {
+        uint32_t idx = gid, src_idx = p.src_offset;
+#pragma unroll
+        for (int dim = 3; dim >= 0; dim--) {
+            uint32_t coord = idx / p.dst_strides[dim];
+            idx = idx % p.dst_strides[dim];
+            src_idx += (coord % p.src_ne[dim]) * p.src_strides[dim];
+        }
+        d[gid] = p.src[src_idx];
+    }
+}
+
+// reference.zig:435-455; dst_offset is read from the program's dynamic-parameter block so a
+// captured graph stays valid across KV positions.
+__global__ void __launch_bounds__(kBlock) slice_assign_kernel(SliceAssignParams p) {
+    uint32_t gid = blockIdx.x * kBlock + threadIdx.x;
+    if (gid >= p.rows * p.cols) return;
+    uint32_t row = gid % p.rows, col = gid / p.rows;
+    uint32_t doff = *p.dyn_dst_offset;
+    p.dst[(uint64_t)doff + (uint64_t)row * p.dst_row_stride + (uint64_t)col * p.dst_col_stride] =
+        p.src[(uint64_t)row * p.src_row_stride + (uint64_t)col * p.src_col_stride];
+}
+
+// reference.zig:457-478 (DeviceOp convention: sin at cs + pair + half_d)
+__global__ void __launch_bounds__(kBlock) rope_kernel(RopeParams p) {
+    uint32_t gid = blockIdx.x * kBlock + threadIdx.x;
+    if (gid >= p.half_d * p.seq_len) return;
+    uint32_t pair = gid % p.half_d, col = gid / p.half_d;
+    float x_lo = p.src[(uint64_t)pair * p.src_rs + (uint64_t)col * p.src_cs];
+    float x_hi = p.src[(uint64_t)(pair + p.half_d) * p.src_rs + (uint64_t)col * p.src_cs];
+    float c = p.cs[pair + (uint64_t)col * p.cs_cs];
+    float s = p.cs[pair + p.half_d + (uint64_t)col * p.cs_cs];
+    p.dst[pair + (uint64_t)col * 2 * p.half_d] = x_lo * c - x_hi * s;
+    p.dst[pair + p.half_d + (uint64_t)col * 2 * p.half_d] = x_hi * c + x_lo * s;
+}
+
+// reference.zig:568-672. One workgroup per query column; keys are processed in tiles of 256 with
+// an online softmax (so there is no seq_kv cap, unlike the 4096-entry score buffers of the Metal
+// and WGSL kernels). Masked (non-finite mask) and non-finite-score keys are skipped exactly as the
+// reference does; a query with no valid key yields zeros.
+__global__ void __launch_bounds__(kBlock) attention_kernel(AttentionParams p) {
+    __shared__ float q_s[512];
+    __shared__ float w_s[kBlock];
+    __shared__ float red[8];
+    __shared__ float acc_s[kBlock]; // cross-group reduction of the V accumulation
+    const uint32_t qi = blockIdx.x, tid = threadIdx.x, dh = p.d_head;
+    const uint32_t seq_kv = *p.dyn_seq_kv;
+    for (uint32_t r = tid; r < dh; r += kBlock) q_s[r] = p.q[(uint64_t)qi * p.q_cs + (uint64_t)r * p.q_rs];
+    __syncthreads();
+
+    // V accumulation layout: dh <= 256 -> G = 256/dh key groups, thread (g, r); else 2 rows/thread.
+    const bool grouped = dh <= kBlock;
+    const uint32_t G = grouped ? kBlock / dh : 1;
+    const uint32_t g = grouped ? tid / dh : 0;
+    const uint32_t r0 = grouped ? tid % dh : tid;
+    const bool v_active = grouped ? (g < G) : true;
+    float acc0 = 0.f, acc1 = 0.f;
+    float m = -INFINITY, l = 0.f;
+
+    for (uint32_t s0 = 0; s0 < seq_kv; s0 += kBlock) {
+        uint32_t s = s0 + tid;
+        bool valid = s < seq_kv;
+        float score = -INFINITY;
+        if (valid) {
+            float mask_add = p.mask ? p.mask[(uint64_t)qi * p.mask_cs + (uint64_t)s * p.mask_rs] : 0.0f;
+            if (isfinite(mask_add)) {
+                const float* kp = p.k + (uint64_t)s * p.k_cs;
+                float dot = 0.f;
+                for (uint32_t r = 0; r < dh; r++) dot += q_s[r] * kp[(uint64_t)r * p.k_rs];
+                score = dot * p.scale + mask_add;
+                if (!isfinite(score)) score = -INFINITY;
+            }
+        }
+        valid = score > -INFINITY;
+        float tile_max = block_max(score, red);
+        float new_m = fmaxf(m, tile_max);
+        if (new_m == -INFINITY) continue; // uniform: nothing valid so far
+        float alpha = (m == -INFINITY) ? 0.0f : expf(m - new_m);
+        float w = valid ? expf(score - new_m) : 0.0f;
+        w_s[tid] = w;
+        float tile_sum = block_sum(w, red); // contains the barrier that publishes w_s
+        l = l * alpha + tile_sum;
+        m = new_m;
+        uint32_t tile_n = min((uint32_t)kBlock, seq_kv - s0);
+        if (v_active) {
+            if (grouped) {
+                float a = acc0 * alpha;
+                for (uint32_t t = g; t < tile_n; t += G)
+                    a += w_s[t] * p.v[(uint64_t)r0 * p.v_rs + (uint64_t)(s0 + t) * p.v_cs];
+                acc0 = a;
+            } else {
+                float a0 = acc0 * alpha, a1 = acc1 * alpha;
+                for (uint32_t t = 0; t < tile_n; t++) {
+                    float wt = w_s[t];
+                    if (r0 < dh) a0 += wt * p.v[(uint64_t)r0 * p.v_rs + (uint64_t)(s0 + t) * p.v_cs];
+                    if (r0 + kBlock < dh)
+                        a1 += wt * p.v[(uint64_t)(r0 + kBlock) * p.v_rs + (uint64_t)(s0 + t) * p.v_cs];
+                }
+                acc0 = a0;
+                acc1 = a1;
+            }
+        }
+        __syncthreads(); // w_s reused next tile
+    }
+
+    float inv_l = l > 0.f ? 1.0f / l : 0.0f;
+    if (grouped) {
+        acc_s[tid] = v_active ? acc0 : 0.f;
+        __syncthreads();
+        if (tid < dh) {
+            float a = 0.f;
+            for (uint32_t gg = 0; gg < G; gg++) a += acc_s[gg * dh + tid];
+            p.dst[(uint64_t)qi * p.dst_cs + (uint64_t)tid * p.dst_rs] = a * inv_l;
+        }
+    } else {
+        if (r0 < dh) p.dst[(uint64_t)qi * p.dst_cs + (uint64_t)r0 * p.dst_rs] = acc0 * inv_l;
+        if (r0 + kBlock < dh) p.dst[(uint64_t)qi * p.dst_cs + (uint64_t)(r0 + kBlock) * p.dst_rs] = acc1 * inv_l;
+    }
+}
+
+// ── dense f32 matmul (reference.zig:480-497 -> forward.blasSgemm index contract) ───────────
+// C[m*dst_rs + n] = sum_k A[m*a_rs + k*a_cs] * B[k*b_rs + n*b_cs]
+
+// B is N-contiguous (b_cs == 1): one thread per n, coalesced across lanes, k sequential.
+template <typename BT>
+__global__ void __launch_bounds__(kBlock) dense_ncontig_kernel(DenseMatmulParams p) {
+    uint32_t n = blockIdx.x * kBlock + threadIdx.x, m = blockIdx.y;
+    if (n >= p.N) return;
+    const float* a = p.a + (uint64_t)m * p.a_rs;
+    const BT* b = (const BT*)p.b + n;
+    float acc = 0.f;
+    for (uint32_t k = 0; k < p.K; k++) acc = fmaf(a[(uint64_t)k * p.a_cs], (float)b[(uint64_t)k * p.b_rs], acc);
+    p.dst[(uint64_t)m * p.dst_rs + n] = acc;
+}
+
+// B is K-contiguous (b_rs == 1, the tied-LM-head layout `trans1`): one wave per output n, lanes
+// stride k with 16-byte loads, 64-lane shuffle reduction. This is the largest single read of a
+// SmolLM decode step (576 x 49152 f32 = 113 MB), so loads are vectorised and a workgroup takes 4
+// consecutive n (4 contiguous rows of B).
+template <typename BT, int VEC>
+__global__ void __launch_bounds__(kBlock) dense_kcontig_kernel(DenseMatmulParams p) {
+    uint32_t n = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), m = blockIdx.y;
+    if (n >= p.N) return;
+    uint32_t lane = threadIdx.x & 63;
+    const float* a = p.a + (uint64_t)m * p.a_rs;
+    const BT* b = (const BT*)p.b + (uint64_t)n * p.b_cs;
+    float acc = 0.f;
+    if (VEC == 4) {
+        // caller guarantees a_cs == 1, K % 4 == 0 and 16-byte (f32) / 8-byte (f16) alignment
+        for (uint32_t k = lane * 4; k < p.K; k += 256) {
+            float4 av = *(const float4*)(a + k);
+            float b0, b1, b2, b3;
+            if (sizeof(BT) == 4) {
+                float4 bv = *(const float4*)((const float*)b + k);
+                b0 = bv.x, b1 = bv.y, b2 = bv.z, b3 = bv.w;
+            } else {
+                const __half2* hp = (const __half2*)((const __half*)b + k);
+                float2 lo = __half22float2(hp[0]), hi = __half22float2(hp[1]);
+                b0 = lo.x, b1 = lo.y, b2 = hi.x, b3 = hi.y;
+            }
+            acc = fmaf(av.x, b0, acc);
+            acc = fmaf(av.y, b1, acc);
+            acc = fmaf(av.z, b2, acc);
+            acc = fmaf(av.w, b3, acc);
+        }
+    } else {
+        for (uint32_t k = lane; k < p.K; k += 64) acc = fmaf(a[(uint64_t)k * p.a_cs], (float)b[k], acc);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) p.dst[(uint64_t)m * p.dst_rs + n] = acc;
+}
+
+template <typename BT>
+__global__ void __launch_bounds__(kBlock) dense_strided_kernel(DenseMatmulParams p) {
+    uint32_t n = blockIdx.x * kBlock + threadIdx.x, m = blockIdx.y;
+    if (n >= p.N) return;
+    const float* a = p.a + (uint64_t)m * p.a_rs;
+    const BT* b = (const BT*)p.b + (uint64_t)n * p.b_cs;
+    float acc = 0.f;
+    for (uint32_t k = 0; k < p.K; k++) acc = fmaf(a[(uint64_t)k * p.a_cs], (float)b[(uint64_t)k * p.b_rs], acc);
+    p.dst[(uint64_t)m * p.dst_rs + n] = acc;
+}
+
+// ── argmax: first index of the maximum (strict >), nn.zig:122-138 ──────────────────────────
+constexpr int kArgBlocks = 256;
+
+__device__ __forceinline__ void arg_combine(float& bv, int64_t& bi, float v, int64_t i) {
+    if (v > bv || (v == bv && i < bi)) {
+        bv = v;
+        bi = i;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) argmax_stage1(const float* __restrict__ v, uint64_t n, float* out_val,
+                                                        int64_t* out_idx) {
+    __shared__ float sv[kBlock];
+    __shared__ int64_t si[kBlock];
+    float bv = -INFINITY;
+    int64_t bi = INT64_MAX;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
+        float x = v[i];
+        if (x > bv || bi == INT64_MAX) { // strict >: earlier index wins within a thread's ascending walk
+            bv = x;
+            bi = (int64_t)i;
+        }
+    }
+    sv[threadIdx.x] = bv;
+    si[threadIdx.x] = bi;
+    __syncthreads();
+    for (int off = kBlock / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) arg_combine(sv[threadIdx.x], si[threadIdx.x], sv[threadIdx.x + off], si[threadIdx.x + off]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out_val[blockIdx.x] = sv[0];
+        out_idx[blockIdx.x] = si[0];
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) argmax_stage2(const float* vals, const int64_t* idxs, int nblk,
+                                                        int64_t* out) {
+    __shared__ float sv[kBlock];
+    __shared__ int64_t si[kBlock];
+    float bv = -INFINITY;
+    int64_t bi = INT64_MAX;
+    for (int i = threadIdx.x; i < nblk; i += kBlock)
+        if (idxs[i] != INT64_MAX) {
+            if (bi == INT64_MAX) {
+                bv = vals[i];
+                bi = idxs[i];
+            } else {
+                arg_combine(bv, bi, vals[i], idxs[i]);
+            }
+        }
+    sv[threadIdx.x] = bv;
+    si[threadIdx.x] = bi;
+    __syncthreads();
+    for (int off = kBlock / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            if (si[threadIdx.x + off] != INT64_MAX) {
+                if (si[threadIdx.x] == INT64_MAX) {
+                    sv[threadIdx.x] = sv[threadIdx.x + off];
+                    si[threadIdx.x] = si[threadIdx.x + off];
+                } else {
+                    arg_combine(sv[threadIdx.x], si[threadIdx.x], sv[threadIdx.x + off], si[threadIdx.x + off]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = si[0] == INT64_MAX ? -1 : si[0];
+}
+
+__global__ void __launch_bounds__(kBlock) copy_f4_kernel(float4* __restrict__ dst, const float4* __restrict__ src,
+                                                         uint64_t n4) {
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (uint64_t)gridDim.x * kBlock)
+        dst[i] = src[i];
+}
+
+__global__ void __launch_bounds__(kBlock) f32_to_f16_kernel(__half* __restrict__ dst, const float* __restrict__ src,
+                                                            uint64_t n) {
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock)
+        dst[i] = __float2half_rn(src[i]);
+}
+
+inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+} // namespace
+
+void launch_elementwise(hipStream_t s, uint32_t op, float* dst, const float* s0, const float* s1, uint32_t n) {
+    if (n == 0) return;
+    elementwise_kernel<<<cdiv(n, kBlock), kBlock, 0, s>>>(op, dst, s0, s1, n);
+}
+
+void launch_fused_elementwise(hipStream_t s, const FusedParams& p) {
+    if (p.n == 0) return;
+    fused_elementwise_kernel<<<cdiv(p.n, kBlock), kBlock, 0, s>>>(p);
+}
+
+void launch_softmax(hipStream_t s, float* dst, const float* src, uint32_t rows, uint32_t cols) {
+    if (rows == 0) return;
+    softmax_kernel<<<rows, kBlock, 0, s>>>(dst, src, cols);
+}
+
+void launch_layernorm(hipStream_t s, float* dst, const float* src, uint32_t rows, uint32_t cols, float eps) {
+    if (rows == 0) return;
+    layernorm_kernel<<<rows, kBlock, 0, s>>>(dst, src, cols, eps);
+}
+
+void launch_rmsnorm(hipStream_t s, float* dst, const float* src, uint32_t rows, uint32_t cols, float eps) {
+    if (rows == 0) return;
+    rmsnorm_kernel<<<rows, kBlock, 0, s>>>(dst, src, cols, eps);
+}
+
+void launch_reduce(hipStream_t s, uint32_t op, float* dst, const float* src, uint32_t n_out, uint32_t reduce_size) {
+    if (n_out == 0) return;
+    reduce_kernel<<<cdiv(n_out, kBlock / 64), kBlock, 0, s>>>(op, dst, src, n_out, reduce_size);
+}
+
+void launch_repeat(hipStream_t s, const RepeatParams& p) {
+    if (p.n == 0) return;
+    repeat_kernel<<<cdiv(p.n, kBlock), kBlock, 0, s>>>(p);
+}
+
+void launch_slice_assign(hipStream_t s, const SliceAssignParams& p) {
+    uint64_t n = (uint64_t)p.rows * p.cols;
+    if (n == 0) return;
+    slice_assign_kernel<<<cdiv(n, kBlock), kBlock, 0, s>>>(p);
+}
+
+void launch_rope(hipStream_t s, const RopeParams& p) {
+    uint64_t n = (uint64_t)p.half_d * p.seq_len;
+    if (n == 0) return;
+    rope_kernel<<<cdiv(n, kBlock), kBlock, 0, s>>>(p);
+}
+
+void launch_attention(hipStream_t s, const AttentionParams& p) {
+    if (p.seq_q == 0) return;
+    attention_kernel<<<p.seq_q, kBlock, 0, s>>>(p);
+}
+
+void launch_dense_matmul(hipStream_t s, const DenseMatmulParams& p) {
+    if (p.M == 0 || p.N == 0) return;
+    const bool f16 = p.b_f16 != 0;
+    if (p.b_cs == 1 && p.b_rs != 1) {
+        dim3 grid(cdiv(p.N, kBlock), p.M);
+        if (f16)
+            dense_ncontig_kernel<__half><<<grid, kBlock, 0, s>>>(p);
+        else
+            dense_ncontig_kernel<float><<<grid, kBlock, 0, s>>>(p);
+    } else if (p.b_rs == 1) {
+        dim3 grid(cdiv(p.N, kBlock / 64), p.M);
+        const uint32_t esz = f16 ? 2 : 4;
+        bool vec = p.a_cs == 1 && (p.K % 4) == 0 && (p.a_rs % 4) == 0 && (p.b_cs % 4) == 0 &&
+                   ((uintptr_t)p.a % 16) == 0 && ((uintptr_t)p.b % (4 * esz)) == 0;
+        if (f16) {
+            if (vec)
+                dense_kcontig_kernel<__half, 4><<<grid, kBlock, 0, s>>>(p);
+            else
+                dense_kcontig_kernel<__half, 1><<<grid, kBlock, 0, s>>>(p);
+        } else {
+            if (vec)
+                dense_kcontig_kernel<float, 4><<<grid, kBlock, 0, s>>>(p);
+            else
+                dense_kcontig_kernel<float, 1><<<grid, kBlock, 0, s>>>(p);
+        }
+    } else {
+        dim3 grid(cdiv(p.N, kBlock), p.M);
+        if (f16)
+            dense_strided_kernel<__half><<<grid, kBlock, 0, s>>>(p);
+        else
+            dense_strided_kernel<float><<<grid, kBlock, 0, s>>>(p);
+    }
+}
+
+void launch_argmax(hipStream_t s, const float* v, uint64_t n, float* scratch_val, int64_t* scratch_idx, int64_t* out) {
+    int nblk = (int)(n / (kBlock * 4) + 1);
+    if (nblk > kArgBlocks) nblk = kArgBlocks;
+    argmax_stage1<<<nblk, kBlock, 0, s>>>(v, n, scratch_val, scratch_idx);
+    argmax_stage2<<<1, kBlock, 0, s>>>(scratch_val, scratch_idx, nblk, out);
+}
+
+void launch_copy_f4(hipStream_t s, void* dst, const void* src, uint64_t bytes) {
+    uint64_t n4 = bytes / 16;
+    if (n4 == 0) return;
+    copy_f4_kernel<<<2048, kBlock, 0, s>>>((float4*)dst, (const float4*)src, n4);
+}
+
+void launch_f32_to_f16(hipStream_t s, void* dst, const float* src, uint64_t n) {
+    if (n == 0) return;
+    f32_to_f16_kernel<<<1024, kBlock, 0, s>>>((__half*)dst, src, n);
+}
+
+} // namespace zgml

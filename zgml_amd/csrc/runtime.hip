@@ -1,0 +1,1123 @@
+// runtime.hip — the C ABI of include/zgml_hip.h: context, program compile / refresh / execute,
+// host dense-matmul override, profiling counters and the measurement extensions.
+//
+// Execution model (MI355X-first, not a translation of the Metal/WGPU backends):
+//   * one HIP stream per context; a compiled program is a fixed launch list captured once into a
+//     hipGraph and replayed per token (decode is launch-bound: ~1.7k DeviceOps per SmolLM token);
+//   * the two per-step dynamic fields of the reference (slice_assign.dst_offset and
+//     attention.seq_kv, src/device_inference.zig:242-256) live in a device-resident word per op
+//     ("dyn block") that kernels dereference, so refresh_program never re-records the graph;
+//   * per-step inputs are packed into one pinned staging buffer, moved with ONE H2D copy and
+//     scattered on the device; outputs are gathered the same way (the reference's per-token
+//     traffic is 32 small uploads + one logits download, src/llama_inference.zig:405-466);
+//   * quantized weights are re-packed on the device at compile time (qmatvec.hip) and buffers no
+//     op references (the dead f32 master copies of quantized weights) are neither
+//     allocated nor uploaded.
+// There is no CPU fallback anywhere: every DeviceOp kind has a kernel.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+using namespace zgml;
+
+namespace {
+
+std::string g_create_error;
+
+struct Launch {
+    uint32_t kind;     // DeviceOp tag the launch is accounted to
+    uint32_t n_ops;    // DeviceOps covered (fusion folds several)
+    std::function<void(hipStream_t)> run;
+};
+
+struct IoEntry {
+    uint16_t buf_idx;
+    uint32_t offset, size;
+    bool operator==(const IoEntry& o) const { return buf_idx == o.buf_idx && offset == o.offset && size == o.size; }
+};
+
+struct IoTableDev { // one row per transfer, consumed by scatter/gather kernels
+    float* dev;      // device address inside the program buffer
+    uint32_t stage_off_words;
+    uint32_t n_words;
+};
+
+struct IoPlan {
+    std::vector<IoEntry> entries;
+    IoTableDev* table_dev = nullptr;
+    uint32_t total_words = 0;
+    bool word_aligned = true;
+};
+
+} // namespace
+
+struct zgml_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    bool opt_fusion = true, opt_graph = true, opt_profile = false, opt_skip_dead = true, opt_f16_dense = false;
+    // host dense override scratch
+    float *mm_a = nullptr, *mm_b = nullptr, *mm_c = nullptr;
+    uint64_t mm_a_cap = 0, mm_b_cap = 0, mm_c_cap = 0;
+    // argmax scratch
+    float* arg_val = nullptr;
+    int64_t* arg_idx = nullptr;
+    int64_t* arg_out = nullptr;
+    int64_t* arg_out_host = nullptr; // pinned
+
+    void fail(const std::string& what) {
+        if (err.empty()) err = what;
+    }
+    bool check(hipError_t e, const char* what) {
+        if (e == hipSuccess) return true;
+        fail(std::string(what) + ": " + hipGetErrorString(e));
+        return false;
+    }
+};
+
+struct zgml_hip_program {
+    zgml_hip_ctx* ctx = nullptr;
+    std::vector<zgml_device_op> ops;
+    std::vector<std::vector<zgml_fused_step>> steps; // owned copies, per op
+    std::vector<uint64_t> sizes;                      // f32 elements
+    std::vector<float*> bufs;                         // device pointers (nullptr = elided)
+    void* arena = nullptr;
+    std::vector<QWeightDev> qweights;
+    std::vector<void*> owned; // other device allocations
+    float* scratch = nullptr;
+    uint64_t scratch_bytes = 0;
+    // dynamic parameter block: one word per op
+    uint32_t* dyn_dev = nullptr;
+    uint32_t* dyn_host = nullptr; // pinned
+    bool dyn_dirty = true;
+    std::vector<Launch> plan;
+    bool plan_dirty = true;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    // host I/O staging
+    void* stage_host = nullptr; // pinned
+    void* stage_dev = nullptr;
+    uint64_t stage_cap = 0;
+    IoPlan in_plan, out_plan;
+    zgml_runtime_profile profile{};
+};
+
+namespace {
+
+#define CTX_CHECK(ctx, expr) (ctx)->check((expr), #expr)
+
+// ── Capabilities.hip ────────────────────────────────────────────────────────────────────────
+void fill_caps(zgml_capabilities* c) {
+    memset(c, 0, sizeof(*c));
+    c->compiled_programs = 1;
+    c->host_visible_program_memory = 0; // discrete HBM: no per-op CPU fallback is possible
+    c->dense_matmul_f32 = 1;
+    c->dense_matmul_f16 = 1;
+    c->qmatmul = 1;
+    c->fused_elementwise = 1;
+    c->max_fused_elementwise_steps_has = 1;
+    c->max_fused_elementwise_steps = kMaxFusedSteps;
+    c->f16_weight_promotion = 1; // opt-in via ZGML_HIP_OPT_F16_DENSE_WEIGHTS
+    c->dynamic_program_refresh = 1;
+    c->prefill_attention = 1;
+    c->decode_attention = 1;
+    c->quantized_kv = 0;
+    c->command_buffer_execution = 1;
+    c->attention_supported = 1;
+    c->attention_max_seq_kv_has = 0; // online softmax over key tiles: no score-buffer cap
+    c->attention_max_d_head_has = 1;
+    c->attention_max_d_head = 512;
+}
+
+bool elementwise_op_ok(uint32_t op) { return op >= ZGML_OP_ADD && op <= ZGML_OP_GELU; }
+
+// buffer ids an op touches (opBuffersValid, src/backend.zig:303-325)
+void op_buffers(const zgml_device_op& op, std::vector<uint16_t>& out) {
+    switch (op.kind) {
+        case ZGML_DOP_ELEMENTWISE:
+            out.insert(out.end(), {op.u.elementwise.dst, op.u.elementwise.src0, op.u.elementwise.src1});
+            break;
+        case ZGML_DOP_MATMUL: out.insert(out.end(), {op.u.matmul.dst, op.u.matmul.a, op.u.matmul.b}); break;
+        case ZGML_DOP_QMATMUL: out.insert(out.end(), {op.u.qmatmul.dst, op.u.qmatmul.input}); break;
+        case ZGML_DOP_SOFTMAX:
+        case ZGML_DOP_LAYERNORM:
+        case ZGML_DOP_RMSNORM: out.insert(out.end(), {op.u.softmax.dst, op.u.softmax.src}); break;
+        case ZGML_DOP_REDUCE: out.insert(out.end(), {op.u.reduce.dst, op.u.reduce.src}); break;
+        case ZGML_DOP_REPEAT: out.insert(out.end(), {op.u.repeat.dst, op.u.repeat.src}); break;
+        case ZGML_DOP_SLICE_ASSIGN: out.insert(out.end(), {op.u.slice_assign.dst, op.u.slice_assign.src}); break;
+        case ZGML_DOP_ROPE: out.insert(out.end(), {op.u.rope.dst, op.u.rope.src, op.u.rope.cos_sin}); break;
+        case ZGML_DOP_ATTENTION:
+            out.insert(out.end(), {op.u.attention.dst, op.u.attention.q, op.u.attention.k, op.u.attention.v,
+                                   op.u.attention.mask});
+            break;
+        case ZGML_DOP_FUSED_ELEMENTWISE: {
+            const auto& fe = op.u.fused_elementwise;
+            out.insert(out.end(), {fe.dst, fe.src});
+            for (uint32_t s = 0; s < fe.n_steps; s++)
+                if (fe.steps[s].op == ZGML_OP_ADD || fe.steps[s].op == ZGML_OP_MUL) out.push_back(fe.steps[s].secondary_buf);
+            break;
+        }
+        default: break;
+    }
+}
+
+// DeviceProgram.isSupportedBy(Capabilities.hip), src/backend.zig:277-297
+bool program_supported(const zgml_device_program* pr) {
+    if (!pr) return false;
+    if ((uint64_t)pr->n_buffers != pr->n_buffer_sizes) return false;
+    std::vector<uint16_t> ids;
+    for (uint64_t i = 0; i < pr->n_ops; i++) {
+        const zgml_device_op& op = pr->ops[i];
+        switch (op.kind) {
+            case ZGML_DOP_ELEMENTWISE:
+                if (!elementwise_op_ok(op.u.elementwise.op)) return false;
+                break;
+            case ZGML_DOP_MATMUL:
+            case ZGML_DOP_SOFTMAX:
+            case ZGML_DOP_LAYERNORM:
+            case ZGML_DOP_RMSNORM:
+            case ZGML_DOP_REPEAT:
+            case ZGML_DOP_SLICE_ASSIGN:
+            case ZGML_DOP_ROPE: break;
+            case ZGML_DOP_QMATMUL: {
+                const auto& q = op.u.qmatmul;
+                if ((uint64_t)q.weight_idx >= pr->n_qweights) return false;
+                const zgml_qweight_upload& qw = pr->qweights[q.weight_idx];
+                if (qw.block_size == 0) return false;
+                if (qw.rows != q.K || qw.cols != q.N) return false;
+                const uint64_t n_elems = (uint64_t)q.K * q.N;
+                const uint64_t n_blocks = (n_elems + qw.block_size - 1) / qw.block_size;
+                if (qw.data_len < n_elems || qw.scales_len < n_blocks) return false;
+                break;
+            }
+            case ZGML_DOP_REDUCE:
+                if (op.u.reduce.op != ZGML_OP_SUM && op.u.reduce.op != ZGML_OP_MAX) return false;
+                break;
+            case ZGML_DOP_ATTENTION:
+                if (op.u.attention.d_head > 512) return false;
+                break;
+            case ZGML_DOP_FUSED_ELEMENTWISE: {
+                const auto& fe = op.u.fused_elementwise;
+                if (fe.n_steps > (uint32_t)kMaxFusedSteps) return false;
+                for (uint32_t s = 0; s < fe.n_steps; s++)
+                    if (!elementwise_op_ok(fe.steps[s].op)) return false;
+                break;
+            }
+            default: return false;
+        }
+        ids.clear();
+        op_buffers(op, ids);
+        for (uint16_t id : ids)
+            if ((uint64_t)id >= pr->n_buffer_sizes) return false;
+    }
+    return true;
+}
+
+// ── small device helpers ────────────────────────────────────────────────────────────────────
+__global__ void scatter_words_kernel(const IoTableDev* table, const uint32_t* stage) {
+    const IoTableDev e = table[blockIdx.x];
+    uint32_t* dst = (uint32_t*)e.dev;
+    const uint32_t* src = stage + e.stage_off_words;
+    for (uint32_t i = threadIdx.x; i < e.n_words; i += blockDim.x) dst[i] = src[i];
+}
+__global__ void gather_words_kernel(const IoTableDev* table, uint32_t* stage) {
+    const IoTableDev e = table[blockIdx.x];
+    const uint32_t* src = (const uint32_t*)e.dev;
+    uint32_t* dst = stage + e.stage_off_words;
+    for (uint32_t i = threadIdx.x; i < e.n_words; i += blockDim.x) dst[i] = src[i];
+}
+
+void free_graph(zgml_hip_program* p) {
+    if (p->graph_exec) hipGraphExecDestroy(p->graph_exec);
+    if (p->graph) hipGraphDestroy(p->graph);
+    p->graph_exec = nullptr;
+    p->graph = nullptr;
+}
+
+bool ensure_stage(zgml_hip_program* p, uint64_t bytes) {
+    if (bytes <= p->stage_cap) return true;
+    zgml_hip_ctx* ctx = p->ctx;
+    hipStreamSynchronize(ctx->stream);
+    if (p->stage_host) hipHostFree(p->stage_host);
+    if (p->stage_dev) hipFree(p->stage_dev);
+    p->stage_host = p->stage_dev = nullptr;
+    uint64_t cap = 1 << 16;
+    while (cap < bytes) cap <<= 1;
+    if (!CTX_CHECK(ctx, hipHostMalloc(&p->stage_host, cap, hipHostMallocDefault))) return false;
+    if (!CTX_CHECK(ctx, hipMalloc(&p->stage_dev, cap))) return false;
+    p->stage_cap = cap;
+    return true;
+}
+
+// (re)build the cached transfer table when the descriptor list changed
+bool prepare_io(zgml_hip_program* p, IoPlan& plan, const zgml_program_io* ios, uint64_t n) {
+    bool same = plan.entries.size() == n;
+    for (uint64_t i = 0; same && i < n; i++)
+        same = plan.entries[i] == IoEntry{ios[i].buf_idx, ios[i].offset, ios[i].size};
+    if (same) return true;
+    zgml_hip_ctx* ctx = p->ctx;
+    hipStreamSynchronize(ctx->stream);
+    plan.entries.clear();
+    plan.word_aligned = true;
+    plan.total_words = 0;
+    if (plan.table_dev) hipFree(plan.table_dev);
+    plan.table_dev = nullptr;
+    std::vector<IoTableDev> table;
+    for (uint64_t i = 0; i < n; i++) {
+        const zgml_program_io& io = ios[i];
+        if (io.buf_idx >= p->bufs.size()) {
+            ctx->fail("program I/O names buffer " + std::to_string(io.buf_idx) + " which does not exist");
+            return false;
+        }
+        if (!p->bufs[io.buf_idx]) {
+            ctx->fail("program I/O names buffer " + std::to_string(io.buf_idx) +
+                      " which no op references and was elided at compile time "
+                      "(set ZGML_HIP_OPT_SKIP_DEAD_UPLOADS=0 before compile to keep it)");
+            return false;
+        }
+        if ((uint64_t)io.offset + io.size > p->sizes[io.buf_idx] * sizeof(float)) {
+            ctx->fail("program I/O out of range for buffer " + std::to_string(io.buf_idx));
+            return false;
+        }
+        plan.entries.push_back({io.buf_idx, io.offset, io.size});
+        if ((io.offset & 3) || (io.size & 3)) plan.word_aligned = false;
+        table.push_back({(float*)((char*)p->bufs[io.buf_idx] + io.offset), plan.total_words, io.size / 4});
+        plan.total_words += (io.size + 3) / 4;
+    }
+    if (plan.word_aligned && !table.empty()) {
+        if (!CTX_CHECK(ctx, hipMalloc((void**)&plan.table_dev, table.size() * sizeof(IoTableDev)))) return false;
+        if (!CTX_CHECK(ctx, hipMemcpy(plan.table_dev, table.data(), table.size() * sizeof(IoTableDev),
+                                      hipMemcpyHostToDevice)))
+            return false;
+    }
+    return ensure_stage(p, (uint64_t)plan.total_words * 4);
+}
+
+// ── plan building: one launch per DeviceOp (fusion passes rewrite this list, see fuse_plan) ──
+float* buf_at(zgml_hip_program* p, uint16_t idx, uint64_t off) { return p->bufs[idx] + off; }
+
+void build_plan(zgml_hip_program* p) {
+    p->plan.clear();
+    for (size_t i = 0; i < p->ops.size(); i++) {
+        const zgml_device_op& op = p->ops[i];
+        Launch L;
+        L.kind = op.kind;
+        L.n_ops = 1;
+        switch (op.kind) {
+            case ZGML_DOP_ELEMENTWISE: {
+                const auto e = op.u.elementwise;
+                float* dst = buf_at(p, e.dst, e.dst_offset);
+                const float* s0 = buf_at(p, e.src0, e.src0_offset);
+                const float* s1 = buf_at(p, e.src1, e.src1_offset);
+                L.run = [=](hipStream_t s) { launch_elementwise(s, e.op, dst, s0, s1, e.n); };
+                break;
+            }
+            case ZGML_DOP_MATMUL: {
+                const auto m = op.u.matmul;
+                DenseMatmulParams dp{};
+                dp.dst = buf_at(p, m.dst, m.geom.dst_offset);
+                dp.a = buf_at(p, m.a, m.geom.a_offset);
+                dp.b = buf_at(p, m.b, m.geom.b_offset);
+                dp.M = (uint32_t)m.geom.M, dp.N = (uint32_t)m.geom.N, dp.K = (uint32_t)m.geom.K;
+                dp.a_rs = (uint32_t)m.geom.a_row_stride, dp.a_cs = (uint32_t)m.geom.a_col_stride;
+                dp.b_rs = (uint32_t)m.geom.b_row_stride, dp.b_cs = (uint32_t)m.geom.b_col_stride;
+                dp.dst_rs = (uint32_t)m.geom.dst_row_stride;
+                dp.b_f16 = 0;
+                L.run = [=](hipStream_t s) { launch_dense_matmul(s, dp); };
+                break;
+            }
+            case ZGML_DOP_QMATMUL: {
+                const auto q = op.u.qmatmul;
+                QMatmulParams qp{};
+                qp.dst = buf_at(p, q.dst, q.dst_offset);
+                qp.input = buf_at(p, q.input, q.input_offset);
+                qp.M = q.M, qp.N = q.N, qp.K = q.K;
+                qp.in_rs = q.input_row_stride ? q.input_row_stride : q.K;
+                qp.dst_rs = q.dst_row_stride ? q.dst_row_stride : q.N;
+                const QWeightDev w = p->qweights[q.weight_idx];
+                float* scratch = p->scratch;
+                L.run = [=](hipStream_t s) { launch_qmatmul(s, w, qp, scratch); };
+                break;
+            }
+            case ZGML_DOP_SOFTMAX: {
+                const auto r = op.u.softmax;
+                float* dst = buf_at(p, r.dst, r.dst_offset);
+                const float* src = buf_at(p, r.src, r.src_offset);
+                L.run = [=](hipStream_t s) { launch_softmax(s, dst, src, r.rows, r.cols); };
+                break;
+            }
+            case ZGML_DOP_LAYERNORM: {
+                const auto r = op.u.layernorm;
+                float* dst = buf_at(p, r.dst, r.dst_offset);
+                const float* src = buf_at(p, r.src, r.src_offset);
+                L.run = [=](hipStream_t s) { launch_layernorm(s, dst, src, r.rows, r.cols, r.eps); };
+                break;
+            }
+            case ZGML_DOP_RMSNORM: {
+                const auto r = op.u.rmsnorm;
+                float* dst = buf_at(p, r.dst, r.dst_offset);
+                const float* src = buf_at(p, r.src, r.src_offset);
+                L.run = [=](hipStream_t s) { launch_rmsnorm(s, dst, src, r.rows, r.cols, r.eps); };
+                break;
+            }
+            case ZGML_DOP_REDUCE: {
+                const auto r = op.u.reduce;
+                float* dst = buf_at(p, r.dst, r.dst_offset);
+                const float* src = buf_at(p, r.src, r.src_offset);
+                L.run = [=](hipStream_t s) { launch_reduce(s, r.op, dst, src, r.n_out, r.reduce_size); };
+                break;
+            }
+            case ZGML_DOP_REPEAT: {
+                const auto r = op.u.repeat;
+                RepeatParams rp{};
+                rp.dst = p->bufs[r.dst];
+                rp.src = p->bufs[r.src];
+                rp.n = r.n;
+                for (int d = 0; d < 4; d++) {
+                    rp.src_ne[d] = r.src_ne[d];
+                    rp.src_strides[d] = r.src_strides[d];
+                    rp.dst_strides[d] = r.dst_strides[d] ? r.dst_strides[d] : 1;
+                }
+                rp.src_offset = r.src_offset, rp.dst_offset = r.dst_offset;
+                const uint64_t src_n = (uint64_t)r.src_ne[0] * r.src_ne[1] * r.src_ne[2] * r.src_ne[3];
+                rp.src_n = (uint32_t)src_n;
+                // the reference's fast paths (reference.zig:401-419), in its order of precedence
+                if (src_n == 1)
+                    rp.mode = 1;
+                else if (src_n >= r.n)
+                    rp.mode = 2;
+                else if (r.n % src_n == 0 && r.src_strides[0] == 1 &&
+                         (r.src_ne[1] <= 1 || r.src_strides[1] == r.src_ne[0]) &&
+                         (r.src_ne[2] <= 1 || r.src_strides[2] == r.src_ne[0] * r.src_ne[1]) &&
+                         (r.src_ne[3] <= 1 || r.src_strides[3] == r.src_ne[0] * r.src_ne[1] * r.src_ne[2]))
+                    rp.mode = 3;
+                else
+                    rp.mode = 0;
+                L.run = [=](hipStream_t s) { launch_repeat(s, rp); };
+                break;
+            }
+            case ZGML_DOP_SLICE_ASSIGN: {
+                const auto sa = op.u.slice_assign;
+                SliceAssignParams sp{};
+                sp.dst = p->bufs[sa.dst];
+                sp.src = buf_at(p, sa.src, sa.src_offset);
+                sp.rows = sa.rows, sp.cols = sa.cols;
+                sp.dst_row_stride = sa.dst_row_stride, sp.dst_col_stride = sa.dst_col_stride;
+                sp.src_row_stride = sa.src_row_stride, sp.src_col_stride = sa.src_col_stride;
+                sp.dyn_dst_offset = p->dyn_dev + i;
+                L.run = [=](hipStream_t s) { launch_slice_assign(s, sp); };
+                break;
+            }
+            case ZGML_DOP_ROPE: {
+                const auto r = op.u.rope;
+                RopeParams rp{};
+                rp.dst = buf_at(p, r.dst, r.dst_off);
+                rp.src = buf_at(p, r.src, r.src_off);
+                rp.cs = buf_at(p, r.cos_sin, r.cs_off);
+                rp.half_d = r.half_d, rp.seq_len = r.seq_len, rp.src_rs = r.src_rs, rp.src_cs = r.src_cs;
+                rp.cs_cs = r.cs_cs;
+                L.run = [=](hipStream_t s) { launch_rope(s, rp); };
+                break;
+            }
+            case ZGML_DOP_ATTENTION: {
+                const auto a = op.u.attention;
+                AttentionParams ap{};
+                ap.dst = buf_at(p, a.dst, a.dst_off);
+                ap.q = buf_at(p, a.q, a.q_off);
+                ap.k = buf_at(p, a.k, a.k_off);
+                ap.v = buf_at(p, a.v, a.v_off);
+                ap.mask = a.has_mask ? buf_at(p, a.mask, a.mask_off) : nullptr;
+                ap.d_head = a.d_head, ap.seq_q = a.seq_q;
+                ap.dyn_seq_kv = p->dyn_dev + i;
+                ap.scale = a.scale;
+                ap.q_rs = a.q_rs, ap.q_cs = a.q_cs, ap.k_rs = a.k_rs, ap.k_cs = a.k_cs, ap.v_rs = a.v_rs;
+                ap.v_cs = a.v_cs, ap.mask_rs = a.mask_rs, ap.mask_cs = a.mask_cs, ap.dst_rs = a.dst_rs;
+                ap.dst_cs = a.dst_cs;
+                L.run = [=](hipStream_t s) { launch_attention(s, ap); };
+                break;
+            }
+            case ZGML_DOP_FUSED_ELEMENTWISE: {
+                const auto fe = op.u.fused_elementwise;
+                FusedParams fp{};
+                fp.dst = buf_at(p, fe.dst, fe.dst_offset);
+                fp.src = buf_at(p, fe.src, fe.src_offset);
+                fp.n = fe.n;
+                fp.n_steps = fe.n_steps;
+                for (uint32_t s = 0; s < fe.n_steps; s++) {
+                    fp.steps[s].op = fe.steps[s].op;
+                    fp.steps[s].swapped = fe.steps[s].is_swapped;
+                    const bool bin = fe.steps[s].op == ZGML_OP_ADD || fe.steps[s].op == ZGML_OP_MUL;
+                    fp.steps[s].secondary = bin ? buf_at(p, fe.steps[s].secondary_buf, fe.steps[s].secondary_offset) : nullptr;
+                }
+                L.run = [=](hipStream_t s) { launch_fused_elementwise(s, fp); };
+                break;
+            }
+            default: continue;
+        }
+        p->plan.push_back(std::move(L));
+    }
+    p->plan_dirty = false;
+}
+
+void set_dyn_from_ops(zgml_hip_program* p) {
+    for (size_t i = 0; i < p->ops.size(); i++) {
+        uint32_t v = 0;
+        if (p->ops[i].kind == ZGML_DOP_SLICE_ASSIGN) v = p->ops[i].u.slice_assign.dst_offset;
+        if (p->ops[i].kind == ZGML_DOP_ATTENTION) v = p->ops[i].u.attention.seq_kv;
+        if (p->dyn_host[i] != v) {
+            p->dyn_host[i] = v;
+            p->dyn_dirty = true;
+        }
+    }
+}
+
+// copy ops (and their fused steps) into program-owned storage
+void own_ops(zgml_hip_program* p, const zgml_device_op* ops, uint64_t n_ops) {
+    p->ops.assign(ops, ops + n_ops);
+    p->steps.assign(n_ops, {});
+    for (uint64_t i = 0; i < n_ops; i++) {
+        if (ops[i].kind == ZGML_DOP_FUSED_ELEMENTWISE) {
+            const auto& fe = ops[i].u.fused_elementwise;
+            p->steps[i].assign(fe.steps, fe.steps + fe.n_steps);
+            p->ops[i].u.fused_elementwise.steps = p->steps[i].data();
+        }
+    }
+}
+
+// true when the static part of two ops is identical (dynamic fields and step pointers ignored)
+bool same_static(const zgml_device_op& a, const zgml_device_op& b) {
+    if (a.kind != b.kind) return false;
+    zgml_device_op x = a, y = b;
+    if (a.kind == ZGML_DOP_SLICE_ASSIGN) x.u.slice_assign.dst_offset = y.u.slice_assign.dst_offset = 0;
+    if (a.kind == ZGML_DOP_ATTENTION) x.u.attention.seq_kv = y.u.attention.seq_kv = 0;
+    if (a.kind == ZGML_DOP_FUSED_ELEMENTWISE) {
+        const auto &fa = a.u.fused_elementwise, &fb = b.u.fused_elementwise;
+        if (fa.n_steps != fb.n_steps) return false;
+        for (uint32_t s = 0; s < fa.n_steps; s++)
+            if (fa.steps[s].op != fb.steps[s].op || fa.steps[s].is_swapped != fb.steps[s].is_swapped ||
+                fa.steps[s].secondary_buf != fb.steps[s].secondary_buf ||
+                fa.steps[s].secondary_offset != fb.steps[s].secondary_offset)
+                return false;
+        x.u.fused_elementwise.steps = y.u.fused_elementwise.steps = nullptr;
+    }
+    // compare only the bytes of the active union member (the rest may be uninitialised padding)
+    size_t len = 0;
+    const void *pa = nullptr, *pb = nullptr;
+#define ARM(tag, member)                \
+    case tag:                           \
+        pa = &x.u.member;               \
+        pb = &y.u.member;               \
+        len = sizeof(x.u.member);       \
+        break;
+    switch (a.kind) {
+        ARM(ZGML_DOP_ELEMENTWISE, elementwise)
+        ARM(ZGML_DOP_MATMUL, matmul)
+        ARM(ZGML_DOP_QMATMUL, qmatmul)
+        ARM(ZGML_DOP_SOFTMAX, softmax)
+        ARM(ZGML_DOP_LAYERNORM, layernorm)
+        ARM(ZGML_DOP_RMSNORM, rmsnorm)
+        ARM(ZGML_DOP_REDUCE, reduce)
+        ARM(ZGML_DOP_REPEAT, repeat)
+        ARM(ZGML_DOP_SLICE_ASSIGN, slice_assign)
+        ARM(ZGML_DOP_ROPE, rope)
+        ARM(ZGML_DOP_ATTENTION, attention)
+        ARM(ZGML_DOP_FUSED_ELEMENTWISE, fused_elementwise)
+        default: return false;
+    }
+#undef ARM
+    return memcmp(pa, pb, len) == 0;
+}
+
+void run_plan(zgml_hip_program* p, hipStream_t s, size_t first, size_t count) {
+    for (size_t i = first; i < first + count && i < p->plan.size(); i++) p->plan[i].run(s);
+}
+
+void flush_dyn(zgml_hip_program* p) {
+    if (!p->dyn_dirty || p->ops.empty()) return;
+    hipMemcpyAsync(p->dyn_dev, p->dyn_host, p->ops.size() * sizeof(uint32_t), hipMemcpyHostToDevice, p->ctx->stream);
+    p->dyn_dirty = false;
+}
+
+// enqueue the whole program on the context stream (graph replay when enabled)
+void enqueue(zgml_hip_program* p) {
+    zgml_hip_ctx* ctx = p->ctx;
+    if (p->plan_dirty) {
+        free_graph(p);
+        build_plan(p);
+    }
+    flush_dyn(p);
+    if (ctx->opt_profile) {
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0);
+        hipEventCreate(&e1);
+        for (auto& L : p->plan) {
+            hipEventRecord(e0, ctx->stream);
+            L.run(ctx->stream);
+            hipEventRecord(e1, ctx->stream);
+            hipEventSynchronize(e1);
+            float ms = 0;
+            hipEventElapsedTime(&ms, e0, e1);
+            p->profile.time_ns[L.kind] += (uint64_t)(ms * 1e6);
+        }
+        hipEventDestroy(e0);
+        hipEventDestroy(e1);
+        return;
+    }
+    if (ctx->opt_graph && !p->plan.empty()) {
+        if (!p->graph_exec) {
+            hipGraph_t g = nullptr;
+            if (CTX_CHECK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal))) {
+                run_plan(p, ctx->stream, 0, p->plan.size());
+                if (CTX_CHECK(ctx, hipStreamEndCapture(ctx->stream, &g)) && g) {
+                    hipGraphExec_t ge = nullptr;
+                    if (CTX_CHECK(ctx, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0))) {
+                        p->graph = g;
+                        p->graph_exec = ge;
+                    } else {
+                        hipGraphDestroy(g);
+                    }
+                }
+            }
+        }
+        if (p->graph_exec) {
+            CTX_CHECK(ctx, hipGraphLaunch(p->graph_exec, ctx->stream));
+            return;
+        }
+    }
+    run_plan(p, ctx->stream, 0, p->plan.size());
+}
+
+uint64_t now_ns() {
+    return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(
+               std::chrono::steady_clock::now().time_since_epoch())
+        .count();
+}
+
+bool grow(zgml_hip_ctx* ctx, float** ptr, uint64_t* cap, uint64_t elems) {
+    if (elems <= *cap) return true;
+    if (*ptr) hipFree(*ptr);
+    *ptr = nullptr;
+    *cap = 0;
+    if (!CTX_CHECK(ctx, hipMalloc((void**)ptr, elems * sizeof(float)))) return false;
+    *cap = elems;
+    return true;
+}
+
+} // namespace
+
+// ════════════════════════════════ C ABI ════════════════════════════════
+
+extern "C" {
+
+zgml_hip_ctx* zgml_hip_create(int device_ordinal) {
+    g_create_error.clear();
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) {
+        g_create_error = std::string("no HIP device: ") + (e == hipSuccess ? "count is 0" : hipGetErrorString(e));
+        return nullptr;
+    }
+    if (device_ordinal < 0 || device_ordinal >= n) {
+        g_create_error = "device ordinal out of range";
+        return nullptr;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_ordinal) != hipSuccess) {
+        g_create_error = "hipGetDeviceProperties failed";
+        return nullptr;
+    }
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {
+        g_create_error = std::string("device is ") + prop.gcnArchName + ", this backend is built for gfx950 only";
+        return nullptr;
+    }
+    if (hipSetDevice(device_ordinal) != hipSuccess) {
+        g_create_error = "hipSetDevice failed";
+        return nullptr;
+    }
+    zgml_hip_ctx* ctx = new zgml_hip_ctx();
+    ctx->device = device_ordinal;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        g_create_error = "hipStreamCreate failed";
+        delete ctx;
+        return nullptr;
+    }
+    hipMalloc((void**)&ctx->arg_val, 256 * sizeof(float));
+    hipMalloc((void**)&ctx->arg_idx, 256 * sizeof(int64_t));
+    hipMalloc((void**)&ctx->arg_out, sizeof(int64_t));
+    hipHostMalloc((void**)&ctx->arg_out_host, sizeof(int64_t), hipHostMallocDefault);
+    return ctx;
+}
+
+void zgml_hip_destroy(zgml_hip_ctx* ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    hipFree(ctx->mm_a);
+    hipFree(ctx->mm_b);
+    hipFree(ctx->mm_c);
+    hipFree(ctx->arg_val);
+    hipFree(ctx->arg_idx);
+    hipFree(ctx->arg_out);
+    hipHostFree(ctx->arg_out_host);
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* zgml_hip_last_error(const zgml_hip_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+void zgml_hip_clear_error(zgml_hip_ctx* ctx) {
+    if (ctx) ctx->err.clear();
+}
+
+void zgml_hip_capabilities(zgml_capabilities* out) {
+    if (out) fill_caps(out);
+}
+
+int zgml_hip_program_supported(const zgml_device_program* program) { return program_supported(program) ? 1 : 0; }
+
+int zgml_hip_set_option(zgml_hip_ctx* ctx, int option, int64_t value) {
+    if (!ctx) return -1;
+    switch (option) {
+        case ZGML_HIP_OPT_FUSION: ctx->opt_fusion = value != 0; return 0;
+        case ZGML_HIP_OPT_GRAPH: ctx->opt_graph = value != 0; return 0;
+        case ZGML_HIP_OPT_PROFILE: ctx->opt_profile = value != 0; return 0;
+        case ZGML_HIP_OPT_SKIP_DEAD_UPLOADS: ctx->opt_skip_dead = value != 0; return 0;
+        case ZGML_HIP_OPT_F16_DENSE_WEIGHTS: ctx->opt_f16_dense = value != 0; return 0;
+        default: return -1;
+    }
+}
+
+int zgml_hip_dense_matmul_f32(zgml_hip_ctx* ctx, float* dst, uint64_t dst_len, const float* a, uint64_t a_len,
+                              const float* b, uint64_t b_len, const zgml_matmul_geom* g) {
+    if (!ctx || !g || !dst || !a || !b) return 0;
+    if (g->M == 0 || g->N == 0) return 1;
+    // spans actually touched (the caller's slices may be larger)
+    const uint64_t a_span = g->a_offset + (g->M - 1) * g->a_row_stride + (g->K ? (g->K - 1) * g->a_col_stride : 0) + 1;
+    const uint64_t b_span = g->b_offset + (g->K ? (g->K - 1) * g->b_row_stride : 0) + (g->N - 1) * g->b_col_stride + 1;
+    const uint64_t c_span = g->dst_offset + (g->M - 1) * g->dst_row_stride + g->N;
+    if (a_span > a_len || b_span > b_len || c_span > dst_len) return 0; // caller falls back
+    if (g->M > UINT32_MAX || g->N > UINT32_MAX || g->K > UINT32_MAX) return 0;
+    hipSetDevice(ctx->device);
+    if (!grow(ctx, &ctx->mm_a, &ctx->mm_a_cap, a_span) || !grow(ctx, &ctx->mm_b, &ctx->mm_b_cap, b_span) ||
+        !grow(ctx, &ctx->mm_c, &ctx->mm_c_cap, c_span))
+        return 0;
+    hipStream_t s = ctx->stream;
+    if (!CTX_CHECK(ctx, hipMemcpyAsync(ctx->mm_a, a, a_span * 4, hipMemcpyHostToDevice, s))) return 0;
+    if (!CTX_CHECK(ctx, hipMemcpyAsync(ctx->mm_b, b, b_span * 4, hipMemcpyHostToDevice, s))) return 0;
+    // rows of dst may be strided: keep the untouched gaps as the caller has them
+    if (g->dst_row_stride != g->N || g->dst_offset != 0)
+        if (!CTX_CHECK(ctx, hipMemcpyAsync(ctx->mm_c, dst, c_span * 4, hipMemcpyHostToDevice, s))) return 0;
+    DenseMatmulParams dp{};
+    dp.dst = ctx->mm_c + g->dst_offset;
+    dp.a = ctx->mm_a + g->a_offset;
+    dp.b = ctx->mm_b + g->b_offset;
+    dp.M = (uint32_t)g->M, dp.N = (uint32_t)g->N, dp.K = (uint32_t)g->K;
+    dp.a_rs = (uint32_t)g->a_row_stride, dp.a_cs = (uint32_t)g->a_col_stride;
+    dp.b_rs = (uint32_t)g->b_row_stride, dp.b_cs = (uint32_t)g->b_col_stride;
+    dp.dst_rs = (uint32_t)g->dst_row_stride;
+    launch_dense_matmul(s, dp);
+    if (!CTX_CHECK(ctx, hipMemcpyAsync(dst, ctx->mm_c, c_span * 4, hipMemcpyDeviceToHost, s))) return 0;
+    if (!CTX_CHECK(ctx, hipStreamSynchronize(s))) return 0;
+    return 1;
+}
+
+zgml_hip_program* zgml_hip_compile_program(zgml_hip_ctx* ctx, const zgml_device_program* prog) {
+    if (!ctx || !prog) return nullptr;
+    if (!program_supported(prog)) {
+        ctx->fail("compile_program: program not supported by Capabilities.hip");
+        return nullptr;
+    }
+    hipSetDevice(ctx->device);
+    zgml_hip_program* p = new zgml_hip_program();
+    p->ctx = ctx;
+    own_ops(p, prog->ops, prog->n_ops);
+    const size_t nb = prog->n_buffers;
+    p->sizes.resize(nb);
+    for (size_t i = 0; i < nb; i++) p->sizes[i] = prog->buffer_sizes[i] ? prog->buffer_sizes[i] : 1;
+
+    // liveness: buffers some op references (F8: the f32 master copy of a quantized weight is not)
+    std::vector<char> live(nb, ctx->opt_skip_dead ? 0 : 1);
+    std::vector<uint16_t> ids;
+    std::vector<char> qw_live(prog->n_qweights, 0);
+    for (const auto& op : p->ops) {
+        ids.clear();
+        op_buffers(op, ids);
+        for (uint16_t id : ids) live[id] = 1;
+        if (op.kind == ZGML_DOP_QMATMUL) qw_live[op.u.qmatmul.weight_idx] = 1;
+    }
+
+    // one arena for all live buffers, 256-byte aligned slots, zero-initialised like
+    // OwnedBufferTable.init (src/backend/reference.zig:81-97)
+    uint64_t total = 0;
+    std::vector<uint64_t> offs(nb, 0);
+    for (size_t i = 0; i < nb; i++) {
+        if (!live[i]) continue;
+        offs[i] = total;
+        total += (p->sizes[i] * sizeof(float) + 255) / 256 * 256;
+    }
+    bool ok = true;
+    if (total) {
+        ok = CTX_CHECK(ctx, hipMalloc(&p->arena, total)) && CTX_CHECK(ctx, hipMemsetAsync(p->arena, 0, total, ctx->stream));
+    }
+    p->bufs.assign(nb, nullptr);
+    if (ok)
+        for (size_t i = 0; i < nb; i++)
+            if (live[i]) p->bufs[i] = (float*)((char*)p->arena + offs[i]);
+
+    // initial uploads (skipped for elided buffers)
+    for (uint64_t i = 0; ok && i < prog->n_initial_uploads; i++) {
+        const zgml_program_io& io = prog->initial_uploads[i];
+        if (io.buf_idx >= nb) {
+            ctx->fail("initial upload names a buffer that does not exist");
+            ok = false;
+            break;
+        }
+        if (!p->bufs[io.buf_idx]) continue;
+        if ((uint64_t)io.offset + io.size > p->sizes[io.buf_idx] * sizeof(float)) {
+            ctx->fail("initial upload out of range");
+            ok = false;
+            break;
+        }
+        ok = CTX_CHECK(ctx, hipMemcpyAsync((char*)p->bufs[io.buf_idx] + io.offset, io.host_ptr, io.size,
+                                           hipMemcpyHostToDevice, ctx->stream));
+    }
+
+    // quantized weights: upload raw, classify and re-pack on the device
+    p->qweights.resize(prog->n_qweights);
+    uint32_t* flags = nullptr;
+    if (ok && prog->n_qweights) ok = CTX_CHECK(ctx, hipMalloc((void**)&flags, 2 * sizeof(uint32_t)));
+    for (uint64_t i = 0; ok && i < prog->n_qweights; i++) {
+        if (!qw_live[i]) continue;
+        const zgml_qweight_upload& qw = prog->qweights[i];
+        QWeightDev& w = p->qweights[i];
+        w.K = (uint32_t)qw.rows, w.N = (uint32_t)qw.cols, w.bs = (uint32_t)qw.block_size;
+        const uint64_t n_elems = qw.rows * qw.cols;
+        const uint64_t n_blocks = (n_elems + qw.block_size - 1) / qw.block_size;
+        int8_t* raw_d = nullptr;
+        float* raw_s = nullptr;
+        ok = CTX_CHECK(ctx, hipMalloc((void**)&raw_d, n_elems ? n_elems : 1)) &&
+             CTX_CHECK(ctx, hipMalloc((void**)&raw_s, (n_blocks ? n_blocks : 1) * sizeof(float))) &&
+             CTX_CHECK(ctx, hipMemcpyAsync(raw_d, qw.data, n_elems, hipMemcpyHostToDevice, ctx->stream)) &&
+             CTX_CHECK(ctx, hipMemcpyAsync(raw_s, qw.scales, n_blocks * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        if (!ok) {
+            hipFree(raw_d);
+            hipFree(raw_s);
+            break;
+        }
+        const bool packable = qw.block_size == 32 && qw.cols % 32 == 0 && qw.cols > 0 && qw.rows > 0;
+        if (!packable) {
+            w.format = QW_RAW;
+            w.qs = raw_d, w.sc = raw_s;
+            w.qs_bytes = n_elems, w.sc_bytes = n_blocks * 4;
+            p->owned.push_back(raw_d);
+            p->owned.push_back(raw_s);
+            continue;
+        }
+        const uint32_t cls = classify_qweight(ctx->stream, raw_d, n_elems, raw_s, n_blocks, flags);
+        w.format = (cls & 1) ? QW_Q4 : QW_Q8;
+        w.scale_f16 = (cls & 2) ? 1 : 0;
+        w.KC = (uint32_t)((qw.rows + 31) / 32);
+        packed_bytes(w.format, w.scale_f16, w.K, w.N, &w.qs_bytes, &w.sc_bytes);
+        ok = CTX_CHECK(ctx, hipMalloc(&w.qs, w.qs_bytes)) && CTX_CHECK(ctx, hipMalloc(&w.sc, w.sc_bytes));
+        if (ok) {
+            p->owned.push_back(w.qs);
+            p->owned.push_back(w.sc);
+            launch_pack_qweight(ctx->stream, raw_d, raw_s, w);
+            ok = CTX_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        hipFree(raw_d);
+        hipFree(raw_s);
+    }
+    if (flags) hipFree(flags);
+
+    // split-K scratch shared by all qmatmul launches (they are serialised on one stream)
+    for (const auto& op : p->ops)
+        if (op.kind == ZGML_DOP_QMATMUL) {
+            uint64_t b = qmatmul_scratch_bytes(p->qweights[op.u.qmatmul.weight_idx], op.u.qmatmul.M);
+            if (b > p->scratch_bytes) p->scratch_bytes = b;
+        }
+    if (ok && p->scratch_bytes) ok = CTX_CHECK(ctx, hipMalloc((void**)&p->scratch, p->scratch_bytes));
+
+    const size_t n_dyn = p->ops.empty() ? 1 : p->ops.size();
+    if (ok)
+        ok = CTX_CHECK(ctx, hipMalloc((void**)&p->dyn_dev, n_dyn * sizeof(uint32_t))) &&
+             CTX_CHECK(ctx, hipHostMalloc((void**)&p->dyn_host, n_dyn * sizeof(uint32_t), hipHostMallocDefault));
+    if (ok) {
+        memset(p->dyn_host, 0xFF, n_dyn * sizeof(uint32_t));
+        set_dyn_from_ops(p);
+        p->dyn_dirty = true;
+        build_plan(p);
+        ok = CTX_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if (!ok) {
+        zgml_hip_free_program(ctx, p);
+        return nullptr;
+    }
+    return p;
+}
+
+void zgml_hip_refresh_program(zgml_hip_ctx* ctx, zgml_hip_program* p, const zgml_device_op* ops, uint64_t n_ops) {
+    if (!ctx || !p || !ops) return;
+    bool static_same = n_ops == p->ops.size();
+    for (uint64_t i = 0; static_same && i < n_ops; i++) static_same = same_static(p->ops[i], ops[i]);
+    if (static_same) {
+        // the common per-token case: only dynamic fields moved
+        for (uint64_t i = 0; i < n_ops; i++) {
+            if (ops[i].kind == ZGML_DOP_SLICE_ASSIGN) p->ops[i].u.slice_assign.dst_offset = ops[i].u.slice_assign.dst_offset;
+            if (ops[i].kind == ZGML_DOP_ATTENTION) p->ops[i].u.attention.seq_kv = ops[i].u.attention.seq_kv;
+        }
+        set_dyn_from_ops(p);
+        return;
+    }
+    if (n_ops != p->ops.size()) {
+        ctx->fail("refresh_program: op list length changed");
+        return;
+    }
+    // a static field changed: legal for the reference's CPU backend (it re-reads ops every
+    // execute, src/backend/cpu.zig:128-131), so honour it by rebuilding the launch list
+    hipStreamSynchronize(ctx->stream);
+    own_ops(p, ops, n_ops);
+    set_dyn_from_ops(p);
+    p->plan_dirty = true;
+}
+
+void zgml_hip_execute_program(zgml_hip_ctx* ctx, zgml_hip_program* p, const zgml_program_io* inputs, uint64_t n_inputs,
+                              const zgml_program_io* outputs, uint64_t n_outputs) {
+    if (!ctx || !p) return;
+    hipSetDevice(ctx->device);
+    hipStream_t s = ctx->stream;
+    if (!prepare_io(p, p->in_plan, inputs, n_inputs)) return;
+    if (!prepare_io(p, p->out_plan, outputs, n_outputs)) return;
+
+    // inputs: pack -> one H2D -> scatter
+    if (n_inputs) {
+        if (p->in_plan.word_aligned) {
+            char* st = (char*)p->stage_host;
+            uint64_t off = 0;
+            for (uint64_t i = 0; i < n_inputs; i++) {
+                memcpy(st + off, inputs[i].host_ptr, inputs[i].size);
+                off += (inputs[i].size + 3) / 4 * 4;
+            }
+            hipMemcpyAsync(p->stage_dev, p->stage_host, off, hipMemcpyHostToDevice, s);
+            scatter_words_kernel<<<(uint32_t)n_inputs, 256, 0, s>>>(p->in_plan.table_dev, (const uint32_t*)p->stage_dev);
+        } else {
+            for (uint64_t i = 0; i < n_inputs; i++)
+                hipMemcpyAsync((char*)p->bufs[inputs[i].buf_idx] + inputs[i].offset, inputs[i].host_ptr,
+                               inputs[i].size, hipMemcpyHostToDevice, s);
+        }
+    }
+
+    enqueue(p);
+
+    // outputs: gather -> one D2H -> unpack
+    if (n_outputs) {
+        if (p->out_plan.word_aligned) {
+            gather_words_kernel<<<(uint32_t)n_outputs, 256, 0, s>>>(p->out_plan.table_dev, (uint32_t*)p->stage_dev);
+            hipMemcpyAsync(p->stage_host, p->stage_dev, (uint64_t)p->out_plan.total_words * 4, hipMemcpyDeviceToHost, s);
+        } else {
+            for (uint64_t i = 0; i < n_outputs; i++)
+                hipMemcpyAsync(outputs[i].host_ptr, (char*)p->bufs[outputs[i].buf_idx] + outputs[i].offset,
+                               outputs[i].size, hipMemcpyDeviceToHost, s);
+        }
+    }
+    const uint64_t t0 = now_ns();
+    CTX_CHECK(ctx, hipStreamSynchronize(s));
+    p->profile.sync_time_ns += now_ns() - t0;
+    p->profile.sync_count++;
+    if (n_outputs && p->out_plan.word_aligned) {
+        const char* st = (const char*)p->stage_host;
+        uint64_t off = 0;
+        for (uint64_t i = 0; i < n_outputs; i++) {
+            memcpy(outputs[i].host_ptr, st + off, outputs[i].size);
+            off += (outputs[i].size + 3) / 4 * 4;
+        }
+    }
+    p->profile.call_count++;
+    p->profile.backend_op_count += p->ops.size();
+    p->profile.backend_dispatch_count += p->plan.size();
+    CTX_CHECK(ctx, hipGetLastError());
+}
+
+void zgml_hip_free_program(zgml_hip_ctx* ctx, zgml_hip_program* p) {
+    if (!p) return;
+    if (ctx) {
+        hipSetDevice(ctx->device);
+        hipStreamSynchronize(ctx->stream);
+    }
+    free_graph(p);
+    if (p->arena) hipFree(p->arena);
+    for (void* d : p->owned) hipFree(d);
+    if (p->scratch) hipFree(p->scratch);
+    if (p->dyn_dev) hipFree(p->dyn_dev);
+    if (p->dyn_host) hipHostFree(p->dyn_host);
+    if (p->stage_host) hipHostFree(p->stage_host);
+    if (p->stage_dev) hipFree(p->stage_dev);
+    if (p->in_plan.table_dev) hipFree(p->in_plan.table_dev);
+    if (p->out_plan.table_dev) hipFree(p->out_plan.table_dev);
+    delete p;
+}
+
+zgml_runtime_profile* zgml_hip_get_runtime_profile(zgml_hip_ctx*, zgml_hip_program* p) {
+    return p ? &p->profile : nullptr;
+}
+
+// ── extensions ──────────────────────────────────────────────────────────────────────────────
+
+void* zgml_hip_program_buffer_ptr(zgml_hip_program* p, uint16_t buf_idx) {
+    return (p && buf_idx < p->bufs.size()) ? p->bufs[buf_idx] : nullptr;
+}
+
+void* zgml_hip_stream(zgml_hip_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+void zgml_hip_enqueue_program(zgml_hip_ctx* ctx, zgml_hip_program* p) {
+    if (!ctx || !p) return;
+    hipSetDevice(ctx->device);
+    enqueue(p);
+}
+
+void zgml_hip_enqueue_ops(zgml_hip_ctx* ctx, zgml_hip_program* p, uint64_t first, uint64_t count) {
+    if (!ctx || !p) return;
+    hipSetDevice(ctx->device);
+    if (p->plan_dirty) {
+        free_graph(p);
+        build_plan(p);
+    }
+    flush_dyn(p);
+    // plan entries are 1:1 with ops here only when fusion is off; map by accumulated op count
+    size_t op_pos = 0;
+    for (auto& L : p->plan) {
+        if (op_pos >= first && op_pos < first + count) L.run(ctx->stream);
+        op_pos += L.n_ops;
+    }
+}
+
+void zgml_hip_synchronize(zgml_hip_ctx* ctx) {
+    if (!ctx) return;
+    CTX_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+}
+
+int64_t zgml_hip_argmax(zgml_hip_ctx* ctx, zgml_hip_program* p, uint16_t buf_idx, uint64_t offset, uint64_t n) {
+    if (!ctx || !p || buf_idx >= p->bufs.size() || !p->bufs[buf_idx] || offset + n > p->sizes[buf_idx]) return -1;
+    hipSetDevice(ctx->device);
+    launch_argmax(ctx->stream, p->bufs[buf_idx] + offset, n, ctx->arg_val, ctx->arg_idx, ctx->arg_out);
+    hipMemcpyAsync(ctx->arg_out_host, ctx->arg_out, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (!CTX_CHECK(ctx, hipStreamSynchronize(ctx->stream))) return -1;
+    return *ctx->arg_out_host;
+}
+
+static bool make_synth_weight(zgml_hip_ctx* ctx, uint32_t K, uint32_t N, int q4, uint32_t id, QWeightDev* w) {
+    w->format = q4 ? QW_Q4 : QW_Q8;
+    w->K = K, w->N = N, w->bs = 32;
+    w->KC = (K + 31) / 32;
+    w->scale_f16 = 1;
+    packed_bytes(w->format, 1, K, N, &w->qs_bytes, &w->sc_bytes);
+    if (!CTX_CHECK(ctx, hipMalloc(&w->qs, w->qs_bytes)) || !CTX_CHECK(ctx, hipMalloc(&w->sc, w->sc_bytes))) return false;
+    launch_synth_packed(ctx->stream, *w, id);
+    return true;
+}
+
+double zgml_hip_qmatvec_bench(zgml_hip_ctx* ctx, uint32_t K, uint32_t N, int q4, uint32_t n_matrices, uint32_t warmup,
+                              uint32_t iters, uint64_t* bytes_per_launch) {
+    if (!ctx || N % 32 || !n_matrices || !iters) return -1.0;
+    hipSetDevice(ctx->device);
+    std::vector<QWeightDev> ring(n_matrices);
+    bool ok = true;
+    for (uint32_t i = 0; ok && i < n_matrices; i++) ok = make_synth_weight(ctx, K, N, q4, i, &ring[i]);
+    float *x = nullptr, *y = nullptr, *scratch = nullptr;
+    std::vector<float> xh(K);
+    for (uint32_t i = 0; i < K; i++) xh[i] = ((int)(i % 17) - 8) * 0.03125f;
+    uint64_t sb = ok ? qmatmul_scratch_bytes(ring[0], 1) : 0;
+    ok = ok && CTX_CHECK(ctx, hipMalloc((void**)&x, K * 4)) && CTX_CHECK(ctx, hipMalloc((void**)&y, N * 4)) &&
+         (!sb || CTX_CHECK(ctx, hipMalloc((void**)&scratch, sb))) &&
+         CTX_CHECK(ctx, hipMemcpy(x, xh.data(), K * 4, hipMemcpyHostToDevice));
+    double us = -1.0;
+    if (ok) {
+        QMatmulParams qp{y, x, 1, N, K, K, N};
+        for (uint32_t i = 0; i < warmup; i++) launch_qmatmul(ctx->stream, ring[i % n_matrices], qp, scratch);
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0);
+        hipEventCreate(&e1);
+        hipEventRecord(e0, ctx->stream);
+        for (uint32_t i = 0; i < iters; i++) launch_qmatmul(ctx->stream, ring[i % n_matrices], qp, scratch);
+        hipEventRecord(e1, ctx->stream);
+        if (CTX_CHECK(ctx, hipEventSynchronize(e1))) {
+            float ms = 0;
+            hipEventElapsedTime(&ms, e0, e1);
+            us = (double)ms * 1000.0 / iters;
+        }
+        hipEventDestroy(e0);
+        hipEventDestroy(e1);
+    }
+    if (bytes_per_launch) *bytes_per_launch = (uint64_t)K * N / 32 * (q4 ? 18 : 34) + 4ull * K + 4ull * N;
+    for (auto& w : ring) {
+        hipFree(w.qs);
+        hipFree(w.sc);
+    }
+    hipFree(x);
+    hipFree(y);
+    hipFree(scratch);
+    return us;
+}
+
+int zgml_hip_qmatvec_synth(zgml_hip_ctx* ctx, uint32_t K, uint32_t N, int q4, uint32_t matrix_id, const float* x_host,
+                           float* y_host) {
+    if (!ctx || N % 32 || !x_host || !y_host) return -1;
+    hipSetDevice(ctx->device);
+    QWeightDev w{};
+    float *x = nullptr, *y = nullptr, *scratch = nullptr;
+    bool ok = make_synth_weight(ctx, K, N, q4, matrix_id, &w);
+    uint64_t sb = ok ? qmatmul_scratch_bytes(w, 1) : 0;
+    ok = ok && CTX_CHECK(ctx, hipMalloc((void**)&x, K * 4)) && CTX_CHECK(ctx, hipMalloc((void**)&y, N * 4)) &&
+         (!sb || CTX_CHECK(ctx, hipMalloc((void**)&scratch, sb))) &&
+         CTX_CHECK(ctx, hipMemcpyAsync(x, x_host, K * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (ok) {
+        QMatmulParams qp{y, x, 1, N, K, K, N};
+        launch_qmatmul(ctx->stream, w, qp, scratch);
+        ok = CTX_CHECK(ctx, hipMemcpyAsync(y_host, y, N * 4, hipMemcpyDeviceToHost, ctx->stream)) &&
+             CTX_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    hipFree(w.qs);
+    hipFree(w.sc);
+    hipFree(x);
+    hipFree(y);
+    hipFree(scratch);
+    return ok ? 0 : -1;
+}
+
+double zgml_hip_copy_bench(zgml_hip_ctx* ctx, uint64_t bytes, uint32_t warmup, uint32_t iters) {
+    if (!ctx || !iters || bytes < 16) return -1.0;
+    hipSetDevice(ctx->device);
+    void *a = nullptr, *b = nullptr;
+    if (!CTX_CHECK(ctx, hipMalloc(&a, bytes)) || !CTX_CHECK(ctx, hipMalloc(&b, bytes))) {
+        hipFree(a);
+        return -1.0;
+    }
+    hipMemsetAsync(a, 1, bytes, ctx->stream);
+    for (uint32_t i = 0; i < warmup; i++) launch_copy_f4(ctx->stream, b, a, bytes);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipEventRecord(e0, ctx->stream);
+    for (uint32_t i = 0; i < iters; i++) launch_copy_f4(ctx->stream, b, a, bytes);
+    hipEventRecord(e1, ctx->stream);
+    double us = -1.0;
+    if (CTX_CHECK(ctx, hipEventSynchronize(e1))) {
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        us = (double)ms * 1000.0 / iters;
+    }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    hipFree(a);
+    hipFree(b);
+    return us;
+}
+
+} // extern "C"
