@@ -9,27 +9,28 @@
 //
 // Device layout ("packed", chosen at compile_program time — the boundary hands int8 + f32 scales,
 // src/backend.zig:259-266; re-packing is backend-internal):
-//   NB = N/32 block-columns, KC = ceil(K/32) k-chunks (zero padded).
+//   NB = N/32 scale block-columns, NB2 = N/16 column groups, KC = ceil(K/32) k-chunks (zero padded).
 //   Q4 (all values in [-8,7]; GGUF Q4_0-sourced weights, 4.5 bit/weight like the file format):
-//     qs: uint4[NB][KC][32]   item (j,c,nl) = the 32 nibbles of column n = 32j+nl for
+//     qs: uint4[NB2][KC][16]  item (g,c,i) = the 32 nibbles of column n = 16g+i for
 //                             k = 32c..32c+31, two's-complement; dword d, byte b holds
 //                             k_local = 8d+b in the low nibble and 8d+4+b in the high nibble.
-//     sc: pair[NB][KC][16]    entry i = { scale(k=32c+i, j), scale(k=32c+16+i, j) }
-//   Q8: qs: uint4[NB][2KC][32] item (j,h,nl) = 16 int8 of column n for k = 16h..16h+15
+//     sc: pair[NB][KC][16]    entry i = { scale(k=32c+i, j), scale(k=32c+16+i, j) }, j = g/2
+//   Q8: qs: uint4[NB2][2KC][16] item (g,h,i) = 16 int8 of column n for k = 16h..16h+15
 //       sc: scalar[NB][2KC][16] entry i = scale(k=16h+i, j)
 //   Scales are stored as f16 when every scale is exactly representable (GGUF-sourced), else f32.
 //
-// Thread mapping: a wave64 is 4 DPP rows of 16 lanes. Row r of a wave owns 16 columns
-// (n-half r&1 of block-column j) for one k-unit (a 32-k chunk for Q4, a 16-k half-chunk for Q8);
-// rows 2,3 take the next unit. One wave-load is 1 KiB contiguous (16 B/lane). Lane i of a row
-// computes t = scale(k_i) * x[k_i] for "its" k of the unit, and the 32 (16) products of a lane's
-// column are   acc += f32(q[k,n]) * t[k]   with t[k] fetched from lane k of the same row by the
-// DPP row_newbcast operand of v_fmac_f32 — no LDS round trip and no scalar broadcast for the
-// per-k multiplier, although the scale grouping runs along n. Weights go HBM -> VGPR directly
-// (GEMV: nothing to reuse, guide §5 "GEMV / M <= 16" row); only x is staged in LDS.
-// A 256-thread workgroup (4 waves) covers one block-column and a K slice; K is split across
-// workgroups (split-K) until the grid has >= ~2 workgroups per CU; partial slabs are combined in
-// fixed split order by a second tiny kernel (deterministic, unlike float atomics).
+// Thread mapping: a wave64 is 4 DPP rows of 16 lanes. A workgroup owns ONE 16-column group g and
+// ALL of K (so there is no cross-workgroup reduction and the mat-vec is a single launch: on this
+// chip a dependent launch boundary costs ~1.7 us, as much as streaming 9.4 MB).
+// Row r of wave w takes k-unit u = 4w + r (+ 4*waves per step); a unit is a 32-k chunk for Q4 and
+// a 16-k half-chunk for Q8. The four rows of a wave read four consecutive units = 1 KiB contiguous
+// (16 B/lane). Lane i of a row computes t = scale(k_i) * x[k_i] for "its" k of the row's unit,
+// and the 32 (16) products of a lane's column are   acc += f32(q[k,n]) * t[k]   with t[k] fetched
+// from lane k of the same row by the DPP row_newbcast operand of v_fmac_f32 — no LDS round trip
+// and no scalar broadcast for the per-k multiplier, although the scale grouping runs along n.
+// Weights go HBM -> VGPR directly (GEMV: nothing to reuse, guide §5 "GEMV / M <= 16" row); only x
+// is staged in LDS. The two column groups of a scale block-column read the same scales; their
+// workgroups are placed 8 blocks apart so they share an XCD L2 (speed only, never correctness).
 #include "kernels.h"
 
 #include <hip/hip_fp16.h>
@@ -37,12 +38,14 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
+
 namespace zgml {
 
 namespace {
 
-constexpr int kBlock = 256;
-constexpr int kWaves = kBlock / 64;
+constexpr int kBlock = 256;      // helper kernels
+constexpr int kMaxWaves = 16;    // mat-vec workgroup: up to 1024 threads
 
 // ── inline-asm helpers ──────────────────────────────────────────────────────────────────────
 // The per-weight work is two VALU instructions: an SDWA convert (nibble or byte -> f32) and a
@@ -116,207 +119,187 @@ struct QMVArgs {
     const uint4* qs;
     const void* sc;
     const float* x; // input (offset applied); row m at x + m*in_rs
-    float* out;     // dst (ksplit==1) or partial slabs
-    uint32_t M, N, K, NB;
-    uint32_t U;            // k-units per block column (Q4: KC, Q8: 2*KC)
-    uint32_t units_per_wg; // multiple of 8
-    uint32_t ksplit;
-    uint32_t in_rs, out_rs; // out_rs: dst_rs when ksplit==1, else N
+    float* out;     // dst (offset applied); row m at out + m*out_rs
+    uint32_t M, N, K, NB2;
+    uint32_t U;     // k-units per column group (Q4: KC, Q8: 2*KC)
+    uint32_t in_rs, out_rs;
 };
 
-// Shared prologue: stage this workgroup's slice of x (zero beyond K) into LDS. 16-byte loads when
-// the slice is aligned, all issued before the first LDS store (one latency, not one per pass).
-__device__ __forceinline__ void stage_x(float* xs, const float* x, uint32_t k_begin, uint32_t k_count, uint32_t K) {
-    const bool vec = ((uintptr_t)(x + k_begin) & 15) == 0;
-    if (vec) {
-        for (uint32_t i = threadIdx.x * 4; i < k_count; i += kBlock * 4) {
-            const uint32_t k = k_begin + i;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (k + 3 < K) {
-                v = *(const float4*)(x + k);
-            } else {
-                if (k < K) v.x = x[k];
-                if (k + 1 < K) v.y = x[k + 1];
-                if (k + 2 < K) v.z = x[k + 2];
-            }
-            *(float4*)(xs + i) = v;
-        }
-    } else {
-        for (uint32_t i = threadIdx.x; i < k_count; i += kBlock) {
-            const uint32_t k = k_begin + i;
-            xs[i] = k < K ? x[k] : 0.0f;
-        }
-    }
+// x staging in two halves so the weight loads can sit between them: x_fetch() issues this thread's
+// global loads of x FIRST (vmcnt is in-order: if x were loaded after the weights, the wait before
+// the LDS store would also wait for every weight load and serialise load and compute), x_commit()
+// stores them to LDS after the weight loads have been issued. Every load here and in the kernels
+// is UNCONDITIONAL (addresses are clamped, values are zeroed by selects): hipcc counts vmcnt
+// exactly only across straight-line code — one load under a divergent branch and it falls back to
+// vmcnt(0) everywhere, which serialises the weight stream behind the LDS store (measured:
+// load and compute times simply added up).
+constexpr int kXRegs = 4; // float4 per thread held in registers (covers K <= 16 * blockDim)
+
+struct XRegs {
+    float4 v[kXRegs];
+};
+
+// XVEC: x is 16-byte aligned and K % 4 == 0 (decided on the host), so a float4 at any i < K with
+// i % 4 == 0 is in range. Loads only here; the out-of-range zeroing happens at commit time so no
+// wait sits between the loads.
+template <bool XVEC>
+__device__ __forceinline__ float4 load_x4(const float* x, uint32_t i, uint32_t K) {
+    if (XVEC) return *(const float4*)(x + (i < K ? i : 0));
+    const uint32_t last = K - 1; // K >= 1
+    return make_float4(x[min(i, last)], x[min(i + 1, last)], x[min(i + 2, last)], x[min(i + 3, last)]);
+}
+__device__ __forceinline__ float4 zero_tail(float4 v, uint32_t i, uint32_t K) {
+    return make_float4(i < K ? v.x : 0.f, i + 1 < K ? v.y : 0.f, i + 2 < K ? v.z : 0.f, i + 3 < K ? v.w : 0.f);
 }
 
-// Shared epilogue: fold rows (r, r+2), then the 4 waves, in fixed order; 32 outputs per WG.
-__device__ __forceinline__ void reduce_store(float acc, float* red, const QMVArgs& a, uint32_t j, uint32_t split,
-                                             uint32_t m) {
-    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+template <bool XVEC>
+__device__ __forceinline__ XRegs x_fetch(const float* x, uint32_t K) {
+    XRegs r;
+#pragma unroll
+    for (int j = 0; j < kXRegs; j++) r.v[j] = load_x4<XVEC>(x, (threadIdx.x + j * blockDim.x) * 4, K);
+    return r;
+}
+
+// k_count is a multiple of 16; xs has 4 spare floats at xs[k_count..] for the out-of-range lanes
+template <bool XVEC>
+__device__ __forceinline__ void x_commit(float* xs, const XRegs& r, const float* x, uint32_t k_count, uint32_t K) {
+#pragma unroll
+    for (int j = 0; j < kXRegs; j++) {
+        const uint32_t i = (threadIdx.x + j * blockDim.x) * 4;
+        *(float4*)(xs + (i < k_count ? i : k_count)) = zero_tail(r.v[j], i, K);
+    }
+    for (uint32_t i = (threadIdx.x + kXRegs * blockDim.x) * 4; i < k_count; i += blockDim.x * 4)
+        *(float4*)(xs + i) = zero_tail(load_x4<XVEC>(x, i, K), i, K); // only for K > 16 * blockDim
+}
+
+// blockIdx.x -> column group. Groups 2j and 2j+1 share the scales of block-column j; the
+// dispatcher deals consecutive blocks round-robin over the 8 XCDs, so blocks b and b+8 share an
+// XCD: put a pair there (full groups of 16 blocks; the tail maps linearly).
+__device__ __forceinline__ uint32_t column_group(uint32_t b, uint32_t NB2) {
+    const uint32_t full = NB2 & ~15u;
+    if (b >= full) return b;
+    const uint32_t j = (b >> 4) * 8 + (b & 7), half = (b >> 3) & 1;
+    return 2 * j + half;
+}
+
+// Fold the 4 rows of each wave, then the waves, in fixed order; 16 outputs per workgroup.
+__device__ __forceinline__ void reduce_store(float acc, float* red, const QMVArgs& a, uint32_t g, uint32_t m) {
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    acc += __shfl_xor(acc, 16, 64);
     acc += __shfl_xor(acc, 32, 64);
-    if (lane < 32) red[w * 32 + lane] = acc;
+    if (lane < 16) red[w * 16 + lane] = acc;
     __syncthreads();
-    if (threadIdx.x < 32) {
+    if (threadIdx.x < 16) {
         float v = red[threadIdx.x];
-#pragma unroll
-        for (int ww = 1; ww < kWaves; ww++) v += red[ww * 32 + threadIdx.x];
-        const uint32_t n = j * 32 + threadIdx.x;
-        if (a.ksplit == 1)
-            a.out[(uint64_t)m * a.out_rs + n] = v;
-        else
-            a.out[((uint64_t)split * a.M + m) * a.N + n] = v;
+        for (uint32_t ww = 1; ww < n_waves; ww++) v += red[ww * 16 + threadIdx.x];
+        a.out[(uint64_t)m * a.out_rs + g * 16 + threadIdx.x] = v;
     }
 }
 
-constexpr int kDepth = 4; // k-units a wave keeps in flight (4 x 1 KiB wave-loads)
+// DEPTH = k-units a lane keeps in flight per group (host picks 1/2/4 from the step count so short
+// K does not issue clamped duplicate loads). Loop shape: load group 0; for every further group
+// {load next; compute current}; compute last — the prefetch is unconditional inside the loop so
+// hipcc can keep counted vmcnt waits (a prefetch under a branch would degrade them to vmcnt(0)).
 
-template <typename ST>
-__global__ void __launch_bounds__(kBlock) qmatvec_q4_kernel(QMVArgs a) {
-    extern __shared__ float smem[];
-    float* xs = smem;                        // units_per_wg * 32 floats
-    float* red = smem + a.units_per_wg * 32; // kWaves * 32 floats
-    const uint32_t j = blockIdx.x % a.NB, split = blockIdx.x / a.NB, m = blockIdx.y;
-    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const uint32_t row = lane >> 4, i = lane & 15, nl = lane & 31;
-    const uint32_t u_begin = split * a.units_per_wg;
-    const uint32_t u_end = min(a.U, u_begin + a.units_per_wg);
-    const uint4* qs = a.qs + (uint64_t)j * a.U * 32 + nl;
-    const Pair<ST>* sc = (const Pair<ST>*)a.sc + (uint64_t)j * a.U * 16 + i;
-    const uint32_t n_steps = (u_end - u_begin + 2 * kWaves - 1) / (2 * kWaves);
-
-    uint32_t u = u_begin + 2 * w + (row >> 1); // this lane's unit at step 0; += 2*kWaves per step
-    uint4 wq[kDepth];
-    Pair<ST> s2[kDepth];
-    // first group of weight loads goes out before the x staging so HBM latency overlaps it
+template <typename ST, int DEPTH>
+struct Q4Group {
+    uint4 wq[DEPTH];
+    Pair<ST> s2[DEPTH];
+    __device__ __forceinline__ void load(const uint4* qs, const Pair<ST>* sc, uint32_t u, uint32_t stride, uint32_t u_last) {
 #pragma unroll
-    for (int d = 0; d < kDepth; d++) {
-        const uint32_t ud = u + d * 2 * kWaves;
-        wq[d] = make_uint4(0, 0, 0, 0);
-        s2[d] = Pair<ST>{ST(0), ST(0)};
-        if (ud < u_end) {
-            wq[d] = qs[(uint64_t)ud * 32];
+        for (int d = 0; d < DEPTH; d++) { // clamped, unconditional
+            const uint32_t ud = min(u + d * stride, u_last);
+            wq[d] = qs[(uint64_t)ud * 16];
             s2[d] = sc[(uint64_t)ud * 16];
         }
     }
-    stage_x(xs, a.x + (uint64_t)m * a.in_rs, u_begin * 32, (u_end - u_begin) * 32, a.K);
-    __syncthreads();
-
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
-    for (uint32_t step = 0; step < n_steps; step += kDepth) {
-        uint4 wn[kDepth];
-        Pair<ST> sn[kDepth];
+    __device__ __forceinline__ void compute(const float* xs, uint32_t u, uint32_t stride, uint32_t U, uint32_t i,
+                                            float& acc0, float& acc1, float& acc2, float& acc3) const {
 #pragma unroll
-        for (int d = 0; d < kDepth; d++) { // next group (zero-filled past the slice end)
-            const uint32_t ud = u + (kDepth + d) * 2 * kWaves;
-            wn[d] = make_uint4(0, 0, 0, 0);
-            sn[d] = Pair<ST>{ST(0), ST(0)};
-            if (ud < u_end) {
-                wn[d] = qs[(uint64_t)ud * 32];
-                sn[d] = sc[(uint64_t)ud * 16];
-            }
-        }
-#pragma unroll
-        for (int d = 0; d < kDepth; d++) {
-            const uint32_t ud = u + d * 2 * kWaves;
-            float xa = 0.f, xb = 0.f;
-            if (ud < u_end) {
-                xa = xs[(ud - u_begin) * 32 + i];
-                xb = xs[(ud - u_begin) * 32 + 16 + i];
-            }
+        for (int d = 0; d < DEPTH; d++) {
+            const uint32_t ud = u + d * stride;
+            const bool ok = ud < U;
+            const uint32_t uc = min(ud, U - 1);
+            const float xa = xs[uc * 32 + i], xb = xs[uc * 32 + 16 + i];
             // all 64 lanes run the DPP section (row_newbcast reads need their source lanes live);
-            // out-of-range units contribute q = 0, t = 0
-            float tA = (to_f32(s2[d].a) * 16.0f) * xa;
-            float tB = (to_f32(s2[d].b) * 16.0f) * xb;
+            // out-of-range units get t = 0 (their clamped weights are finite, so 0 * q = 0).
+            // cvt_nib yields q/16: the 16 is folded into t (exact power of two)
+            float tA = ok ? (to_f32(s2[d].a) * 16.0f) * xa : 0.f;
+            float tB = ok ? (to_f32(s2[d].b) * 16.0f) * xb : 0.f;
             dpp_fence(tA, tB);
             q4_dword<0>(acc0, acc1, wq[d].x, tA);
             q4_dword<8>(acc2, acc3, wq[d].y, tA);
             q4_dword<0>(acc0, acc1, wq[d].z, tB);
             q4_dword<8>(acc2, acc3, wq[d].w, tB);
         }
-#pragma unroll
-        for (int d = 0; d < kDepth; d++) {
-            wq[d] = wn[d];
-            s2[d] = sn[d];
-        }
-        u += kDepth * 2 * kWaves;
     }
-    reduce_store((acc0 + acc1) + (acc2 + acc3), red, a, j, split, m);
-}
+};
 
-template <typename ST>
-__global__ void __launch_bounds__(kBlock) qmatvec_q8_kernel(QMVArgs a) {
-    extern __shared__ float smem[];
-    float* xs = smem;                        // units_per_wg * 16 floats
-    float* red = smem + a.units_per_wg * 16; // kWaves * 32 floats
-    const uint32_t j = blockIdx.x % a.NB, split = blockIdx.x / a.NB, m = blockIdx.y;
-    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const uint32_t row = lane >> 4, i = lane & 15, nl = lane & 31;
-    const uint32_t u_begin = split * a.units_per_wg;
-    const uint32_t u_end = min(a.U, u_begin + a.units_per_wg);
-    const uint4* qs = a.qs + (uint64_t)j * a.U * 32 + nl;
-    const ST* sc = (const ST*)a.sc + (uint64_t)j * a.U * 16 + i;
-    const uint32_t n_steps = (u_end - u_begin + 2 * kWaves - 1) / (2 * kWaves);
-
-    uint32_t u = u_begin + 2 * w + (row >> 1);
-    uint4 wq[kDepth];
-    ST s1[kDepth];
+template <typename ST, int DEPTH>
+struct Q8Group {
+    uint4 wq[DEPTH];
+    ST s1[DEPTH];
+    __device__ __forceinline__ void load(const uint4* qs, const ST* sc, uint32_t u, uint32_t stride, uint32_t u_last) {
 #pragma unroll
-    for (int d = 0; d < kDepth; d++) {
-        const uint32_t ud = u + d * 2 * kWaves;
-        wq[d] = make_uint4(0, 0, 0, 0);
-        s1[d] = ST(0);
-        if (ud < u_end) {
-            wq[d] = qs[(uint64_t)ud * 32];
+        for (int d = 0; d < DEPTH; d++) {
+            const uint32_t ud = min(u + d * stride, u_last);
+            wq[d] = qs[(uint64_t)ud * 16];
             s1[d] = sc[(uint64_t)ud * 16];
         }
     }
-    stage_x(xs, a.x + (uint64_t)m * a.in_rs, u_begin * 16, (u_end - u_begin) * 16, a.K);
-    __syncthreads();
-
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
-    for (uint32_t step = 0; step < n_steps; step += kDepth) {
-        uint4 wn[kDepth];
-        ST sn[kDepth];
+    __device__ __forceinline__ void compute(const float* xs, uint32_t u, uint32_t stride, uint32_t U, uint32_t i,
+                                            float& acc0, float& acc1, float& acc2, float& acc3) const {
 #pragma unroll
-        for (int d = 0; d < kDepth; d++) {
-            const uint32_t ud = u + (kDepth + d) * 2 * kWaves;
-            wn[d] = make_uint4(0, 0, 0, 0);
-            sn[d] = ST(0);
-            if (ud < u_end) {
-                wn[d] = qs[(uint64_t)ud * 32];
-                sn[d] = sc[(uint64_t)ud * 16];
-            }
-        }
-#pragma unroll
-        for (int d = 0; d < kDepth; d++) {
-            const uint32_t ud = u + d * 2 * kWaves;
-            const float xa = (ud < u_end) ? xs[(ud - u_begin) * 16 + i] : 0.f;
-            float t = to_f32(s1[d]) * xa;
+        for (int d = 0; d < DEPTH; d++) {
+            const uint32_t ud = u + d * stride;
+            const bool ok = ud < U;
+            const float xa = xs[min(ud, U - 1) * 16 + i];
+            float t = ok ? to_f32(s1[d]) * xa : 0.f;
             dpp_fence(t);
             q8_dword<0>(acc0, acc1, wq[d].x, t);
             q8_dword<4>(acc2, acc3, wq[d].y, t);
             q8_dword<8>(acc0, acc1, wq[d].z, t);
             q8_dword<12>(acc2, acc3, wq[d].w, t);
         }
-#pragma unroll
-        for (int d = 0; d < kDepth; d++) {
-            wq[d] = wn[d];
-            s1[d] = sn[d];
-        }
-        u += kDepth * 2 * kWaves;
     }
-    reduce_store((acc0 + acc1) + (acc2 + acc3), red, a, j, split, m);
-}
+};
 
-// dst[m*dst_rs + n] = sum_s part[(s*M+m)*N + n], s ascending
-__global__ void __launch_bounds__(kBlock) splitk_combine_kernel(float* __restrict__ dst, const float* __restrict__ part,
-                                                                uint32_t M, uint32_t N, uint32_t ksplit,
-                                                                uint32_t dst_rs) {
-    uint32_t n = blockIdx.x * kBlock + threadIdx.x, m = blockIdx.y;
-    if (n >= N) return;
-    float v = part[(uint64_t)m * N + n];
-    for (uint32_t s = 1; s < ksplit; s++) v += part[((uint64_t)s * M + m) * N + n];
-    dst[(uint64_t)m * dst_rs + n] = v;
+// Q4: unit = 32 k, UNIT_X = 32 floats of x per unit; Q8: unit = 16 k.
+template <typename ST, bool XVEC, int DEPTH, bool Q4>
+__global__ void __launch_bounds__(1024) qmatvec_kernel(QMVArgs a) {
+    constexpr uint32_t UNIT_X = Q4 ? 32 : 16;
+    using ScaleT = typename std::conditional<Q4, Pair<ST>, ST>::type;
+    using Group = typename std::conditional<Q4, Q4Group<ST, DEPTH>, Q8Group<ST, DEPTH>>::type;
+    extern __shared__ float smem[];
+    float* xs = smem;                     // U * UNIT_X floats (+4 spare)
+    float* red = smem + a.U * UNIT_X + 4; // waves * 16 floats
+    const uint32_t g = column_group(blockIdx.x, a.NB2), m = blockIdx.y;
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t row = lane >> 4, i = lane & 15;
+    const uint32_t stride = (blockDim.x >> 6) * 4; // units per step (4 rows per wave)
+    const uint4* qs = a.qs + (uint64_t)g * a.U * 16 + i;
+    const ScaleT* sc = (const ScaleT*)a.sc + (uint64_t)(g >> 1) * a.U * 16 + i;
+    const uint32_t n_groups = (a.U + stride * DEPTH - 1) / (stride * DEPTH);
+    const uint32_t u_last = a.U - 1;
+
+    const float* xrow = a.x + (uint64_t)m * a.in_rs;
+    const XRegs xr = x_fetch<XVEC>(xrow, a.K);
+    uint32_t u = 4 * w + row; // this row's unit in step 0
+    Group cur;
+    cur.load(qs, sc, u, stride, u_last);
+    x_commit<XVEC>(xs, xr, xrow, a.U * UNIT_X, a.K);
+    __syncthreads();
+
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+    for (uint32_t gi = 1; gi < n_groups; gi++) {
+        Group nxt;
+        nxt.load(qs, sc, u + DEPTH * stride, stride, u_last);
+        cur.compute(xs, u, stride, a.U, i, acc0, acc1, acc2, acc3);
+        cur = nxt;
+        u += DEPTH * stride;
+    }
+    cur.compute(xs, u, stride, a.U, i, acc0, acc1, acc2, acc3);
+    reduce_store((acc0 + acc1) + (acc2 + acc3), red, a, g, m);
 }
 
 // Raw layout (any block size, any N): one thread per (m, n), k sequential — exactly the
@@ -347,50 +330,6 @@ __device__ __forceinline__ float synth_scale(uint64_t block, uint32_t id) {
     return 0.015625f * (1.0f + (float)((block + id) % 7) * 0.125f); // exact in f16
 }
 
-template <typename ST>
-__global__ void __launch_bounds__(kBlock) synth_packed_kernel(QWeightDev w, uint32_t id) {
-    const uint32_t NB = w.N / 32;
-    const bool q4 = w.format == QW_Q4;
-    const uint32_t U = q4 ? w.KC : 2 * w.KC;
-    const uint64_t n_items = (uint64_t)NB * U * 32;
-    for (uint64_t it = (uint64_t)blockIdx.x * kBlock + threadIdx.x; it < n_items; it += (uint64_t)gridDim.x * kBlock) {
-        const uint32_t nl = it & 31;
-        const uint64_t ju = it >> 5;
-        const uint32_t u = ju % U, j = ju / U;
-        const uint32_t n = j * 32 + nl;
-        uint32_t d[4];
-        for (int dd = 0; dd < 4; dd++) {
-            uint32_t word = 0;
-            for (int b = 0; b < 4; b++) {
-                if (q4) {
-                    uint32_t k_lo = u * 32 + 8 * dd + b, k_hi = k_lo + 4;
-                    uint32_t lo = k_lo < w.K ? (uint32_t)synth_q4((uint64_t)k_lo * w.N + n, id) & 15u : 0u;
-                    uint32_t hi = k_hi < w.K ? (uint32_t)synth_q4((uint64_t)k_hi * w.N + n, id) & 15u : 0u;
-                    word |= (lo | (hi << 4)) << (8 * b);
-                } else {
-                    uint32_t k = u * 16 + 4 * dd + b;
-                    uint32_t q = k < w.K ? (uint32_t)synth_q8((uint64_t)k * w.N + n, id) & 255u : 0u;
-                    word |= q << (8 * b);
-                }
-            }
-            d[dd] = word;
-        }
-        ((uint4*)w.qs)[it] = make_uint4(d[0], d[1], d[2], d[3]);
-        if (nl < 16) {
-            const uint32_t i = nl;
-            if (q4) {
-                uint32_t ka = u * 32 + i, kb = ka + 16;
-                float sa = ka < w.K ? synth_scale((uint64_t)ka * NB + j, id) : 0.f;
-                float sb = kb < w.K ? synth_scale((uint64_t)kb * NB + j, id) : 0.f;
-                ((Pair<ST>*)w.sc)[ju * 16 + i] = Pair<ST>{ST(sa), ST(sb)};
-            } else {
-                uint32_t k = u * 16 + i;
-                ((ST*)w.sc)[ju * 16 + i] = ST(k < w.K ? synth_scale((uint64_t)k * NB + j, id) : 0.f);
-            }
-        }
-    }
-}
-
 // flags[0] != 0: some value outside [-8,7]; flags[1] != 0: some scale not exact in f16
 __global__ void __launch_bounds__(kBlock) classify_kernel(const int8_t* __restrict__ data, uint64_t n_elems,
                                                           const float* __restrict__ scales, uint64_t n_blocks,
@@ -403,86 +342,99 @@ __global__ void __launch_bounds__(kBlock) classify_kernel(const int8_t* __restri
     if (__any(bad_s) && (threadIdx.x & 63) == 0) atomicOr(&flags[1], 1u);
 }
 
-// raw [K,N] int8 + f32 scale per 32 flat elements -> packed layout (see file header). One thread
-// per 16-byte item; reads are 32-byte coalesced across the 32 columns of a block-column.
-template <typename ST>
-__global__ void __launch_bounds__(kBlock) pack_kernel(const int8_t* __restrict__ data,
-                                                      const float* __restrict__ scales, QWeightDev w) {
-    const uint32_t NB = w.N / 32;
+// Writes the packed layout from an element source: Src::q(k, n) / Src::scale(k, j).
+// One thread per 16-byte item; for the raw source reads are 16-byte coalesced across a group.
+template <typename ST, typename Src>
+__device__ __forceinline__ void write_packed(const QWeightDev& w, const Src& src) {
+    const uint32_t NB = w.N / 32, NB2 = w.N / 16;
     const bool q4 = w.format == QW_Q4;
     const uint32_t U = q4 ? w.KC : 2 * w.KC;
-    const uint64_t n_items = (uint64_t)NB * U * 32;
+    const uint64_t n_items = (uint64_t)NB2 * U * 16;
     for (uint64_t it = (uint64_t)blockIdx.x * kBlock + threadIdx.x; it < n_items; it += (uint64_t)gridDim.x * kBlock) {
-        const uint32_t nl = it & 31;
-        const uint64_t ju = it >> 5;
-        const uint32_t u = ju % U, j = ju / U;
-        const uint32_t n = j * 32 + nl;
+        const uint32_t i = it & 15;
+        const uint64_t gu = it >> 4;
+        const uint32_t u = gu % U, g = gu / U;
+        const uint32_t n = g * 16 + i;
         uint32_t d[4];
         for (int dd = 0; dd < 4; dd++) {
             uint32_t word = 0;
             for (int b = 0; b < 4; b++) {
                 if (q4) {
-                    uint32_t k_lo = u * 32 + 8 * dd + b, k_hi = k_lo + 4;
-                    uint32_t lo = k_lo < w.K ? (uint32_t)data[(uint64_t)k_lo * w.N + n] & 15u : 0u;
-                    uint32_t hi = k_hi < w.K ? (uint32_t)data[(uint64_t)k_hi * w.N + n] & 15u : 0u;
+                    const uint32_t k_lo = u * 32 + 8 * dd + b, k_hi = k_lo + 4;
+                    const uint32_t lo = k_lo < w.K ? (uint32_t)src.q(k_lo, n) & 15u : 0u;
+                    const uint32_t hi = k_hi < w.K ? (uint32_t)src.q(k_hi, n) & 15u : 0u;
                     word |= (lo | (hi << 4)) << (8 * b);
                 } else {
-                    uint32_t k = u * 16 + 4 * dd + b;
-                    uint32_t q = k < w.K ? (uint32_t)data[(uint64_t)k * w.N + n] & 255u : 0u;
+                    const uint32_t k = u * 16 + 4 * dd + b;
+                    const uint32_t q = k < w.K ? (uint32_t)src.q(k, n) & 255u : 0u;
                     word |= q << (8 * b);
                 }
             }
             d[dd] = word;
         }
         ((uint4*)w.qs)[it] = make_uint4(d[0], d[1], d[2], d[3]);
-        if (nl < 16) {
-            const uint32_t i = nl;
+        if ((g & 1) == 0) { // scales are per 32-column block-column: written by the even group
+            const uint32_t j = g >> 1;
+            const uint64_t ju = (uint64_t)j * U + u;
             if (q4) {
-                uint32_t ka = u * 32 + i, kb = ka + 16;
-                float sa = ka < w.K ? scales[(uint64_t)ka * NB + j] : 0.f;
-                float sb = kb < w.K ? scales[(uint64_t)kb * NB + j] : 0.f;
+                const uint32_t ka = u * 32 + i, kb = ka + 16;
+                const float sa = ka < w.K ? src.scale(ka, j, NB) : 0.f;
+                const float sb = kb < w.K ? src.scale(kb, j, NB) : 0.f;
                 ((Pair<ST>*)w.sc)[ju * 16 + i] = Pair<ST>{ST(sa), ST(sb)};
             } else {
-                uint32_t k = u * 16 + i;
-                ((ST*)w.sc)[ju * 16 + i] = ST(k < w.K ? scales[(uint64_t)k * NB + j] : 0.f);
+                const uint32_t k = u * 16 + i;
+                ((ST*)w.sc)[ju * 16 + i] = ST(k < w.K ? src.scale(k, j, NB) : 0.f);
             }
         }
     }
 }
 
-inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
-
-struct SplitPlan {
-    uint32_t units_per_wg, ksplit;
+struct SynthSrc { // SURVEY §8d generator
+    uint32_t N, id;
+    bool q4;
+    __device__ int q(uint32_t k, uint32_t n) const {
+        const uint64_t flat = (uint64_t)k * N + n;
+        return q4 ? synth_q4(flat, id) : synth_q8(flat, id);
+    }
+    __device__ float scale(uint32_t k, uint32_t j, uint32_t NB) const { return synth_scale((uint64_t)k * NB + j, id); }
 };
 
-// Choose the K split: enough workgroups to cover the chip ~2x, slices a multiple of 8 units
-// (one unit pair per wave per step), LDS slice of x bounded to 32 KiB.
-SplitPlan plan_split(const QWeightDev& w, uint32_t M) {
-    const uint32_t NB = w.N / 32;
-    const uint32_t U = w.format == QW_Q4 ? w.KC : 2 * w.KC;
-    const uint32_t unit_k = w.format == QW_Q4 ? 32 : 16;
-    const uint32_t max_units = (32 * 1024 / 4) / unit_k; // x slice <= 32 KiB of LDS
-    const uint32_t target_wgs = 512;
-    uint32_t ksplit = 1;
-    uint64_t wgs = (uint64_t)NB * (M ? M : 1);
-    if (wgs < target_wgs) ksplit = cdiv(target_wgs, wgs);
-    uint32_t upw = cdiv(U, ksplit);
-    upw = (upw + 7) / 8 * 8;
-    if (upw < 8) upw = 8;
-    if (upw > max_units) upw = max_units / 8 * 8;
-    ksplit = cdiv(U, upw);
-    return {upw, ksplit};
+struct RawSrc { // QuantizedWeightUpload as uploaded: int8 [K,N] + one f32 scale per 32 flat elements
+    const int8_t* data;
+    const float* scales;
+    uint32_t N;
+    __device__ int q(uint32_t k, uint32_t n) const { return data[(uint64_t)k * N + n]; }
+    __device__ float scale(uint32_t k, uint32_t j, uint32_t NB) const { return scales[(uint64_t)k * NB + j]; }
+};
+
+template <typename ST>
+__global__ void __launch_bounds__(kBlock) synth_packed_kernel(QWeightDev w, uint32_t id) {
+    write_packed<ST>(w, SynthSrc{w.N, id, w.format == QW_Q4});
 }
+
+template <typename ST>
+__global__ void __launch_bounds__(kBlock) pack_kernel(const int8_t* __restrict__ data,
+                                                      const float* __restrict__ scales, QWeightDev w) {
+    write_packed<ST>(w, RawSrc{data, scales, w.N});
+}
+
+inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+// LDS the mat-vec needs: x (K padded to whole units) + the cross-wave reduction area.
+size_t qmv_lds_bytes(const QWeightDev& w) {
+    const uint32_t U = w.format == QW_Q4 ? w.KC : 2 * w.KC;
+    return ((size_t)U * (w.format == QW_Q4 ? 32 : 16) + 4 + kMaxWaves * 16) * sizeof(float);
+}
+constexpr size_t kMaxLds = 160 * 1024;
 
 } // namespace
 
 // ── device-side repack (compile_program time) ───────────────────────────────────────────────
 void packed_bytes(QWFormat format, uint32_t scale_f16, uint64_t K, uint64_t N, uint64_t* qs_bytes,
                   uint64_t* sc_bytes) {
-    const uint64_t NB = N / 32, KC = (K + 31) / 32;
+    const uint64_t NB = N / 32, NB2 = N / 16, KC = (K + 31) / 32;
     const uint64_t U = format == QW_Q4 ? KC : 2 * KC;
-    *qs_bytes = NB * U * 32 * 16;
+    *qs_bytes = NB2 * U * 16 * 16;
     const uint64_t n_sc = format == QW_Q4 ? NB * KC * 32 : NB * U * 16;
     *sc_bytes = n_sc * (scale_f16 ? 2 : 4);
 }
@@ -504,54 +456,57 @@ void launch_pack_qweight(hipStream_t s, const int8_t* raw_data, const float* raw
         pack_kernel<float><<<2048, kBlock, 0, s>>>(raw_data, raw_scales, out);
 }
 
-uint64_t qmatmul_scratch_bytes(const QWeightDev& w, uint32_t M) {
-    if (w.format == QW_RAW) return 0;
-    SplitPlan sp = plan_split(w, M);
-    return sp.ksplit > 1 ? (uint64_t)sp.ksplit * M * w.N * sizeof(float) : 0;
+uint64_t qmatmul_scratch_bytes(const QWeightDev&, uint32_t) { return 0; } // single launch: no split-K slabs
+
+bool qweight_packable(uint64_t K, uint64_t N, uint64_t bs) {
+    if (bs != 32 || N == 0 || K == 0 || N % 32 != 0) return false;
+    // x (padded K) must fit the workgroup's LDS next to the reduction area
+    const uint64_t KC = (K + 31) / 32;
+    return (KC * 32 + 4 + kMaxWaves * 16) * sizeof(float) <= kMaxLds;
 }
 
-void launch_qmatmul(hipStream_t s, const QWeightDev& w, const QMatmulParams& p, float* scratch) {
+void launch_qmatmul(hipStream_t s, const QWeightDev& w, const QMatmulParams& p, float*) {
     if (p.M == 0 || p.N == 0) return;
     if (w.format == QW_RAW) {
         dim3 grid(cdiv(p.N, kBlock), p.M);
         qmatmul_raw_kernel<<<grid, kBlock, 0, s>>>((const int8_t*)w.qs, (const float*)w.sc, w.bs, p);
         return;
     }
-    const SplitPlan sp = plan_split(w, p.M);
     const bool q4 = w.format == QW_Q4;
     QMVArgs a{};
     a.qs = (const uint4*)w.qs;
     a.sc = w.sc;
     a.x = p.input;
-    a.M = p.M, a.N = p.N, a.K = p.K, a.NB = p.N / 32;
+    a.out = p.dst;
+    a.M = p.M, a.N = p.N, a.K = p.K, a.NB2 = p.N / 16;
     a.U = q4 ? w.KC : 2 * w.KC;
-    a.units_per_wg = sp.units_per_wg;
-    a.ksplit = sp.ksplit;
     a.in_rs = p.in_rs;
-    if (sp.ksplit == 1) {
-        a.out = p.dst;
-        a.out_rs = p.dst_rs;
-    } else {
-        a.out = scratch;
-        a.out_rs = p.N;
+    a.out_rs = p.dst_rs;
+    // one workgroup per 16-column group; enough waves that each row gets >= 1 unit, at most 16
+    uint32_t waves = cdiv(a.U, 4);
+    if (waves > (uint32_t)kMaxWaves) waves = kMaxWaves;
+    if (waves < 1) waves = 1;
+    dim3 grid(a.NB2, p.M);
+    const size_t lds = qmv_lds_bytes(w);
+    const bool xvec = ((uintptr_t)p.input % 16 == 0) && (p.K % 4 == 0) && (p.M == 1 || p.in_rs % 4 == 0);
+    const uint32_t n_steps = cdiv(a.U, waves * 4);
+    const int depth_sel = n_steps >= 4 ? 2 : (n_steps >= 2 ? 1 : 0); // DEPTH 4 / 2 / 1
+    using KernelFn = void (*)(QMVArgs);
+#define ZGML_QMV_ROW(ST, XV, Q) {qmatvec_kernel<ST, XV, 1, Q>, qmatvec_kernel<ST, XV, 2, Q>, qmatvec_kernel<ST, XV, 4, Q>}
+    static const KernelFn table[2][2][2][3] = {
+        {{ZGML_QMV_ROW(float, false, false), ZGML_QMV_ROW(float, true, false)},
+         {ZGML_QMV_ROW(__half, false, false), ZGML_QMV_ROW(__half, true, false)}},
+        {{ZGML_QMV_ROW(float, false, true), ZGML_QMV_ROW(float, true, true)},
+         {ZGML_QMV_ROW(__half, false, true), ZGML_QMV_ROW(__half, true, true)}}};
+#undef ZGML_QMV_ROW
+    static bool lds_opt_in = false; // > 64 KiB of dynamic LDS needs an explicit opt-in per kernel
+    if (!lds_opt_in) {
+        for (int i = 0; i < 24; i++)
+            hipFuncSetAttribute((const void*)table[i / 12][(i / 6) & 1][(i / 3) & 1][i % 3],
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+        lds_opt_in = true;
     }
-    dim3 grid(a.NB * sp.ksplit, p.M);
-    const size_t lds = ((size_t)sp.units_per_wg * (q4 ? 32 : 16) + kWaves * 32) * sizeof(float);
-    if (q4) {
-        if (w.scale_f16)
-            qmatvec_q4_kernel<__half><<<grid, kBlock, lds, s>>>(a);
-        else
-            qmatvec_q4_kernel<float><<<grid, kBlock, lds, s>>>(a);
-    } else {
-        if (w.scale_f16)
-            qmatvec_q8_kernel<__half><<<grid, kBlock, lds, s>>>(a);
-        else
-            qmatvec_q8_kernel<float><<<grid, kBlock, lds, s>>>(a);
-    }
-    if (sp.ksplit > 1) {
-        dim3 g2(cdiv(p.N, kBlock), p.M);
-        splitk_combine_kernel<<<g2, kBlock, 0, s>>>(p.dst, scratch, p.M, p.N, sp.ksplit, p.dst_rs);
-    }
+    hipLaunchKernelGGL(table[q4 ? 1 : 0][w.scale_f16 ? 1 : 0][xvec ? 1 : 0][depth_sel], grid, dim3(waves * 64), lds, s, a);
 }
 
 void launch_synth_packed(hipStream_t s, const QWeightDev& w, uint32_t matrix_id) {

@@ -811,7 +811,7 @@ zgml_hip_program* zgml_hip_compile_program(zgml_hip_ctx* ctx, const zgml_device_
             hipFree(raw_s);
             break;
         }
-        const bool packable = qw.block_size == 32 && qw.cols % 32 == 0 && qw.cols > 0 && qw.rows > 0;
+        const bool packable = qweight_packable(qw.rows, qw.cols, qw.block_size);
         if (!packable) {
             w.format = QW_RAW;
             w.qs = raw_d, w.sc = raw_s;
@@ -1041,19 +1041,35 @@ double zgml_hip_qmatvec_bench(zgml_hip_ctx* ctx, uint32_t K, uint32_t N, int q4,
     if (ok) {
         QMatmulParams qp{y, x, 1, N, K, K, N};
         for (uint32_t i = 0; i < warmup; i++) launch_qmatmul(ctx->stream, ring[i % n_matrices], qp, scratch);
-        hipEvent_t e0, e1;
-        hipEventCreate(&e0);
-        hipEventCreate(&e1);
-        hipEventRecord(e0, ctx->stream);
-        for (uint32_t i = 0; i < iters; i++) launch_qmatmul(ctx->stream, ring[i % n_matrices], qp, scratch);
-        hipEventRecord(e1, ctx->stream);
-        if (CTX_CHECK(ctx, hipEventSynchronize(e1))) {
-            float ms = 0;
-            hipEventElapsedTime(&ms, e0, e1);
-            us = (double)ms * 1000.0 / iters;
+        // One pass over the ring is captured into a hipGraph and replayed: back-to-back eager
+        // launches are host-bound below ~3 us per kernel on this platform, a graph is not.
+        hipGraph_t g = nullptr;
+        hipGraphExec_t ge = nullptr;
+        ok = CTX_CHECK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+        if (ok) {
+            for (uint32_t i = 0; i < n_matrices; i++) launch_qmatmul(ctx->stream, ring[i], qp, scratch);
+            ok = CTX_CHECK(ctx, hipStreamEndCapture(ctx->stream, &g)) &&
+                 CTX_CHECK(ctx, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
         }
-        hipEventDestroy(e0);
-        hipEventDestroy(e1);
+        if (ok) {
+            const uint32_t reps = (iters + n_matrices - 1) / n_matrices;
+            hipGraphLaunch(ge, ctx->stream); // warm replay
+            hipEvent_t e0, e1;
+            hipEventCreate(&e0);
+            hipEventCreate(&e1);
+            hipEventRecord(e0, ctx->stream);
+            for (uint32_t r = 0; r < reps; r++) hipGraphLaunch(ge, ctx->stream);
+            hipEventRecord(e1, ctx->stream);
+            if (CTX_CHECK(ctx, hipEventSynchronize(e1))) {
+                float ms = 0;
+                hipEventElapsedTime(&ms, e0, e1);
+                us = (double)ms * 1000.0 / ((double)reps * n_matrices);
+            }
+            hipEventDestroy(e0);
+            hipEventDestroy(e1);
+        }
+        if (ge) hipGraphExecDestroy(ge);
+        if (g) hipGraphDestroy(g);
     }
     if (bytes_per_launch) *bytes_per_launch = (uint64_t)K * N / 32 * (q4 ? 18 : 34) + 4ull * K + 4ull * N;
     for (auto& w : ring) {
