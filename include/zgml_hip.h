@@ -335,6 +335,12 @@ void zgml_hip_enqueue_program(zgml_hip_ctx* ctx, zgml_hip_program* handle);
 /* Enqueue ops [first, first+count) only (multi-GPU harness interleaves collectives). */
 void zgml_hip_enqueue_ops(zgml_hip_ctx* ctx, zgml_hip_program* handle, uint64_t first, uint64_t count);
 void zgml_hip_synchronize(zgml_hip_ctx* ctx);
+/* The two halves of execute_program on their own, for harnesses that interleave collectives with
+ * op ranges: enqueue the host->device transfers / run the device->host transfers (blocking). */
+void zgml_hip_upload_inputs(zgml_hip_ctx* ctx, zgml_hip_program* handle, const zgml_program_io* inputs,
+                            uint64_t n_inputs);
+void zgml_hip_download_outputs(zgml_hip_ctx* ctx, zgml_hip_program* handle, const zgml_program_io* outputs,
+                               uint64_t n_outputs);
 /* On-device greedy argmax over f32 elements [offset, offset+n) of a program buffer: first index
  * of the maximum (strict >), as scripts/generate_llama.zig:101-110 / src/nn.zig:122-138. */
 int64_t zgml_hip_argmax(zgml_hip_ctx* ctx, zgml_hip_program* handle, uint16_t buf_idx,

@@ -191,3 +191,14 @@ def rope_tables(d: int, max_seq: int, base: float = 10000.0):
 def argmax(v: np.ndarray) -> int:
     v = np.ascontiguousarray(v, dtype=np.float32)
     return int(load().zo_argmax(_p(v), v.size))
+
+
+def backend_fns():
+    """zgml_amd.llama.BackendFns table backed by the oracle (tests / cpu_baseline only)."""
+    from zgml_amd.llama import BackendFns
+    lib = load()
+
+    def addr(name):
+        return C.cast(getattr(lib, name), C.c_void_p).value
+    return BackendFns(None, addr("zo_vt_compile_program"), addr("zo_vt_refresh_program"),
+                      addr("zo_vt_execute_program"), addr("zo_vt_free_program"))

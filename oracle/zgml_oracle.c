@@ -650,6 +650,15 @@ void zo_execute_program(zo_program* p, const zgml_program_io* inputs, uint64_t n
     zo_download(p, outputs, n_outputs);
 }
 
+void zo_program_execute_range(zo_program* p, uint64_t first, uint64_t count) {
+    if (first > p->n_ops) return;
+    if (first + count > p->n_ops) count = p->n_ops - first;
+    zo_execute_ops(p->buffers, p->qweights, p->ops + first, count);
+}
+
+void zo_program_upload(zo_program* p, const zgml_program_io* io, uint64_t n) { zo_upload(p, io, n); }
+void zo_program_download(zo_program* p, const zgml_program_io* io, uint64_t n) { zo_download(p, io, n); }
+
 void zo_free_program(zo_program* p) {
     if (!p) return;
     for (uint64_t i = 0; i < p->n_buffers; i++) free(p->buffers[i].ptr);
@@ -986,4 +995,24 @@ int64_t zo_argmax(const float* v, uint64_t n) {
         }
     }
     return (int64_t)best;
+}
+
+/* ── ctx-taking wrappers with the exact signatures of the zgml_hip_* entry points, so the host
+ *    session code (zgml_amd/host) can be driven by the oracle in parity tests ─────────────── */
+void* zo_vt_compile_program(void* ctx, const zgml_device_program* program) {
+    (void)ctx;
+    return zo_compile_program(program);
+}
+void zo_vt_refresh_program(void* ctx, void* handle, const zgml_device_op* ops, uint64_t n_ops) {
+    (void)ctx;
+    zo_refresh_program((zo_program*)handle, ops, n_ops);
+}
+void zo_vt_execute_program(void* ctx, void* handle, const zgml_program_io* inputs, uint64_t n_inputs,
+                           const zgml_program_io* outputs, uint64_t n_outputs) {
+    (void)ctx;
+    zo_execute_program((zo_program*)handle, inputs, n_inputs, outputs, n_outputs);
+}
+void zo_vt_free_program(void* ctx, void* handle) {
+    (void)ctx;
+    zo_free_program((zo_program*)handle);
 }

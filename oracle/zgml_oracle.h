@@ -59,6 +59,17 @@ void zo_execute_program(zo_program* p, const zgml_program_io* inputs, uint64_t n
                         const zgml_program_io* outputs, uint64_t n_outputs);
 void zo_free_program(zo_program* p);
 float* zo_program_buffer(zo_program* p, uint16_t idx, uint64_t* len_out);
+/* pieces of execute for harnesses that interleave collectives with op ranges (row-shard tests) */
+void zo_program_execute_range(zo_program* p, uint64_t first, uint64_t count);
+void zo_program_upload(zo_program* p, const zgml_program_io* io, uint64_t n);
+void zo_program_download(zo_program* p, const zgml_program_io* io, uint64_t n);
+
+/* the same four calls with a leading (ignored) ctx, i.e. the zgml_hip_* signatures */
+void* zo_vt_compile_program(void* ctx, const zgml_device_program* program);
+void zo_vt_refresh_program(void* ctx, void* handle, const zgml_device_op* ops, uint64_t n_ops);
+void zo_vt_execute_program(void* ctx, void* handle, const zgml_program_io* inputs, uint64_t n_inputs,
+                           const zgml_program_io* outputs, uint64_t n_outputs);
+void zo_vt_free_program(void* ctx, void* handle);
 
 /* DeviceProgram.isSupportedBy(Capabilities.reference_cpu-like), src/backend.zig:277-325.
  * max_fused_steps < 0 means "no limit". */

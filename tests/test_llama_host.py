@@ -1,0 +1,143 @@
+"""CPU tests of the host side: the decode DeviceProgram has the reference's op stream
+(SURVEY Appendix A), per-step patching follows llama_smollm_bench.zig doStep, and the row-sharded
+program reproduces the unsharded logits (single process here; 2-process gloo in
+test_sharded_gloo.py)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from zgml_amd import capi, llama
+from tests.oracle_executor import OracleExecutor
+from zgml_amd.sharded import ShardedDecoder
+
+KIND = capi.DOP
+
+
+def op_kinds(model):
+    prog = model.program
+    return [prog.ops[i].kind for i in range(prog.n_ops)]
+
+
+def test_smollm_program_shape():
+    cfg = llama.preset("smollm-135m")
+    m = llama.Model(cfg, llama.Q4_0, threads=8)
+    kinds = op_kinds(m)
+    L, H, KV = cfg.n_layers, cfg.n_heads, cfg.n_kv_heads
+    count = lambda k: sum(1 for x in kinds if x == KIND[k])
+    assert count("qmatmul") == 7 * L
+    assert count("matmul") == 1                      # tied LM head stays dense f32 (F10)
+    assert count("rmsnorm") == 2 * L + 1
+    assert count("repeat") == 3 * L + 1
+    assert count("rope") == (H + KV) * L
+    assert count("attention") == H * L
+    assert count("slice_assign") == (2 * KV + H) * L
+    assert count("fused_elementwise") == 2 * L
+    assert len(kinds) == 1654                        # docs/perf-targets.md:83 reports 1,654 ops
+    qb, n = m.quant_bytes()
+    assert n == 106_168_320 and qb == n // 32 * 18   # 59.7 MB of Q4_0
+    m.close()
+
+
+def test_unfused_lowering_when_backend_lacks_fused_elementwise():
+    cfg = llama.preset("tiny")
+    m = llama.Model(cfg, fused_elementwise=False)
+    kinds = op_kinds(m)
+    assert KIND["fused_elementwise"] not in kinds
+    assert kinds.count(KIND["elementwise"]) == (3 + 5 + 2) * cfg.n_layers + 1  # norm muls, silu chain(5)+act, adds
+    m.close()
+
+
+def test_step_patching_matches_bench_dostep(oracle):
+    cfg = llama.preset("tiny")
+    m = llama.Model(cfg)
+    m.patch(7, 5)
+    prog = m.program
+    n = C.c_uint64()
+    ins = m.lib.zh_model_step_inputs(m.ptr, C.byref(n))
+    assert n.value == 2 + cfg.n_layers
+    tok = np.ctypeslib.as_array(C.cast(ins[0].host_ptr, C.POINTER(C.c_float)), shape=(cfg.d_model,))
+    mask = np.ctypeslib.as_array(C.cast(ins[1].host_ptr, C.POINTER(C.c_float)), shape=(cfg.max_seq_len,))
+    rope = np.ctypeslib.as_array(C.cast(ins[2].host_ptr, C.POINTER(C.c_float)), shape=(2 * cfg.d_head,))
+    assert np.array_equal(tok, m.token_embed()[7])
+    assert np.all(mask[:6] == 0) and np.all(np.isneginf(mask[6:]))
+    cos, sin = m.rope_tables()
+    ocos, osin = oracle.rope_tables(cfg.d_head, cfg.max_seq_len, cfg.rope_base)
+    np.testing.assert_allclose(cos, ocos, atol=1e-6)
+    np.testing.assert_allclose(sin, osin, atol=1e-6)
+    assert np.array_equal(rope[:cfg.d_head], cos[5]) and np.array_equal(rope[cfg.d_head:], sin[5])
+    for i in range(prog.n_ops):
+        op = prog.ops[i]
+        if op.kind == KIND["slice_assign"]:
+            sa = op.u.slice_assign
+            assert sa.dst_offset == sa.dst_base_offset + 5 * sa.patch_stride or sa.patch_stride == 0
+        if op.kind == KIND["attention"]:
+            assert op.u.attention.seq_kv == 6
+    m.close()
+
+
+def run_decode(m, n_steps, first=3):
+    s = llama.Session(m, __import__("oracle.oracle", fromlist=["x"]).backend_fns())
+    tok, out = first, []
+    for pos in range(n_steps):
+        tok, logits = s.step(tok, pos)
+        out.append(logits)
+    s.close()
+    return out
+
+
+@pytest.mark.parametrize("kind", [llama.Q4_0, llama.Q8_0])
+def test_sharded_program_reproduces_unsharded_logits(oracle, kind):
+    """world_size 2 and 4 emulated in one process: every rank's program runs on the oracle and
+    the all-gathers are done by hand between the op ranges."""
+    cfg = llama.preset("tiny")
+    cfg.tied_lm_head = 0
+    cfg.n_kv_heads = 4
+    full = llama.Model(cfg, kind)
+    ref = run_decode(full, 4)
+    full.close()
+    for ws in (2, 4):
+        models, exs = [], []
+        for r in range(ws):
+            c = llama.preset("tiny")
+            c.tied_lm_head, c.n_kv_heads, c.shard_rank, c.shard_world = 0, 4, r, ws
+            models.append(llama.Model(c, kind))
+            exs.append(OracleExecutor(models[-1]))
+        points = models[0].gather_points()
+        assert len(points) == 4 * cfg.n_layers + 1
+        tok = 3
+        for pos in range(4):
+            for m, ex in zip(models, exs):
+                m.patch(tok, pos)
+                ex.refresh()
+                ex.upload()
+            prev = 0
+            for gp in points + [None]:
+                end = gp.op_end if gp else exs[0].n_ops
+                for ex in exs:
+                    ex.run_ops(prev, end - prev)
+                if gp:
+                    n = gp.len_per_rank
+                    views = [ex.tensor(gp.buf, gp.offset, ws * n) for ex in exs]
+                    for r in range(ws):
+                        for v in views:
+                            v[r * n:(r + 1) * n] = views[r][r * n:(r + 1) * n].clone()
+                prev = end
+            logits = [ex.download_logits() for ex in exs]
+            for lg in logits:
+                np.testing.assert_allclose(lg, ref[pos], atol=2e-5 * np.abs(ref[pos]).max(), rtol=0)
+            tok = int(np.argmax(ref[pos]))
+        for ex, m in zip(exs, models):
+            ex.close()
+            m.close()
+
+
+def test_invalid_shard_specs_rejected():
+    c = llama.preset("tiny")
+    c.shard_world = 2  # tied LM head cannot shard
+    with pytest.raises(ValueError):
+        llama.Model(c)
+    c = llama.preset("smollm-135m")
+    c.tied_lm_head, c.shard_world = 0, 2  # 3 kv heads do not split in two: replicas only
+    with pytest.raises(ValueError):
+        llama.Model(c)

@@ -888,35 +888,32 @@ void zgml_hip_refresh_program(zgml_hip_ctx* ctx, zgml_hip_program* p, const zgml
     p->plan_dirty = true;
 }
 
-void zgml_hip_execute_program(zgml_hip_ctx* ctx, zgml_hip_program* p, const zgml_program_io* inputs, uint64_t n_inputs,
-                              const zgml_program_io* outputs, uint64_t n_outputs) {
-    if (!ctx || !p) return;
-    hipSetDevice(ctx->device);
+// inputs: pack -> one H2D -> scatter kernel
+static bool upload_inputs(zgml_hip_ctx* ctx, zgml_hip_program* p, const zgml_program_io* inputs, uint64_t n_inputs) {
     hipStream_t s = ctx->stream;
-    if (!prepare_io(p, p->in_plan, inputs, n_inputs)) return;
-    if (!prepare_io(p, p->out_plan, outputs, n_outputs)) return;
-
-    // inputs: pack -> one H2D -> scatter
-    if (n_inputs) {
-        if (p->in_plan.word_aligned) {
-            char* st = (char*)p->stage_host;
-            uint64_t off = 0;
-            for (uint64_t i = 0; i < n_inputs; i++) {
-                memcpy(st + off, inputs[i].host_ptr, inputs[i].size);
-                off += (inputs[i].size + 3) / 4 * 4;
-            }
-            hipMemcpyAsync(p->stage_dev, p->stage_host, off, hipMemcpyHostToDevice, s);
-            scatter_words_kernel<<<(uint32_t)n_inputs, 256, 0, s>>>(p->in_plan.table_dev, (const uint32_t*)p->stage_dev);
-        } else {
-            for (uint64_t i = 0; i < n_inputs; i++)
-                hipMemcpyAsync((char*)p->bufs[inputs[i].buf_idx] + inputs[i].offset, inputs[i].host_ptr,
-                               inputs[i].size, hipMemcpyHostToDevice, s);
+    if (!prepare_io(p, p->in_plan, inputs, n_inputs)) return false;
+    if (!n_inputs) return true;
+    if (p->in_plan.word_aligned) {
+        char* st = (char*)p->stage_host;
+        uint64_t off = 0;
+        for (uint64_t i = 0; i < n_inputs; i++) {
+            memcpy(st + off, inputs[i].host_ptr, inputs[i].size);
+            off += (inputs[i].size + 3) / 4 * 4;
         }
+        hipMemcpyAsync(p->stage_dev, p->stage_host, off, hipMemcpyHostToDevice, s);
+        scatter_words_kernel<<<(uint32_t)n_inputs, 256, 0, s>>>(p->in_plan.table_dev, (const uint32_t*)p->stage_dev);
+    } else {
+        for (uint64_t i = 0; i < n_inputs; i++)
+            hipMemcpyAsync((char*)p->bufs[inputs[i].buf_idx] + inputs[i].offset, inputs[i].host_ptr, inputs[i].size,
+                           hipMemcpyHostToDevice, s);
     }
+    return true;
+}
 
-    enqueue(p);
-
-    // outputs: gather -> one D2H -> unpack
+// outputs: gather kernel -> one D2H -> sync -> unpack
+static bool download_outputs(zgml_hip_ctx* ctx, zgml_hip_program* p, const zgml_program_io* outputs, uint64_t n_outputs) {
+    hipStream_t s = ctx->stream;
+    if (!prepare_io(p, p->out_plan, outputs, n_outputs)) return false;
     if (n_outputs) {
         if (p->out_plan.word_aligned) {
             gather_words_kernel<<<(uint32_t)n_outputs, 256, 0, s>>>(p->out_plan.table_dev, (uint32_t*)p->stage_dev);
@@ -928,7 +925,7 @@ void zgml_hip_execute_program(zgml_hip_ctx* ctx, zgml_hip_program* p, const zgml
         }
     }
     const uint64_t t0 = now_ns();
-    CTX_CHECK(ctx, hipStreamSynchronize(s));
+    const bool ok = CTX_CHECK(ctx, hipStreamSynchronize(s));
     p->profile.sync_time_ns += now_ns() - t0;
     p->profile.sync_count++;
     if (n_outputs && p->out_plan.word_aligned) {
@@ -939,10 +936,34 @@ void zgml_hip_execute_program(zgml_hip_ctx* ctx, zgml_hip_program* p, const zgml
             off += (outputs[i].size + 3) / 4 * 4;
         }
     }
+    return ok;
+}
+
+void zgml_hip_execute_program(zgml_hip_ctx* ctx, zgml_hip_program* p, const zgml_program_io* inputs, uint64_t n_inputs,
+                              const zgml_program_io* outputs, uint64_t n_outputs) {
+    if (!ctx || !p) return;
+    hipSetDevice(ctx->device);
+    // both transfer tables are validated before anything is enqueued
+    if (!prepare_io(p, p->in_plan, inputs, n_inputs) || !prepare_io(p, p->out_plan, outputs, n_outputs)) return;
+    if (!upload_inputs(ctx, p, inputs, n_inputs)) return;
+    enqueue(p);
+    download_outputs(ctx, p, outputs, n_outputs);
     p->profile.call_count++;
     p->profile.backend_op_count += p->ops.size();
     p->profile.backend_dispatch_count += p->plan.size();
     CTX_CHECK(ctx, hipGetLastError());
+}
+
+void zgml_hip_upload_inputs(zgml_hip_ctx* ctx, zgml_hip_program* p, const zgml_program_io* inputs, uint64_t n_inputs) {
+    if (!ctx || !p) return;
+    hipSetDevice(ctx->device);
+    upload_inputs(ctx, p, inputs, n_inputs);
+}
+
+void zgml_hip_download_outputs(zgml_hip_ctx* ctx, zgml_hip_program* p, const zgml_program_io* outputs, uint64_t n_outputs) {
+    if (!ctx || !p) return;
+    hipSetDevice(ctx->device);
+    download_outputs(ctx, p, outputs, n_outputs);
 }
 
 void zgml_hip_free_program(zgml_hip_ctx* ctx, zgml_hip_program* p) {

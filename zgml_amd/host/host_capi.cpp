@@ -1,0 +1,157 @@
+// host_capi.cpp — plain-C exports of the C++ host side for Python harnesses (tests, bench.py).
+// The compute backend is passed in as a function table whose signatures are exactly the
+// zgml_hip_* entry points (ctx first), so the same session code drives the HIP library or — in
+// tests only — the CPU oracle's ctx-taking wrappers.
+#include <chrono>
+#include <cstring>
+#include <functional>
+
+#include "llama_decode.hpp"
+
+using namespace zgml;
+using namespace zgml::llama;
+
+extern "C" {
+
+typedef struct zh_config {
+    uint32_t vocab_size, d_model, n_heads, n_kv_heads, d_ff, n_layers, max_seq_len;
+    float rope_base, rms_norm_eps;
+    uint32_t tied_lm_head;
+    uint32_t shard_rank, shard_world;
+} zh_config;
+
+typedef struct zh_backend_fns { // same signatures as include/zgml_hip.h
+    void* ctx;
+    void* (*compile_program)(void* ctx, const zgml_device_program* program);
+    void (*refresh_program)(void* ctx, void* handle, const zgml_device_op* ops, uint64_t n_ops);
+    void (*execute_program)(void* ctx, void* handle, const zgml_program_io* inputs, uint64_t n_inputs,
+                            const zgml_program_io* outputs, uint64_t n_outputs);
+    void (*free_program)(void* ctx, void* handle);
+} zh_backend_fns;
+
+typedef struct zh_gather_point {
+    uint32_t op_end;
+    uint16_t buf;
+    uint16_t _pad;
+    uint32_t offset, len_per_rank;
+} zh_gather_point;
+
+struct zh_model {
+    std::unique_ptr<LlamaModel> model;
+    std::unique_ptr<DecodeProgram> dp;
+    std::vector<zgml_qweight_upload> qw_storage;
+    zgml_device_program flat;
+};
+
+struct zh_session {
+    zh_model* m;
+    zh_backend_fns fns;
+    void* handle;
+};
+
+void zh_preset(const char* name, uint32_t max_seq, zh_config* out) {
+    LlamaConfig c = !strcmp(name, "smollm-135m") ? smollm_135m() : !strcmp(name, "llama2-7b") ? llama2_7b(max_seq ? max_seq : 2048) : tiny_test();
+    if (max_seq) c.max_seq_len = max_seq;
+    *out = {c.vocab_size, c.d_model, c.n_heads, c.n_kv_heads, c.d_ff, c.n_layers, c.max_seq_len, c.rope_base, c.rms_norm_eps,
+            c.tied_lm_head ? 1u : 0u, 0, 1};
+}
+
+zh_model* zh_model_create(const zh_config* cfg, int weight_kind, int fused_elementwise, int include_dead_f32, int threads) {
+    LlamaConfig c;
+    c.vocab_size = cfg->vocab_size, c.d_model = cfg->d_model, c.n_heads = cfg->n_heads, c.n_kv_heads = cfg->n_kv_heads;
+    c.d_ff = cfg->d_ff, c.n_layers = cfg->n_layers, c.max_seq_len = cfg->max_seq_len, c.rope_base = cfg->rope_base;
+    c.rms_norm_eps = cfg->rms_norm_eps, c.tied_lm_head = cfg->tied_lm_head != 0;
+    c.shard_rank = cfg->shard_rank, c.shard_world = cfg->shard_world ? cfg->shard_world : 1;
+    if (c.n_heads == 0 || c.d_model % c.n_heads || c.n_heads % c.n_kv_heads) return nullptr;
+    if (c.shard_world > 1 && (c.tied_lm_head || c.n_kv_heads % c.shard_world || (c.d_model / c.shard_world) % 32 ||
+                              (c.d_ff / c.shard_world) % 32 || (c.vocab_size / c.shard_world) % 32 || c.d_ff % c.shard_world ||
+                              c.vocab_size % c.shard_world))
+        return nullptr; // shard slices must stay whole 32-column scale blocks
+    auto* m = new zh_model();
+    m->model = make_synthetic_model(c, (WeightKind)weight_kind, threads);
+    m->dp = build_decode_program(*m->model, fused_elementwise != 0, include_dead_f32 != 0);
+    m->flat = m->dp->program.view(m->qw_storage);
+    return m;
+}
+
+void zh_model_free(zh_model* m) { delete m; }
+
+const zgml_device_program* zh_model_program(zh_model* m) { return &m->flat; }
+
+void zh_model_patch(zh_model* m, uint32_t token, uint32_t pos) { patch_step(*m->model, *m->dp, token, pos); }
+
+const zgml_program_io* zh_model_step_inputs(zh_model* m, uint64_t* n) {
+    *n = m->dp->step_inputs.size();
+    return m->dp->step_inputs.data();
+}
+const zgml_program_io* zh_model_step_outputs(zh_model* m, uint64_t* n) {
+    *n = m->dp->step_outputs.size();
+    return m->dp->step_outputs.data();
+}
+const float* zh_model_logits(zh_model* m) { return m->dp->logits_host.data(); }
+const float* zh_model_token_embed(zh_model* m) { return m->model->token_embed.data(); }
+const float* zh_model_rope_table(zh_model* m, int sin_table) {
+    return sin_table ? m->model->sin_table.data() : m->model->cos_table.data();
+}
+uint16_t zh_model_buf(zh_model* m, int which, uint32_t layer) {
+    switch (which) {
+        case 0: return m->dp->buf_token_input;
+        case 1: return m->dp->buf_attn_mask;
+        case 2: return m->dp->buf_logits;
+        case 3: return m->dp->buf_rope[layer];
+        case 4: return m->dp->buf_k_cache[layer];
+        case 5: return m->dp->buf_v_cache[layer];
+        default: return 0;
+    }
+}
+uint64_t zh_model_gather_points(zh_model* m, zh_gather_point* out, uint64_t cap) {
+    const auto& g = m->dp->gather_points;
+    for (uint64_t i = 0; i < g.size() && i < cap; i++) out[i] = {g[i].op_end, g[i].buf, 0, g[i].offset, g[i].len_per_rank};
+    return g.size();
+}
+uint64_t zh_model_quant_bytes(zh_model* m, uint64_t* n_weights) { // Q4_0/Q8_0 file-format bytes of the quantized weights
+    uint64_t elems = 0;
+    for (const auto& q : m->model->qweights) elems += q.K * q.N;
+    if (n_weights) *n_weights = elems;
+    return elems / 32 * (m->model->kind == WeightKind::q4_0 ? 18 : 34);
+}
+
+zh_session* zh_session_create(zh_model* m, const zh_backend_fns* fns) {
+    void* h = fns->compile_program(fns->ctx, &m->flat);
+    if (!h) return nullptr;
+    return new zh_session{m, *fns, h};
+}
+
+void zh_session_free(zh_session* s) {
+    if (!s) return;
+    s->fns.free_program(s->fns.ctx, s->handle);
+    delete s;
+}
+
+void* zh_session_handle(zh_session* s) { return s->handle; }
+
+// doStep (llama_smollm_bench.zig:290-314): patch, refresh, execute. Returns the greedy token.
+int64_t zh_session_step(zh_session* s, uint32_t token, uint32_t pos, float* logits_out) {
+    DecodeProgram& dp = *s->m->dp;
+    patch_step(*s->m->model, dp, token, pos);
+    s->fns.refresh_program(s->fns.ctx, s->handle, dp.program.ops.data(), dp.program.ops.size());
+    s->fns.execute_program(s->fns.ctx, s->handle, dp.step_inputs.data(), dp.step_inputs.size(), dp.step_outputs.data(),
+                           dp.step_outputs.size());
+    if (logits_out) std::memcpy(logits_out, dp.logits_host.data(), dp.logits_host.size() * sizeof(float));
+    return LlamaDeviceSession::argmax(dp.logits_host.data(), (uint32_t)dp.logits_host.size());
+}
+
+// Greedy decode through the vtable contract (host logits every step): feeds `first_token` at
+// `start_pos`, then its own argmax, for n_steps; writes the produced tokens; returns seconds.
+double zh_session_decode(zh_session* s, uint32_t first_token, uint32_t start_pos, uint32_t n_steps, int64_t* tokens_out) {
+    uint32_t tok = first_token;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t i = 0; i < n_steps; i++) {
+        const int64_t next = zh_session_step(s, tok, start_pos + i, nullptr);
+        if (tokens_out) tokens_out[i] = next;
+        tok = (uint32_t)next;
+    }
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+} // extern "C"

@@ -1,0 +1,162 @@
+"""Python binding of the C++ host side (zgml_amd/host): synthetic LLaMA models, the decode
+DeviceProgram (DeviceInference lowering) and the per-token session loop. The compute backend is a
+function table with the zgml_hip_* signatures — the HIP library in the product, the oracle's
+`zo_vt_*` wrappers in tests."""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+from . import capi
+
+Q4_0, Q8_0 = 0, 1
+
+
+class Config(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("vocab_size", "d_model", "n_heads", "n_kv_heads", "d_ff", "n_layers",
+                                           "max_seq_len")] + [
+        ("rope_base", C.c_float), ("rms_norm_eps", C.c_float), ("tied_lm_head", C.c_uint32),
+        ("shard_rank", C.c_uint32), ("shard_world", C.c_uint32)]
+
+    @property
+    def d_head(self):
+        return self.d_model // self.n_heads
+
+
+class BackendFns(C.Structure):
+    _fields_ = [("ctx", C.c_void_p), ("compile_program", C.c_void_p), ("refresh_program", C.c_void_p),
+                ("execute_program", C.c_void_p), ("free_program", C.c_void_p)]
+
+
+class GatherPoint(C.Structure):
+    _fields_ = [("op_end", C.c_uint32), ("buf", C.c_uint16), ("_pad", C.c_uint16), ("offset", C.c_uint32),
+                ("len_per_rank", C.c_uint32)]
+
+
+_lib = None
+
+
+def load_host() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        path = capi.HOST_LIB_PATH
+        if not Path(path).exists():
+            raise RuntimeError(f"{path} not found: run __graft_entry__.build()")
+        lib = C.CDLL(str(path))
+        vp, u32, u64 = C.c_void_p, C.c_uint32, C.c_uint64
+        lib.zh_preset.argtypes, lib.zh_preset.restype = [C.c_char_p, u32, C.POINTER(Config)], None
+        lib.zh_model_create.argtypes, lib.zh_model_create.restype = [C.POINTER(Config), C.c_int, C.c_int, C.c_int, C.c_int], vp
+        lib.zh_model_free.argtypes, lib.zh_model_free.restype = [vp], None
+        lib.zh_model_program.argtypes, lib.zh_model_program.restype = [vp], C.POINTER(capi.DeviceProgramC)
+        lib.zh_model_patch.argtypes, lib.zh_model_patch.restype = [vp, u32, u32], None
+        lib.zh_model_step_inputs.argtypes, lib.zh_model_step_inputs.restype = [vp, C.POINTER(u64)], C.POINTER(capi.ProgramIOC)
+        lib.zh_model_step_outputs.argtypes, lib.zh_model_step_outputs.restype = [vp, C.POINTER(u64)], C.POINTER(capi.ProgramIOC)
+        lib.zh_model_logits.argtypes, lib.zh_model_logits.restype = [vp], C.POINTER(C.c_float)
+        lib.zh_model_token_embed.argtypes, lib.zh_model_token_embed.restype = [vp], C.POINTER(C.c_float)
+        lib.zh_model_rope_table.argtypes, lib.zh_model_rope_table.restype = [vp, C.c_int], C.POINTER(C.c_float)
+        lib.zh_model_buf.argtypes, lib.zh_model_buf.restype = [vp, C.c_int, u32], C.c_uint16
+        lib.zh_model_gather_points.argtypes, lib.zh_model_gather_points.restype = [vp, C.POINTER(GatherPoint), u64], u64
+        lib.zh_model_quant_bytes.argtypes, lib.zh_model_quant_bytes.restype = [vp, C.POINTER(u64)], u64
+        lib.zh_session_create.argtypes, lib.zh_session_create.restype = [vp, C.POINTER(BackendFns)], vp
+        lib.zh_session_free.argtypes, lib.zh_session_free.restype = [vp], None
+        lib.zh_session_handle.argtypes, lib.zh_session_handle.restype = [vp], vp
+        lib.zh_session_step.argtypes, lib.zh_session_step.restype = [vp, u32, u32, vp], C.c_int64
+        lib.zh_session_decode.argtypes, lib.zh_session_decode.restype = [vp, u32, u32, u32, vp], C.c_double
+        _lib = lib
+    return _lib
+
+
+def preset(name: str, max_seq: int = 0) -> Config:
+    c = Config()
+    load_host().zh_preset(name.encode(), max_seq, C.byref(c))
+    return c
+
+
+def _fn_addr(lib, name) -> int:
+    return C.cast(getattr(lib, name), C.c_void_p).value
+
+
+def hip_backend_fns(backend) -> BackendFns:
+    """Function table of the HIP library for context `backend.ctx` (zgml_amd.Backend)."""
+    lib = capi.load_hip()
+    return BackendFns(backend.ctx, _fn_addr(lib, "zgml_hip_compile_program"), _fn_addr(lib, "zgml_hip_refresh_program"),
+                      _fn_addr(lib, "zgml_hip_execute_program"), _fn_addr(lib, "zgml_hip_free_program"))
+
+
+class Model:
+    """Synthetic LLaMA weights + the decode DeviceProgram (`DeviceInference.init`, token_len = 1)."""
+
+    def __init__(self, cfg: Config, weight_kind: int = Q4_0, fused_elementwise: bool = True,
+                 include_dead_f32: bool = False, threads: int = 8):
+        self.lib = load_host()
+        self.cfg = cfg
+        self.ptr = self.lib.zh_model_create(C.byref(cfg), weight_kind, int(fused_elementwise), int(include_dead_f32), threads)
+        if not self.ptr:
+            raise ValueError("invalid LlamaConfig / shard spec")
+
+    def close(self):
+        if self.ptr:
+            self.lib.zh_model_free(self.ptr)
+            self.ptr = None
+
+    @property
+    def program(self) -> capi.DeviceProgramC:
+        return self.lib.zh_model_program(self.ptr).contents
+
+    def patch(self, token: int, pos: int) -> None:
+        self.lib.zh_model_patch(self.ptr, token, pos)
+
+    def buf(self, which: str, layer: int = 0) -> int:
+        idx = {"token_input": 0, "attn_mask": 1, "logits": 2, "rope": 3, "k_cache": 4, "v_cache": 5}[which]
+        return int(self.lib.zh_model_buf(self.ptr, idx, layer))
+
+    def token_embed(self) -> np.ndarray:
+        p = self.lib.zh_model_token_embed(self.ptr)
+        return np.ctypeslib.as_array(p, shape=(self.cfg.vocab_size, self.cfg.d_model))
+
+    def rope_tables(self):
+        shape = (self.cfg.max_seq_len, self.cfg.d_head)
+        return (np.ctypeslib.as_array(self.lib.zh_model_rope_table(self.ptr, 0), shape=shape),
+                np.ctypeslib.as_array(self.lib.zh_model_rope_table(self.ptr, 1), shape=shape))
+
+    def gather_points(self):
+        n = self.lib.zh_model_gather_points(self.ptr, None, 0)
+        arr = (GatherPoint * max(1, n))()
+        self.lib.zh_model_gather_points(self.ptr, arr, n)
+        return list(arr[:n])
+
+    def quant_bytes(self):
+        n = C.c_uint64()
+        b = self.lib.zh_model_quant_bytes(self.ptr, C.byref(n))
+        return int(b), int(n.value)
+
+
+class Session:
+    """`LlamaDeviceSession`: compile once, then doStep per token through the vtable."""
+
+    def __init__(self, model: Model, fns: BackendFns):
+        self.model, self.lib, self.fns = model, model.lib, fns
+        self.ptr = self.lib.zh_session_create(model.ptr, C.byref(fns))
+        if not self.ptr:
+            raise RuntimeError("compile_program failed")
+
+    @property
+    def handle(self):
+        return self.lib.zh_session_handle(self.ptr)
+
+    def step(self, token: int, pos: int, want_logits: bool = True):
+        logits = np.zeros(self.model.cfg.vocab_size, np.float32) if want_logits else None
+        nxt = self.lib.zh_session_step(self.ptr, token, pos, logits.ctypes.data if want_logits else None)
+        return int(nxt), logits
+
+    def decode(self, first_token: int, start_pos: int, n_steps: int):
+        toks = np.zeros(n_steps, np.int64)
+        secs = self.lib.zh_session_decode(self.ptr, first_token, start_pos, n_steps, toks.ctypes.data)
+        return toks, secs
+
+    def close(self):
+        if self.ptr:
+            self.lib.zh_session_free(self.ptr)
+            self.ptr = None

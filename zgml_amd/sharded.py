@@ -1,0 +1,115 @@
+"""Row-sharded (N-split) Llama decode across ranks: one process per GPU, `torch.distributed`
+(backend "nccl" = RCCL over xGMI) all-gathers between op ranges of the per-rank DeviceProgram.
+
+The reference has no distributed code; this is the multi-GPU extension of its decode
+path: every quantized weight is split along N (output features, whole 32-column scale
+blocks), activations are replicated, KV caches are head-sharded. Per layer there are 4 gathers
+(attention output, O-proj, SwiGLU activation, down-proj) plus one for the logits; each moves
+N/ws f32 per rank (2-44 KB): latency-bound, not bandwidth-bound.
+
+`ShardedDecoder` is executor-agnostic: `HipExecutor` drives the HIP library; the CPU tests plug
+the oracle in through the same interface with the gloo backend.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import capi
+from .llama import Model
+
+
+class _DevArray:
+    """Minimal __cuda_array_interface__ holder so torch can wrap a raw device pointer."""
+
+    def __init__(self, ptr: int, n: int):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+
+
+class HipExecutor:
+    def __init__(self, backend, model: Model, device: int):
+        self.be, self.model, self.lib = backend, model, capi.load_hip()
+        prog = model.program
+        self.handle = self.lib.zgml_hip_compile_program(backend.ctx, C.byref(prog))
+        if not self.handle:
+            raise RuntimeError("compile failed: " + backend.last_error())
+        self.n_ops = int(prog.n_ops)
+        self.device = torch.device("cuda", device)
+        self.stream = torch.cuda.ExternalStream(self.lib.zgml_hip_stream(backend.ctx), device=self.device)
+        self._views = {}
+        n = C.c_uint64()
+        self._in = model.lib.zh_model_step_inputs(model.ptr, C.byref(n)), n.value
+        n = C.c_uint64()
+        self._out = model.lib.zh_model_step_outputs(model.ptr, C.byref(n)), n.value
+
+    def refresh(self):
+        prog = self.model.program
+        self.lib.zgml_hip_refresh_program(self.be.ctx, self.handle, prog.ops, prog.n_ops)
+
+    def upload(self):
+        self.lib.zgml_hip_upload_inputs(self.be.ctx, self.handle, self._in[0], self._in[1])
+
+    def run_ops(self, first: int, count: int):
+        if count > 0:
+            self.lib.zgml_hip_enqueue_ops(self.be.ctx, self.handle, first, count)
+
+    def tensor(self, buf: int, offset: int, n: int) -> torch.Tensor:
+        key = (buf, offset, n)
+        if key not in self._views:
+            base = self.lib.zgml_hip_program_buffer_ptr(self.handle, buf)
+            self._views[key] = torch.as_tensor(_DevArray(base + 4 * offset, n), device=self.device)
+        return self._views[key]
+
+    def collective_stream(self):
+        return torch.cuda.stream(self.stream)
+
+    def download_logits(self) -> np.ndarray:
+        self.lib.zgml_hip_download_outputs(self.be.ctx, self.handle, self._out[0], self._out[1])
+        p = self.model.lib.zh_model_logits(self.model.ptr)
+        return np.ctypeslib.as_array(p, shape=(self.model.cfg.vocab_size,))
+
+    def synchronize(self):
+        self.lib.zgml_hip_synchronize(self.be.ctx)
+
+    def close(self):
+        if self.handle:
+            self.lib.zgml_hip_free_program(self.be.ctx, self.handle)
+            self.handle = None
+
+
+class ShardedDecoder:
+    """One decode step = op ranges separated by in-place all-gathers of replicated activations."""
+
+    def __init__(self, model: Model, executor, group=None, inplace: bool = True):
+        self.model, self.ex, self.group = model, executor, group
+        self.ws = model.cfg.shard_world
+        self.rank = model.cfg.shard_rank
+        self.points = model.gather_points()
+        self.inplace = inplace
+
+    def _all_gather(self, full: torch.Tensor, n: int):
+        mine = full[self.rank * n:(self.rank + 1) * n]
+        if self.inplace:
+            dist.all_gather_into_tensor(full, mine, group=self.group)
+        else:  # backends without an in-place flat all-gather (gloo)
+            chunks = [torch.empty_like(mine) for _ in range(self.ws)]
+            dist.all_gather(chunks, mine.clone(), group=self.group)
+            for r, c in enumerate(chunks):
+                full[r * n:(r + 1) * n].copy_(c)
+
+    def step(self, token: int, pos: int, download: bool = True):
+        self.model.patch(token, pos)
+        self.ex.refresh()
+        self.ex.upload()
+        prev = 0
+        with self.ex.collective_stream():
+            for gp in self.points:
+                self.ex.run_ops(prev, gp.op_end - prev)
+                if self.ws > 1:
+                    self._all_gather(self.ex.tensor(gp.buf, gp.offset, self.ws * gp.len_per_rank), gp.len_per_rank)
+                prev = gp.op_end
+            self.ex.run_ops(prev, self.ex.n_ops - prev)
+        return self.ex.download_logits() if download else None
