@@ -346,6 +346,29 @@ void zgml_hip_download_outputs(zgml_hip_ctx* ctx, zgml_hip_program* handle, cons
 int64_t zgml_hip_argmax(zgml_hip_ctx* ctx, zgml_hip_program* handle, uint16_t buf_idx,
                         uint64_t offset, uint64_t n);
 
+/* Device-resident greedy decode for LLaMA-shaped programs (measurement protocol: inputs already
+ * in HBM when the timed region starts). The reference's per-token host work — embedding-row
+ * copy, causal-mask column, RoPE row, KV position / seq_kv patching, logits download + argmax
+ * (src/llama_inference.zig:405-466, benchmarks/llama_smollm_bench.zig:290-314,
+ * scripts/generate_llama.zig:101-110) — is done by one small device kernel before and one after
+ * the program graph, from tables uploaded once; a token costs one graph launch and no host<->
+ * device traffic. Results are identical to stepping through execute_program (tests check it). */
+typedef struct zgml_resident_llama {
+    const float* token_embed; /* host [vocab][d_model], uploaded once */
+    const float* cos_table;   /* host [max_seq][d_head] */
+    const float* sin_table;   /* host [max_seq][d_head] */
+    uint32_t vocab, d_model, max_seq, d_head;
+    uint16_t buf_token_input, buf_attn_mask, buf_logits, _pad;
+    const uint16_t* buf_rope; /* one packed cos|sin leaf per layer */
+    uint32_t n_rope;
+    uint32_t _pad2;
+} zgml_resident_llama;
+int zgml_hip_resident_setup(zgml_hip_ctx* ctx, zgml_hip_program* handle, const zgml_resident_llama* desc);
+/* Feed `first_token` at `start_pos`, then the argmax of each step, for n_steps; blocking. Writes
+ * the n_steps produced tokens. Returns 0 on success. */
+int zgml_hip_resident_decode(zgml_hip_ctx* ctx, zgml_hip_program* handle, uint32_t first_token,
+                             uint32_t start_pos, uint32_t n_steps, int64_t* tokens_out);
+
 /* Mat-vec roofline micro-benchmark: builds `n_matrices` distinct K x N quantized
  * matrices on the device from the deterministic synthetic generator (q4: nibbles in [-8,7];
  * otherwise int8), runs `warmup` + `iters` launches round-robin over the ring and returns the

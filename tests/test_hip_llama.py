@@ -69,3 +69,22 @@ def test_kv_cache_position_independence(hip_backend, oracle):
         assert np.array_equal(x, y)
     s.close()
     m.close()
+
+
+@pytest.mark.parametrize("name,kind", [("tiny", llama.Q4_0), ("tiny", llama.Q8_0), ("smollm-135m", llama.Q4_0)])
+def test_resident_decode_equals_vtable_stepping(hip_backend, name, kind):
+    """The device-resident loop (on-device embedding/mask/rope/argmax) must produce exactly the
+    tokens of doStep through execute_program, and leave the program usable by the vtable path."""
+    m = llama.Model(llama.preset(name), kind, threads=8)
+    s = llama.Session(m, llama.hip_backend_fns(hip_backend))
+    n = 24 if name == "tiny" else 12
+    s.resident_setup(hip_backend)
+    got = s.resident_decode(5, 0, n)  # first execution of the program is the resident loop
+    want, _ = s.decode(5, 0, n)
+    assert got.tolist() == want.tolist()
+    again, _ = s.decode(5, 0, n)  # vtable path after a resident run
+    assert again.tolist() == want.tolist()
+    half = s.resident_decode(int(want[n // 2 - 1]), n // 2, n - n // 2)  # resume mid-stream on the warm KV cache
+    assert half.tolist() == want[n // 2:].tolist()
+    s.close()
+    m.close()

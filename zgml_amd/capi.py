@@ -150,6 +150,13 @@ class CapabilitiesC(C.Structure):
         ("attention_max_d_head", C.c_uint32)]
 
 
+class ResidentLlamaC(C.Structure):
+    _fields_ = [("token_embed", C.c_void_p), ("cos_table", C.c_void_p), ("sin_table", C.c_void_p),
+                ("vocab", C.c_uint32), ("d_model", C.c_uint32), ("max_seq", C.c_uint32), ("d_head", C.c_uint32),
+                ("buf_token_input", C.c_uint16), ("buf_attn_mask", C.c_uint16), ("buf_logits", C.c_uint16),
+                ("_pad", C.c_uint16), ("buf_rope", C.POINTER(C.c_uint16)), ("n_rope", C.c_uint32), ("_pad2", C.c_uint32)]
+
+
 class RuntimeProfileC(C.Structure):
     _fields_ = [("time_ns", C.c_uint64 * 12), ("backend_op_count", C.c_uint64),
                 ("fallback_op_count", C.c_uint64), ("backend_dispatch_count", C.c_uint64),
@@ -166,7 +173,7 @@ HIP_SYMBOLS = [
     "zgml_hip_free_program", "zgml_hip_get_runtime_profile", "zgml_hip_set_option",
     "zgml_hip_program_buffer_ptr", "zgml_hip_stream", "zgml_hip_enqueue_program",
     "zgml_hip_enqueue_ops", "zgml_hip_synchronize", "zgml_hip_upload_inputs", "zgml_hip_download_outputs", "zgml_hip_argmax", "zgml_hip_qmatvec_bench",
-    "zgml_hip_qmatvec_synth", "zgml_hip_copy_bench",
+    "zgml_hip_qmatvec_synth", "zgml_hip_copy_bench", "zgml_hip_resident_setup", "zgml_hip_resident_decode",
 ]
 
 OPT_FUSION, OPT_GRAPH, OPT_PROFILE, OPT_SKIP_DEAD_UPLOADS, OPT_F16_DENSE_WEIGHTS = 1, 2, 3, 4, 5
@@ -214,6 +221,10 @@ def _bind_hip(lib: C.CDLL) -> None:
     lib.zgml_hip_qmatvec_bench.argtypes = [vp, u32, u32, i32, u32, u32, u32, C.POINTER(u64)]
     lib.zgml_hip_qmatvec_synth.restype = i32
     lib.zgml_hip_qmatvec_synth.argtypes = [vp, u32, u32, i32, u32, vp, vp]
+    lib.zgml_hip_resident_setup.restype = i32
+    lib.zgml_hip_resident_setup.argtypes = [vp, vp, C.POINTER(ResidentLlamaC)]
+    lib.zgml_hip_resident_decode.restype = i32
+    lib.zgml_hip_resident_decode.argtypes = [vp, vp, u32, u32, u32, vp]
     lib.zgml_hip_copy_bench.restype = C.c_double
     lib.zgml_hip_copy_bench.argtypes = [vp, u64, u32, u32]
 

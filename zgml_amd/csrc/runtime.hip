@@ -82,6 +82,7 @@ struct zgml_hip_ctx {
     }
 };
 
+struct zgml_resident;
 struct zgml_hip_program {
     zgml_hip_ctx* ctx = nullptr;
     std::vector<zgml_device_op> ops;
@@ -107,6 +108,7 @@ struct zgml_hip_program {
     uint64_t stage_cap = 0;
     IoPlan in_plan, out_plan;
     zgml_runtime_profile profile{};
+    zgml_resident* resident = nullptr;
 };
 
 namespace {
@@ -610,6 +612,88 @@ bool grow(zgml_hip_ctx* ctx, float** ptr, uint64_t* cap, uint64_t elems) {
     return true;
 }
 
+// ── device-resident LLaMA decode (extension; see include/zgml_hip.h) ─────────────────────────
+} // namespace
+struct zgml_resident {
+    float *embed = nullptr, *cos = nullptr, *sin = nullptr;
+    uint32_t vocab = 0, d = 0, max_seq = 0, dh = 0, n_rope = 0;
+    float *tok_in = nullptr, *mask = nullptr, *logits = nullptr;
+    float** rope_bufs = nullptr;   // device array of n_rope pointers
+    uint32_t* dyn_kind = nullptr;  // per op: 0 static, 1 slice_assign(base,stride), 2 attention
+    uint32_t* dyn_base = nullptr;
+    uint32_t* dyn_stride = nullptr;
+    uint32_t* state = nullptr;     // [0] token, [1] pos, [2] produced count
+    int64_t* tokens = nullptr;     // produced tokens (device)
+    uint32_t tokens_cap = 0;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+};
+using Resident = zgml_resident;
+namespace {
+
+void free_resident(zgml_hip_program* p) {
+    Resident* r = p->resident;
+    if (!r) return;
+    if (r->graph_exec) hipGraphExecDestroy(r->graph_exec);
+    if (r->graph) hipGraphDestroy(r->graph);
+    hipFree(r->embed);
+    hipFree(r->cos);
+    hipFree(r->sin);
+    hipFree(r->rope_bufs);
+    hipFree(r->dyn_kind);
+    hipFree(r->dyn_base);
+    hipFree(r->dyn_stride);
+    hipFree(r->state);
+    hipFree(r->tokens);
+    delete r;
+    p->resident = nullptr;
+}
+
+struct ResidentPrepArgs {
+    const float *embed, *cos, *sin;
+    float *tok_in, *mask;
+    float* const* rope_bufs;
+    const uint32_t *dyn_kind, *dyn_base, *dyn_stride;
+    uint32_t* dyn;
+    const uint32_t* state;
+    uint32_t d, max_seq, dh, n_rope, n_ops;
+};
+
+// Everything LlamaInferencePlan.execute patches on the host per token, as one flat index space.
+__global__ void __launch_bounds__(256) resident_prep_kernel(ResidentPrepArgs a) {
+    const uint32_t token = a.state[0], pos = a.state[1];
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < a.d) {
+        a.tok_in[i] = a.embed[(uint64_t)token * a.d + i];
+        return;
+    }
+    i -= a.d;
+    if (i < a.max_seq) {
+        a.mask[i] = i <= pos ? 0.0f : -INFINITY;
+        return;
+    }
+    i -= a.max_seq;
+    if (i < a.n_rope * 2 * a.dh) {
+        const uint32_t l = i / (2 * a.dh), j = i % (2 * a.dh);
+        a.rope_bufs[l][j] = j < a.dh ? a.cos[(uint64_t)pos * a.dh + j] : a.sin[(uint64_t)pos * a.dh + j - a.dh];
+        return;
+    }
+    i -= a.n_rope * 2 * a.dh;
+    if (i < a.n_ops) {
+        if (a.dyn_kind[i] == 1) a.dyn[i] = a.dyn_base[i] + pos * a.dyn_stride[i];
+        if (a.dyn_kind[i] == 2) a.dyn[i] = pos + 1;
+    }
+}
+
+__global__ void resident_advance_kernel(const int64_t* arg_out, uint32_t* state, int64_t* tokens, uint32_t cap) {
+    const int64_t next = *arg_out;
+    const uint32_t n = state[2];
+    if (n < cap) tokens[n] = next;
+    state[0] = (uint32_t)next;
+    state[1] += 1;
+    state[2] = n + 1;
+}
+
 } // namespace
 
 // ════════════════════════════════ C ABI ════════════════════════════════
@@ -973,6 +1057,7 @@ void zgml_hip_free_program(zgml_hip_ctx* ctx, zgml_hip_program* p) {
         hipStreamSynchronize(ctx->stream);
     }
     free_graph(p);
+    free_resident(p);
     if (p->arena) hipFree(p->arena);
     for (void* d : p->owned) hipFree(d);
     if (p->scratch) hipFree(p->scratch);
@@ -1155,6 +1240,130 @@ double zgml_hip_copy_bench(zgml_hip_ctx* ctx, uint64_t bytes, uint32_t warmup, u
     hipFree(a);
     hipFree(b);
     return us;
+}
+
+int zgml_hip_resident_setup(zgml_hip_ctx* ctx, zgml_hip_program* p, const zgml_resident_llama* d) {
+    if (!ctx || !p || !d) return -1;
+    hipSetDevice(ctx->device);
+    free_resident(p);
+    auto live = [&](uint16_t b) { return b < p->bufs.size() && p->bufs[b]; };
+    if (!live(d->buf_token_input) || !live(d->buf_attn_mask) || !live(d->buf_logits) ||
+        p->sizes[d->buf_token_input] < d->d_model || p->sizes[d->buf_attn_mask] < d->max_seq ||
+        p->sizes[d->buf_logits] < d->vocab) {
+        ctx->fail("resident_setup: bad buffer ids");
+        return -1;
+    }
+    Resident* r = new Resident();
+    p->resident = r;
+    r->vocab = d->vocab, r->d = d->d_model, r->max_seq = d->max_seq, r->dh = d->d_head, r->n_rope = d->n_rope;
+    r->tok_in = p->bufs[d->buf_token_input], r->mask = p->bufs[d->buf_attn_mask], r->logits = p->bufs[d->buf_logits];
+    const size_t n_ops = p->ops.size();
+    std::vector<float*> ropes(d->n_rope);
+    for (uint32_t l = 0; l < d->n_rope; l++) {
+        if (!live(d->buf_rope[l]) || p->sizes[d->buf_rope[l]] < 2 * d->d_head) {
+            ctx->fail("resident_setup: bad rope buffer");
+            return -1;
+        }
+        ropes[l] = p->bufs[d->buf_rope[l]];
+    }
+    std::vector<uint32_t> kind(n_ops, 0), base(n_ops, 0), stride(n_ops, 0);
+    for (size_t i = 0; i < n_ops; i++) {
+        if (p->ops[i].kind == ZGML_DOP_SLICE_ASSIGN && p->ops[i].u.slice_assign.patch_stride) {
+            kind[i] = 1, base[i] = p->ops[i].u.slice_assign.dst_base_offset, stride[i] = p->ops[i].u.slice_assign.patch_stride;
+        } else if (p->ops[i].kind == ZGML_DOP_ATTENTION) {
+            kind[i] = 2;
+        }
+    }
+    const size_t tab = (size_t)d->max_seq * d->d_head * 4, emb = (size_t)d->vocab * d->d_model * 4;
+    bool ok = CTX_CHECK(ctx, hipMalloc((void**)&r->embed, emb)) && CTX_CHECK(ctx, hipMalloc((void**)&r->cos, tab)) &&
+              CTX_CHECK(ctx, hipMalloc((void**)&r->sin, tab)) &&
+              CTX_CHECK(ctx, hipMalloc((void**)&r->rope_bufs, (ropes.size() + 1) * sizeof(float*))) &&
+              CTX_CHECK(ctx, hipMalloc((void**)&r->dyn_kind, (n_ops + 1) * 4)) &&
+              CTX_CHECK(ctx, hipMalloc((void**)&r->dyn_base, (n_ops + 1) * 4)) &&
+              CTX_CHECK(ctx, hipMalloc((void**)&r->dyn_stride, (n_ops + 1) * 4)) &&
+              CTX_CHECK(ctx, hipMalloc((void**)&r->state, 4 * 4)) &&
+              CTX_CHECK(ctx, hipMemcpy(r->embed, d->token_embed, emb, hipMemcpyHostToDevice)) &&
+              CTX_CHECK(ctx, hipMemcpy(r->cos, d->cos_table, tab, hipMemcpyHostToDevice)) &&
+              CTX_CHECK(ctx, hipMemcpy(r->sin, d->sin_table, tab, hipMemcpyHostToDevice)) &&
+              CTX_CHECK(ctx, hipMemcpy(r->rope_bufs, ropes.data(), ropes.size() * sizeof(float*), hipMemcpyHostToDevice)) &&
+              CTX_CHECK(ctx, hipMemcpy(r->dyn_kind, kind.data(), n_ops * 4, hipMemcpyHostToDevice)) &&
+              CTX_CHECK(ctx, hipMemcpy(r->dyn_base, base.data(), n_ops * 4, hipMemcpyHostToDevice)) &&
+              CTX_CHECK(ctx, hipMemcpy(r->dyn_stride, stride.data(), n_ops * 4, hipMemcpyHostToDevice));
+    if (!ok) {
+        free_resident(p);
+        return -1;
+    }
+    return 0;
+}
+
+int zgml_hip_resident_decode(zgml_hip_ctx* ctx, zgml_hip_program* p, uint32_t first_token, uint32_t start_pos,
+                             uint32_t n_steps, int64_t* tokens_out) {
+    if (!ctx || !p || !p->resident || !tokens_out) return -1;
+    Resident* r = p->resident;
+    if (first_token >= r->vocab || (uint64_t)start_pos + n_steps > r->max_seq) {
+        ctx->fail("resident_decode: token or position out of range");
+        return -1;
+    }
+    hipSetDevice(ctx->device);
+    hipStream_t s = ctx->stream;
+    if (p->plan_dirty) {
+        free_graph(p);
+        build_plan(p);
+    }
+    if (r->tokens_cap < n_steps) {
+        hipStreamSynchronize(s);
+        hipFree(r->tokens);
+        r->tokens = nullptr;
+        if (!CTX_CHECK(ctx, hipMalloc((void**)&r->tokens, (size_t)n_steps * 8))) return -1;
+        r->tokens_cap = n_steps;
+        if (r->graph_exec) hipGraphExecDestroy(r->graph_exec); // the graph baked the old pointer/cap
+        if (r->graph) hipGraphDestroy(r->graph);
+        r->graph_exec = nullptr, r->graph = nullptr;
+    }
+    ResidentPrepArgs a{r->embed, r->cos, r->sin, r->tok_in, r->mask, r->rope_bufs, r->dyn_kind, r->dyn_base, r->dyn_stride,
+                       p->dyn_dev, r->state, r->d, r->max_seq, r->dh, r->n_rope, (uint32_t)p->ops.size()};
+    const uint32_t total = r->d + r->max_seq + r->n_rope * 2 * r->dh + (uint32_t)p->ops.size();
+    auto one_token = [&](hipStream_t st) {
+        resident_prep_kernel<<<(total + 255) / 256, 256, 0, st>>>(a);
+        run_plan(p, st, 0, p->plan.size());
+        launch_argmax(st, r->logits, r->vocab, ctx->arg_val, ctx->arg_idx, ctx->arg_out);
+        resident_advance_kernel<<<1, 1, 0, st>>>(ctx->arg_out, r->state, r->tokens, r->tokens_cap);
+    };
+    // static dyn words (row stores with patch_stride 0) come from the host mirror; the prep kernel
+    // only rewrites the position-dependent ones
+    set_dyn_from_ops(p);
+    p->dyn_dirty = true;
+    flush_dyn(p);
+    const uint32_t st0[4] = {first_token, start_pos, 0, 0};
+    if (!CTX_CHECK(ctx, hipMemcpyAsync(r->state, st0, sizeof(st0), hipMemcpyHostToDevice, s))) return -1;
+    if (ctx->opt_graph && !r->graph_exec) {
+        hipGraph_t g = nullptr;
+        if (CTX_CHECK(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal))) {
+            one_token(s);
+            if (CTX_CHECK(ctx, hipStreamEndCapture(s, &g)) && g) {
+                if (CTX_CHECK(ctx, hipGraphInstantiate(&r->graph_exec, g, nullptr, nullptr, 0)))
+                    r->graph = g;
+                else
+                    hipGraphDestroy(g);
+            }
+        }
+    }
+    for (uint32_t i = 0; i < n_steps; i++) {
+        if (r->graph_exec)
+            hipGraphLaunch(r->graph_exec, s);
+        else
+            one_token(s);
+    }
+    hipMemcpyAsync(tokens_out, r->tokens, (size_t)n_steps * 8, hipMemcpyDeviceToHost, s);
+    const bool ok = CTX_CHECK(ctx, hipStreamSynchronize(s));
+    // the device rewrote the dyn block behind the host mirror's back: force a re-upload next time
+    memset(p->dyn_host, 0xFF, p->ops.size() * sizeof(uint32_t));
+    set_dyn_from_ops(p);
+    p->dyn_dirty = true;
+    p->profile.call_count += n_steps;
+    p->profile.backend_op_count += (uint64_t)n_steps * p->ops.size();
+    p->profile.backend_dispatch_count += (uint64_t)n_steps * (p->plan.size() + 4);
+    return ok ? 0 : -1;
 }
 
 } // extern "C"

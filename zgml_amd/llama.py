@@ -156,6 +156,31 @@ class Session:
         secs = self.lib.zh_session_decode(self.ptr, first_token, start_pos, n_steps, toks.ctypes.data)
         return toks, secs
 
+    # ── device-resident loop (HIP backend only; include/zgml_hip.h zgml_hip_resident_*) ──
+    def resident_setup(self, backend) -> None:
+        m, cfg = self.model, self.model.cfg
+        hip = capi.load_hip()
+        cos, sin = m.rope_tables()
+        ropes = (C.c_uint16 * cfg.n_layers)(*[m.buf("rope", l) for l in range(cfg.n_layers)])
+        d = capi.ResidentLlamaC()
+        d.token_embed = m.token_embed().ctypes.data
+        d.cos_table, d.sin_table = cos.ctypes.data, sin.ctypes.data
+        d.vocab, d.d_model, d.max_seq, d.d_head = cfg.vocab_size, cfg.d_model, cfg.max_seq_len, cfg.d_head
+        d.buf_token_input, d.buf_attn_mask, d.buf_logits = m.buf("token_input"), m.buf("attn_mask"), m.buf("logits")
+        d.buf_rope, d.n_rope = C.cast(ropes, C.POINTER(C.c_uint16)), cfg.n_layers
+        self._resident_keep = (ropes, cos, sin)
+        if hip.zgml_hip_resident_setup(backend.ctx, self.handle, C.byref(d)) != 0:
+            raise RuntimeError("resident_setup: " + backend.last_error())
+        self._backend = backend
+
+    def resident_decode(self, first_token: int, start_pos: int, n_steps: int) -> np.ndarray:
+        toks = np.zeros(n_steps, np.int64)
+        rc = capi.load_hip().zgml_hip_resident_decode(self._backend.ctx, self.handle, first_token, start_pos, n_steps,
+                                                      toks.ctypes.data)
+        if rc != 0:
+            raise RuntimeError("resident_decode: " + self._backend.last_error())
+        return toks
+
     def close(self):
         if self.ptr:
             self.lib.zh_session_free(self.ptr)
