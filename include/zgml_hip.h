@@ -334,6 +334,10 @@ void* zgml_hip_stream(zgml_hip_ctx* ctx);
 void zgml_hip_enqueue_program(zgml_hip_ctx* ctx, zgml_hip_program* handle);
 /* Enqueue ops [first, first+count) only (multi-GPU harness interleaves collectives). */
 void zgml_hip_enqueue_ops(zgml_hip_ctx* ctx, zgml_hip_program* handle, uint64_t first, uint64_t count);
+/* Declare op indices that batched launches must not straddle (the positions of the harness's
+ * collectives); enqueue_ops ranges must start/end on them. */
+int zgml_hip_program_set_barriers(zgml_hip_ctx* ctx, zgml_hip_program* handle, const uint64_t* op_indices,
+                                  uint64_t n);
 void zgml_hip_synchronize(zgml_hip_ctx* ctx);
 /* The two halves of execute_program on their own, for harnesses that interleave collectives with
  * op ranges: enqueue the host->device transfers / run the device->host transfers (blocking). */

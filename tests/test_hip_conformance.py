@@ -203,3 +203,32 @@ def test_argmax_first_max_wins(hip_backend, oracle):
     assert hip_backend.argmax(h, 0, 0, v.size) == oracle.argmax(v) == 100
     assert hip_backend.argmax(h, 0, 101, v.size - 101) == 40000 - 101
     hip_backend.freeProgram(h)
+
+
+def test_refresh_beyond_assumed_bounds_falls_back_correctly(hip_backend, oracle):
+    """The level-batched plan assumes seq_kv never exceeds its compile-time value and that a
+    dynamic store stays inside its slab; a refresh that breaks the assumption must still give the
+    reference's result (the runtime drops to program order)."""
+    rng = np.random.default_rng(11)
+    dh, skv = 32, 300
+    q, k, v = (rng.standard_normal(n).astype(f32) for n in (dh, dh * skv, dh * skv))
+    src = rng.standard_normal(dh).astype(f32)
+    # store a new key column at a dynamic position, then attend over seq_kv keys
+    sa = DeviceOp.slice_assign(1, 5, dh, 1, dst_base_offset=0, dst_offset=0, dst_row_stride=1, dst_col_stride=dh,
+                               src_offset=0, src_row_stride=1, src_col_stride=dh, patch_stride=dh)
+    att = DeviceOp.attention(4, 0, 1, 2, 3, False, dh, 1, 2, 0.2, 0, 0, 0, 0, 0, 1, dh, 1, dh, 1, dh, 0, 0, 1, dh)
+    prog = DeviceProgram(ops=[sa, att], buffer_sizes=[dh, dh * skv, dh * skv, 1, dh, dh],
+                         initial_uploads=[ProgramIO(0, q), ProgramIO(1, k), ProgramIO(2, v), ProgramIO(5, src)])
+    res = {}
+    for name, be in (("ref", oracle.OracleBackend()), ("hip", hip_backend)):
+        h = be.compileProgram(prog)
+        outs = []
+        for pos, n in ((1, 2), (250, 300), (7, 100)):  # seq_kv 300 > compile-time 2
+            be.refreshProgram(h, [sa.with_(dst_offset=pos * dh), att.with_(seq_kv=n)])
+            o = np.zeros(dh, f32)
+            be.executeProgram(h, [], [ProgramIO(4, o)])
+            outs.append(o)
+        be.freeProgram(h)
+        res[name] = outs
+    for r, g in zip(res["ref"], res["hip"]):
+        np.testing.assert_allclose(g, r, atol=2e-5, rtol=0)

@@ -172,7 +172,7 @@ HIP_SYMBOLS = [
     "zgml_hip_compile_program", "zgml_hip_refresh_program", "zgml_hip_execute_program",
     "zgml_hip_free_program", "zgml_hip_get_runtime_profile", "zgml_hip_set_option",
     "zgml_hip_program_buffer_ptr", "zgml_hip_stream", "zgml_hip_enqueue_program",
-    "zgml_hip_enqueue_ops", "zgml_hip_synchronize", "zgml_hip_upload_inputs", "zgml_hip_download_outputs", "zgml_hip_argmax", "zgml_hip_qmatvec_bench",
+    "zgml_hip_enqueue_ops", "zgml_hip_program_set_barriers", "zgml_hip_synchronize", "zgml_hip_upload_inputs", "zgml_hip_download_outputs", "zgml_hip_argmax", "zgml_hip_qmatvec_bench",
     "zgml_hip_qmatvec_synth", "zgml_hip_copy_bench", "zgml_hip_resident_setup", "zgml_hip_resident_decode",
 ]
 
@@ -211,6 +211,8 @@ def _bind_hip(lib: C.CDLL) -> None:
     lib.zgml_hip_enqueue_program.restype, lib.zgml_hip_enqueue_program.argtypes = None, [vp, vp]
     lib.zgml_hip_enqueue_ops.restype, lib.zgml_hip_enqueue_ops.argtypes = None, [vp, vp, u64, u64]
     lib.zgml_hip_synchronize.restype, lib.zgml_hip_synchronize.argtypes = None, [vp]
+    lib.zgml_hip_program_set_barriers.restype = i32
+    lib.zgml_hip_program_set_barriers.argtypes = [vp, vp, C.POINTER(u64), u64]
     lib.zgml_hip_upload_inputs.restype = None
     lib.zgml_hip_upload_inputs.argtypes = [vp, vp, C.POINTER(ProgramIOC), u64]
     lib.zgml_hip_download_outputs.restype = None

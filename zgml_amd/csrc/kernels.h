@@ -102,10 +102,11 @@ void launch_softmax(hipStream_t s, float* dst, const float* src, uint32_t rows, 
 void launch_layernorm(hipStream_t s, float* dst, const float* src, uint32_t rows, uint32_t cols, float eps);
 void launch_rmsnorm(hipStream_t s, float* dst, const float* src, uint32_t rows, uint32_t cols, float eps);
 void launch_reduce(hipStream_t s, uint32_t op, float* dst, const float* src, uint32_t n_out, uint32_t reduce_size);
-void launch_repeat(hipStream_t s, const RepeatParams& p);
-void launch_slice_assign(hipStream_t s, const SliceAssignParams& p);
-void launch_rope(hipStream_t s, const RopeParams& p);
-void launch_attention(hipStream_t s, const AttentionParams& p);
+// batched: dev_params = device array of n_ops records; one launch covers all of them
+void launch_repeat_batch(hipStream_t s, const RepeatParams* dev_params, uint32_t n_ops, uint32_t max_elems);
+void launch_slice_assign_batch(hipStream_t s, const SliceAssignParams* dev_params, uint32_t n_ops, uint32_t max_elems);
+void launch_rope_batch(hipStream_t s, const RopeParams* dev_params, uint32_t n_ops, uint32_t max_elems);
+void launch_attention_batch(hipStream_t s, const AttentionParams* dev_params, uint32_t n_ops, uint32_t max_seq_q);
 void launch_dense_matmul(hipStream_t s, const DenseMatmulParams& p);
 void launch_argmax(hipStream_t s, const float* v, uint64_t n, float* scratch_val, int64_t* scratch_idx, int64_t* out);
 void launch_copy_f4(hipStream_t s, void* dst, const void* src, uint64_t bytes);

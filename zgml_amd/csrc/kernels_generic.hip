@@ -181,7 +181,8 @@ __global__ void __launch_bounds__(kBlock) reduce_kernel(uint32_t op, float* __re
 
 // reference.zig:391-433 (bit-exact copy semantics; the three fast paths are special cases of the
 // generic index math and are kept only because they avoid the div/mod chain)
-__global__ void __launch_bounds__(kBlock) repeat_kernel(RepeatParams p) {
+__global__ void __launch_bounds__(kBlock) repeat_kernel(const RepeatParams* __restrict__ params) {
+    const RepeatParams& p = params[blockIdx.y];
     uint32_t gid = blockIdx.x * kBlock + threadIdx.x;
     if (gid >= p.n) return;
     float* d = p.dst + p.dst_offset;
@@ -206,7 +207,8 @@ __global__ void __launch_bounds__(kBlock) repeat_kernel(RepeatParams p) {
 
 // reference.zig:435-455; dst_offset is read from the program's dynamic-parameter block so a
 // captured graph stays valid across KV positions.
-__global__ void __launch_bounds__(kBlock) slice_assign_kernel(SliceAssignParams p) {
+__global__ void __launch_bounds__(kBlock) slice_assign_kernel(const SliceAssignParams* __restrict__ params) {
+    const SliceAssignParams& p = params[blockIdx.y];
     uint32_t gid = blockIdx.x * kBlock + threadIdx.x;
     if (gid >= p.rows * p.cols) return;
     uint32_t row = gid % p.rows, col = gid / p.rows;
@@ -216,7 +218,8 @@ __global__ void __launch_bounds__(kBlock) slice_assign_kernel(SliceAssignParams 
 }
 
 // reference.zig:457-478 (DeviceOp convention: sin at cs + pair + half_d)
-__global__ void __launch_bounds__(kBlock) rope_kernel(RopeParams p) {
+__global__ void __launch_bounds__(kBlock) rope_kernel(const RopeParams* __restrict__ params) {
+    const RopeParams& p = params[blockIdx.y];
     uint32_t gid = blockIdx.x * kBlock + threadIdx.x;
     if (gid >= p.half_d * p.seq_len) return;
     uint32_t pair = gid % p.half_d, col = gid / p.half_d;
@@ -232,7 +235,9 @@ __global__ void __launch_bounds__(kBlock) rope_kernel(RopeParams p) {
 // an online softmax (so there is no seq_kv cap, unlike the 4096-entry score buffers of the Metal
 // and WGSL kernels). Masked (non-finite mask) and non-finite-score keys are skipped exactly as the
 // reference does; a query with no valid key yields zeros.
-__global__ void __launch_bounds__(kBlock) attention_kernel(AttentionParams p) {
+__global__ void __launch_bounds__(kBlock) attention_kernel(const AttentionParams* __restrict__ params) {
+    const AttentionParams p = params[blockIdx.y];
+    if (blockIdx.x >= p.seq_q) return; // batched ops may have fewer queries than the grid
     __shared__ float q_s[512];
     __shared__ float w_s[kBlock];
     __shared__ float red[8];
@@ -491,26 +496,26 @@ void launch_reduce(hipStream_t s, uint32_t op, float* dst, const float* src, uin
     reduce_kernel<<<cdiv(n_out, kBlock / 64), kBlock, 0, s>>>(op, dst, src, n_out, reduce_size);
 }
 
-void launch_repeat(hipStream_t s, const RepeatParams& p) {
-    if (p.n == 0) return;
-    repeat_kernel<<<cdiv(p.n, kBlock), kBlock, 0, s>>>(p);
+// Batched forms: `dev_params` is a device array of n_ops parameter records (blockIdx.y = op);
+// max_elems / max_seq_q size grid.x for the largest op, smaller ops early-exit.
+void launch_repeat_batch(hipStream_t s, const RepeatParams* dev_params, uint32_t n_ops, uint32_t max_elems) {
+    if (!n_ops || !max_elems) return;
+    repeat_kernel<<<dim3(cdiv(max_elems, kBlock), n_ops), kBlock, 0, s>>>(dev_params);
 }
 
-void launch_slice_assign(hipStream_t s, const SliceAssignParams& p) {
-    uint64_t n = (uint64_t)p.rows * p.cols;
-    if (n == 0) return;
-    slice_assign_kernel<<<cdiv(n, kBlock), kBlock, 0, s>>>(p);
+void launch_slice_assign_batch(hipStream_t s, const SliceAssignParams* dev_params, uint32_t n_ops, uint32_t max_elems) {
+    if (!n_ops || !max_elems) return;
+    slice_assign_kernel<<<dim3(cdiv(max_elems, kBlock), n_ops), kBlock, 0, s>>>(dev_params);
 }
 
-void launch_rope(hipStream_t s, const RopeParams& p) {
-    uint64_t n = (uint64_t)p.half_d * p.seq_len;
-    if (n == 0) return;
-    rope_kernel<<<cdiv(n, kBlock), kBlock, 0, s>>>(p);
+void launch_rope_batch(hipStream_t s, const RopeParams* dev_params, uint32_t n_ops, uint32_t max_elems) {
+    if (!n_ops || !max_elems) return;
+    rope_kernel<<<dim3(cdiv(max_elems, kBlock), n_ops), kBlock, 0, s>>>(dev_params);
 }
 
-void launch_attention(hipStream_t s, const AttentionParams& p) {
-    if (p.seq_q == 0) return;
-    attention_kernel<<<p.seq_q, kBlock, 0, s>>>(p);
+void launch_attention_batch(hipStream_t s, const AttentionParams* dev_params, uint32_t n_ops, uint32_t max_seq_q) {
+    if (!n_ops || !max_seq_q) return;
+    attention_kernel<<<dim3(max_seq_q, n_ops), kBlock, 0, s>>>(dev_params);
 }
 
 void launch_dense_matmul(hipStream_t s, const DenseMatmulParams& p) {

@@ -16,6 +16,7 @@
 // There is no CPU fallback anywhere: every DeviceOp kind has a kernel.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -24,6 +25,7 @@
 #include <vector>
 
 #include "kernels.h"
+#include "schedule.h"
 
 using namespace zgml;
 
@@ -32,8 +34,9 @@ namespace {
 std::string g_create_error;
 
 struct Launch {
-    uint32_t kind;     // DeviceOp tag the launch is accounted to
-    uint32_t n_ops;    // DeviceOps covered (fusion folds several)
+    uint32_t kind;           // DeviceOp tag the launch is accounted to
+    uint32_t n_ops;          // DeviceOps covered (batching folds several)
+    uint32_t op_lo, op_hi;   // smallest / largest op index covered
     std::function<void(hipStream_t)> run;
 };
 
@@ -100,6 +103,11 @@ struct zgml_hip_program {
     bool dyn_dirty = true;
     std::vector<Launch> plan;
     bool plan_dirty = true;
+    Schedule sched;                  // valid when plan_batched
+    bool plan_batched = false;       // plan was built from dependency levels
+    bool batching_safe = true;       // cleared when a refresh leaves the assumed dynamic bounds
+    std::vector<uint64_t> barriers;  // op indices nothing may be moved across (multi-GPU harness)
+    std::vector<void*> param_blobs;  // device parameter arrays of batched launches
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     // host I/O staging
@@ -302,168 +310,252 @@ bool prepare_io(zgml_hip_program* p, IoPlan& plan, const zgml_program_io* ios, u
     return ensure_stage(p, (uint64_t)plan.total_words * 4);
 }
 
-// ── plan building: one launch per DeviceOp (fusion passes rewrite this list, see fuse_plan) ──
+// ── plan building ───────────────────────────────────────────────────────────────────────────
+// Serial mode: one launch per DeviceOp in program order. Batched mode (ZGML_HIP_OPT_FUSION, the
+// default): ops are grouped by dependency level (schedule.h); inside a level every rope /
+// slice_assign / attention / repeat goes into ONE launch of its kind (parameters in a device
+// array, blockIdx.y = op), the rest launch one by one.
 float* buf_at(zgml_hip_program* p, uint16_t idx, uint64_t off) { return p->bufs[idx] + off; }
 
-void build_plan(zgml_hip_program* p) {
-    p->plan.clear();
-    for (size_t i = 0; i < p->ops.size(); i++) {
-        const zgml_device_op& op = p->ops[i];
-        Launch L;
-        L.kind = op.kind;
-        L.n_ops = 1;
-        switch (op.kind) {
-            case ZGML_DOP_ELEMENTWISE: {
-                const auto e = op.u.elementwise;
-                float* dst = buf_at(p, e.dst, e.dst_offset);
-                const float* s0 = buf_at(p, e.src0, e.src0_offset);
-                const float* s1 = buf_at(p, e.src1, e.src1_offset);
-                L.run = [=](hipStream_t s) { launch_elementwise(s, e.op, dst, s0, s1, e.n); };
-                break;
-            }
-            case ZGML_DOP_MATMUL: {
-                const auto m = op.u.matmul;
-                DenseMatmulParams dp{};
-                dp.dst = buf_at(p, m.dst, m.geom.dst_offset);
-                dp.a = buf_at(p, m.a, m.geom.a_offset);
-                dp.b = buf_at(p, m.b, m.geom.b_offset);
-                dp.M = (uint32_t)m.geom.M, dp.N = (uint32_t)m.geom.N, dp.K = (uint32_t)m.geom.K;
-                dp.a_rs = (uint32_t)m.geom.a_row_stride, dp.a_cs = (uint32_t)m.geom.a_col_stride;
-                dp.b_rs = (uint32_t)m.geom.b_row_stride, dp.b_cs = (uint32_t)m.geom.b_col_stride;
-                dp.dst_rs = (uint32_t)m.geom.dst_row_stride;
-                dp.b_f16 = 0;
-                L.run = [=](hipStream_t s) { launch_dense_matmul(s, dp); };
-                break;
-            }
-            case ZGML_DOP_QMATMUL: {
-                const auto q = op.u.qmatmul;
-                QMatmulParams qp{};
-                qp.dst = buf_at(p, q.dst, q.dst_offset);
-                qp.input = buf_at(p, q.input, q.input_offset);
-                qp.M = q.M, qp.N = q.N, qp.K = q.K;
-                qp.in_rs = q.input_row_stride ? q.input_row_stride : q.K;
-                qp.dst_rs = q.dst_row_stride ? q.dst_row_stride : q.N;
-                const QWeightDev w = p->qweights[q.weight_idx];
-                float* scratch = p->scratch;
-                L.run = [=](hipStream_t s) { launch_qmatmul(s, w, qp, scratch); };
-                break;
-            }
-            case ZGML_DOP_SOFTMAX: {
-                const auto r = op.u.softmax;
-                float* dst = buf_at(p, r.dst, r.dst_offset);
-                const float* src = buf_at(p, r.src, r.src_offset);
-                L.run = [=](hipStream_t s) { launch_softmax(s, dst, src, r.rows, r.cols); };
-                break;
-            }
-            case ZGML_DOP_LAYERNORM: {
-                const auto r = op.u.layernorm;
-                float* dst = buf_at(p, r.dst, r.dst_offset);
-                const float* src = buf_at(p, r.src, r.src_offset);
-                L.run = [=](hipStream_t s) { launch_layernorm(s, dst, src, r.rows, r.cols, r.eps); };
-                break;
-            }
-            case ZGML_DOP_RMSNORM: {
-                const auto r = op.u.rmsnorm;
-                float* dst = buf_at(p, r.dst, r.dst_offset);
-                const float* src = buf_at(p, r.src, r.src_offset);
-                L.run = [=](hipStream_t s) { launch_rmsnorm(s, dst, src, r.rows, r.cols, r.eps); };
-                break;
-            }
-            case ZGML_DOP_REDUCE: {
-                const auto r = op.u.reduce;
-                float* dst = buf_at(p, r.dst, r.dst_offset);
-                const float* src = buf_at(p, r.src, r.src_offset);
-                L.run = [=](hipStream_t s) { launch_reduce(s, r.op, dst, src, r.n_out, r.reduce_size); };
-                break;
-            }
-            case ZGML_DOP_REPEAT: {
-                const auto r = op.u.repeat;
-                RepeatParams rp{};
-                rp.dst = p->bufs[r.dst];
-                rp.src = p->bufs[r.src];
-                rp.n = r.n;
-                for (int d = 0; d < 4; d++) {
-                    rp.src_ne[d] = r.src_ne[d];
-                    rp.src_strides[d] = r.src_strides[d];
-                    rp.dst_strides[d] = r.dst_strides[d] ? r.dst_strides[d] : 1;
-                }
-                rp.src_offset = r.src_offset, rp.dst_offset = r.dst_offset;
-                const uint64_t src_n = (uint64_t)r.src_ne[0] * r.src_ne[1] * r.src_ne[2] * r.src_ne[3];
-                rp.src_n = (uint32_t)src_n;
-                // the reference's fast paths (reference.zig:401-419), in its order of precedence
-                if (src_n == 1)
-                    rp.mode = 1;
-                else if (src_n >= r.n)
-                    rp.mode = 2;
-                else if (r.n % src_n == 0 && r.src_strides[0] == 1 &&
-                         (r.src_ne[1] <= 1 || r.src_strides[1] == r.src_ne[0]) &&
-                         (r.src_ne[2] <= 1 || r.src_strides[2] == r.src_ne[0] * r.src_ne[1]) &&
-                         (r.src_ne[3] <= 1 || r.src_strides[3] == r.src_ne[0] * r.src_ne[1] * r.src_ne[2]))
-                    rp.mode = 3;
-                else
-                    rp.mode = 0;
-                L.run = [=](hipStream_t s) { launch_repeat(s, rp); };
-                break;
-            }
-            case ZGML_DOP_SLICE_ASSIGN: {
-                const auto sa = op.u.slice_assign;
-                SliceAssignParams sp{};
-                sp.dst = p->bufs[sa.dst];
-                sp.src = buf_at(p, sa.src, sa.src_offset);
-                sp.rows = sa.rows, sp.cols = sa.cols;
-                sp.dst_row_stride = sa.dst_row_stride, sp.dst_col_stride = sa.dst_col_stride;
-                sp.src_row_stride = sa.src_row_stride, sp.src_col_stride = sa.src_col_stride;
-                sp.dyn_dst_offset = p->dyn_dev + i;
-                L.run = [=](hipStream_t s) { launch_slice_assign(s, sp); };
-                break;
-            }
-            case ZGML_DOP_ROPE: {
-                const auto r = op.u.rope;
-                RopeParams rp{};
-                rp.dst = buf_at(p, r.dst, r.dst_off);
-                rp.src = buf_at(p, r.src, r.src_off);
-                rp.cs = buf_at(p, r.cos_sin, r.cs_off);
-                rp.half_d = r.half_d, rp.seq_len = r.seq_len, rp.src_rs = r.src_rs, rp.src_cs = r.src_cs;
-                rp.cs_cs = r.cs_cs;
-                L.run = [=](hipStream_t s) { launch_rope(s, rp); };
-                break;
-            }
-            case ZGML_DOP_ATTENTION: {
-                const auto a = op.u.attention;
-                AttentionParams ap{};
-                ap.dst = buf_at(p, a.dst, a.dst_off);
-                ap.q = buf_at(p, a.q, a.q_off);
-                ap.k = buf_at(p, a.k, a.k_off);
-                ap.v = buf_at(p, a.v, a.v_off);
-                ap.mask = a.has_mask ? buf_at(p, a.mask, a.mask_off) : nullptr;
-                ap.d_head = a.d_head, ap.seq_q = a.seq_q;
-                ap.dyn_seq_kv = p->dyn_dev + i;
-                ap.scale = a.scale;
-                ap.q_rs = a.q_rs, ap.q_cs = a.q_cs, ap.k_rs = a.k_rs, ap.k_cs = a.k_cs, ap.v_rs = a.v_rs;
-                ap.v_cs = a.v_cs, ap.mask_rs = a.mask_rs, ap.mask_cs = a.mask_cs, ap.dst_rs = a.dst_rs;
-                ap.dst_cs = a.dst_cs;
-                L.run = [=](hipStream_t s) { launch_attention(s, ap); };
-                break;
-            }
-            case ZGML_DOP_FUSED_ELEMENTWISE: {
-                const auto fe = op.u.fused_elementwise;
-                FusedParams fp{};
-                fp.dst = buf_at(p, fe.dst, fe.dst_offset);
-                fp.src = buf_at(p, fe.src, fe.src_offset);
-                fp.n = fe.n;
-                fp.n_steps = fe.n_steps;
-                for (uint32_t s = 0; s < fe.n_steps; s++) {
-                    fp.steps[s].op = fe.steps[s].op;
-                    fp.steps[s].swapped = fe.steps[s].is_swapped;
-                    const bool bin = fe.steps[s].op == ZGML_OP_ADD || fe.steps[s].op == ZGML_OP_MUL;
-                    fp.steps[s].secondary = bin ? buf_at(p, fe.steps[s].secondary_buf, fe.steps[s].secondary_offset) : nullptr;
-                }
-                L.run = [=](hipStream_t s) { launch_fused_elementwise(s, fp); };
-                break;
-            }
-            default: continue;
+template <typename T>
+const T* upload_params(zgml_hip_program* p, const std::vector<T>& v) {
+    void* d = nullptr;
+    if (hipMalloc(&d, v.size() * sizeof(T)) != hipSuccess) {
+        p->ctx->fail("plan: parameter array allocation failed");
+        return nullptr;
+    }
+    hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    p->param_blobs.push_back(d);
+    return (const T*)d;
+}
+
+RepeatParams make_repeat(zgml_hip_program* p, const zgml_op_repeat& r) {
+    RepeatParams rp{};
+    rp.dst = p->bufs[r.dst];
+    rp.src = p->bufs[r.src];
+    rp.n = r.n;
+    for (int d = 0; d < 4; d++) {
+        rp.src_ne[d] = r.src_ne[d] ? r.src_ne[d] : 1;
+        rp.src_strides[d] = r.src_strides[d];
+        rp.dst_strides[d] = r.dst_strides[d] ? r.dst_strides[d] : 1;
+    }
+    rp.src_offset = r.src_offset, rp.dst_offset = r.dst_offset;
+    const uint64_t src_n = (uint64_t)r.src_ne[0] * r.src_ne[1] * r.src_ne[2] * r.src_ne[3];
+    rp.src_n = (uint32_t)src_n;
+    // the reference's fast paths (reference.zig:401-419), in its order of precedence
+    if (src_n == 1)
+        rp.mode = 1;
+    else if (src_n >= r.n)
+        rp.mode = 2;
+    else if (r.n % src_n == 0 && r.src_strides[0] == 1 && (r.src_ne[1] <= 1 || r.src_strides[1] == r.src_ne[0]) &&
+             (r.src_ne[2] <= 1 || r.src_strides[2] == r.src_ne[0] * r.src_ne[1]) &&
+             (r.src_ne[3] <= 1 || r.src_strides[3] == r.src_ne[0] * r.src_ne[1] * r.src_ne[2]))
+        rp.mode = 3;
+    else
+        rp.mode = 0;
+    return rp;
+}
+
+SliceAssignParams make_slice_assign(zgml_hip_program* p, const zgml_op_slice_assign& sa, size_t op_index) {
+    SliceAssignParams sp{};
+    sp.dst = p->bufs[sa.dst];
+    sp.src = buf_at(p, sa.src, sa.src_offset);
+    sp.rows = sa.rows, sp.cols = sa.cols;
+    sp.dst_row_stride = sa.dst_row_stride, sp.dst_col_stride = sa.dst_col_stride;
+    sp.src_row_stride = sa.src_row_stride, sp.src_col_stride = sa.src_col_stride;
+    sp.dyn_dst_offset = p->dyn_dev + op_index;
+    return sp;
+}
+
+RopeParams make_rope(zgml_hip_program* p, const zgml_op_rope& r) {
+    RopeParams rp{};
+    rp.dst = buf_at(p, r.dst, r.dst_off);
+    rp.src = buf_at(p, r.src, r.src_off);
+    rp.cs = buf_at(p, r.cos_sin, r.cs_off);
+    rp.half_d = r.half_d, rp.seq_len = r.seq_len, rp.src_rs = r.src_rs, rp.src_cs = r.src_cs, rp.cs_cs = r.cs_cs;
+    return rp;
+}
+
+AttentionParams make_attention(zgml_hip_program* p, const zgml_op_attention& a, size_t op_index) {
+    AttentionParams ap{};
+    ap.dst = buf_at(p, a.dst, a.dst_off);
+    ap.q = buf_at(p, a.q, a.q_off);
+    ap.k = buf_at(p, a.k, a.k_off);
+    ap.v = buf_at(p, a.v, a.v_off);
+    ap.mask = a.has_mask ? buf_at(p, a.mask, a.mask_off) : nullptr;
+    ap.d_head = a.d_head, ap.seq_q = a.seq_q;
+    ap.dyn_seq_kv = p->dyn_dev + op_index;
+    ap.scale = a.scale;
+    ap.q_rs = a.q_rs, ap.q_cs = a.q_cs, ap.k_rs = a.k_rs, ap.k_cs = a.k_cs, ap.v_rs = a.v_rs, ap.v_cs = a.v_cs;
+    ap.mask_rs = a.mask_rs, ap.mask_cs = a.mask_cs, ap.dst_rs = a.dst_rs, ap.dst_cs = a.dst_cs;
+    return ap;
+}
+
+// launch for a single op of a kind that is never batched
+bool make_single(zgml_hip_program* p, size_t i, Launch& L) {
+    const zgml_device_op& op = p->ops[i];
+    L.kind = op.kind, L.n_ops = 1, L.op_lo = L.op_hi = (uint32_t)i;
+    switch (op.kind) {
+        case ZGML_DOP_ELEMENTWISE: {
+            const auto e = op.u.elementwise;
+            float* dst = buf_at(p, e.dst, e.dst_offset);
+            const float* s0 = buf_at(p, e.src0, e.src0_offset);
+            const float* s1 = buf_at(p, e.src1, e.src1_offset);
+            L.run = [=](hipStream_t s) { launch_elementwise(s, e.op, dst, s0, s1, e.n); };
+            return true;
         }
-        p->plan.push_back(std::move(L));
+        case ZGML_DOP_MATMUL: {
+            const auto m = op.u.matmul;
+            DenseMatmulParams dp{};
+            dp.dst = buf_at(p, m.dst, m.geom.dst_offset);
+            dp.a = buf_at(p, m.a, m.geom.a_offset);
+            dp.b = buf_at(p, m.b, m.geom.b_offset);
+            dp.M = (uint32_t)m.geom.M, dp.N = (uint32_t)m.geom.N, dp.K = (uint32_t)m.geom.K;
+            dp.a_rs = (uint32_t)m.geom.a_row_stride, dp.a_cs = (uint32_t)m.geom.a_col_stride;
+            dp.b_rs = (uint32_t)m.geom.b_row_stride, dp.b_cs = (uint32_t)m.geom.b_col_stride;
+            dp.dst_rs = (uint32_t)m.geom.dst_row_stride;
+            dp.b_f16 = 0;
+            L.run = [=](hipStream_t s) { launch_dense_matmul(s, dp); };
+            return true;
+        }
+        case ZGML_DOP_QMATMUL: {
+            const auto q = op.u.qmatmul;
+            QMatmulParams qp{};
+            qp.dst = buf_at(p, q.dst, q.dst_offset);
+            qp.input = buf_at(p, q.input, q.input_offset);
+            qp.M = q.M, qp.N = q.N, qp.K = q.K;
+            qp.in_rs = q.input_row_stride ? q.input_row_stride : q.K;
+            qp.dst_rs = q.dst_row_stride ? q.dst_row_stride : q.N;
+            const QWeightDev w = p->qweights[q.weight_idx];
+            float* scratch = p->scratch;
+            L.run = [=](hipStream_t s) { launch_qmatmul(s, w, qp, scratch); };
+            return true;
+        }
+        case ZGML_DOP_SOFTMAX:
+        case ZGML_DOP_LAYERNORM:
+        case ZGML_DOP_RMSNORM: {
+            const auto r = op.u.rmsnorm;
+            float* dst = buf_at(p, r.dst, r.dst_offset);
+            const float* src = buf_at(p, r.src, r.src_offset);
+            const uint32_t kind = op.kind;
+            L.run = [=](hipStream_t s) {
+                if (kind == ZGML_DOP_SOFTMAX)
+                    launch_softmax(s, dst, src, r.rows, r.cols);
+                else if (kind == ZGML_DOP_LAYERNORM)
+                    launch_layernorm(s, dst, src, r.rows, r.cols, r.eps);
+                else
+                    launch_rmsnorm(s, dst, src, r.rows, r.cols, r.eps);
+            };
+            return true;
+        }
+        case ZGML_DOP_REDUCE: {
+            const auto r = op.u.reduce;
+            float* dst = buf_at(p, r.dst, r.dst_offset);
+            const float* src = buf_at(p, r.src, r.src_offset);
+            L.run = [=](hipStream_t s) { launch_reduce(s, r.op, dst, src, r.n_out, r.reduce_size); };
+            return true;
+        }
+        case ZGML_DOP_FUSED_ELEMENTWISE: {
+            const auto fe = op.u.fused_elementwise;
+            FusedParams fp{};
+            fp.dst = buf_at(p, fe.dst, fe.dst_offset);
+            fp.src = buf_at(p, fe.src, fe.src_offset);
+            fp.n = fe.n;
+            fp.n_steps = fe.n_steps;
+            for (uint32_t s = 0; s < fe.n_steps; s++) {
+                fp.steps[s].op = fe.steps[s].op;
+                fp.steps[s].swapped = fe.steps[s].is_swapped;
+                const bool bin = fe.steps[s].op == ZGML_OP_ADD || fe.steps[s].op == ZGML_OP_MUL;
+                fp.steps[s].secondary = bin ? buf_at(p, fe.steps[s].secondary_buf, fe.steps[s].secondary_offset) : nullptr;
+            }
+            L.run = [=](hipStream_t s) { launch_fused_elementwise(s, fp); };
+            return true;
+        }
+        default: return false;
+    }
+}
+
+// the batchable kinds of one group of mutually independent ops -> at most one launch per kind
+void emit_batches(zgml_hip_program* p, const std::vector<uint32_t>& group) {
+    std::vector<RepeatParams> reps;
+    std::vector<SliceAssignParams> sas;
+    std::vector<RopeParams> ropes;
+    std::vector<AttentionParams> atts;
+    uint32_t rep_max = 0, sa_max = 0, rope_max = 0, att_max = 0;
+    uint32_t lo[4] = {UINT32_MAX, UINT32_MAX, UINT32_MAX, UINT32_MAX}, hi[4] = {0, 0, 0, 0};
+    auto track = [&](int k, uint32_t i) {
+        lo[k] = std::min(lo[k], i);
+        hi[k] = std::max(hi[k], i);
+    };
+    for (uint32_t i : group) {
+        const zgml_device_op& op = p->ops[i];
+        switch (op.kind) {
+            case ZGML_DOP_REPEAT:
+                reps.push_back(make_repeat(p, op.u.repeat));
+                rep_max = std::max(rep_max, op.u.repeat.n);
+                track(0, i);
+                break;
+            case ZGML_DOP_SLICE_ASSIGN:
+                sas.push_back(make_slice_assign(p, op.u.slice_assign, i));
+                sa_max = std::max(sa_max, op.u.slice_assign.rows * op.u.slice_assign.cols);
+                track(1, i);
+                break;
+            case ZGML_DOP_ROPE:
+                ropes.push_back(make_rope(p, op.u.rope));
+                rope_max = std::max(rope_max, op.u.rope.half_d * op.u.rope.seq_len);
+                track(2, i);
+                break;
+            case ZGML_DOP_ATTENTION:
+                atts.push_back(make_attention(p, op.u.attention, i));
+                att_max = std::max(att_max, op.u.attention.seq_q);
+                track(3, i);
+                break;
+            default: {
+                Launch L;
+                if (make_single(p, i, L)) p->plan.push_back(std::move(L));
+            }
+        }
+    }
+    if (!reps.empty()) {
+        const RepeatParams* d = upload_params(p, reps);
+        const uint32_t n = (uint32_t)reps.size(), mx = rep_max;
+        p->plan.push_back({ZGML_DOP_REPEAT, n, lo[0], hi[0], [=](hipStream_t s) { launch_repeat_batch(s, d, n, mx); }});
+    }
+    if (!sas.empty()) {
+        const SliceAssignParams* d = upload_params(p, sas);
+        const uint32_t n = (uint32_t)sas.size(), mx = sa_max;
+        p->plan.push_back({ZGML_DOP_SLICE_ASSIGN, n, lo[1], hi[1], [=](hipStream_t s) { launch_slice_assign_batch(s, d, n, mx); }});
+    }
+    if (!ropes.empty()) {
+        const RopeParams* d = upload_params(p, ropes);
+        const uint32_t n = (uint32_t)ropes.size(), mx = rope_max;
+        p->plan.push_back({ZGML_DOP_ROPE, n, lo[2], hi[2], [=](hipStream_t s) { launch_rope_batch(s, d, n, mx); }});
+    }
+    if (!atts.empty()) {
+        const AttentionParams* d = upload_params(p, atts);
+        const uint32_t n = (uint32_t)atts.size(), mx = att_max;
+        p->plan.push_back({ZGML_DOP_ATTENTION, n, lo[3], hi[3], [=](hipStream_t s) { launch_attention_batch(s, d, n, mx); }});
+    }
+}
+
+void free_param_blobs(zgml_hip_program* p) {
+    for (void* d : p->param_blobs) hipFree(d);
+    p->param_blobs.clear();
+}
+
+void build_plan(zgml_hip_program* p) {
+    hipStreamSynchronize(p->ctx->stream); // the previous plan's parameter arrays may still be in use
+    p->plan.clear();
+    free_param_blobs(p);
+    p->plan_batched = p->ctx->opt_fusion && p->batching_safe;
+    if (p->plan_batched) {
+        p->sched = build_schedule(p->ops, p->sizes, p->barriers);
+        if (!dynamic_fields_in_bounds(p->sched, p->ops)) p->plan_batched = false;
+    }
+    if (p->plan_batched) {
+        for (const auto& level : p->sched.levels) emit_batches(p, level);
+    } else {
+        for (uint32_t i = 0; i < p->ops.size(); i++) emit_batches(p, {i});
     }
     p->plan_dirty = false;
 }
@@ -958,6 +1050,12 @@ void zgml_hip_refresh_program(zgml_hip_ctx* ctx, zgml_hip_program* p, const zgml
             if (ops[i].kind == ZGML_DOP_ATTENTION) p->ops[i].u.attention.seq_kv = ops[i].u.attention.seq_kv;
         }
         set_dyn_from_ops(p);
+        if (p->plan_batched && !dynamic_fields_in_bounds(p->sched, p->ops)) {
+            // a dynamic field left the span the level schedule assumed: the reordered plan is no
+            // longer provably equivalent, fall back to program order for good
+            p->batching_safe = false;
+            p->plan_dirty = true;
+        }
         return;
     }
     if (n_ops != p->ops.size()) {
@@ -1058,6 +1156,7 @@ void zgml_hip_free_program(zgml_hip_ctx* ctx, zgml_hip_program* p) {
     }
     free_graph(p);
     free_resident(p);
+    free_param_blobs(p);
     if (p->arena) hipFree(p->arena);
     for (void* d : p->owned) hipFree(d);
     if (p->scratch) hipFree(p->scratch);
@@ -1096,12 +1195,24 @@ void zgml_hip_enqueue_ops(zgml_hip_ctx* ctx, zgml_hip_program* p, uint64_t first
         build_plan(p);
     }
     flush_dyn(p);
-    // plan entries are 1:1 with ops here only when fusion is off; map by accumulated op count
-    size_t op_pos = 0;
+    // a launch belongs to the range when every op it covers does; barriers (set_barriers) make
+    // sure batching never straddles the harness's collective points
     for (auto& L : p->plan) {
-        if (op_pos >= first && op_pos < first + count) L.run(ctx->stream);
-        op_pos += L.n_ops;
+        if (L.op_lo >= first && L.op_hi < first + count) {
+            L.run(ctx->stream);
+        } else if (!(L.op_hi < first || L.op_lo >= first + count)) {
+            ctx->fail("enqueue_ops: range cuts through a batched launch; declare it with zgml_hip_program_set_barriers");
+            return;
+        }
     }
+}
+
+int zgml_hip_program_set_barriers(zgml_hip_ctx* ctx, zgml_hip_program* p, const uint64_t* op_indices, uint64_t n) {
+    if (!ctx || !p) return -1;
+    p->barriers.assign(op_indices, op_indices + n);
+    std::sort(p->barriers.begin(), p->barriers.end());
+    p->plan_dirty = true;
+    return 0;
 }
 
 void zgml_hip_synchronize(zgml_hip_ctx* ctx) {

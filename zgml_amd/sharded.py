@@ -37,6 +37,10 @@ class HipExecutor:
         if not self.handle:
             raise RuntimeError("compile failed: " + backend.last_error())
         self.n_ops = int(prog.n_ops)
+        pts = [gp.op_end for gp in model.gather_points()]
+        if pts:  # batched launches must not straddle the collectives
+            arr = (C.c_uint64 * len(pts))(*pts)
+            self.lib.zgml_hip_program_set_barriers(backend.ctx, self.handle, arr, len(pts))
         self.device = torch.device("cuda", device)
         self.stream = torch.cuda.ExternalStream(self.lib.zgml_hip_stream(backend.ctx), device=self.device)
         self._views = {}
