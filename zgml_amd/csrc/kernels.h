@@ -88,6 +88,51 @@ struct QWeightDev {
     uint64_t qs_bytes = 0, sc_bytes = 0;
 };
 
+// ── fused mat-vec launch description (M == 1 decode path) ────────────────────────────────────
+// One launch = up to 4 weight matrices that read the same input vector (q/k/v, gate/up), an
+// optional PROLOGUE that produces that vector on the fly and an optional elementwise EPILOGUE
+// per matrix. Every intermediate the unfused program would have written is still stored (by
+// workgroup 0 for prologue values, by the owning lanes for epilogue values), so any buffer a
+// host could download holds the same numbers as in the one-op-per-launch plan.
+constexpr int kMaxQmvParts = 4;
+constexpr int kMaxEpiSteps = 6;
+
+struct QmvEpiStep {
+    uint32_t op;          // ZGML_OP_*; binary ops read operand[n]
+    uint32_t swapped;     // chain value is the right-hand operand
+    const float* operand; // indexed by output column n (nullptr for unary)
+    float* store;         // optional: write the value after this step to store[n]
+};
+
+enum QmvPrologueKind : uint32_t {
+    QMV_PRO_NONE = 0,        // x = a
+    QMV_PRO_MUL = 1,         // x = a * b                         (elementwise mul feeding the mat-vec)
+    QMV_PRO_RMSNORM_MUL = 2, // mid = a / sqrt(mean(a^2) + eps); x = mid * b   (rmsnorm -> mul gamma)
+};
+
+struct QmvPrologue {
+    uint32_t kind = QMV_PRO_NONE;
+    float eps = 0.f;
+    const float* a = nullptr;
+    const float* b = nullptr;
+    float* store_mid = nullptr; // RMSNORM_MUL: the bare normalised vector
+    float* store_x = nullptr;   // MUL / RMSNORM_MUL: the vector the mat-vec consumes
+};
+
+struct QmvPart {
+    QWeightDev w;
+    float* dst = nullptr; // y (offset applied)
+    uint32_t n_epi = 0;
+    QmvEpiStep epi[kMaxEpiSteps];
+};
+
+struct QmvLaunch {
+    uint32_t n_parts = 0;
+    QmvPart parts[kMaxQmvParts];
+    QmvPrologue pro;
+    uint32_t K = 0;
+};
+
 struct QMatmulParams {
     float* dst;         // dst_offset applied
     const float* input; // input_offset applied
@@ -128,6 +173,11 @@ void launch_pack_qweight(hipStream_t s, const int8_t* raw_data, const float* raw
 // Bytes of split-K scratch a qmatmul launch may need (f32 partial slabs).
 uint64_t qmatmul_scratch_bytes(const QWeightDev& w, uint32_t M);
 void launch_qmatmul(hipStream_t s, const QWeightDev& w, const QMatmulParams& p, float* scratch);
+// Fused M == 1 launch; all parts must be packed, share K, format and scale type (qmv_can_group).
+bool qmv_can_group(const QWeightDev& a, const QWeightDev& b);
+// Prologue kinds other than NONE keep the whole input in registers: K <= qmv_max_prologue_k(w).
+uint32_t qmv_max_prologue_k(const QWeightDev& w);
+void launch_qmatvec_fused(hipStream_t s, const QmvLaunch& L);
 // Deterministic synthetic weights for the roofline micro-benchmark, generated on the device
 // directly in the packed layout (SURVEY §8d generator).
 void launch_synth_packed(hipStream_t s, const QWeightDev& w, uint32_t matrix_id);

@@ -115,14 +115,24 @@ struct Pair {
     ST a, b;
 };
 
-struct QMVArgs {
+struct QMVPartDev {
     const uint4* qs;
     const void* sc;
-    const float* x; // input (offset applied); row m at x + m*in_rs
-    float* out;     // dst (offset applied); row m at out + m*out_rs
-    uint32_t M, N, K, NB2;
-    uint32_t U;     // k-units per column group (Q4: KC, Q8: 2*KC)
-    uint32_t in_rs, out_rs;
+    float* out;           // row m at out + m*out_rs
+    uint32_t NB2;         // 16-column groups of this matrix
+    uint32_t block_begin; // first blockIdx.x of this part
+    uint32_t out_rs;
+    uint32_t n_epi;
+    QmvEpiStep epi[kMaxEpiSteps];
+};
+
+struct QMVArgs {
+    QMVPartDev parts[kMaxQmvParts];
+    uint32_t n_parts;
+    QmvPrologue pro; // pro.a is the input vector for kind NONE
+    uint32_t M, K;
+    uint32_t U;      // k-units per column group (Q4: KC, Q8: 2*KC)
+    uint32_t in_rs;
 };
 
 // x staging in two halves so the weight loads can sit between them: x_fetch() issues this thread's
@@ -160,16 +170,81 @@ __device__ __forceinline__ XRegs x_fetch(const float* x, uint32_t K) {
     return r;
 }
 
-// k_count is a multiple of 16; xs has 4 spare floats at xs[k_count..] for the out-of-range lanes
+__device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float4 scale4(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
+
+// k_count is a multiple of 16; xs has 4 spare floats at xs[k_count..] for the out-of-range lanes.
+// KIND selects the prologue (kernels.h QmvPrologueKind); `inv` is the rmsnorm factor for kind 2.
+// Workgroup (0,0) also stores the prologue's intermediates to global memory so the buffers of
+// the absorbed ops hold what the unfused plan would have written.
 template <bool XVEC>
-__device__ __forceinline__ void x_commit(float* xs, const XRegs& r, const float* x, uint32_t k_count, uint32_t K) {
+__device__ __forceinline__ void x_commit(float* xs, const XRegs& ra, const XRegs& rb, const QmvPrologue& pro, float inv,
+                                         uint32_t k_count, uint32_t K, const float* xa_row) {
+    const bool owner = blockIdx.x == 0 && blockIdx.y == 0;
 #pragma unroll
     for (int j = 0; j < kXRegs; j++) {
         const uint32_t i = (threadIdx.x + j * blockDim.x) * 4;
-        *(float4*)(xs + (i < k_count ? i : k_count)) = zero_tail(r.v[j], i, K);
+        float4 v = zero_tail(ra.v[j], i, K);
+        if (pro.kind == QMV_PRO_RMSNORM_MUL) {
+            v = scale4(v, inv);
+            if (owner && pro.store_mid && i < K) {
+                if (i + 3 < K) *(float4*)(pro.store_mid + i) = v;
+                else { pro.store_mid[i] = v.x; if (i + 1 < K) pro.store_mid[i + 1] = v.y; if (i + 2 < K) pro.store_mid[i + 2] = v.z; }
+            }
+        }
+        if (pro.kind != QMV_PRO_NONE) {
+            v = mul4(v, zero_tail(rb.v[j], i, K));
+            if (owner && pro.store_x && i < K) {
+                if (i + 3 < K) *(float4*)(pro.store_x + i) = v;
+                else { pro.store_x[i] = v.x; if (i + 1 < K) pro.store_x[i + 1] = v.y; if (i + 2 < K) pro.store_x[i + 2] = v.z; }
+            }
+        }
+        *(float4*)(xs + (i < k_count ? i : k_count)) = v;
     }
-    for (uint32_t i = (threadIdx.x + kXRegs * blockDim.x) * 4; i < k_count; i += blockDim.x * 4)
-        *(float4*)(xs + i) = zero_tail(load_x4<XVEC>(x, i, K), i, K); // only for K > 16 * blockDim
+    if (pro.kind == QMV_PRO_NONE) // only for K > 16 * blockDim (prologues are limited to the register window)
+        for (uint32_t i = (threadIdx.x + kXRegs * blockDim.x) * 4; i < k_count; i += blockDim.x * 4)
+            *(float4*)(xs + i) = zero_tail(load_x4<XVEC>(xa_row, i, K), i, K);
+}
+
+// sum of squares of the (zero-tailed) register window, fixed reduction order: lanes, then waves
+__device__ __forceinline__ float block_sumsq(const XRegs& r, uint32_t K, float* red) {
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < kXRegs; j++) {
+        const uint32_t i = (threadIdx.x + j * blockDim.x) * 4;
+        const float4 v = zero_tail(r.v[j], i, K);
+        ss += v.x * v.x;
+        ss += v.y * v.y;
+        ss += v.z * v.z;
+        ss += v.w * v.w;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    float t = 0.f;
+    for (uint32_t w = 0; w < (blockDim.x >> 6); w++) t += red[w];
+    __syncthreads();
+    return t;
+}
+
+__device__ __forceinline__ float epi_unary(uint32_t op, float a) {
+    switch (op) {
+        case ZGML_OP_NEG: return -a;
+        case ZGML_OP_ABS: return fabsf(a);
+        case ZGML_OP_SGN: return a > 0.f ? 1.f : (a < 0.f ? -1.f : 0.f);
+        case ZGML_OP_STEP: return a > 0.f ? 1.f : 0.f;
+        case ZGML_OP_RELU: return fmaxf(a, 0.f);
+        case ZGML_OP_SQRT: return sqrtf(a);
+        case ZGML_OP_RECIP: return 1.0f / a;
+        case ZGML_OP_EXP: return expf(a);
+        case ZGML_OP_LOG: return logf(a);
+        case ZGML_OP_GELU: {
+            const float kk = 0.7978845608f * (a + 0.044715f * a * a * a);
+            return 0.5f * a * (1.0f + tanhf(kk));
+        }
+        default: return a;
+    }
 }
 
 // blockIdx.x -> column group. Groups 2j and 2j+1 share the scales of block-column j; the
@@ -182,8 +257,9 @@ __device__ __forceinline__ uint32_t column_group(uint32_t b, uint32_t NB2) {
     return 2 * j + half;
 }
 
-// Fold the 4 rows of each wave, then the waves, in fixed order; 16 outputs per workgroup.
-__device__ __forceinline__ void reduce_store(float acc, float* red, const QMVArgs& a, uint32_t g, uint32_t m) {
+// Fold the 4 rows of each wave, then the waves, in fixed order; 16 outputs per workgroup. The 16
+// owning lanes then run the part's elementwise epilogue (residual add, SiLU chain, ...).
+__device__ __forceinline__ void reduce_store(float acc, float* red, const QMVPartDev& part, uint32_t g, uint32_t m) {
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     acc += __shfl_xor(acc, 16, 64);
     acc += __shfl_xor(acc, 32, 64);
@@ -192,7 +268,21 @@ __device__ __forceinline__ void reduce_store(float acc, float* red, const QMVArg
     if (threadIdx.x < 16) {
         float v = red[threadIdx.x];
         for (uint32_t ww = 1; ww < n_waves; ww++) v += red[ww * 16 + threadIdx.x];
-        a.out[(uint64_t)m * a.out_rs + g * 16 + threadIdx.x] = v;
+        const uint32_t n = g * 16 + threadIdx.x;
+        part.out[(uint64_t)m * part.out_rs + n] = v;
+        for (uint32_t e = 0; e < part.n_epi; e++) { // M == 1 whenever n_epi != 0
+            const QmvEpiStep st = part.epi[e];
+            if (st.op == ZGML_OP_ADD) {
+                const float o = st.operand[n];
+                v = st.swapped ? o + v : v + o;
+            } else if (st.op == ZGML_OP_MUL) {
+                const float o = st.operand[n];
+                v = st.swapped ? o * v : v * o;
+            } else {
+                v = epi_unary(st.op, v);
+            }
+            if (st.store) st.store[n] = v;
+        }
     }
 }
 
@@ -273,21 +363,34 @@ __global__ void __launch_bounds__(1024) qmatvec_kernel(QMVArgs a) {
     extern __shared__ float smem[];
     float* xs = smem;                     // U * UNIT_X floats (+4 spare)
     float* red = smem + a.U * UNIT_X + 4; // waves * 16 floats
-    const uint32_t g = column_group(blockIdx.x, a.NB2), m = blockIdx.y;
+    // which matrix of the group this workgroup belongs to (wave-uniform)
+    uint32_t pi = 0;
+    for (uint32_t t = 1; t < a.n_parts; t++)
+        if (blockIdx.x >= a.parts[t].block_begin) pi = t;
+    const QMVPartDev& part = a.parts[pi];
+    const uint32_t g = column_group(blockIdx.x - part.block_begin, part.NB2), m = blockIdx.y;
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint32_t row = lane >> 4, i = lane & 15;
     const uint32_t stride = (blockDim.x >> 6) * 4; // units per step (4 rows per wave)
-    const uint4* qs = a.qs + (uint64_t)g * a.U * 16 + i;
-    const ScaleT* sc = (const ScaleT*)a.sc + (uint64_t)(g >> 1) * a.U * 16 + i;
+    const uint4* qs = part.qs + (uint64_t)g * a.U * 16 + i;
+    const ScaleT* sc = (const ScaleT*)part.sc + (uint64_t)(g >> 1) * a.U * 16 + i;
     const uint32_t n_groups = (a.U + stride * DEPTH - 1) / (stride * DEPTH);
     const uint32_t u_last = a.U - 1;
 
-    const float* xrow = a.x + (uint64_t)m * a.in_rs;
-    const XRegs xr = x_fetch<XVEC>(xrow, a.K);
+    const float* xa_row = a.pro.a + (uint64_t)m * a.in_rs;
+    const XRegs xa = x_fetch<XVEC>(xa_row, a.K);
+    // unconditional (the host points pro.b at pro.a when there is no prologue): a load under a
+    // branch would make hipcc fall back to vmcnt(0) waits
+    const XRegs xb = x_fetch<XVEC>(a.pro.b, a.K);
     uint32_t u = 4 * w + row; // this row's unit in step 0
     Group cur;
     cur.load(qs, sc, u, stride, u_last);
-    x_commit<XVEC>(xs, xr, xrow, a.U * UNIT_X, a.K);
+    float inv = 1.0f;
+    if (a.pro.kind == QMV_PRO_RMSNORM_MUL) {
+        const float ss = block_sumsq(xa, a.K, red);
+        inv = 1.0f / sqrtf(ss / (float)a.K + a.pro.eps); // reference.zig:365
+    }
+    x_commit<XVEC>(xs, xa, xb, a.pro, inv, a.U * UNIT_X, a.K, xa_row);
     __syncthreads();
 
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
@@ -299,7 +402,7 @@ __global__ void __launch_bounds__(1024) qmatvec_kernel(QMVArgs a) {
         u += DEPTH * stride;
     }
     cur.compute(xs, u, stride, a.U, i, acc0, acc1, acc2, acc3);
-    reduce_store((acc0 + acc1) + (acc2 + acc3), red, a, g, m);
+    reduce_store((acc0 + acc1) + (acc2 + acc3), red, part, g, m);
 }
 
 // Raw layout (any block size, any N): one thread per (m, n), k sequential — exactly the
@@ -465,30 +568,24 @@ bool qweight_packable(uint64_t K, uint64_t N, uint64_t bs) {
     return (KC * 32 + 4 + kMaxWaves * 16) * sizeof(float) <= kMaxLds;
 }
 
-void launch_qmatmul(hipStream_t s, const QWeightDev& w, const QMatmulParams& p, float*) {
-    if (p.M == 0 || p.N == 0) return;
-    if (w.format == QW_RAW) {
-        dim3 grid(cdiv(p.N, kBlock), p.M);
-        qmatmul_raw_kernel<<<grid, kBlock, 0, s>>>((const int8_t*)w.qs, (const float*)w.sc, w.bs, p);
-        return;
-    }
-    const bool q4 = w.format == QW_Q4;
-    QMVArgs a{};
-    a.qs = (const uint4*)w.qs;
-    a.sc = w.sc;
-    a.x = p.input;
-    a.out = p.dst;
-    a.M = p.M, a.N = p.N, a.K = p.K, a.NB2 = p.N / 16;
-    a.U = q4 ? w.KC : 2 * w.KC;
-    a.in_rs = p.in_rs;
-    a.out_rs = p.dst_rs;
-    // one workgroup per 16-column group; enough waves that each row gets >= 1 unit, at most 16
-    uint32_t waves = cdiv(a.U, 4);
+bool qmv_can_group(const QWeightDev& a, const QWeightDev& b) {
+    return a.format != QW_RAW && a.format == b.format && a.scale_f16 == b.scale_f16 && a.K == b.K && a.KC == b.KC;
+}
+
+namespace {
+
+uint32_t qmv_waves(const QWeightDev& w) {
+    const uint32_t U = w.format == QW_Q4 ? w.KC : 2 * w.KC;
+    uint32_t waves = cdiv(U, 4);
     if (waves > (uint32_t)kMaxWaves) waves = kMaxWaves;
-    if (waves < 1) waves = 1;
-    dim3 grid(a.NB2, p.M);
-    const size_t lds = qmv_lds_bytes(w);
-    const bool xvec = ((uintptr_t)p.input % 16 == 0) && (p.K % 4 == 0) && (p.M == 1 || p.in_rs % 4 == 0);
+    return waves < 1 ? 1 : waves;
+}
+
+void launch_packed(hipStream_t s, QMVArgs& a, const QWeightDev& w0, uint32_t total_blocks, uint32_t M, bool xvec) {
+    const bool q4 = w0.format == QW_Q4;
+    const uint32_t waves = qmv_waves(w0);
+    dim3 grid(total_blocks, M);
+    const size_t lds = qmv_lds_bytes(w0);
     const uint32_t n_steps = cdiv(a.U, waves * 4);
     const int depth_sel = n_steps >= 4 ? 2 : (n_steps >= 2 ? 1 : 0); // DEPTH 4 / 2 / 1
     using KernelFn = void (*)(QMVArgs);
@@ -506,7 +603,66 @@ void launch_qmatmul(hipStream_t s, const QWeightDev& w, const QMatmulParams& p, 
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
         lds_opt_in = true;
     }
-    hipLaunchKernelGGL(table[q4 ? 1 : 0][w.scale_f16 ? 1 : 0][xvec ? 1 : 0][depth_sel], grid, dim3(waves * 64), lds, s, a);
+    hipLaunchKernelGGL(table[q4 ? 1 : 0][w0.scale_f16 ? 1 : 0][xvec ? 1 : 0][depth_sel], grid, dim3(waves * 64), lds, s, a);
+}
+
+} // namespace
+
+uint32_t qmv_max_prologue_k(const QWeightDev& w) { return qmv_waves(w) * 64 * 4 * kXRegs; }
+
+void launch_qmatmul(hipStream_t s, const QWeightDev& w, const QMatmulParams& p, float*) {
+    if (p.M == 0 || p.N == 0) return;
+    if (w.format == QW_RAW) {
+        dim3 grid(cdiv(p.N, kBlock), p.M);
+        qmatmul_raw_kernel<<<grid, kBlock, 0, s>>>((const int8_t*)w.qs, (const float*)w.sc, w.bs, p);
+        return;
+    }
+    QMVArgs a{};
+    a.n_parts = 1;
+    a.parts[0].qs = (const uint4*)w.qs;
+    a.parts[0].sc = w.sc;
+    a.parts[0].out = p.dst;
+    a.parts[0].NB2 = p.N / 16;
+    a.parts[0].block_begin = 0;
+    a.parts[0].out_rs = p.dst_rs;
+    a.parts[0].n_epi = 0;
+    a.pro.kind = QMV_PRO_NONE;
+    a.pro.a = p.input;
+    a.pro.b = p.input;
+    a.M = p.M, a.K = p.K;
+    a.U = w.format == QW_Q4 ? w.KC : 2 * w.KC;
+    a.in_rs = p.in_rs;
+    const bool xvec = ((uintptr_t)p.input % 16 == 0) && (p.K % 4 == 0) && (p.M == 1 || p.in_rs % 4 == 0);
+    launch_packed(s, a, w, a.parts[0].NB2, p.M, xvec);
+}
+
+void launch_qmatvec_fused(hipStream_t s, const QmvLaunch& L) {
+    if (L.n_parts == 0) return;
+    const QWeightDev& w0 = L.parts[0].w;
+    QMVArgs a{};
+    a.n_parts = L.n_parts;
+    uint32_t blocks = 0;
+    for (uint32_t i = 0; i < L.n_parts; i++) {
+        const QmvPart& pt = L.parts[i];
+        QMVPartDev& d = a.parts[i];
+        d.qs = (const uint4*)pt.w.qs;
+        d.sc = pt.w.sc;
+        d.out = pt.dst;
+        d.NB2 = pt.w.N / 16;
+        d.block_begin = blocks;
+        d.out_rs = pt.w.N;
+        d.n_epi = pt.n_epi;
+        for (uint32_t e = 0; e < pt.n_epi; e++) d.epi[e] = pt.epi[e];
+        blocks += d.NB2;
+    }
+    a.pro = L.pro;
+    if (a.pro.kind == QMV_PRO_NONE) a.pro.b = a.pro.a;
+    a.M = 1, a.K = L.K;
+    a.U = w0.format == QW_Q4 ? w0.KC : 2 * w0.KC;
+    a.in_rs = L.K;
+    bool xvec = ((uintptr_t)L.pro.a % 16 == 0) && (L.K % 4 == 0);
+    if (L.pro.kind != QMV_PRO_NONE) xvec = xvec && ((uintptr_t)L.pro.b % 16 == 0);
+    launch_packed(s, a, w0, blocks, 1, xvec);
 }
 
 void launch_synth_packed(hipStream_t s, const QWeightDev& w, uint32_t matrix_id) {

@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <string>
@@ -543,6 +544,391 @@ void free_param_blobs(zgml_hip_program* p) {
     p->param_blobs.clear();
 }
 
+// ── macro-op fusion around the quantized mat-vecs (M == 1) ───────────────────────────────────
+// PROLOGUE  : the elementwise mul (optionally preceded by rmsnorm) that produces a mat-vec's input
+//             is computed inside the mat-vec while it stages x (each workgroup recomputes it from
+//             L2-resident vectors; workgroup 0 stores the intermediates);
+// EPILOGUE  : elementwise / fused_elementwise ops that consume the mat-vec output column-wise are
+//             applied by the 16 lanes that own the outputs (residual add, the SiLU chain, ...);
+// GROUPING  : mat-vecs of one dependency level that read the same vector (q/k/v, gate/up) share
+//             one launch.
+// Legality is decided from access spans only (no LLaMA-specific pattern): a macro-op is placed at
+// its last member; a member X may be delayed past a non-member C only if X and C do not conflict.
+struct Macro {
+    std::vector<uint32_t> members; // op indices, ascending
+    uint32_t position = 0;         // index of the last member
+    bool qmv = false;
+    uint32_t anchor = 0;           // the qmatmul op
+    QmvPrologue pro;
+    uint64_t pro_sig[3] = {0, 0, 0}; // (kind, a, b) identity for grouping
+    bool owns_prologue = false;
+    uint32_t n_epi = 0;
+    QmvEpiStep epi[kMaxEpiSteps];
+    OpAccess access;
+};
+
+bool ops_conflict(const OpAccess& x, const OpAccess& c) {
+    for (const Span& w : x.writes) {
+        for (const Span& r : c.reads)
+            if (spans_overlap(w, r)) return true;
+        for (const Span& w2 : c.writes)
+            if (spans_overlap(w, w2)) return true;
+    }
+    for (const Span& r : x.reads)
+        for (const Span& w2 : c.writes)
+            if (spans_overlap(r, w2)) return true;
+    return false;
+}
+
+struct ExactSpan {
+    uint16_t buf;
+    uint64_t off, n;
+    bool operator==(const ExactSpan& o) const { return buf == o.buf && off == o.off && n == o.n; }
+};
+
+bool barrier_between(const std::vector<uint64_t>& barriers, uint32_t lo, uint32_t hi) { // a barrier b with lo < b <= hi
+    for (uint64_t b : barriers)
+        if (b > lo && b <= hi) return true;
+    return false;
+}
+
+void add_access(OpAccess& dst, const OpAccess& src) {
+    dst.reads.insert(dst.reads.end(), src.reads.begin(), src.reads.end());
+    dst.writes.insert(dst.writes.end(), src.writes.begin(), src.writes.end());
+}
+
+bool anchor_ok(zgml_hip_program* p, uint32_t i) {
+    const zgml_device_op& op = p->ops[i];
+    if (op.kind != ZGML_DOP_QMATMUL || op.u.qmatmul.M != 1) return false;
+    const QWeightDev& w = p->qweights[op.u.qmatmul.weight_idx];
+    return w.format != QW_RAW && (op.u.qmatmul.input_offset % 4) == 0;
+}
+
+void build_fused_plan(zgml_hip_program* p) {
+    const auto& ops = p->ops;
+    const size_t n = ops.size();
+    const Schedule& s0 = p->sched; // per-op access spans
+    std::vector<int> owner(n, -1);  // op -> macro id that absorbed it
+    std::vector<Macro> macros;
+
+    auto exact_dst = [&](uint32_t i, ExactSpan& out) -> bool { // contiguous vector outputs only
+        const zgml_device_op& o = ops[i];
+        switch (o.kind) {
+            case ZGML_DOP_ELEMENTWISE: out = {o.u.elementwise.dst, o.u.elementwise.dst_offset, o.u.elementwise.n}; return true;
+            case ZGML_DOP_FUSED_ELEMENTWISE:
+                out = {o.u.fused_elementwise.dst, o.u.fused_elementwise.dst_offset, o.u.fused_elementwise.n};
+                return true;
+            case ZGML_DOP_RMSNORM:
+                if (o.u.rmsnorm.rows != 1) return false;
+                out = {o.u.rmsnorm.dst, o.u.rmsnorm.dst_offset, o.u.rmsnorm.cols};
+                return true;
+            case ZGML_DOP_QMATMUL:
+                if (o.u.qmatmul.M != 1) return false;
+                out = {o.u.qmatmul.dst, o.u.qmatmul.dst_offset, o.u.qmatmul.N};
+                return true;
+            default: return false;
+        }
+    };
+    auto last_writer = [&](const ExactSpan& sp, uint32_t before) -> int { // latest op < before writing into sp
+        const Span q{sp.buf, sp.off, sp.off + sp.n};
+        for (int j = (int)before - 1; j >= 0; j--)
+            for (const Span& w : s0.access[j].writes)
+                if (spans_overlap(w, q)) return j;
+        return -1;
+    };
+    auto readers_until_overwrite = [&](const ExactSpan& sp, uint32_t after, std::vector<uint32_t>& out) {
+        const Span q{sp.buf, sp.off, sp.off + sp.n};
+        for (uint32_t j = after + 1; j < n; j++) {
+            for (const Span& r : s0.access[j].reads)
+                if (spans_overlap(r, q)) {
+                    out.push_back(j);
+                    break;
+                }
+            for (const Span& w : s0.access[j].writes)
+                if (spans_overlap(w, q)) return;
+        }
+    };
+    // members may be delayed to `last` only if they conflict with no non-member in between
+    auto delay_legal = [&](const std::vector<uint32_t>& members, uint32_t last) -> bool {
+        for (uint32_t x : members)
+            for (uint32_t c = x + 1; c < last; c++) {
+                if (std::find(members.begin(), members.end(), c) != members.end()) continue;
+                if (ops_conflict(s0.access[x], s0.access[c])) return false;
+            }
+        return !members.empty() && !barrier_between(p->barriers, members.front(), last);
+    };
+
+    // ---- prologues: one absorbed producer chain per input vector, shared by all its consumers
+    struct ProInfo {
+        QmvPrologue pro;
+        std::vector<uint32_t> absorbed;  // P (and Q)
+        std::vector<uint32_t> consumers; // qmatmul ops
+        OpAccess reads;                  // what a non-owner consumer reads instead of P.dst
+    };
+    std::vector<ProInfo> pros;
+    std::vector<int> pro_of(n, -1);
+    for (uint32_t i = 0; i < n; i++) {
+        if (!anchor_ok(p, i) || pro_of[i] >= 0) continue;
+        const auto& q = ops[i].u.qmatmul;
+        const ExactSpan in{q.input, q.input_offset, q.K};
+        const int P = last_writer(in, i);
+        if (P < 0 || owner[P] >= 0) continue;
+        const zgml_device_op& po = ops[P];
+        if (po.kind != ZGML_DOP_ELEMENTWISE || po.u.elementwise.op != ZGML_OP_MUL) continue;
+        const auto& e = po.u.elementwise;
+        if (!(ExactSpan{e.dst, e.dst_offset, e.n} == in)) continue;
+        if ((e.dst_offset % 4) || (e.src0_offset % 4) || (e.src1_offset % 4)) continue;
+        std::vector<uint32_t> readers;
+        readers_until_overwrite(in, (uint32_t)P, readers);
+        bool ok = !readers.empty();
+        for (uint32_t r : readers) {
+            if (!anchor_ok(p, r)) ok = false;
+            else {
+                const auto& rq = ops[r].u.qmatmul;
+                if (!(ExactSpan{rq.input, rq.input_offset, rq.K} == in)) ok = false;
+                if (rq.K > qmv_max_prologue_k(p->qweights[rq.weight_idx])) ok = false;
+            }
+        }
+        if (!ok) continue;
+        ProInfo info;
+        info.absorbed = {(uint32_t)P};
+        info.consumers = readers;
+        info.pro.kind = QMV_PRO_MUL;
+        info.pro.a = buf_at(p, e.src0, e.src0_offset);
+        info.pro.b = buf_at(p, e.src1, e.src1_offset);
+        info.pro.store_x = buf_at(p, e.dst, e.dst_offset);
+        info.reads.reads = s0.access[P].reads;
+        // rmsnorm feeding one side of the mul?
+        for (int side = 0; side < 2; side++) {
+            const ExactSpan sp = side == 0 ? ExactSpan{e.src0, e.src0_offset, e.n} : ExactSpan{e.src1, e.src1_offset, e.n};
+            const int Q = last_writer(sp, (uint32_t)P);
+            if (Q < 0 || owner[Q] >= 0 || ops[Q].kind != ZGML_DOP_RMSNORM) continue;
+            const auto& rn = ops[Q].u.rmsnorm;
+            ExactSpan qd{};
+            if (!exact_dst((uint32_t)Q, qd) || !(qd == sp) || (rn.src_offset % 4) || (rn.dst_offset % 4)) continue;
+            std::vector<uint32_t> qreaders;
+            readers_until_overwrite(sp, (uint32_t)Q, qreaders);
+            if (qreaders.size() != 1 || qreaders[0] != (uint32_t)P) continue;
+            info.absorbed = {(uint32_t)Q, (uint32_t)P};
+            info.pro.kind = QMV_PRO_RMSNORM_MUL;
+            info.pro.eps = rn.eps;
+            info.pro.a = buf_at(p, rn.src, rn.src_offset);
+            info.pro.b = side == 0 ? buf_at(p, e.src1, e.src1_offset) : buf_at(p, e.src0, e.src0_offset);
+            info.pro.store_mid = buf_at(p, rn.dst, rn.dst_offset);
+            info.reads.reads = s0.access[Q].reads;
+            info.reads.reads.push_back(side == 0 ? s0.access[P].reads[1] : s0.access[P].reads[0]);
+            break;
+        }
+        // the absorbed ops are delayed to the first consumer, and their inputs must survive until the last
+        std::vector<uint32_t> mem = info.absorbed;
+        if (!delay_legal(mem, info.consumers.front())) continue;
+        // every consumer recomputes the prologue from its inputs, so each input must keep its value
+        // from the op that originally read it (Q for the rmsnorm source, P for the rest) up to the
+        // last consumer
+        bool inputs_live = true;
+        auto live = [&](const Span& r, uint32_t from) {
+            for (uint32_t c = from + 1; c < info.consumers.back() && inputs_live; c++) {
+                if (std::find(info.absorbed.begin(), info.absorbed.end(), c) != info.absorbed.end()) continue;
+                for (const Span& w : s0.access[c].writes)
+                    if (spans_overlap(r, w)) inputs_live = false;
+            }
+        };
+        if (info.pro.kind == QMV_PRO_RMSNORM_MUL) {
+            live(info.reads.reads[0], info.absorbed.front()); // x, read by the rmsnorm
+            live(info.reads.reads[1], (uint32_t)P);            // gamma (repeat output), read by the mul
+        } else {
+            for (const Span& r : info.reads.reads) live(r, (uint32_t)P);
+        }
+        if (!inputs_live || barrier_between(p->barriers, info.absorbed.front(), info.consumers.back())) continue;
+        const int id = (int)pros.size();
+        for (uint32_t c : info.consumers) pro_of[c] = id;
+        for (uint32_t x : info.absorbed) owner[x] = -2; // claimed; macro id assigned below
+        pros.push_back(std::move(info));
+    }
+
+    // ---- one macro per mat-vec anchor: (prologue) + anchor + epilogue chain
+    std::vector<char> in_macro(n, 0);
+    for (uint32_t i = 0; i < n; i++) {
+        if (!anchor_ok(p, i)) continue;
+        Macro m;
+        m.qmv = true;
+        m.anchor = i;
+        const auto& q = ops[i].u.qmatmul;
+        m.pro.kind = QMV_PRO_NONE;
+        m.pro.a = buf_at(p, q.input, q.input_offset);
+        OpAccess acc = s0.access[i];
+        if (pro_of[i] >= 0) {
+            const ProInfo& info = pros[pro_of[i]];
+            m.pro = info.pro;
+            m.owns_prologue = info.consumers.front() == i;
+            if (m.owns_prologue) {
+                for (uint32_t x : info.absorbed) {
+                    m.members.push_back(x);
+                    add_access(acc, s0.access[x]);
+                }
+            } else { // recompute without storing: read the prologue's inputs instead of its output
+                m.pro.store_mid = nullptr;
+                m.pro.store_x = nullptr;
+                acc.reads = info.reads.reads;
+            }
+        }
+        m.pro_sig[0] = m.pro.kind, m.pro_sig[1] = (uint64_t)(uintptr_t)m.pro.a, m.pro_sig[2] = (uint64_t)(uintptr_t)m.pro.b;
+        m.members.push_back(i);
+        // epilogue chain
+        ExactSpan cur{q.dst, q.dst_offset, q.N};
+        uint32_t cur_idx = i;
+        for (;;) {
+            std::vector<uint32_t> readers;
+            readers_until_overwrite(cur, cur_idx, readers);
+            int B = -1;
+            for (uint32_t r : readers)
+                if (!in_macro[r] && owner[r] == -1 &&
+                    (ops[r].kind == ZGML_DOP_ELEMENTWISE || ops[r].kind == ZGML_DOP_FUSED_ELEMENTWISE)) {
+                    B = (int)r;
+                    break;
+                }
+            if (B < 0) break;
+            const zgml_device_op& bo = ops[B];
+            QmvEpiStep steps[kMaxEpiSteps];
+            uint32_t ns = 0;
+            ExactSpan bdst{};
+            bool ok = exact_dst((uint32_t)B, bdst) && bdst.n == cur.n;
+            if (ok && bo.kind == ZGML_DOP_ELEMENTWISE) {
+                const auto& e = bo.u.elementwise;
+                const bool binary = e.op == ZGML_OP_ADD || e.op == ZGML_OP_MUL;
+                const ExactSpan s0sp{e.src0, e.src0_offset, e.n}, s1sp{e.src1, e.src1_offset, e.n};
+                if (s0sp == cur)
+                    steps[ns++] = {e.op, 0, binary ? buf_at(p, e.src1, e.src1_offset) : nullptr, nullptr};
+                else if (binary && s1sp == cur)
+                    steps[ns++] = {e.op, 1, buf_at(p, e.src0, e.src0_offset), nullptr};
+                else
+                    ok = false;
+            } else if (ok) {
+                const auto& f = bo.u.fused_elementwise;
+                ok = ExactSpan{f.src, f.src_offset, f.n} == cur && f.n_steps <= (uint32_t)kMaxEpiSteps;
+                for (uint32_t t = 0; ok && t < f.n_steps; t++) {
+                    const bool binary = f.steps[t].op == ZGML_OP_ADD || f.steps[t].op == ZGML_OP_MUL;
+                    steps[ns++] = {f.steps[t].op, f.steps[t].is_swapped,
+                                   binary ? buf_at(p, f.steps[t].secondary_buf, f.steps[t].secondary_offset) : nullptr, nullptr};
+                }
+            }
+            if (!ok || ns == 0 || m.n_epi + ns > (uint32_t)kMaxEpiSteps) break;
+            std::vector<uint32_t> trial = m.members;
+            trial.push_back((uint32_t)B);
+            if (!delay_legal(trial, (uint32_t)B)) break;
+            steps[ns - 1].store = buf_at(p, bdst.buf, bdst.off);
+            for (uint32_t t = 0; t < ns; t++) m.epi[m.n_epi++] = steps[t];
+            m.members.push_back((uint32_t)B);
+            in_macro[B] = 1;
+            add_access(acc, s0.access[B]);
+            cur = bdst;
+            cur_idx = (uint32_t)B;
+        }
+        if (m.members.size() > 1 && !delay_legal(m.members, m.members.back())) { // absorbed prologue + epilogue together
+            // fall back to the bare anchor (keeps correctness trivially)
+            for (uint32_t x : m.members)
+                if (x != i) in_macro[x] = 0;
+            Macro plain;
+            plain.qmv = true, plain.anchor = i, plain.members = {i};
+            plain.pro.kind = QMV_PRO_NONE, plain.pro.a = buf_at(p, q.input, q.input_offset);
+            plain.pro_sig[0] = 0, plain.pro_sig[1] = (uint64_t)(uintptr_t)plain.pro.a;
+            plain.access = s0.access[i];
+            m = plain;
+            if (pro_of[i] >= 0) { // the prologue ops must then run on their own
+                for (uint32_t x : pros[pro_of[i]].absorbed) owner[x] = -1;
+                for (uint32_t c : pros[pro_of[i]].consumers) pro_of[c] = -1;
+            }
+        } else {
+            m.access = acc;
+        }
+        std::sort(m.members.begin(), m.members.end());
+        m.position = m.members.back();
+        for (uint32_t x : m.members) in_macro[x] = 1;
+        macros.push_back(std::move(m));
+    }
+    // consumers whose prologue was revoked after their macro was built: rebuild plainly
+    for (Macro& m : macros)
+        if (m.qmv && m.pro.kind != QMV_PRO_NONE && pro_of[m.anchor] < 0) {
+            const auto& q = ops[m.anchor].u.qmatmul;
+            std::vector<uint32_t> keep;
+            for (uint32_t x : m.members)
+                if (x >= m.anchor) keep.push_back(x);
+            for (uint32_t x : m.members)
+                if (x < m.anchor) in_macro[x] = 0;
+            m.members = keep;
+            m.pro = QmvPrologue{};
+            m.pro.a = buf_at(p, q.input, q.input_offset);
+            m.pro_sig[0] = 0, m.pro_sig[1] = (uint64_t)(uintptr_t)m.pro.a, m.pro_sig[2] = 0;
+            m.access = OpAccess{};
+            for (uint32_t x : m.members) add_access(m.access, s0.access[x]);
+        }
+    // everything else is a singleton
+    for (uint32_t i = 0; i < n; i++) {
+        if (in_macro[i]) continue;
+        Macro m;
+        m.members = {i};
+        m.position = i;
+        m.access = s0.access[i];
+        macros.push_back(std::move(m));
+    }
+    std::sort(macros.begin(), macros.end(), [](const Macro& a, const Macro& b) { return a.position < b.position; });
+
+    std::vector<OpAccess> access(macros.size());
+    std::vector<uint64_t> position(macros.size());
+    for (size_t i = 0; i < macros.size(); i++) access[i] = macros[i].access, position[i] = macros[i].position;
+    std::vector<uint32_t> level;
+    std::vector<std::vector<uint32_t>> levels;
+    levels_from_access(access, position, p->barriers, level, levels);
+
+    for (const auto& lv : levels) {
+        std::vector<uint32_t> plain_ops;
+        std::vector<const Macro*> qmvs;
+        for (uint32_t mi : lv) {
+            if (macros[mi].qmv)
+                qmvs.push_back(&macros[mi]);
+            else
+                plain_ops.push_back(macros[mi].members[0]);
+        }
+        emit_batches(p, plain_ops);
+        // group mat-vecs that stage the same vector
+        std::vector<char> used(qmvs.size(), 0);
+        for (size_t i = 0; i < qmvs.size(); i++) {
+            if (used[i]) continue;
+            QmvLaunch L;
+            std::vector<const Macro*> grp;
+            const Macro* first = qmvs[i];
+            const QWeightDev& w0 = p->qweights[ops[first->anchor].u.qmatmul.weight_idx];
+            for (size_t j = i; j < qmvs.size() && grp.size() < (size_t)kMaxQmvParts; j++) {
+                if (used[j]) continue;
+                const Macro* c = qmvs[j];
+                const QWeightDev& wj = p->qweights[ops[c->anchor].u.qmatmul.weight_idx];
+                if (c->pro_sig[0] != first->pro_sig[0] || c->pro_sig[1] != first->pro_sig[1] || c->pro_sig[2] != first->pro_sig[2]) continue;
+                if (!qmv_can_group(w0, wj)) continue;
+                used[j] = 1;
+                grp.push_back(c);
+            }
+            L.n_parts = (uint32_t)grp.size();
+            L.K = w0.K;
+            L.pro = first->pro;
+            L.pro.store_mid = nullptr, L.pro.store_x = nullptr;
+            uint32_t lo = UINT32_MAX, hi = 0, n_ops = 0;
+            for (size_t k = 0; k < grp.size(); k++) {
+                const Macro* c = grp[k];
+                const auto& q = ops[c->anchor].u.qmatmul;
+                L.parts[k].w = p->qweights[q.weight_idx];
+                L.parts[k].dst = buf_at(p, q.dst, q.dst_offset);
+                L.parts[k].n_epi = c->n_epi;
+                for (uint32_t e = 0; e < c->n_epi; e++) L.parts[k].epi[e] = c->epi[e];
+                if (c->owns_prologue) L.pro.store_mid = c->pro.store_mid, L.pro.store_x = c->pro.store_x;
+                lo = std::min(lo, c->members.front());
+                hi = std::max(hi, c->members.back());
+                n_ops += (uint32_t)c->members.size();
+            }
+            p->plan.push_back({ZGML_DOP_QMATMUL, n_ops, lo, hi, [=](hipStream_t s) { launch_qmatvec_fused(s, L); }});
+        }
+    }
+}
+
 void build_plan(zgml_hip_program* p) {
     hipStreamSynchronize(p->ctx->stream); // the previous plan's parameter arrays may still be in use
     p->plan.clear();
@@ -553,11 +939,19 @@ void build_plan(zgml_hip_program* p) {
         if (!dynamic_fields_in_bounds(p->sched, p->ops)) p->plan_batched = false;
     }
     if (p->plan_batched) {
-        for (const auto& level : p->sched.levels) emit_batches(p, level);
+        build_fused_plan(p);
     } else {
         for (uint32_t i = 0; i < p->ops.size(); i++) emit_batches(p, {i});
     }
     p->plan_dirty = false;
+    if (getenv("ZGML_HIP_DEBUG_PLAN")) {
+        uint64_t by_kind[ZGML_DOP_COUNT] = {0}, ops_by_kind[ZGML_DOP_COUNT] = {0};
+        for (const auto& L : p->plan) by_kind[L.kind]++, ops_by_kind[L.kind] += L.n_ops;
+        fprintf(stderr, "[zgml_hip] plan: %zu launches for %zu ops (batched=%d):", p->plan.size(), p->ops.size(), (int)p->plan_batched);
+        for (int k = 0; k < ZGML_DOP_COUNT; k++)
+            if (by_kind[k]) fprintf(stderr, " kind%d=%llu(%llu ops)", k, (unsigned long long)by_kind[k], (unsigned long long)ops_by_kind[k]);
+        fprintf(stderr, "\n");
+    }
 }
 
 void set_dyn_from_ops(zgml_hip_program* p) {
@@ -819,6 +1213,9 @@ zgml_hip_ctx* zgml_hip_create(int device_ordinal) {
     }
     zgml_hip_ctx* ctx = new zgml_hip_ctx();
     ctx->device = device_ordinal;
+    // environment overrides of the option defaults (profilers: ZGML_HIP_GRAPH=0 traces eager launches)
+    if (const char* e = getenv("ZGML_HIP_GRAPH")) ctx->opt_graph = atoi(e) != 0;
+    if (const char* e = getenv("ZGML_HIP_FUSION")) ctx->opt_fusion = atoi(e) != 0;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         g_create_error = "hipStreamCreate failed";
         delete ctx;

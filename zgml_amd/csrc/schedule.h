@@ -48,6 +48,15 @@ struct Schedule {
 Schedule build_schedule(const std::vector<zgml_device_op>& ops, const std::vector<uint64_t>& buffer_sizes,
                         const std::vector<uint64_t>& barriers);
 
+// Levels of an arbitrary list of items with access lists (used for fused macro-ops). `position[i]`
+// is the program-order op index the item stands at (for barrier placement); items must be sorted
+// by position.
+void levels_from_access(const std::vector<OpAccess>& access, const std::vector<uint64_t>& position,
+                        const std::vector<uint64_t>& barriers, std::vector<uint32_t>& level,
+                        std::vector<std::vector<uint32_t>>& levels);
+
+inline bool spans_overlap(const Span& x, const Span& y) { return x.buf == y.buf && x.lo < y.hi && y.lo < x.hi; }
+
 // true when every dynamic field of `ops` respects the bounds assumed by `s`
 bool dynamic_fields_in_bounds(const Schedule& s, const std::vector<zgml_device_op>& ops);
 

@@ -137,37 +137,46 @@ Schedule build_schedule(const std::vector<zgml_device_op>& ops, const std::vecto
     s.access.resize(n);
     for (size_t i = 0; i < n; i++) s.access[i] = op_access(ops[i], s.bounds[i]);
 
-    // hazard DAG -> levels. Per buffer we keep the accesses seen so far; an op's level is one more
-    // than the deepest earlier op it conflicts with (RAW, WAW or WAR).
+    std::vector<uint64_t> position(n);
+    for (size_t i = 0; i < n; i++) position[i] = i;
+    levels_from_access(s.access, position, barriers, s.level, s.levels);
+    return s;
+}
+
+// hazard DAG -> levels. Per buffer we keep the accesses seen so far; an item's level is one more
+// than the deepest earlier item it conflicts with (RAW, WAW or WAR).
+void levels_from_access(const std::vector<OpAccess>& access, const std::vector<uint64_t>& position,
+                        const std::vector<uint64_t>& barriers, std::vector<uint32_t>& level,
+                        std::vector<std::vector<uint32_t>>& levels) {
     struct Seen {
         Span sp;
         uint32_t level;
         bool write;
     };
+    const size_t n = access.size();
     std::map<uint16_t, std::vector<Seen>> seen;
-    s.level.assign(n, 0);
+    level.assign(n, 0);
     uint32_t floor_level = 0, max_level = 0;
     size_t next_barrier = 0;
     for (size_t i = 0; i < n; i++) {
-        while (next_barrier < barriers.size() && barriers[next_barrier] <= i) { // nothing crosses a barrier
+        while (next_barrier < barriers.size() && barriers[next_barrier] <= position[i]) { // nothing crosses a barrier
             floor_level = max_level + 1;
             next_barrier++;
         }
         uint32_t lv = floor_level;
-        for (const Span& w : s.access[i].writes)
+        for (const Span& w : access[i].writes)
             for (const Seen& e : seen[w.buf])
                 if (overlap(w, e.sp)) lv = std::max(lv, e.level + 1);
-        for (const Span& r : s.access[i].reads)
+        for (const Span& r : access[i].reads)
             for (const Seen& e : seen[r.buf])
                 if (e.write && overlap(r, e.sp)) lv = std::max(lv, e.level + 1);
-        s.level[i] = lv;
-        if (i == 0 || lv > max_level) max_level = std::max(max_level, lv);
-        for (const Span& w : s.access[i].writes) seen[w.buf].push_back({w, lv, true});
-        for (const Span& r : s.access[i].reads) seen[r.buf].push_back({r, lv, false});
+        level[i] = lv;
+        max_level = std::max(max_level, lv);
+        for (const Span& w : access[i].writes) seen[w.buf].push_back({w, lv, true});
+        for (const Span& r : access[i].reads) seen[r.buf].push_back({r, lv, false});
     }
-    s.levels.assign((size_t)max_level + 1, {});
-    for (size_t i = 0; i < n; i++) s.levels[s.level[i]].push_back((uint32_t)i);
-    return s;
+    levels.assign((size_t)max_level + 1, {});
+    for (size_t i = 0; i < n; i++) levels[level[i]].push_back((uint32_t)i);
 }
 
 bool dynamic_fields_in_bounds(const Schedule& s, const std::vector<zgml_device_op>& ops) {
