@@ -48,6 +48,20 @@ struct RopeParams {
     const float* src;
     const float* cs;
     uint32_t half_d, seq_len, src_rs, src_cs, cs_cs;
+    // optional fused slice_assign of the rotated block (rope k -> KV cache): second destination
+    float* dst2;                  // buffer base; nullptr = none
+    const uint32_t* dyn_dst2_off; // device word with the current dst_offset
+    uint32_t d2_rs, d2_cs;
+};
+
+// One record of the batched "movement" launch: a rope (kind 0) or a slice_assign (kind 1).
+struct MoveParams {
+    uint32_t kind;
+    uint32_t n_elems; // threads needed
+    union {
+        RopeParams rope;
+        SliceAssignParams sa;
+    };
 };
 
 struct AttentionParams {
@@ -60,6 +74,10 @@ struct AttentionParams {
     const uint32_t* dyn_seq_kv; // device word holding the current seq_kv
     float scale;
     uint32_t q_rs, q_cs, k_rs, k_cs, v_rs, v_cs, mask_rs, mask_cs, dst_rs, dst_cs;
+    // optional fused slice_assign of the head output (row store into the concatenated buffer)
+    float* dst2;
+    const uint32_t* dyn_dst2_off;
+    uint32_t d2_rs, d2_cs;
 };
 
 struct DenseMatmulParams {
@@ -149,9 +167,10 @@ void launch_rmsnorm(hipStream_t s, float* dst, const float* src, uint32_t rows, 
 void launch_reduce(hipStream_t s, uint32_t op, float* dst, const float* src, uint32_t n_out, uint32_t reduce_size);
 // batched: dev_params = device array of n_ops records; one launch covers all of them
 void launch_repeat_batch(hipStream_t s, const RepeatParams* dev_params, uint32_t n_ops, uint32_t max_elems);
-void launch_slice_assign_batch(hipStream_t s, const SliceAssignParams* dev_params, uint32_t n_ops, uint32_t max_elems);
-void launch_rope_batch(hipStream_t s, const RopeParams* dev_params, uint32_t n_ops, uint32_t max_elems);
-void launch_attention_batch(hipStream_t s, const AttentionParams* dev_params, uint32_t n_ops, uint32_t max_seq_q);
+void launch_move_batch(hipStream_t s, const MoveParams* dev_params, uint32_t n_ops, uint32_t max_elems);
+// all_dense: every op has unit row strides, 16-byte aligned q/k/v rows, d_head a power of two in [4, 256]
+void launch_attention_batch(hipStream_t s, const AttentionParams* dev_params, uint32_t n_ops, uint32_t max_seq_q,
+                            bool all_dense);
 void launch_dense_matmul(hipStream_t s, const DenseMatmulParams& p);
 void launch_argmax(hipStream_t s, const float* v, uint64_t n, float* scratch_val, int64_t* scratch_idx, int64_t* out);
 void launch_copy_f4(hipStream_t s, void* dst, const void* src, uint64_t bytes);

@@ -207,9 +207,7 @@ __global__ void __launch_bounds__(kBlock) repeat_kernel(const RepeatParams* __re
 
 // reference.zig:435-455; dst_offset is read from the program's dynamic-parameter block so a
 // captured graph stays valid across KV positions.
-__global__ void __launch_bounds__(kBlock) slice_assign_kernel(const SliceAssignParams* __restrict__ params) {
-    const SliceAssignParams& p = params[blockIdx.y];
-    uint32_t gid = blockIdx.x * kBlock + threadIdx.x;
+__device__ __forceinline__ void slice_assign_body(const SliceAssignParams& p, uint32_t gid) {
     if (gid >= p.rows * p.cols) return;
     uint32_t row = gid % p.rows, col = gid / p.rows;
     uint32_t doff = *p.dyn_dst_offset;
@@ -217,24 +215,46 @@ __global__ void __launch_bounds__(kBlock) slice_assign_kernel(const SliceAssignP
         p.src[(uint64_t)row * p.src_row_stride + (uint64_t)col * p.src_col_stride];
 }
 
-// reference.zig:457-478 (DeviceOp convention: sin at cs + pair + half_d)
-__global__ void __launch_bounds__(kBlock) rope_kernel(const RopeParams* __restrict__ params) {
-    const RopeParams& p = params[blockIdx.y];
-    uint32_t gid = blockIdx.x * kBlock + threadIdx.x;
+// reference.zig:457-478 (DeviceOp convention: sin at cs + pair + half_d). With dst2 set the rotated
+// values are also stored through the fused slice_assign (src = this rope's dense [2*half_d, seq]
+// output: row = pair or pair + half_d, col = col).
+__device__ __forceinline__ void rope_body(const RopeParams& p, uint32_t gid) {
     if (gid >= p.half_d * p.seq_len) return;
     uint32_t pair = gid % p.half_d, col = gid / p.half_d;
     float x_lo = p.src[(uint64_t)pair * p.src_rs + (uint64_t)col * p.src_cs];
     float x_hi = p.src[(uint64_t)(pair + p.half_d) * p.src_rs + (uint64_t)col * p.src_cs];
     float c = p.cs[pair + (uint64_t)col * p.cs_cs];
     float s = p.cs[pair + p.half_d + (uint64_t)col * p.cs_cs];
-    p.dst[pair + (uint64_t)col * 2 * p.half_d] = x_lo * c - x_hi * s;
-    p.dst[pair + p.half_d + (uint64_t)col * 2 * p.half_d] = x_hi * c + x_lo * s;
+    const float lo = x_lo * c - x_hi * s, hi = x_hi * c + x_lo * s;
+    p.dst[pair + (uint64_t)col * 2 * p.half_d] = lo;
+    p.dst[pair + p.half_d + (uint64_t)col * 2 * p.half_d] = hi;
+    if (p.dst2) {
+        const uint64_t doff = *p.dyn_dst2_off;
+        p.dst2[doff + (uint64_t)pair * p.d2_rs + (uint64_t)col * p.d2_cs] = lo;
+        p.dst2[doff + (uint64_t)(pair + p.half_d) * p.d2_rs + (uint64_t)col * p.d2_cs] = hi;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) move_kernel(const MoveParams* __restrict__ params) {
+    const MoveParams& p = params[blockIdx.y];
+    const uint32_t gid = blockIdx.x * kBlock + threadIdx.x;
+    if (gid >= p.n_elems) return;
+    if (p.kind == 0)
+        rope_body(p.rope, gid);
+    else
+        slice_assign_body(p.sa, gid);
 }
 
 // reference.zig:568-672. One workgroup per query column; keys are processed in tiles of 256 with
 // an online softmax (so there is no seq_kv cap, unlike the 4096-entry score buffers of the Metal
 // and WGSL kernels). Masked (non-finite mask) and non-finite-score keys are skipped exactly as the
 // reference does; a query with no valid key yields zeros.
+// head output element (row r of query column qi), plus the fused row store when present
+__device__ __forceinline__ void store_out(const AttentionParams& p, uint32_t qi, uint32_t r, float v) {
+    p.dst[(uint64_t)qi * p.dst_cs + (uint64_t)r * p.dst_rs] = v;
+    if (p.dst2) p.dst2[(uint64_t)*p.dyn_dst2_off + (uint64_t)r * p.d2_rs + (uint64_t)qi * p.d2_cs] = v;
+}
+
 __global__ void __launch_bounds__(kBlock) attention_kernel(const AttentionParams* __restrict__ params) {
     const AttentionParams p = params[blockIdx.y];
     if (blockIdx.x >= p.seq_q) return; // batched ops may have fewer queries than the grid
@@ -309,11 +329,108 @@ __global__ void __launch_bounds__(kBlock) attention_kernel(const AttentionParams
         if (tid < dh) {
             float a = 0.f;
             for (uint32_t gg = 0; gg < G; gg++) a += acc_s[gg * dh + tid];
-            p.dst[(uint64_t)qi * p.dst_cs + (uint64_t)tid * p.dst_rs] = a * inv_l;
+            store_out(p, qi, tid, a * inv_l);
         }
     } else {
-        if (r0 < dh) p.dst[(uint64_t)qi * p.dst_cs + (uint64_t)r0 * p.dst_rs] = acc0 * inv_l;
-        if (r0 + kBlock < dh) p.dst[(uint64_t)qi * p.dst_cs + (uint64_t)(r0 + kBlock) * p.dst_rs] = acc1 * inv_l;
+        if (r0 < dh) store_out(p, qi, r0, acc0 * inv_l);
+        if (r0 + kBlock < dh) store_out(p, qi, r0 + kBlock, acc1 * inv_l);
+    }
+}
+
+// Decode-shaped fast path: unit row strides on q/k/v/dst and d_head % 4 == 0, d_head <= 256
+// (checked on the host). A key is handled by LPK = d_head/4 adjacent lanes holding one float4 each
+// (one coalesced row read per key), so a wave scores 64/LPK keys per iteration; waves stride over
+// the keys. Scores of a tile (<= kTile keys) live in LDS; tiles chain with the online-softmax
+// rescale, so seq_kv is unbounded. P.V uses the same lane layout (float4 of the head dimension per
+// lane), folded across lane groups by shuffles and across waves through LDS.
+constexpr uint32_t kTile = 1024;
+
+__global__ void __launch_bounds__(kBlock) attention_dense_kernel(const AttentionParams* __restrict__ params) {
+    const AttentionParams p = params[blockIdx.y];
+    if (blockIdx.x >= p.seq_q) return;
+    __shared__ float sc_s[kTile];
+    __shared__ float red[8];
+    __shared__ float4 acc_s[kBlock];
+    const uint32_t qi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, dh = p.d_head;
+    const uint32_t LPK = dh >> 2, KPW = 64 / LPK, sub = lane / LPK, li = lane % LPK; // LPK in {1..64}, power of two checked on host
+    const uint32_t seq_kv = *p.dyn_seq_kv;
+    const float4 qv = *(const float4*)(p.q + (uint64_t)qi * p.q_cs + 4 * li);
+    const uint32_t keys_per_iter = KPW * (kBlock / 64);
+    float m = -INFINITY, l = 0.f;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    for (uint32_t t0 = 0; t0 < seq_kv; t0 += kTile) {
+        const uint32_t tn = min(kTile, seq_kv - t0);
+        // scores
+        float tmax = -INFINITY;
+        for (uint32_t base = 0; base < tn; base += keys_per_iter) {
+            const uint32_t t = base + w * KPW + sub;
+            float score = -INFINITY;
+            const bool in = t < tn;
+            const uint32_t s = t0 + (in ? t : 0);
+            const float4 kv = *(const float4*)(p.k + (uint64_t)s * p.k_cs + 4 * li);
+            float dot = qv.x * kv.x + qv.y * kv.y + qv.z * kv.z + qv.w * kv.w;
+            for (uint32_t off = LPK >> 1; off > 0; off >>= 1) dot += __shfl_xor(dot, off, 64);
+            if (in) {
+                const float mask_add = p.mask ? p.mask[(uint64_t)qi * p.mask_cs + (uint64_t)s * p.mask_rs] : 0.0f;
+                if (isfinite(mask_add)) {
+                    score = dot * p.scale + mask_add;
+                    if (!isfinite(score)) score = -INFINITY;
+                }
+                if (li == 0) sc_s[t] = score;
+            }
+            tmax = fmaxf(tmax, score);
+        }
+        tmax = block_max(tmax, red); // barriers also publish sc_s
+        const float new_m = fmaxf(m, tmax);
+        if (new_m == -INFINITY) continue; // uniform: no valid key yet
+        const float alpha = (m == -INFINITY) ? 0.0f : expf(m - new_m);
+        // weights (in place) and their sum
+        float tsum = 0.f;
+        for (uint32_t t = tid; t < tn; t += kBlock) {
+            const float sc = sc_s[t];
+            const float wgt = sc > -INFINITY ? expf(sc - new_m) : 0.0f;
+            sc_s[t] = wgt;
+            tsum += wgt;
+        }
+        tsum = block_sum(tsum, red); // barriers publish the weights
+        l = l * alpha + tsum;
+        m = new_m;
+        // P.V
+        acc = make_float4(acc.x * alpha, acc.y * alpha, acc.z * alpha, acc.w * alpha);
+        for (uint32_t base = 0; base < tn; base += keys_per_iter) {
+            const uint32_t t = base + w * KPW + sub;
+            const bool in = t < tn;
+            const uint32_t s = t0 + (in ? t : 0);
+            const float wgt = in ? sc_s[t] : 0.0f;
+            const float4 vv = *(const float4*)(p.v + (uint64_t)s * p.v_cs + 4 * li);
+            acc.x += wgt * vv.x;
+            acc.y += wgt * vv.y;
+            acc.z += wgt * vv.z;
+            acc.w += wgt * vv.w;
+        }
+        __syncthreads(); // sc_s reused by the next tile
+    }
+    // fold the KPW lane groups of each wave, then the waves
+    for (uint32_t off = LPK; off < 64; off <<= 1) {
+        acc.x += __shfl_xor(acc.x, off, 64);
+        acc.y += __shfl_xor(acc.y, off, 64);
+        acc.z += __shfl_xor(acc.z, off, 64);
+        acc.w += __shfl_xor(acc.w, off, 64);
+    }
+    acc_s[tid] = acc;
+    __syncthreads();
+    if (tid < LPK) {
+        float4 a = acc_s[tid];
+        for (uint32_t ww = 1; ww < kBlock / 64; ww++) {
+            const float4 b = acc_s[ww * 64 + tid];
+            a.x += b.x, a.y += b.y, a.z += b.z, a.w += b.w;
+        }
+        const float inv_l = l > 0.f ? 1.0f / l : 0.0f;
+        store_out(p, qi, 4 * tid + 0, a.x * inv_l);
+        store_out(p, qi, 4 * tid + 1, a.y * inv_l);
+        store_out(p, qi, 4 * tid + 2, a.z * inv_l);
+        store_out(p, qi, 4 * tid + 3, a.w * inv_l);
     }
 }
 
@@ -503,19 +620,18 @@ void launch_repeat_batch(hipStream_t s, const RepeatParams* dev_params, uint32_t
     repeat_kernel<<<dim3(cdiv(max_elems, kBlock), n_ops), kBlock, 0, s>>>(dev_params);
 }
 
-void launch_slice_assign_batch(hipStream_t s, const SliceAssignParams* dev_params, uint32_t n_ops, uint32_t max_elems) {
+void launch_move_batch(hipStream_t s, const MoveParams* dev_params, uint32_t n_ops, uint32_t max_elems) {
     if (!n_ops || !max_elems) return;
-    slice_assign_kernel<<<dim3(cdiv(max_elems, kBlock), n_ops), kBlock, 0, s>>>(dev_params);
+    move_kernel<<<dim3(cdiv(max_elems, kBlock), n_ops), kBlock, 0, s>>>(dev_params);
 }
 
-void launch_rope_batch(hipStream_t s, const RopeParams* dev_params, uint32_t n_ops, uint32_t max_elems) {
-    if (!n_ops || !max_elems) return;
-    rope_kernel<<<dim3(cdiv(max_elems, kBlock), n_ops), kBlock, 0, s>>>(dev_params);
-}
-
-void launch_attention_batch(hipStream_t s, const AttentionParams* dev_params, uint32_t n_ops, uint32_t max_seq_q) {
+void launch_attention_batch(hipStream_t s, const AttentionParams* dev_params, uint32_t n_ops, uint32_t max_seq_q,
+                            bool all_dense) {
     if (!n_ops || !max_seq_q) return;
-    attention_kernel<<<dim3(max_seq_q, n_ops), kBlock, 0, s>>>(dev_params);
+    if (all_dense)
+        attention_dense_kernel<<<dim3(max_seq_q, n_ops), kBlock, 0, s>>>(dev_params);
+    else
+        attention_kernel<<<dim3(max_seq_q, n_ops), kBlock, 0, s>>>(dev_params);
 }
 
 void launch_dense_matmul(hipStream_t s, const DenseMatmulParams& p) {

@@ -374,6 +374,7 @@ RopeParams make_rope(zgml_hip_program* p, const zgml_op_rope& r) {
     rp.src = buf_at(p, r.src, r.src_off);
     rp.cs = buf_at(p, r.cos_sin, r.cs_off);
     rp.half_d = r.half_d, rp.seq_len = r.seq_len, rp.src_rs = r.src_rs, rp.src_cs = r.src_cs, rp.cs_cs = r.cs_cs;
+    rp.dst2 = nullptr, rp.dyn_dst2_off = nullptr, rp.d2_rs = rp.d2_cs = 0;
     return rp;
 }
 
@@ -389,6 +390,7 @@ AttentionParams make_attention(zgml_hip_program* p, const zgml_op_attention& a, 
     ap.scale = a.scale;
     ap.q_rs = a.q_rs, ap.q_cs = a.q_cs, ap.k_rs = a.k_rs, ap.k_cs = a.k_cs, ap.v_rs = a.v_rs, ap.v_cs = a.v_cs;
     ap.mask_rs = a.mask_rs, ap.mask_cs = a.mask_cs, ap.dst_rs = a.dst_rs, ap.dst_cs = a.dst_cs;
+    ap.dst2 = nullptr, ap.dyn_dst2_off = nullptr, ap.d2_rs = ap.d2_cs = 0;
     return ap;
 }
 
@@ -476,41 +478,79 @@ bool make_single(zgml_hip_program* p, size_t i, Launch& L) {
     }
 }
 
-// the batchable kinds of one group of mutually independent ops -> at most one launch per kind
-void emit_batches(zgml_hip_program* p, const std::vector<uint32_t>& group) {
+// One schedulable item: an op, optionally with the slice_assign that was folded into it
+// (rope -> KV store, attention -> row store).
+struct PlanItem {
+    uint32_t op;
+    int store = -1;
+};
+
+// the batchable kinds of one group of mutually independent items -> one "movement" launch (ropes
+// and slice_assigns together), one attention launch, one repeat launch; the rest one by one
+void emit_batches(zgml_hip_program* p, const std::vector<PlanItem>& group) {
     std::vector<RepeatParams> reps;
-    std::vector<SliceAssignParams> sas;
-    std::vector<RopeParams> ropes;
+    std::vector<MoveParams> moves;
     std::vector<AttentionParams> atts;
-    uint32_t rep_max = 0, sa_max = 0, rope_max = 0, att_max = 0;
-    uint32_t lo[4] = {UINT32_MAX, UINT32_MAX, UINT32_MAX, UINT32_MAX}, hi[4] = {0, 0, 0, 0};
-    auto track = [&](int k, uint32_t i) {
-        lo[k] = std::min(lo[k], i);
-        hi[k] = std::max(hi[k], i);
+    uint32_t rep_max = 0, move_max = 0, att_max = 0, n_rep = 0, n_move = 0, n_att = 0;
+    uint32_t lo[3] = {UINT32_MAX, UINT32_MAX, UINT32_MAX}, hi[3] = {0, 0, 0};
+    auto track = [&](int k, const PlanItem& it) {
+        lo[k] = std::min(lo[k], it.op);
+        hi[k] = std::max(hi[k], it.store >= 0 ? std::max(it.op, (uint32_t)it.store) : it.op);
     };
-    for (uint32_t i : group) {
+    for (const PlanItem& it : group) {
+        const uint32_t i = it.op;
         const zgml_device_op& op = p->ops[i];
         switch (op.kind) {
             case ZGML_DOP_REPEAT:
                 reps.push_back(make_repeat(p, op.u.repeat));
                 rep_max = std::max(rep_max, op.u.repeat.n);
-                track(0, i);
+                n_rep++;
+                track(0, it);
                 break;
-            case ZGML_DOP_SLICE_ASSIGN:
-                sas.push_back(make_slice_assign(p, op.u.slice_assign, i));
-                sa_max = std::max(sa_max, op.u.slice_assign.rows * op.u.slice_assign.cols);
-                track(1, i);
+            case ZGML_DOP_SLICE_ASSIGN: {
+                MoveParams m{};
+                m.kind = 1;
+                m.n_elems = op.u.slice_assign.rows * op.u.slice_assign.cols;
+                m.sa = make_slice_assign(p, op.u.slice_assign, i);
+                moves.push_back(m);
+                move_max = std::max(move_max, m.n_elems);
+                n_move++;
+                track(1, it);
                 break;
-            case ZGML_DOP_ROPE:
-                ropes.push_back(make_rope(p, op.u.rope));
-                rope_max = std::max(rope_max, op.u.rope.half_d * op.u.rope.seq_len);
-                track(2, i);
+            }
+            case ZGML_DOP_ROPE: {
+                MoveParams m{};
+                m.kind = 0;
+                m.n_elems = op.u.rope.half_d * op.u.rope.seq_len;
+                m.rope = make_rope(p, op.u.rope);
+                if (it.store >= 0) {
+                    const auto& sa = p->ops[it.store].u.slice_assign;
+                    m.rope.dst2 = p->bufs[sa.dst];
+                    m.rope.dyn_dst2_off = p->dyn_dev + it.store;
+                    m.rope.d2_rs = sa.dst_row_stride, m.rope.d2_cs = sa.dst_col_stride;
+                    n_move++;
+                }
+                moves.push_back(m);
+                move_max = std::max(move_max, m.n_elems);
+                n_move++;
+                track(1, it);
                 break;
-            case ZGML_DOP_ATTENTION:
-                atts.push_back(make_attention(p, op.u.attention, i));
+            }
+            case ZGML_DOP_ATTENTION: {
+                AttentionParams ap = make_attention(p, op.u.attention, i);
+                if (it.store >= 0) {
+                    const auto& sa = p->ops[it.store].u.slice_assign;
+                    ap.dst2 = p->bufs[sa.dst];
+                    ap.dyn_dst2_off = p->dyn_dev + it.store;
+                    ap.d2_rs = sa.dst_row_stride, ap.d2_cs = sa.dst_col_stride;
+                    n_att++;
+                }
+                atts.push_back(ap);
                 att_max = std::max(att_max, op.u.attention.seq_q);
-                track(3, i);
+                n_att++;
+                track(2, it);
                 break;
+            }
             default: {
                 Launch L;
                 if (make_single(p, i, L)) p->plan.push_back(std::move(L));
@@ -520,22 +560,24 @@ void emit_batches(zgml_hip_program* p, const std::vector<uint32_t>& group) {
     if (!reps.empty()) {
         const RepeatParams* d = upload_params(p, reps);
         const uint32_t n = (uint32_t)reps.size(), mx = rep_max;
-        p->plan.push_back({ZGML_DOP_REPEAT, n, lo[0], hi[0], [=](hipStream_t s) { launch_repeat_batch(s, d, n, mx); }});
+        p->plan.push_back({ZGML_DOP_REPEAT, n_rep, lo[0], hi[0], [=](hipStream_t s) { launch_repeat_batch(s, d, n, mx); }});
     }
-    if (!sas.empty()) {
-        const SliceAssignParams* d = upload_params(p, sas);
-        const uint32_t n = (uint32_t)sas.size(), mx = sa_max;
-        p->plan.push_back({ZGML_DOP_SLICE_ASSIGN, n, lo[1], hi[1], [=](hipStream_t s) { launch_slice_assign_batch(s, d, n, mx); }});
-    }
-    if (!ropes.empty()) {
-        const RopeParams* d = upload_params(p, ropes);
-        const uint32_t n = (uint32_t)ropes.size(), mx = rope_max;
-        p->plan.push_back({ZGML_DOP_ROPE, n, lo[2], hi[2], [=](hipStream_t s) { launch_rope_batch(s, d, n, mx); }});
+    if (!moves.empty()) {
+        const MoveParams* d = upload_params(p, moves);
+        const uint32_t n = (uint32_t)moves.size(), mx = move_max;
+        p->plan.push_back({ZGML_DOP_SLICE_ASSIGN, n_move, lo[1], hi[1], [=](hipStream_t s) { launch_move_batch(s, d, n, mx); }});
     }
     if (!atts.empty()) {
+        bool dense = true;
+        for (const AttentionParams& a : atts) {
+            const uint32_t dh = a.d_head;
+            dense = dense && a.q_rs == 1 && a.k_rs == 1 && a.v_rs == 1 && dh >= 4 && dh <= 256 && (dh & (dh - 1)) == 0 &&
+                    (a.q_cs % 4) == 0 && (a.k_cs % 4) == 0 && (a.v_cs % 4) == 0 && ((uintptr_t)a.q % 16) == 0 &&
+                    ((uintptr_t)a.k % 16) == 0 && ((uintptr_t)a.v % 16) == 0;
+        }
         const AttentionParams* d = upload_params(p, atts);
         const uint32_t n = (uint32_t)atts.size(), mx = att_max;
-        p->plan.push_back({ZGML_DOP_ATTENTION, n, lo[3], hi[3], [=](hipStream_t s) { launch_attention_batch(s, d, n, mx); }});
+        p->plan.push_back({ZGML_DOP_ATTENTION, n_att, lo[2], hi[2], [=](hipStream_t s) { launch_attention_batch(s, d, n, mx, dense); }});
     }
 }
 
@@ -558,7 +600,8 @@ struct Macro {
     std::vector<uint32_t> members; // op indices, ascending
     uint32_t position = 0;         // index of the last member
     bool qmv = false;
-    uint32_t anchor = 0;           // the qmatmul op
+    int store = -1;                // rope / attention anchors: the slice_assign folded into them
+    uint32_t anchor = 0;           // the qmatmul op (or the rope / attention op)
     QmvPrologue pro;
     uint64_t pro_sig[3] = {0, 0, 0}; // (kind, a, b) identity for grouping
     bool owns_prologue = false;
@@ -862,6 +905,43 @@ void build_fused_plan(zgml_hip_program* p) {
             m.access = OpAccess{};
             for (uint32_t x : m.members) add_access(m.access, s0.access[x]);
         }
+    // rope -> slice_assign (K into the cache) and attention -> slice_assign (head output into the
+    // concatenated buffer): the copy of the anchor's dense output is done by the anchor itself
+    for (uint32_t i = 0; i < n; i++) {
+        if (in_macro[i] || (ops[i].kind != ZGML_DOP_ROPE && ops[i].kind != ZGML_DOP_ATTENTION)) continue;
+        ExactSpan out{};
+        uint32_t rows, cols, srs, scs;
+        if (ops[i].kind == ZGML_DOP_ROPE) {
+            const auto& r = ops[i].u.rope;
+            rows = 2 * r.half_d, cols = r.seq_len, srs = 1, scs = rows;
+            out = {r.dst, r.dst_off, (uint64_t)rows * cols};
+        } else {
+            const auto& t = ops[i].u.attention;
+            rows = t.d_head, cols = t.seq_q, srs = t.dst_rs, scs = t.dst_cs;
+            if (srs != 1 || scs != rows) continue; // dense head output only
+            out = {t.dst, t.dst_off, (uint64_t)rows * cols};
+        }
+        std::vector<uint32_t> readers;
+        readers_until_overwrite(out, i, readers);
+        for (uint32_t r : readers) {
+            if (in_macro[r] || ops[r].kind != ZGML_DOP_SLICE_ASSIGN) continue;
+            const auto& sa = ops[r].u.slice_assign;
+            if (sa.src != out.buf || sa.src_offset != out.off || sa.rows != rows || sa.cols != cols ||
+                sa.src_row_stride != srs || sa.src_col_stride != scs)
+                continue;
+            if (!delay_legal({i, r}, r)) continue;
+            Macro m;
+            m.members = {i, r};
+            m.position = r;
+            m.anchor = i;
+            m.store = (int)r;
+            m.access = s0.access[i];
+            add_access(m.access, s0.access[r]);
+            in_macro[i] = in_macro[r] = 1;
+            macros.push_back(std::move(m));
+            break;
+        }
+    }
     // everything else is a singleton
     for (uint32_t i = 0; i < n; i++) {
         if (in_macro[i]) continue;
@@ -881,13 +961,15 @@ void build_fused_plan(zgml_hip_program* p) {
     levels_from_access(access, position, p->barriers, level, levels);
 
     for (const auto& lv : levels) {
-        std::vector<uint32_t> plain_ops;
+        std::vector<PlanItem> plain_ops;
         std::vector<const Macro*> qmvs;
         for (uint32_t mi : lv) {
             if (macros[mi].qmv)
                 qmvs.push_back(&macros[mi]);
+            else if (macros[mi].store >= 0)
+                plain_ops.push_back({macros[mi].anchor, macros[mi].store});
             else
-                plain_ops.push_back(macros[mi].members[0]);
+                plain_ops.push_back({macros[mi].members[0], -1});
         }
         emit_batches(p, plain_ops);
         // group mat-vecs that stage the same vector
@@ -941,7 +1023,7 @@ void build_plan(zgml_hip_program* p) {
     if (p->plan_batched) {
         build_fused_plan(p);
     } else {
-        for (uint32_t i = 0; i < p->ops.size(); i++) emit_batches(p, {i});
+        for (uint32_t i = 0; i < p->ops.size(); i++) emit_batches(p, {PlanItem{i, -1}});
     }
     p->plan_dirty = false;
     if (getenv("ZGML_HIP_DEBUG_PLAN")) {
