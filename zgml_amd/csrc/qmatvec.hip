@@ -177,22 +177,22 @@ __device__ __forceinline__ float4 scale4(float4 a, float s) { return make_float4
 // KIND selects the prologue (kernels.h QmvPrologueKind); `inv` is the rmsnorm factor for kind 2.
 // Workgroup (0,0) also stores the prologue's intermediates to global memory so the buffers of
 // the absorbed ops hold what the unfused plan would have written.
-template <bool XVEC>
+template <bool XVEC, bool PRO>
 __device__ __forceinline__ void x_commit(float* xs, const XRegs& ra, const XRegs& rb, const QmvPrologue& pro, float inv,
                                          uint32_t k_count, uint32_t K, const float* xa_row) {
-    const bool owner = blockIdx.x == 0 && blockIdx.y == 0;
+    const bool owner = PRO && blockIdx.x == 0 && blockIdx.y == 0;
 #pragma unroll
     for (int j = 0; j < kXRegs; j++) {
         const uint32_t i = (threadIdx.x + j * blockDim.x) * 4;
         float4 v = zero_tail(ra.v[j], i, K);
-        if (pro.kind == QMV_PRO_RMSNORM_MUL) {
+        if (PRO && pro.kind == QMV_PRO_RMSNORM_MUL) {
             v = scale4(v, inv);
             if (owner && pro.store_mid && i < K) {
                 if (i + 3 < K) *(float4*)(pro.store_mid + i) = v;
                 else { pro.store_mid[i] = v.x; if (i + 1 < K) pro.store_mid[i + 1] = v.y; if (i + 2 < K) pro.store_mid[i + 2] = v.z; }
             }
         }
-        if (pro.kind != QMV_PRO_NONE) {
+        if (PRO) {
             v = mul4(v, zero_tail(rb.v[j], i, K));
             if (owner && pro.store_x && i < K) {
                 if (i + 3 < K) *(float4*)(pro.store_x + i) = v;
@@ -201,7 +201,7 @@ __device__ __forceinline__ void x_commit(float* xs, const XRegs& ra, const XRegs
         }
         *(float4*)(xs + (i < k_count ? i : k_count)) = v;
     }
-    if (pro.kind == QMV_PRO_NONE) // only for K > 16 * blockDim (prologues are limited to the register window)
+    if (!PRO) // only for K > 16 * blockDim (prologues are limited to the register window)
         for (uint32_t i = (threadIdx.x + kXRegs * blockDim.x) * 4; i < k_count; i += blockDim.x * 4)
             *(float4*)(xs + i) = zero_tail(load_x4<XVEC>(xa_row, i, K), i, K);
 }
@@ -257,9 +257,31 @@ __device__ __forceinline__ uint32_t column_group(uint32_t b, uint32_t NB2) {
     return 2 * j + half;
 }
 
+// the part's elementwise epilogue on one output value (residual add, SiLU chain, ...)
+__device__ __forceinline__ void run_epilogue(const QMVPartDev& part, uint32_t n, float v) {
+    for (uint32_t e = 0; e < part.n_epi; e++) { // M == 1 whenever n_epi != 0
+        const QmvEpiStep st = part.epi[e];
+        if (st.op == ZGML_OP_ADD) {
+            const float o = st.operand[n];
+            v = st.swapped ? o + v : v + o;
+        } else if (st.op == ZGML_OP_MUL) {
+            const float o = st.operand[n];
+            v = st.swapped ? o * v : v * o;
+        } else {
+            v = epi_unary(st.op, v);
+        }
+        if (st.store) st.store[n] = v;
+    }
+}
+
 // Fold the 4 rows of each wave, then the waves, in fixed order; 16 outputs per workgroup. The 16
-// owning lanes then run the part's elementwise epilogue (residual add, SiLU chain, ...).
-__device__ __forceinline__ void reduce_store(float acc, float* red, const QMVPartDev& part, uint32_t g, uint32_t m) {
+// owning lanes then run the part's epilogue. `pi` is the (wave-uniform) part index: every use of
+// `a.parts[...]` below is a COMPILE-TIME index so the kernel-argument loads are issued up front —
+// a run-time index into the argument block is a dependent scalar load that costs ~1 us at the
+// start and again in the tail of a 5 us kernel.
+template <bool GROUPED>
+__device__ __forceinline__ void reduce_store(float acc, float* red, const QMVArgs& a, uint32_t pi, float* out,
+                                             uint32_t out_rs, uint32_t g, uint32_t m) {
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     acc += __shfl_xor(acc, 16, 64);
     acc += __shfl_xor(acc, 32, 64);
@@ -269,20 +291,15 @@ __device__ __forceinline__ void reduce_store(float acc, float* red, const QMVPar
         float v = red[threadIdx.x];
         for (uint32_t ww = 1; ww < n_waves; ww++) v += red[ww * 16 + threadIdx.x];
         const uint32_t n = g * 16 + threadIdx.x;
-        part.out[(uint64_t)m * part.out_rs + n] = v;
-        for (uint32_t e = 0; e < part.n_epi; e++) { // M == 1 whenever n_epi != 0
-            const QmvEpiStep st = part.epi[e];
-            if (st.op == ZGML_OP_ADD) {
-                const float o = st.operand[n];
-                v = st.swapped ? o + v : v + o;
-            } else if (st.op == ZGML_OP_MUL) {
-                const float o = st.operand[n];
-                v = st.swapped ? o * v : v * o;
-            } else {
-                v = epi_unary(st.op, v);
-            }
-            if (st.store) st.store[n] = v;
-        }
+        out[(uint64_t)m * out_rs + n] = v;
+        if (!GROUPED || pi == 0)
+            run_epilogue(a.parts[0], n, v);
+        else if (pi == 1)
+            run_epilogue(a.parts[1], n, v);
+        else if (pi == 2)
+            run_epilogue(a.parts[2], n, v);
+        else
+            run_epilogue(a.parts[3], n, v);
     }
 }
 
@@ -355,7 +372,8 @@ struct Q8Group {
 };
 
 // Q4: unit = 32 k, UNIT_X = 32 floats of x per unit; Q8: unit = 16 k.
-template <typename ST, bool XVEC, int DEPTH, bool Q4>
+// PRO: the launch has a prologue (second vector b, optional rmsnorm); GROUPED: more than one matrix.
+template <typename ST, bool XVEC, int DEPTH, bool Q4, bool PRO, bool GROUPED>
 __global__ void __launch_bounds__(1024) qmatvec_kernel(QMVArgs a) {
     constexpr uint32_t UNIT_X = Q4 ? 32 : 16;
     using ScaleT = typename std::conditional<Q4, Pair<ST>, ST>::type;
@@ -363,34 +381,47 @@ __global__ void __launch_bounds__(1024) qmatvec_kernel(QMVArgs a) {
     extern __shared__ float smem[];
     float* xs = smem;                     // U * UNIT_X floats (+4 spare)
     float* red = smem + a.U * UNIT_X + 4; // waves * 16 floats
-    // which matrix of the group this workgroup belongs to (wave-uniform)
+    // which matrix of the group this workgroup belongs to (wave-uniform); fields are selected from
+    // statically indexed argument loads
     uint32_t pi = 0;
-    for (uint32_t t = 1; t < a.n_parts; t++)
-        if (blockIdx.x >= a.parts[t].block_begin) pi = t;
-    const QMVPartDev& part = a.parts[pi];
-    const uint32_t g = column_group(blockIdx.x - part.block_begin, part.NB2), m = blockIdx.y;
+    const uint4* qs_base = a.parts[0].qs;
+    const void* sc_base = a.parts[0].sc;
+    float* out = a.parts[0].out;
+    uint32_t NB2 = a.parts[0].NB2, block_begin = 0, out_rs = a.parts[0].out_rs;
+    if (GROUPED) {
+#pragma unroll
+        for (uint32_t t = 1; t < (uint32_t)kMaxQmvParts; t++) {
+            const bool take = t < a.n_parts && blockIdx.x >= a.parts[t].block_begin;
+            pi = take ? t : pi;
+            qs_base = take ? a.parts[t].qs : qs_base;
+            sc_base = take ? a.parts[t].sc : sc_base;
+            out = take ? a.parts[t].out : out;
+            NB2 = take ? a.parts[t].NB2 : NB2;
+            block_begin = take ? a.parts[t].block_begin : block_begin;
+            out_rs = take ? a.parts[t].out_rs : out_rs;
+        }
+    }
+    const uint32_t g = column_group(blockIdx.x - block_begin, NB2), m = blockIdx.y;
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint32_t row = lane >> 4, i = lane & 15;
     const uint32_t stride = (blockDim.x >> 6) * 4; // units per step (4 rows per wave)
-    const uint4* qs = part.qs + (uint64_t)g * a.U * 16 + i;
-    const ScaleT* sc = (const ScaleT*)part.sc + (uint64_t)(g >> 1) * a.U * 16 + i;
+    const uint4* qs = qs_base + (uint64_t)g * a.U * 16 + i;
+    const ScaleT* sc = (const ScaleT*)sc_base + (uint64_t)(g >> 1) * a.U * 16 + i;
     const uint32_t n_groups = (a.U + stride * DEPTH - 1) / (stride * DEPTH);
     const uint32_t u_last = a.U - 1;
 
     const float* xa_row = a.pro.a + (uint64_t)m * a.in_rs;
     const XRegs xa = x_fetch<XVEC>(xa_row, a.K);
-    // unconditional (the host points pro.b at pro.a when there is no prologue): a load under a
-    // branch would make hipcc fall back to vmcnt(0) waits
-    const XRegs xb = x_fetch<XVEC>(a.pro.b, a.K);
+    const XRegs xb = PRO ? x_fetch<XVEC>(a.pro.b, a.K) : xa;
     uint32_t u = 4 * w + row; // this row's unit in step 0
     Group cur;
     cur.load(qs, sc, u, stride, u_last);
     float inv = 1.0f;
-    if (a.pro.kind == QMV_PRO_RMSNORM_MUL) {
+    if (PRO && a.pro.kind == QMV_PRO_RMSNORM_MUL) {
         const float ss = block_sumsq(xa, a.K, red);
         inv = 1.0f / sqrtf(ss / (float)a.K + a.pro.eps); // reference.zig:365
     }
-    x_commit<XVEC>(xs, xa, xb, a.pro, inv, a.U * UNIT_X, a.K, xa_row);
+    x_commit<XVEC, PRO>(xs, xa, xb, a.pro, inv, a.U * UNIT_X, a.K, xa_row);
     __syncthreads();
 
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
@@ -402,7 +433,7 @@ __global__ void __launch_bounds__(1024) qmatvec_kernel(QMVArgs a) {
         u += DEPTH * stride;
     }
     cur.compute(xs, u, stride, a.U, i, acc0, acc1, acc2, acc3);
-    reduce_store((acc0 + acc1) + (acc2 + acc3), red, part, g, m);
+    reduce_store<GROUPED>((acc0 + acc1) + (acc2 + acc3), red, a, pi, out, out_rs, g, m);
 }
 
 // Raw layout (any block size, any N): one thread per (m, n), k sequential — exactly the
@@ -574,41 +605,64 @@ bool qmv_can_group(const QWeightDev& a, const QWeightDev& b) {
 
 namespace {
 
-uint32_t qmv_waves(const QWeightDev& w) {
+// Waves per workgroup (measured sweep over 1..16 waves on 576^2 .. 4096x32000, tools/bench_matvec.py
+// with ZGML_QMV_WAVES): 4 waves (each streaming K/16 units with the depth-4 pipeline) wins or ties
+// everywhere up to K ~ 4096 — narrower workgroups keep more of them co-resident per CU, so one
+// workgroup's x staging / reduction tail overlaps another's streaming — and 8 waves win for the long
+// K of the down projection (11008). 16-wave workgroups (the first design) lose up to 35 % on
+// multi-round grids.
+uint32_t qmv_waves(const QWeightDev& w, uint32_t total_blocks = 0) {
+    (void)total_blocks;
     const uint32_t U = w.format == QW_Q4 ? w.KC : 2 * w.KC;
     uint32_t waves = cdiv(U, 4);
-    if (waves > (uint32_t)kMaxWaves) waves = kMaxWaves;
+    uint32_t cap = w.K > 6144 ? 8 : 4;
+    static const int env_cap = getenv("ZGML_QMV_WAVES") ? atoi(getenv("ZGML_QMV_WAVES")) : 0;
+    if (env_cap > 0) cap = (uint32_t)env_cap;
+    if (waves > cap) waves = cap;
     return waves < 1 ? 1 : waves;
+}
+
+using KernelFn = void (*)(QMVArgs);
+
+template <typename ST, bool XV, bool Q, bool PRO, bool GRP>
+KernelFn pick_depth(int depth_sel) {
+    switch (depth_sel) {
+        case 0: return qmatvec_kernel<ST, XV, 1, Q, PRO, GRP>;
+        case 1: return qmatvec_kernel<ST, XV, 2, Q, PRO, GRP>;
+        default: return qmatvec_kernel<ST, XV, 4, Q, PRO, GRP>;
+    }
+}
+template <typename ST, bool XV, bool Q>
+KernelFn pick_mode(bool pro, bool grp, int depth_sel) {
+    if (pro) return grp ? pick_depth<ST, XV, Q, true, true>(depth_sel) : pick_depth<ST, XV, Q, true, false>(depth_sel);
+    return grp ? pick_depth<ST, XV, Q, false, true>(depth_sel) : pick_depth<ST, XV, Q, false, false>(depth_sel);
+}
+template <typename ST>
+KernelFn pick_kernel(bool xvec, bool q4, bool pro, bool grp, int depth_sel) {
+    if (xvec) return q4 ? pick_mode<ST, true, true>(pro, grp, depth_sel) : pick_mode<ST, true, false>(pro, grp, depth_sel);
+    return q4 ? pick_mode<ST, false, true>(pro, grp, depth_sel) : pick_mode<ST, false, false>(pro, grp, depth_sel);
 }
 
 void launch_packed(hipStream_t s, QMVArgs& a, const QWeightDev& w0, uint32_t total_blocks, uint32_t M, bool xvec) {
     const bool q4 = w0.format == QW_Q4;
-    const uint32_t waves = qmv_waves(w0);
+    uint32_t waves = qmv_waves(w0, total_blocks);
+    if (a.pro.kind != QMV_PRO_NONE) // a prologue keeps all of x in the register window: 16 floats per thread
+        while (waves < (uint32_t)kMaxWaves && waves * 64 * 4 * kXRegs < a.K) waves++;
     dim3 grid(total_blocks, M);
     const size_t lds = qmv_lds_bytes(w0);
     const uint32_t n_steps = cdiv(a.U, waves * 4);
     const int depth_sel = n_steps >= 4 ? 2 : (n_steps >= 2 ? 1 : 0); // DEPTH 4 / 2 / 1
-    using KernelFn = void (*)(QMVArgs);
-#define ZGML_QMV_ROW(ST, XV, Q) {qmatvec_kernel<ST, XV, 1, Q>, qmatvec_kernel<ST, XV, 2, Q>, qmatvec_kernel<ST, XV, 4, Q>}
-    static const KernelFn table[2][2][2][3] = {
-        {{ZGML_QMV_ROW(float, false, false), ZGML_QMV_ROW(float, true, false)},
-         {ZGML_QMV_ROW(__half, false, false), ZGML_QMV_ROW(__half, true, false)}},
-        {{ZGML_QMV_ROW(float, false, true), ZGML_QMV_ROW(float, true, true)},
-         {ZGML_QMV_ROW(__half, false, true), ZGML_QMV_ROW(__half, true, true)}}};
-#undef ZGML_QMV_ROW
-    static bool lds_opt_in = false; // > 64 KiB of dynamic LDS needs an explicit opt-in per kernel
-    if (!lds_opt_in) {
-        for (int i = 0; i < 24; i++)
-            hipFuncSetAttribute((const void*)table[i / 12][(i / 6) & 1][(i / 3) & 1][i % 3],
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
-        lds_opt_in = true;
-    }
-    hipLaunchKernelGGL(table[q4 ? 1 : 0][w0.scale_f16 ? 1 : 0][xvec ? 1 : 0][depth_sel], grid, dim3(waves * 64), lds, s, a);
+    const bool pro = a.pro.kind != QMV_PRO_NONE, grp = a.n_parts > 1;
+    const KernelFn fn = w0.scale_f16 ? pick_kernel<__half>(xvec, q4, pro, grp, depth_sel)
+                                     : pick_kernel<float>(xvec, q4, pro, grp, depth_sel);
+    if (lds > 64 * 1024) // > 64 KiB of dynamic LDS needs an explicit opt-in per kernel (idempotent)
+        hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+    hipLaunchKernelGGL(fn, grid, dim3(waves * 64), lds, s, a);
 }
 
 } // namespace
 
-uint32_t qmv_max_prologue_k(const QWeightDev& w) { return qmv_waves(w) * 64 * 4 * kXRegs; }
+uint32_t qmv_max_prologue_k(const QWeightDev&) { return kMaxWaves * 64 * 4 * kXRegs; } // widest workgroup; launch_packed widens to fit
 
 void launch_qmatmul(hipStream_t s, const QWeightDev& w, const QMatmulParams& p, float*) {
     if (p.M == 0 || p.N == 0) return;

@@ -39,6 +39,8 @@ struct Launch {
     uint32_t n_ops;          // DeviceOps covered (batching folds several)
     uint32_t op_lo, op_hi;   // smallest / largest op index covered
     std::function<void(hipStream_t)> run;
+    uint64_t prof_ns = 0;    // ZGML_HIP_OPT_PROFILE: accumulated event time of this launch
+    uint32_t prof_calls = 0;
 };
 
 struct IoEntry {
@@ -1106,7 +1108,21 @@ bool same_static(const zgml_device_op& a, const zgml_device_op& b) {
 }
 
 void run_plan(zgml_hip_program* p, hipStream_t s, size_t first, size_t count) {
-    for (size_t i = first; i < first + count && i < p->plan.size(); i++) p->plan[i].run(s);
+    // diagnostics: ZGML_HIP_SKIP_KINDS=<bitmask of DeviceOp tags> drops those launches (timing ablation
+    // only; results are garbage)
+    static const unsigned skip = getenv("ZGML_HIP_SKIP_KINDS") ? (unsigned)strtoul(getenv("ZGML_HIP_SKIP_KINDS"), nullptr, 0) : 0u;
+    // ZGML_HIP_SKIP_MOD="<period>:<bitmask>" drops launch i >= 1 when bit ((i-1) % period) is set
+    static unsigned mod_period = 0, mod_mask = 0;
+    static bool mod_init = false;
+    if (!mod_init) {
+        mod_init = true;
+        if (const char* e = getenv("ZGML_HIP_SKIP_MOD")) sscanf(e, "%u:%x", &mod_period, &mod_mask);
+    }
+    for (size_t i = first; i < first + count && i < p->plan.size(); i++) {
+        if (skip & (1u << p->plan[i].kind)) continue;
+        if (mod_period && i >= 1 && (mod_mask & (1u << ((i - 1) % mod_period)))) continue;
+        p->plan[i].run(s);
+    }
 }
 
 void flush_dyn(zgml_hip_program* p) {
@@ -1135,9 +1151,17 @@ void enqueue(zgml_hip_program* p) {
             float ms = 0;
             hipEventElapsedTime(&ms, e0, e1);
             p->profile.time_ns[L.kind] += (uint64_t)(ms * 1e6);
+            L.prof_ns += (uint64_t)(ms * 1e6);
+            L.prof_calls++;
         }
         hipEventDestroy(e0);
         hipEventDestroy(e1);
+        if (getenv("ZGML_HIP_DEBUG_PLAN") && atoi(getenv("ZGML_HIP_DEBUG_PLAN")) >= 2 && p->plan[0].prof_calls == 8) {
+            // per-launch table after 8 profiled executions (first 40 launches: one layer and a bit)
+            for (size_t i = 0; i < p->plan.size() && i < 40; i++)
+                fprintf(stderr, "[zgml_hip] launch %3zu kind %2u ops %4u [%u..%u]  %.2f us\n", i, p->plan[i].kind, p->plan[i].n_ops,
+                        p->plan[i].op_lo, p->plan[i].op_hi, p->plan[i].prof_ns / 1e3 / p->plan[i].prof_calls);
+        }
         return;
     }
     if (ctx->opt_graph && !p->plan.empty()) {
