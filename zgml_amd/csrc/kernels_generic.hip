@@ -337,25 +337,49 @@ __global__ void __launch_bounds__(kBlock) attention_kernel(const AttentionParams
     }
 }
 
-// Decode-shaped fast path: unit row strides on q/k/v/dst and d_head % 4 == 0, d_head <= 256
+// Decode-shaped fast path: unit row strides on q/k/v/dst and d_head a power of two in [4, 256]
 // (checked on the host). A key is handled by LPK = d_head/4 adjacent lanes holding one float4 each
-// (one coalesced row read per key), so a wave scores 64/LPK keys per iteration; waves stride over
-// the keys. Scores of a tile (<= kTile keys) live in LDS; tiles chain with the online-softmax
-// rescale, so seq_kv is unbounded. P.V uses the same lane layout (float4 of the head dimension per
-// lane), folded across lane groups by shuffles and across waves through LDS.
-constexpr uint32_t kTile = 1024;
+// (one coalesced row read per key), so a wave scores 64/LPK keys per iteration and the 16 waves of
+// the workgroup stride over the keys. The loop is unrolled by kAttnUnroll with all K (and later all V)
+// row loads issued before the first use: at decode lengths the kernel is a chain of dependent
+// memory round trips, not bandwidth. Scores of a tile (<= kTile keys) live in LDS; tiles chain with
+// the online-softmax rescale, so seq_kv is unbounded. P.V uses the same lane layout (float4 of the
+// head dimension per lane), folded across lane groups by shuffles and across waves through LDS.
+constexpr uint32_t kTile = 2048;
+constexpr int kAttnBlock = 1024;
+constexpr int kAttnUnroll = 4;
 
-__global__ void __launch_bounds__(kBlock) attention_dense_kernel(const AttentionParams* __restrict__ params) {
+__device__ __forceinline__ float block_max_n(float v, float* red, int n_waves) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = -INFINITY;
+    for (int i = 0; i < n_waves; i++) t = fmaxf(t, red[i]);
+    return t;
+}
+__device__ __forceinline__ float block_sum_n(float v, float* red, int n_waves) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < n_waves; i++) t += red[i];
+    return t;
+}
+
+__global__ void __launch_bounds__(kAttnBlock) attention_dense_kernel(const AttentionParams* __restrict__ params) {
     const AttentionParams p = params[blockIdx.y];
     if (blockIdx.x >= p.seq_q) return;
     __shared__ float sc_s[kTile];
-    __shared__ float red[8];
-    __shared__ float4 acc_s[kBlock];
+    __shared__ float red[32];
+    __shared__ float4 acc_s[kAttnBlock / 64 * 64];
+    constexpr int NW = kAttnBlock / 64;
     const uint32_t qi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, dh = p.d_head;
-    const uint32_t LPK = dh >> 2, KPW = 64 / LPK, sub = lane / LPK, li = lane % LPK; // LPK in {1..64}, power of two checked on host
+    const uint32_t LPK = dh >> 2, KPW = 64 / LPK, sub = lane / LPK, li = lane % LPK;
     const uint32_t seq_kv = *p.dyn_seq_kv;
     const float4 qv = *(const float4*)(p.q + (uint64_t)qi * p.q_cs + 4 * li);
-    const uint32_t keys_per_iter = KPW * (kBlock / 64);
+    const uint32_t keys_per_iter = KPW * NW;
     float m = -INFINITY, l = 0.f;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 
@@ -363,51 +387,65 @@ __global__ void __launch_bounds__(kBlock) attention_dense_kernel(const Attention
         const uint32_t tn = min(kTile, seq_kv - t0);
         // scores
         float tmax = -INFINITY;
-        for (uint32_t base = 0; base < tn; base += keys_per_iter) {
-            const uint32_t t = base + w * KPW + sub;
-            float score = -INFINITY;
-            const bool in = t < tn;
-            const uint32_t s = t0 + (in ? t : 0);
-            const float4 kv = *(const float4*)(p.k + (uint64_t)s * p.k_cs + 4 * li);
-            float dot = qv.x * kv.x + qv.y * kv.y + qv.z * kv.z + qv.w * kv.w;
-            for (uint32_t off = LPK >> 1; off > 0; off >>= 1) dot += __shfl_xor(dot, off, 64);
-            if (in) {
-                const float mask_add = p.mask ? p.mask[(uint64_t)qi * p.mask_cs + (uint64_t)s * p.mask_rs] : 0.0f;
-                if (isfinite(mask_add)) {
-                    score = dot * p.scale + mask_add;
-                    if (!isfinite(score)) score = -INFINITY;
-                }
-                if (li == 0) sc_s[t] = score;
+        for (uint32_t base = 0; base < tn; base += keys_per_iter * kAttnUnroll) {
+            float4 kv[kAttnUnroll];
+            float mk[kAttnUnroll];
+#pragma unroll
+            for (int j = 0; j < kAttnUnroll; j++) { // all loads first (clamped, unconditional)
+                const uint32_t t = base + j * keys_per_iter + w * KPW + sub;
+                const uint32_t s = t0 + min(t, tn - 1);
+                kv[j] = *(const float4*)(p.k + (uint64_t)s * p.k_cs + 4 * li);
+                mk[j] = p.mask ? p.mask[(uint64_t)qi * p.mask_cs + (uint64_t)s * p.mask_rs] : 0.0f;
             }
-            tmax = fmaxf(tmax, score);
+#pragma unroll
+            for (int j = 0; j < kAttnUnroll; j++) {
+                const uint32_t t = base + j * keys_per_iter + w * KPW + sub;
+                float dot = qv.x * kv[j].x + qv.y * kv[j].y + qv.z * kv[j].z + qv.w * kv[j].w;
+                for (uint32_t off = LPK >> 1; off > 0; off >>= 1) dot += __shfl_xor(dot, off, 64);
+                float score = -INFINITY;
+                if (t < tn) {
+                    if (isfinite(mk[j])) {
+                        score = dot * p.scale + mk[j];
+                        if (!isfinite(score)) score = -INFINITY;
+                    }
+                    if (li == 0) sc_s[t] = score;
+                }
+                tmax = fmaxf(tmax, score);
+            }
         }
-        tmax = block_max(tmax, red); // barriers also publish sc_s
+        tmax = block_max_n(tmax, red, NW); // barriers also publish sc_s
         const float new_m = fmaxf(m, tmax);
         if (new_m == -INFINITY) continue; // uniform: no valid key yet
         const float alpha = (m == -INFINITY) ? 0.0f : expf(m - new_m);
         // weights (in place) and their sum
         float tsum = 0.f;
-        for (uint32_t t = tid; t < tn; t += kBlock) {
+        for (uint32_t t = tid; t < tn; t += kAttnBlock) {
             const float sc = sc_s[t];
             const float wgt = sc > -INFINITY ? expf(sc - new_m) : 0.0f;
             sc_s[t] = wgt;
             tsum += wgt;
         }
-        tsum = block_sum(tsum, red); // barriers publish the weights
+        tsum = block_sum_n(tsum, red, NW); // barriers publish the weights
         l = l * alpha + tsum;
         m = new_m;
         // P.V
         acc = make_float4(acc.x * alpha, acc.y * alpha, acc.z * alpha, acc.w * alpha);
-        for (uint32_t base = 0; base < tn; base += keys_per_iter) {
-            const uint32_t t = base + w * KPW + sub;
-            const bool in = t < tn;
-            const uint32_t s = t0 + (in ? t : 0);
-            const float wgt = in ? sc_s[t] : 0.0f;
-            const float4 vv = *(const float4*)(p.v + (uint64_t)s * p.v_cs + 4 * li);
-            acc.x += wgt * vv.x;
-            acc.y += wgt * vv.y;
-            acc.z += wgt * vv.z;
-            acc.w += wgt * vv.w;
+        for (uint32_t base = 0; base < tn; base += keys_per_iter * kAttnUnroll) {
+            float4 vv[kAttnUnroll];
+#pragma unroll
+            for (int j = 0; j < kAttnUnroll; j++) {
+                const uint32_t t = base + j * keys_per_iter + w * KPW + sub;
+                vv[j] = *(const float4*)(p.v + (uint64_t)(t0 + min(t, tn - 1)) * p.v_cs + 4 * li);
+            }
+#pragma unroll
+            for (int j = 0; j < kAttnUnroll; j++) {
+                const uint32_t t = base + j * keys_per_iter + w * KPW + sub;
+                const float wgt = t < tn ? sc_s[t] : 0.0f;
+                acc.x += wgt * vv[j].x;
+                acc.y += wgt * vv[j].y;
+                acc.z += wgt * vv[j].z;
+                acc.w += wgt * vv[j].w;
+            }
         }
         __syncthreads(); // sc_s reused by the next tile
     }
@@ -422,7 +460,7 @@ __global__ void __launch_bounds__(kBlock) attention_dense_kernel(const Attention
     __syncthreads();
     if (tid < LPK) {
         float4 a = acc_s[tid];
-        for (uint32_t ww = 1; ww < kBlock / 64; ww++) {
+        for (int ww = 1; ww < NW; ww++) {
             const float4 b = acc_s[ww * 64 + tid];
             a.x += b.x, a.y += b.y, a.z += b.z, a.w += b.w;
         }
@@ -629,7 +667,7 @@ void launch_attention_batch(hipStream_t s, const AttentionParams* dev_params, ui
                             bool all_dense) {
     if (!n_ops || !max_seq_q) return;
     if (all_dense)
-        attention_dense_kernel<<<dim3(max_seq_q, n_ops), kBlock, 0, s>>>(dev_params);
+        attention_dense_kernel<<<dim3(max_seq_q, n_ops), kAttnBlock, 0, s>>>(dev_params);
     else
         attention_kernel<<<dim3(max_seq_q, n_ops), kBlock, 0, s>>>(dev_params);
 }
