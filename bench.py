@@ -178,12 +178,20 @@ def bench_sharded(args):
     from zgml_amd import Backend, llama
     from zgml_amd.sharded import HipExecutor, ShardedDecoder
 
+    # RCCL prints a version banner on stdout at init; the contract is ONE JSON line there, so
+    # everything until the final print goes to stderr
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank, ws = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", rank))
     if ws != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={ws}: launch with torch.distributed.run")
     torch.cuda.set_device(local)
-    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    torch.cuda.init()  # torch's HIP runtime must be up before libzgml_hip.so is loaded (it then binds to it)
+    if "MASTER_ADDR" not in os.environ:  # single-process rehearsal (ZGML_BENCH_FORCE_SHARDED)
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29533"
+    dist.init_process_group("nccl", rank=rank, world_size=ws, device_id=torch.device("cuda", local))
     be = Backend(local)
     from zgml_amd import capi
     be.set_option(capi.OPT_GRAPH, 0)  # op ranges are launched directly between collectives
@@ -227,7 +235,10 @@ def bench_sharded(args):
             "roofline": None, "cpu_baseline": None,
             "extra": {"q4_0_weight_bytes_per_rank": qb},
         }
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     ex.close()
     model.close()
     be.close()
@@ -245,7 +256,7 @@ def main():
     if not (ROOT / "zgml_amd" / "lib" / "libzgml_hip.so").exists():
         import __graft_entry__ as g
         g.build()
-    if args.gpus <= 1:
+    if args.gpus <= 1 and not os.environ.get("ZGML_BENCH_FORCE_SHARDED"):
         bench_single(args)
     else:
         bench_sharded(args)
