@@ -49,8 +49,13 @@ def matvec_roofline(be, K=4096, N=4096, q4=1, ring=64, iters=2048):
     if us <= 0:
         raise RuntimeError("qmatvec_bench: " + be.last_error())
     gbps = nbytes.value / us / 1e3
+    # HBM bytes per launch from the committed PMC pass (FETCH_SIZE x 2 on gfx950, see the json)
+    traffic = None
+    pmc = ROOT / "profiles" / "r01_qmatvec_pmc.json"
+    if pmc.exists() and (K, N, q4) == (4096, 4096, 1):
+        traffic = json.loads(pmc.read_text())["4096x4096_q4_0"]["traffic_bytes_per_launch"]
     return {"bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": None,
+            "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": traffic,
             "kernel": f"qmatvec_kernel<q4_0> {K}x{N} (single launch per mat-vec)",
             "bytes_per_launch": nbytes.value, "us_per_launch": round(us, 3), "ring_matrices": ring,
             "launches": iters, "timing": "HIP events on the launch stream; ring captured in a hipGraph"}
