@@ -380,6 +380,10 @@ int zgml_hip_resident_decode(zgml_hip_ctx* ctx, zgml_hip_program* handle, uint32
  * error). `bytes_per_launch` receives the algorithmic bytes (K*N/32*{18|34} + 4K + 4N). */
 double zgml_hip_qmatvec_bench(zgml_hip_ctx* ctx, uint32_t K, uint32_t N, int q4, uint32_t n_matrices,
                               uint32_t warmup, uint32_t iters, uint64_t* bytes_per_launch);
+/* Same ring with M input rows (M > 1 runs the f32-MFMA tile kernel used by prefill plans);
+ * bytes = weights + 4*M*K + 4*M*N, flops = 2*M*K*N. */
+double zgml_hip_qmatmul_bench(zgml_hip_ctx* ctx, uint32_t M, uint32_t K, uint32_t N, int q4, uint32_t n_matrices,
+                              uint32_t warmup, uint32_t iters, uint64_t* bytes_per_launch);
 /* One mat-vec y = x^T W with synthetic matrix `matrix_id` of the same generator (parity tests
  * rebuild that matrix on the host in int8 + f32-scale form and check y against the oracle).
  * Returns 0 on success. */

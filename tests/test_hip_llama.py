@@ -88,3 +88,34 @@ def test_resident_decode_equals_vtable_stepping(hip_backend, name, kind):
     assert half.tolist() == want[n // 2:].tolist()
     s.close()
     m.close()
+
+
+@pytest.mark.parametrize("kind", [llama.Q4_0, llama.Q8_0])
+@pytest.mark.parametrize("T", [5, 32])
+def test_prefill_plan_matches_oracle_and_sequential(hip_backend, oracle, kind, T):
+    """token_len = T plan (LlamaInferencePlan with token_len N; the reference's own check is
+    'prefill == sequential decode', tol 1e-4, src/llama_inference.zig:983-1034): the HIP prefill
+    matches the oracle's prefill of the same program, and HIP sequential stepping."""
+    cfg = llama.preset("tiny")
+    toks = [(7 * i + 3) % cfg.vocab_size for i in range(T)]
+    mN = llama.Model(cfg, kind, token_len=T)
+    s_ref = llama.Session(mN, oracle.backend_fns())
+    s_hip = llama.Session(mN, llama.hip_backend_fns(hip_backend))
+    t_ref, l_ref = s_ref.prefill(toks, 0)
+    t_hip, l_hip = s_hip.prefill(toks, 0)
+    assert not hip_backend.last_error(), hip_backend.last_error()
+    scale = np.abs(l_ref).max()
+    assert np.abs(l_hip - l_ref).max() / scale < 2e-4
+    assert t_hip == t_ref
+    # a second chunk at pos = T continues the same cache
+    toks2 = [(5 * i + 11) % cfg.vocab_size for i in range(T)]
+    t_ref2, l_ref2 = s_ref.prefill(toks2, T)
+    t_hip2, l_hip2 = s_hip.prefill(toks2, T)
+    assert np.abs(l_hip2 - l_ref2).max() / np.abs(l_ref2).max() < 2e-4 and t_hip2 == t_ref2
+    s_ref.close(), s_hip.close(), mN.close()
+    m1 = llama.Model(cfg, kind)
+    s1 = llama.Session(m1, llama.hip_backend_fns(hip_backend))
+    for p, t in enumerate(toks + toks2):
+        t_seq, l_seq = s1.step(t, p)
+    assert np.abs(l_seq - l_hip2).max() / np.abs(l_seq).max() < 2e-4 and t_seq == t_hip2
+    s1.close(), m1.close()

@@ -65,6 +65,31 @@ def test_matmul_rows_offsets_strides(hip_backend, oracle):
     assert np.array_equal(got == -7, want == -7)  # sentinels untouched in the same places
 
 
+@pytest.mark.parametrize("M", [2, 5, 16, 17, 32, 45])
+@pytest.mark.parametrize("K,N,kind", [(576, 192, "q4"), (1536, 576, "q4"), (100, 64, "q4"), (4096, 512, "q4"),
+                                      (11008, 64, "q4"), (576, 192, "q8"), (100, 64, "q8"), (2048, 96, "q8f16")])
+def test_matmul_tile_kernel_matches_oracle(hip_backend, oracle, M, K, N, kind):
+    """M > 1 goes to the f32-MFMA tile kernel (prefill plans): same tolerance as the mat-vec,
+    with ragged M (partial 16-row tiles), K tails and row strides."""
+    rng = np.random.default_rng(0xA11 + M * 7 + K + N)
+    x = rng.standard_normal(M * K).astype(f32)
+    if kind == "q4":
+        data = rng.integers(-8, 8, K * N).astype(np.int8)
+        scales = (rng.random((K * N + 31) // 32).astype(np.float16) * 0.05 + 0.001).astype(f32)
+    elif kind == "q8f16":  # GGUF Q8_0-sourced: full-range int8 with f16-exact scales
+        data = rng.integers(-127, 128, K * N).astype(np.int8)
+        scales = (rng.random((K * N + 31) // 32).astype(np.float16) * 0.01 + 0.001).astype(f32)
+    else:
+        data, scales = oracle.quantize_from_slice(rng.standard_normal(K * N).astype(f32) * 0.05, K, N, 32)
+    want, got = run_both(hip_backend, oracle, data, scales, x, M, N, K, in_off=4, in_rs=K + 4, dst_off=1, dst_rs=N + 5)
+    b = np.zeros_like(want, dtype=np.float64)
+    bb = bound(data, scales, x, M, N, K, 32)
+    for m in range(M):
+        b[1 + m * (N + 5):][:N] = bb[m]
+    assert np.all(np.abs(got - want) <= TOL * b + 1e-30), np.max(np.abs(got - want) / (b + 1e-30))
+    assert np.array_equal(got == -7, want == -7)  # sentinels between rows untouched
+
+
 def test_raw_layout_odd_shapes_bit_exact(hip_backend, oracle):
     """bs != 32 or N % 32 != 0 uses the k-sequential kernel: same loop order as the reference."""
     rng = np.random.default_rng(8)

@@ -141,3 +141,21 @@ def test_invalid_shard_specs_rejected():
     c.tied_lm_head, c.shard_world = 0, 2  # 3 kv heads do not split in two: replicas only
     with pytest.raises(ValueError):
         llama.Model(c)
+
+
+def test_prefill_plan_equals_sequential_on_oracle():
+    """token_len = N plan vs N single-token steps (src/llama_inference.zig:983-1034, tol 1e-4)."""
+    from oracle import oracle as O
+    cfg = llama.preset("tiny")
+    toks = [3, 17, 200, 5, 9, 44, 1]
+    m1 = llama.Model(cfg, llama.Q4_0)
+    s1 = llama.Session(m1, O.backend_fns())
+    for p, t in enumerate(toks):
+        nxt, lg = s1.step(t, p)
+    mN = llama.Model(cfg, llama.Q4_0, token_len=len(toks))
+    assert mN.program.n_ops == m1.program.n_ops  # same op stream, wider shapes
+    sN = llama.Session(mN, O.backend_fns())
+    nxt2, lg2 = sN.prefill(toks, 0)
+    assert nxt2 == nxt
+    np.testing.assert_allclose(lg2, lg, atol=1e-4)
+    s1.close(), sN.close(), m1.close(), mN.close()

@@ -12,14 +12,18 @@ from zgml_amd import Backend  # noqa: E402
 PEAK = 8000.0  # GB/s, MI355X HBM3E nominal
 
 
-def run(be, K, N, q4, ring, warmup, iters):
+def run(be, K, N, q4, ring, warmup, iters, M=1):
     nbytes = C.c_uint64()
-    us = be._lib.zgml_hip_qmatvec_bench(be.ctx, K, N, q4, ring, warmup, iters, C.byref(nbytes))
+    us = be._lib.zgml_hip_qmatmul_bench(be.ctx, M, K, N, q4, ring, warmup, iters, C.byref(nbytes))
     if us <= 0:
         raise RuntimeError(be.last_error())
     gbs = nbytes.value / us / 1e3
-    return {"K": K, "N": N, "fmt": "q4_0" if q4 else "q8_0", "ring": ring, "us": round(us, 3),
-            "bytes": nbytes.value, "GBps": round(gbs, 1), "frac": round(gbs / PEAK, 4)}
+    r = {"K": K, "N": N, "fmt": "q4_0" if q4 else "q8_0", "ring": ring, "us": round(us, 3),
+         "bytes": nbytes.value, "GBps": round(gbs, 1), "frac": round(gbs / PEAK, 4)}
+    if M > 1:
+        r["M"] = M
+        r["TFLOPs"] = round(2.0 * M * K * N / us / 1e6, 2)
+    return r
 
 
 if __name__ == "__main__":
@@ -27,6 +31,7 @@ if __name__ == "__main__":
     ap.add_argument("--iters", type=int, default=2000)
     ap.add_argument("--ring", type=int, default=64)
     ap.add_argument("--shapes", default="4096x4096,4096x11008,11008x4096,4096x32000,576x576,576x1536,1536x576")
+    ap.add_argument("--M", default="1", help="comma list of input row counts (M > 1: tile kernel)")
     a = ap.parse_args()
     be = Backend(0)
     cp = be._lib.zgml_hip_copy_bench(be.ctx, 1 << 30, 3, 20)
@@ -35,5 +40,6 @@ if __name__ == "__main__":
         K, N = map(int, shp.split("x"))
         for q4 in (1, 0):
             ring = max(2, min(a.ring, int(40e9 // (K * N))))
-            print(json.dumps(run(be, K, N, q4, ring, 20, a.iters)), flush=True)
+            for M in map(int, a.M.split(",")):
+                print(json.dumps(run(be, K, N, q4, ring, 20, max(64, a.iters // M) if M > 1 else a.iters, M)), flush=True)
     be.close()

@@ -436,6 +436,205 @@ __global__ void __launch_bounds__(1024) qmatvec_kernel(QMVArgs a) {
     reduce_store<GROUPED>((acc0 + acc1) + (acc2 + acc3), red, a, pi, out, out_rs, g, m);
 }
 
+// ── M > 1 (prefill): tile kernel on the f32 matrix cores ─────────────────────────────────────
+// With M rows of x the same weight stream feeds M dot products, so the op is a real contraction
+// and goes to MFMA — in f32 (v_mfma_f32_16x16x4_f32), so products and sums stay f32 exactly as in
+// the reference's loop (quant.zig:475-578); only the summation order differs. Same packed layout
+// and the same thread mapping as the mat-vec: lane (i, r) of a wave holds column n = 16g+i of the
+// row's k-unit u_r (16 B = 32 nibbles / 16 bytes). One MFMA step takes k_local = e of the FOUR
+// units of the wave's rows as its 4 k-slots:  B[kslot=r][n=i] = f32(q[u_r, e][n]) and
+// A[m=i][kslot=r] = x[m, k(u_r, e)] * scale(k(u_r, e), j)  — the per-(k, block-column) scale folds
+// into the A operand exactly like the mat-vec's t[k]. R m-tiles of 16 rows share each converted B
+// value. Waves of a workgroup split K; their partial tiles are summed through LDS in wave order.
+// x: the A operand wants "lane = row m", i.e. 16 different rows per load instruction. Loading that
+// straight from global memory costs 64 cache lines per instruction (measured: 5x slower than the
+// MFMA bound), so each step's x chunk [16R rows][4*waves units] is staged through LDS with
+// row-contiguous (coalesced) global loads (prefetched into registers one step ahead), rows padded
+// by 4 floats so the per-lane ds_read_b128 of 16 different rows is bank-conflict free.
+// A wave cannot overlap its own VALU work with its own MFMAs (measured, tools/exp/mfma.hip: every
+// VALU instruction between two MFMAs adds its full issue time), so workgroups are 8 waves = 2 per
+// SIMD, and the per-B-value VALU work (convert + scale) is shared by R m-tiles.
+struct QMMArgs {
+    const uint4* qs;
+    const void* sc;
+    const float* x;
+    float* out;
+    uint32_t M, K, U, in_rs, out_rs, NB2;
+};
+
+typedef float mfma_f4 __attribute__((ext_vector_type(4)));
+
+// Single-instruction converts for the tile kernel (separate asm statements so hipcc can place
+// them between the MFMAs): nibble -> q/16, byte -> q.
+template <int BYTE>
+__device__ __forceinline__ float cvt_nib(uint32_t w) {
+    float c;
+    if (BYTE == 0) asm("v_cvt_off_f32_i4_sdwa %0, %1 " ZGML_SDWA "0" : "=v"(c) : "v"(w));
+    if (BYTE == 1) asm("v_cvt_off_f32_i4_sdwa %0, %1 " ZGML_SDWA "1" : "=v"(c) : "v"(w));
+    if (BYTE == 2) asm("v_cvt_off_f32_i4_sdwa %0, %1 " ZGML_SDWA "2" : "=v"(c) : "v"(w));
+    if (BYTE == 3) asm("v_cvt_off_f32_i4_sdwa %0, %1 " ZGML_SDWA "3" : "=v"(c) : "v"(w));
+    return c;
+}
+template <int BYTE>
+__device__ __forceinline__ float cvt_i8(uint32_t w) {
+    float c;
+    if (BYTE == 0) asm("v_cvt_f32_i32_sdwa %0, sext(%1) " ZGML_SDWA "0" : "=v"(c) : "v"(w));
+    if (BYTE == 1) asm("v_cvt_f32_i32_sdwa %0, sext(%1) " ZGML_SDWA "1" : "=v"(c) : "v"(w));
+    if (BYTE == 2) asm("v_cvt_f32_i32_sdwa %0, sext(%1) " ZGML_SDWA "2" : "=v"(c) : "v"(w));
+    if (BYTE == 3) asm("v_cvt_f32_i32_sdwa %0, sext(%1) " ZGML_SDWA "3" : "=v"(c) : "v"(w));
+    return c;
+}
+// One k-unit of one column held by a lane: 16 B of weights + the unit's scales. compute() turns
+// it into 32 (16) B-operand values  b = f32(q) * scale  — for GGUF-sourced weights the product of
+// a 4/8-bit integer and an f16 scale is exact in f32 — and feeds R MFMAs per value with the A
+// operand x[m, k] read straight from the staged LDS chunk. (Q4 values come out of the convert as
+// q/16; the kernel multiplies the finished tile by 16, exact.)
+template <typename ST, bool Q4>
+struct TileUnit {
+    static constexpr int KU = Q4 ? 32 : 16;             // k per unit
+    static constexpr int NS = KU * (int)sizeof(ST) / 16; // uint4 of scales per unit
+    static constexpr bool kHalf = sizeof(ST) == 2;
+    uint4 wq;
+    uint4 sraw[NS];
+    __device__ __forceinline__ void load(const uint4* qs, const uint4* sc, uint32_t u, uint32_t U) {
+        const uint32_t uc = min(u, U - 1); // clamped, unconditional; x of units >= U is staged as zero
+        wq = qs[(uint64_t)uc * 16];
+#pragma unroll
+        for (int q = 0; q < NS; q++) sraw[q] = sc[(uint64_t)uc * NS + q];
+    }
+    // scale of k_local applied to a converted value. The multiply is left to hipcc on purpose: the
+    // value feeds an MFMA next, and gfx950 needs wait states between a VALU write and the MFMA read
+    // that the compiler only inserts for producers it can see (an inline-asm v_fma_mix here read
+    // stale registers).
+    template <int K_LOCAL>
+    __device__ __forceinline__ float scaled(float c) const {
+        constexpr int E = Q4 ? 2 * (K_LOCAL % 16) + K_LOCAL / 16 : K_LOCAL; // element index in the unit's scale array
+        return c * to_f32(((const ST*)sraw)[E]);
+    }
+    template <int R, int DD, int BY, int H>
+    __device__ __forceinline__ void one(mfma_f4 (&acc)[R], const float4 (&xv)[R][2], uint32_t w) const {
+        constexpr int K_LOCAL = Q4 ? 8 * DD + BY + 4 * H : 4 * DD + BY;
+        const float b = scaled<K_LOCAL>(Q4 ? cvt_nib<BY>(w) : cvt_i8<BY>(w));
+#pragma unroll
+        for (int t = 0; t < R; t++) {
+            constexpr int J = Q4 ? (BY + 4 * H) : BY; // position within the dword's 8 (4) k values
+            const float4 v = xv[t][J / 4];
+            const float xk = (J % 4) == 0 ? v.x : (J % 4) == 1 ? v.y : (J % 4) == 2 ? v.z : v.w;
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xk, b, acc[t], 0, 0, 0);
+        }
+    }
+    template <int R, int DD>
+    __device__ __forceinline__ void dword(mfma_f4 (&acc)[R], const float* xs, uint32_t tile_stride, uint32_t w) const {
+        constexpr int KD = Q4 ? 8 : 4; // k values per weight dword
+        float4 xv[R][2];
+#pragma unroll
+        for (int t = 0; t < R; t++)
+#pragma unroll
+            for (int c = 0; c < KD / 4; c++) xv[t][c] = *(const float4*)(xs + t * tile_stride + DD * KD + 4 * c);
+        one<R, DD, 0, 0>(acc, xv, w);
+        one<R, DD, 1, 0>(acc, xv, w);
+        one<R, DD, 2, 0>(acc, xv, w);
+        one<R, DD, 3, 0>(acc, xv, w);
+        if (Q4) {
+            const uint32_t h = w >> 4;
+            one<R, DD, 0, 1>(acc, xv, h);
+            one<R, DD, 1, 1>(acc, xv, h);
+            one<R, DD, 2, 1>(acc, xv, h);
+            one<R, DD, 3, 1>(acc, xv, h);
+        }
+    }
+    // xs: this lane's row of the staged chunk at its unit; m-tiles are `tile_stride` floats apart
+    template <int R>
+    __device__ __forceinline__ void compute(mfma_f4 (&acc)[R], const float* xs, uint32_t tile_stride) const {
+        dword<R, 0>(acc, xs, tile_stride, wq.x);
+        dword<R, 1>(acc, xs, tile_stride, wq.y);
+        dword<R, 2>(acc, xs, tile_stride, wq.z);
+        dword<R, 3>(acc, xs, tile_stride, wq.w);
+    }
+};
+
+template <typename ST, bool Q4, int R, bool XVEC>
+__global__ void __launch_bounds__(512) qmatmul_tile_kernel(QMMArgs a) {
+    using Unit = TileUnit<ST, Q4>;
+    constexpr int KU = Unit::KU;
+    constexpr int NX = R * KU / 4; // float4 of x each thread stages per step
+    extern __shared__ float smem[];
+    const uint32_t g = column_group(blockIdx.x, a.NB2), m0 = blockIdx.y * 16 * R;
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    const uint32_t row = lane >> 4, i = lane & 15;
+    const uint32_t stride = n_waves * 4;          // units per step
+    const uint32_t chf = stride * KU;             // floats of k per step
+    const uint32_t row_stride = chf + 4;          // padded LDS row
+    const uint4* qs = a.qs + (uint64_t)g * a.U * 16 + i;
+    const uint4* sc = (const uint4*)((const char*)a.sc + (uint64_t)(g >> 1) * a.U * Unit::NS * 16);
+    const uint32_t n_steps = (a.U + stride - 1) / stride;
+
+    // staging map: float4 slot f = tid + j*blockDim -> (row f / (chf/4), column 4*(f % (chf/4)))
+    const uint32_t f4_per_row = chf / 4;
+    uint32_t st_col[NX], st_lds[NX];
+    const float* st_src[NX];
+#pragma unroll
+    for (int j = 0; j < NX; j++) {
+        const uint32_t f = threadIdx.x + j * blockDim.x, r = f / f4_per_row;
+        st_col[j] = 4 * (f % f4_per_row);
+        st_lds[j] = r * row_stride + st_col[j];
+        st_src[j] = a.x + (uint64_t)min(m0 + r, a.M - 1) * a.in_rs;
+    }
+    float4 stage[NX];
+    auto stage_load = [&](uint32_t step) {
+#pragma unroll
+        for (int j = 0; j < NX; j++) stage[j] = load_x4<XVEC>(st_src[j], step * chf + st_col[j], a.K);
+    };
+    auto stage_store = [&](uint32_t step) {
+        if ((step + 1) * chf <= a.K) { // whole chunk inside K (uniform): no selects
+#pragma unroll
+            for (int j = 0; j < NX; j++) *(float4*)(smem + st_lds[j]) = stage[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < NX; j++) *(float4*)(smem + st_lds[j]) = zero_tail(stage[j], step * chf + st_col[j], a.K);
+        }
+    };
+
+    mfma_f4 acc[R];
+#pragma unroll
+    for (int t = 0; t < R; t++) acc[t] = mfma_f4{0.f, 0.f, 0.f, 0.f};
+    const uint32_t ul = 4 * w + row; // this row's unit within a step
+    const float* xs = smem + i * row_stride + ul * KU;
+    stage_load(0);
+    Unit cur;
+    cur.load(qs, sc, ul, a.U);
+    stage_store(0);
+    __syncthreads();
+    for (uint32_t st = 1; st < n_steps; st++) {
+        stage_load(st); // next chunk -> registers while this one is consumed from LDS
+        Unit nxt;
+        nxt.load(qs, sc, ul + st * stride, a.U);
+        __builtin_amdgcn_sched_barrier(0); // keep the prefetch ahead of the MFMA block (hipcc sinks it otherwise)
+        cur.template compute<R>(acc, xs, 16 * row_stride);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        stage_store(st);
+        __syncthreads();
+        cur = nxt;
+    }
+    cur.template compute<R>(acc, xs, 16 * row_stride);
+    __syncthreads();
+
+    // D[m = 4*row + v][n = i] in acc[t][v]; fold the waves in fixed order (reuses the x buffer)
+#pragma unroll
+    for (int t = 0; t < R; t++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) smem[((w * R + t) * 4 + v) * 64 + lane] = Q4 ? acc[t][v] * 16.0f : acc[t][v];
+    __syncthreads();
+    for (uint32_t idx = threadIdx.x; idx < (uint32_t)R * 256; idx += blockDim.x) {
+        const uint32_t t = idx >> 8, v = (idx >> 6) & 3, l = idx & 63;
+        float sum = smem[(t * 4 + v) * 64 + l];
+        for (uint32_t ww = 1; ww < n_waves; ww++) sum += smem[((ww * R + t) * 4 + v) * 64 + l];
+        const uint32_t m = m0 + t * 16 + 4 * (l >> 4) + v, n = g * 16 + (l & 15);
+        if (m < a.M) a.out[(uint64_t)m * a.out_rs + n] = sum;
+    }
+}
+
 // Raw layout (any block size, any N): one thread per (m, n), k sequential — exactly the
 // reference's loop order, coalesced along n. Used for odd shapes (e.g. the bs=4 conformance case).
 __global__ void __launch_bounds__(kBlock) qmatmul_raw_kernel(const int8_t* __restrict__ data,
@@ -660,6 +859,30 @@ void launch_packed(hipStream_t s, QMVArgs& a, const QWeightDev& w0, uint32_t tot
     hipLaunchKernelGGL(fn, grid, dim3(waves * 64), lds, s, a);
 }
 
+using TileFn = void (*)(QMMArgs);
+template <typename ST, bool Q4>
+TileFn pick_tile(bool two, bool xvec) {
+    if (two) return xvec ? qmatmul_tile_kernel<ST, Q4, 2, true> : qmatmul_tile_kernel<ST, Q4, 2, false>;
+    return xvec ? qmatmul_tile_kernel<ST, Q4, 1, true> : qmatmul_tile_kernel<ST, Q4, 1, false>;
+}
+
+void launch_tile(hipStream_t s, const QWeightDev& w, const QMatmulParams& p, bool xvec) {
+    const bool q4 = w.format == QW_Q4, two = p.M > 16;
+    const uint32_t R = two ? 2 : 1, KU = q4 ? 32 : 16;
+    QMMArgs a{(const uint4*)w.qs, w.sc, p.input, p.dst, p.M, p.K, q4 ? w.KC : 2 * w.KC, p.in_rs, p.dst_rs, p.N / 16};
+    uint32_t waves = cdiv(a.U, 4);
+    static const int env_w = getenv("ZGML_QMM_WAVES") ? atoi(getenv("ZGML_QMM_WAVES")) : 8;
+    if (waves > (uint32_t)env_w) waves = env_w; // x chunk per step = 16R rows x 4*waves units in LDS
+    const TileFn fn = w.scale_f16 ? (q4 ? pick_tile<__half, true>(two, xvec) : pick_tile<__half, false>(two, xvec))
+                                  : (q4 ? pick_tile<float, true>(two, xvec) : pick_tile<float, false>(two, xvec));
+    dim3 grid(a.NB2, cdiv(p.M, 16 * R));
+    const size_t x_bytes = 16ull * R * (waves * 4 * KU + 4) * sizeof(float);
+    const size_t red_bytes = (size_t)waves * R * 256 * sizeof(float);
+    const size_t lds = x_bytes > red_bytes ? x_bytes : red_bytes;
+    if (lds > 64 * 1024) hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+    hipLaunchKernelGGL(fn, grid, dim3(waves * 64), lds, s, a);
+}
+
 } // namespace
 
 uint32_t qmv_max_prologue_k(const QWeightDev&) { return kMaxWaves * 64 * 4 * kXRegs; } // widest workgroup; launch_packed widens to fit
@@ -669,6 +892,12 @@ void launch_qmatmul(hipStream_t s, const QWeightDev& w, const QMatmulParams& p, 
     if (w.format == QW_RAW) {
         dim3 grid(cdiv(p.N, kBlock), p.M);
         qmatmul_raw_kernel<<<grid, kBlock, 0, s>>>((const int8_t*)w.qs, (const float*)w.sc, w.bs, p);
+        return;
+    }
+    const bool xvec = ((uintptr_t)p.input % 16 == 0) && (p.K % 4 == 0) && (p.M == 1 || p.in_rs % 4 == 0);
+    static const int tile_min_m = getenv("ZGML_QMM_TILE_MIN_M") ? atoi(getenv("ZGML_QMM_TILE_MIN_M")) : 2;
+    if (p.M >= (uint32_t)tile_min_m && p.M > 1) {
+        launch_tile(s, w, p, xvec);
         return;
     }
     QMVArgs a{};
@@ -686,7 +915,6 @@ void launch_qmatmul(hipStream_t s, const QWeightDev& w, const QMatmulParams& p, 
     a.M = p.M, a.K = p.K;
     a.U = w.format == QW_Q4 ? w.KC : 2 * w.KC;
     a.in_rs = p.in_rs;
-    const bool xvec = ((uintptr_t)p.input % 16 == 0) && (p.K % 4 == 0) && (p.M == 1 || p.in_rs % 4 == 0);
     launch_packed(s, a, w, a.parts[0].NB2, p.M, xvec);
 }
 

@@ -1745,21 +1745,26 @@ static bool make_synth_weight(zgml_hip_ctx* ctx, uint32_t K, uint32_t N, int q4,
 
 double zgml_hip_qmatvec_bench(zgml_hip_ctx* ctx, uint32_t K, uint32_t N, int q4, uint32_t n_matrices, uint32_t warmup,
                               uint32_t iters, uint64_t* bytes_per_launch) {
-    if (!ctx || N % 32 || !n_matrices || !iters) return -1.0;
+    return zgml_hip_qmatmul_bench(ctx, 1, K, N, q4, n_matrices, warmup, iters, bytes_per_launch);
+}
+
+double zgml_hip_qmatmul_bench(zgml_hip_ctx* ctx, uint32_t M, uint32_t K, uint32_t N, int q4, uint32_t n_matrices,
+                              uint32_t warmup, uint32_t iters, uint64_t* bytes_per_launch) {
+    if (!ctx || N % 32 || !n_matrices || !iters || !M) return -1.0;
     hipSetDevice(ctx->device);
     std::vector<QWeightDev> ring(n_matrices);
     bool ok = true;
     for (uint32_t i = 0; ok && i < n_matrices; i++) ok = make_synth_weight(ctx, K, N, q4, i, &ring[i]);
     float *x = nullptr, *y = nullptr, *scratch = nullptr;
-    std::vector<float> xh(K);
-    for (uint32_t i = 0; i < K; i++) xh[i] = ((int)(i % 17) - 8) * 0.03125f;
+    std::vector<float> xh((size_t)M * K);
+    for (size_t i = 0; i < xh.size(); i++) xh[i] = ((int)(i % 17) - 8) * 0.03125f;
     uint64_t sb = ok ? qmatmul_scratch_bytes(ring[0], 1) : 0;
-    ok = ok && CTX_CHECK(ctx, hipMalloc((void**)&x, K * 4)) && CTX_CHECK(ctx, hipMalloc((void**)&y, N * 4)) &&
+    ok = ok && CTX_CHECK(ctx, hipMalloc((void**)&x, xh.size() * 4)) && CTX_CHECK(ctx, hipMalloc((void**)&y, (size_t)M * N * 4)) &&
          (!sb || CTX_CHECK(ctx, hipMalloc((void**)&scratch, sb))) &&
-         CTX_CHECK(ctx, hipMemcpy(x, xh.data(), K * 4, hipMemcpyHostToDevice));
+         CTX_CHECK(ctx, hipMemcpy(x, xh.data(), xh.size() * 4, hipMemcpyHostToDevice));
     double us = -1.0;
     if (ok) {
-        QMatmulParams qp{y, x, 1, N, K, K, N};
+        QMatmulParams qp{y, x, M, N, K, K, N};
         for (uint32_t i = 0; i < warmup; i++) launch_qmatmul(ctx->stream, ring[i % n_matrices], qp, scratch);
         // One pass over the ring is captured into a hipGraph and replayed: back-to-back eager
         // launches are host-bound below ~3 us per kernel on this platform, a graph is not.
@@ -1791,7 +1796,7 @@ double zgml_hip_qmatvec_bench(zgml_hip_ctx* ctx, uint32_t K, uint32_t N, int q4,
         if (ge) hipGraphExecDestroy(ge);
         if (g) hipGraphDestroy(g);
     }
-    if (bytes_per_launch) *bytes_per_launch = (uint64_t)K * N / 32 * (q4 ? 18 : 34) + 4ull * K + 4ull * N;
+    if (bytes_per_launch) *bytes_per_launch = (uint64_t)K * N / 32 * (q4 ? 18 : 34) + 4ull * M * K + 4ull * M * N;
     for (auto& w : ring) {
         hipFree(w.qs);
         hipFree(w.sc);

@@ -56,7 +56,14 @@ void zh_preset(const char* name, uint32_t max_seq, zh_config* out) {
             c.tied_lm_head ? 1u : 0u, 0, 1};
 }
 
+zh_model* zh_model_create_ex(const zh_config* cfg, int weight_kind, int fused_elementwise, int include_dead_f32, int threads,
+                             uint32_t token_len);
 zh_model* zh_model_create(const zh_config* cfg, int weight_kind, int fused_elementwise, int include_dead_f32, int threads) {
+    return zh_model_create_ex(cfg, weight_kind, fused_elementwise, include_dead_f32, threads, 1);
+}
+
+zh_model* zh_model_create_ex(const zh_config* cfg, int weight_kind, int fused_elementwise, int include_dead_f32, int threads,
+                             uint32_t token_len) {
     LlamaConfig c;
     c.vocab_size = cfg->vocab_size, c.d_model = cfg->d_model, c.n_heads = cfg->n_heads, c.n_kv_heads = cfg->n_kv_heads;
     c.d_ff = cfg->d_ff, c.n_layers = cfg->n_layers, c.max_seq_len = cfg->max_seq_len, c.rope_base = cfg->rope_base;
@@ -69,7 +76,8 @@ zh_model* zh_model_create(const zh_config* cfg, int weight_kind, int fused_eleme
         return nullptr; // shard slices must stay whole 32-column scale blocks
     auto* m = new zh_model();
     m->model = make_synthetic_model(c, (WeightKind)weight_kind, threads);
-    m->dp = build_decode_program(*m->model, fused_elementwise != 0, include_dead_f32 != 0);
+    if (token_len > 1 && c.shard_world > 1) return nullptr; // the row-shard driver is decode-only
+    m->dp = build_decode_program(*m->model, fused_elementwise != 0, include_dead_f32 != 0, token_len ? token_len : 1);
     m->flat = m->dp->program.view(m->qw_storage);
     return m;
 }
@@ -79,6 +87,12 @@ void zh_model_free(zh_model* m) { delete m; }
 const zgml_device_program* zh_model_program(zh_model* m) { return &m->flat; }
 
 void zh_model_patch(zh_model* m, uint32_t token, uint32_t pos) { patch_step(*m->model, *m->dp, token, pos); }
+void zh_model_patch_tokens(zh_model* m, const uint32_t* tokens, uint32_t pos) { patch_tokens(*m->model, *m->dp, tokens, pos); }
+uint32_t zh_model_token_len(zh_model* m) { return m->dp->token_len; }
+
+// One execution of a token_len = N plan (prefill chunk): patch, refresh, execute; logits of the
+// last position are left in the model's host buffer. Returns its greedy token.
+int64_t zh_session_prefill(struct zh_session* s, const uint32_t* tokens, uint32_t pos, float* logits_out);
 
 const zgml_program_io* zh_model_step_inputs(zh_model* m, uint64_t* n) {
     *n = m->dp->step_inputs.size();
@@ -134,6 +148,16 @@ void* zh_session_handle(zh_session* s) { return s->handle; }
 int64_t zh_session_step(zh_session* s, uint32_t token, uint32_t pos, float* logits_out) {
     DecodeProgram& dp = *s->m->dp;
     patch_step(*s->m->model, dp, token, pos);
+    s->fns.refresh_program(s->fns.ctx, s->handle, dp.program.ops.data(), dp.program.ops.size());
+    s->fns.execute_program(s->fns.ctx, s->handle, dp.step_inputs.data(), dp.step_inputs.size(), dp.step_outputs.data(),
+                           dp.step_outputs.size());
+    if (logits_out) std::memcpy(logits_out, dp.logits_host.data(), dp.logits_host.size() * sizeof(float));
+    return LlamaDeviceSession::argmax(dp.logits_host.data(), (uint32_t)dp.logits_host.size());
+}
+
+int64_t zh_session_prefill(zh_session* s, const uint32_t* tokens, uint32_t pos, float* logits_out) {
+    DecodeProgram& dp = *s->m->dp;
+    patch_tokens(*s->m->model, dp, tokens, pos);
     s->fns.refresh_program(s->fns.ctx, s->handle, dp.program.ops.data(), dp.program.ops.size());
     s->fns.execute_program(s->fns.ctx, s->handle, dp.step_inputs.data(), dp.step_inputs.size(), dp.step_outputs.data(),
                            dp.step_outputs.size());

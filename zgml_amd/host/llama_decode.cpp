@@ -197,12 +197,12 @@ struct Builder {
     }
     void op(const DeviceOp& o) { dp.program.ops.push_back(o); }
     // rmsnorm -> repeat(gamma) -> mul  (applyRmsNorm, llama_transformer.zig:120-127)
-    uint16_t rms_norm(uint16_t x, uint16_t gamma, uint32_t d, float eps) {
-        const uint16_t bare = buffer(d), rep = buffer(d), out = buffer(d);
-        op(DeviceOp::rmsnorm(bare, x, 1, d, eps));
-        const uint32_t ne[4] = {d, 1, 1, 1}, st[4] = {1, d, d, d};
-        op(DeviceOp::repeat(rep, gamma, d, ne, ne, st, st));
-        op(DeviceOp::elementwise(ZGML_OP_MUL, out, bare, rep, d));
+    uint16_t rms_norm(uint16_t x, uint16_t gamma, uint32_t d, float eps, uint32_t T) {
+        const uint16_t bare = buffer((uint64_t)d * T), rep = buffer((uint64_t)d * T), out = buffer((uint64_t)d * T);
+        op(DeviceOp::rmsnorm(bare, x, T, d, eps));
+        const uint32_t sne[4] = {d, 1, 1, 1}, sst[4] = {1, d, d, d}, dne[4] = {d, T, 1, 1}, dst_[4] = {1, d, d * T, d * T};
+        op(DeviceOp::repeat(rep, gamma, d * T, sne, dne, sst, dst_)); // gamma.repeatLike(bare): [d] -> [d, T]
+        op(DeviceOp::elementwise(ZGML_OP_MUL, out, bare, rep, d * T));
         return out;
     }
     const FusedEwStep* steps(std::initializer_list<FusedEwStep> s) {
@@ -214,7 +214,7 @@ struct Builder {
 } // namespace
 
 std::unique_ptr<DecodeProgram> build_decode_program(const LlamaModel& model, bool fused_elementwise,
-                                                    bool include_dead_f32) {
+                                                    bool include_dead_f32, uint32_t token_len) {
     const LlamaConfig& c = model.cfg;
     auto dpp = std::make_unique<DecodeProgram>();
     DecodeProgram& dp = *dpp;
@@ -225,14 +225,17 @@ std::unique_ptr<DecodeProgram> build_decode_program(const LlamaModel& model, boo
     const uint32_t d_loc = d / ws, kvd_loc = c.kv_dim() / ws, ff_loc = ff / ws;
     const float attn_scale = 1.0f / std::sqrt((float)dh);
     const bool sharded = ws > 1;
+    const uint32_t T = token_len ? token_len : 1; // tokens per execution: 1 = decode plan, N = prefill plan
+    dp.token_len = T;
 
     // quantized weight table (all borrowed from the model)
     for (const auto& qw : model.qweights)
         dp.program.qweights.push_back({qw.data.data(), qw.data.size(), qw.scales.data(), qw.scales.size(), qw.K, qw.N, 32});
 
-    dp.token_input.assign(d, 0.f);
-    dp.attn_mask.assign(S, -std::numeric_limits<float>::infinity());
-    dp.attn_mask[0] = 0.f;
+    dp.token_input.assign((size_t)d * T, 0.f);
+    dp.attn_mask.assign((size_t)S * T, -std::numeric_limits<float>::infinity()); // [max_seq, T], column per query
+    for (uint32_t j = 0; j < T; j++)
+        for (uint32_t s2 = 0; s2 <= j; s2++) dp.attn_mask[(size_t)j * S + s2] = 0.f;
     dp.scalar_one.assign(1, 1.0f);
     dp.buf_token_input = b.leaf(dp.token_input);
     dp.buf_attn_mask = b.leaf(dp.attn_mask);
@@ -241,7 +244,7 @@ std::unique_ptr<DecodeProgram> build_decode_program(const LlamaModel& model, boo
     for (uint32_t l = 0; l < c.n_layers; l++) {
         const uint16_t wq = l * 7 + 0, wk = l * 7 + 1, wv = l * 7 + 2, wo = l * 7 + 3, wg = l * 7 + 4, wu = l * 7 + 5, wd = l * 7 + 6;
         const uint16_t g1 = b.leaf(model.gamma1[l]), g2 = b.leaf(model.gamma2[l]);
-        dp.rope_leaf.emplace_back(2 * dh, 0.f);
+        dp.rope_leaf.emplace_back((size_t)2 * dh * T, 0.f);
         const uint16_t rope_cs = b.leaf(dp.rope_leaf.back());
         dp.buf_rope.push_back(rope_cs);
         // consolidated KV caches [d_head, max_seq * n_kv_heads] (this rank's kv heads), zero-initialised:
@@ -258,13 +261,14 @@ std::unique_ptr<DecodeProgram> build_decode_program(const LlamaModel& model, boo
                 b.leaf(f);
             }
         }
-        const uint16_t attn_buf = b.buffer(d);
+        const uint16_t attn_buf = b.buffer((uint64_t)d * T);
 
         // ---- attention half; DFS post-order of the graph rooted at `output` (graph.zig:1294-1311):
         // the sliceAssignRows chain is visited from its last link, so head H-1 comes first and the
         // row stores unwind in ascending order afterwards.
-        const uint16_t norm1 = b.rms_norm(x, g1, d, c.rms_norm_eps);
-        const uint16_t q_proj = b.buffer(d_loc), k_proj = b.buffer(kvd_loc), v_proj = b.buffer(kvd_loc);
+        const uint16_t norm1 = b.rms_norm(x, g1, d, c.rms_norm_eps, T);
+        const uint16_t q_proj = b.buffer((uint64_t)d_loc * T), k_proj = b.buffer((uint64_t)kvd_loc * T),
+                       v_proj = b.buffer((uint64_t)kvd_loc * T);
         bool q_done = false;
         std::vector<char> kv_done(KV_loc, 0);
         bool k_proj_done = false, v_proj_done = false;
@@ -272,33 +276,33 @@ std::unique_ptr<DecodeProgram> build_decode_program(const LlamaModel& model, boo
         for (int hl = (int)H_loc - 1; hl >= 0; hl--) {
             const uint32_t h = h0 + hl, kvh = h / n_rep, kvl = kvh - kv0;
             if (!q_done) {
-                b.op(DeviceOp::qmatmul(q_proj, norm1, wq, 1, d_loc, d, 0, d, 0, d_loc));
+                b.op(DeviceOp::qmatmul(q_proj, norm1, wq, T, d_loc, d, 0, d, 0, d_loc));
                 q_done = true;
             }
-            const uint16_t q_rot = b.buffer(dh);
-            b.op(DeviceOp::rope(q_rot, q_proj, rope_cs, dh / 2, 1, hl * dh, 0, 0, 1, d_loc, 2 * dh));
+            const uint16_t q_rot = b.buffer((uint64_t)dh * T);
+            b.op(DeviceOp::rope(q_rot, q_proj, rope_cs, dh / 2, T, hl * dh, 0, 0, 1, d_loc, 2 * dh));
             if (!kv_done[kvl]) {
                 kv_done[kvl] = 1;
                 if (!k_proj_done) {
-                    b.op(DeviceOp::qmatmul(k_proj, norm1, wk, 1, kvd_loc, d, 0, d, 0, kvd_loc));
+                    b.op(DeviceOp::qmatmul(k_proj, norm1, wk, T, kvd_loc, d, 0, d, 0, kvd_loc));
                     k_proj_done = true;
                 }
-                const uint16_t k_rot = b.buffer(dh);
-                b.op(DeviceOp::rope(k_rot, k_proj, rope_cs, dh / 2, 1, kvl * dh, 0, 0, 1, kvd_loc, 2 * dh));
+                const uint16_t k_rot = b.buffer((uint64_t)dh * T);
+                b.op(DeviceOp::rope(k_rot, k_proj, rope_cs, dh / 2, T, kvl * dh, 0, 0, 1, kvd_loc, 2 * dh));
                 const uint32_t slab = kvl * S * dh; // k_cache.sliceColumns(kv_h*max_seq, ...)
                 dp.slice_assign_op_indices.push_back((uint32_t)dp.program.ops.size());
-                b.op(DeviceOp::slice_assign(k_cache, k_rot, dh, 1, slab, slab, 1, dh, 0, 1, dh, dh));
+                b.op(DeviceOp::slice_assign(k_cache, k_rot, dh, T, slab, slab, 1, dh, 0, 1, dh, dh));
                 if (!v_proj_done) {
-                    b.op(DeviceOp::qmatmul(v_proj, norm1, wv, 1, kvd_loc, d, 0, d, 0, kvd_loc));
+                    b.op(DeviceOp::qmatmul(v_proj, norm1, wv, T, kvd_loc, d, 0, d, 0, kvd_loc));
                     v_proj_done = true;
                 }
                 dp.slice_assign_op_indices.push_back((uint32_t)dp.program.ops.size());
-                b.op(DeviceOp::slice_assign(v_cache, v_proj, dh, 1, slab, slab, 1, dh, kvl * dh, 1, kvd_loc, dh));
+                b.op(DeviceOp::slice_assign(v_cache, v_proj, dh, T, slab, slab, 1, dh, kvl * dh, 1, kvd_loc, dh));
             }
-            attn_out[hl] = b.buffer(dh);
+            attn_out[hl] = b.buffer((uint64_t)dh * T);
             zgml_op_attention a{};
             a.dst = attn_out[hl], a.q = q_rot, a.k = k_cache, a.v = v_cache, a.mask = dp.buf_attn_mask, a.has_mask = 1;
-            a.d_head = dh, a.seq_q = 1, a.seq_kv = S, a.scale = attn_scale;
+            a.d_head = dh, a.seq_q = T, a.seq_kv = S, a.scale = attn_scale;
             a.q_off = 0, a.k_off = kvl * S * dh, a.v_off = kvl * S * dh, a.mask_off = 0, a.dst_off = 0;
             a.q_rs = 1, a.q_cs = dh, a.k_rs = 1, a.k_cs = dh, a.v_rs = 1, a.v_cs = dh;
             a.mask_rs = 1, a.mask_cs = S, a.dst_rs = 1, a.dst_cs = dh;
@@ -308,59 +312,62 @@ std::unique_ptr<DecodeProgram> build_decode_program(const LlamaModel& model, boo
         for (uint32_t hl = 0; hl < H_loc; hl++) { // sliceAssignRows(attn_out, h*d_head): patch_stride 0
             const uint32_t row = (h0 + hl) * dh;
             dp.slice_assign_op_indices.push_back((uint32_t)dp.program.ops.size());
-            b.op(DeviceOp::slice_assign(attn_buf, attn_out[hl], dh, 1, 0, row, 1, d, 0, 1, dh, 0));
+            b.op(DeviceOp::slice_assign(attn_buf, attn_out[hl], dh, T, 0, row, 1, d, 0, 1, dh, 0));
         }
         if (sharded) dp.gather_points.push_back({(uint32_t)dp.program.ops.size(), attn_buf, 0, d_loc});
-        const uint16_t attn_proj = b.buffer(d), after_attn = b.buffer(d);
-        b.op(DeviceOp::qmatmul(attn_proj, attn_buf, wo, 1, d_loc, d, 0, d, r * d_loc, d_loc));
+        const uint16_t attn_proj = b.buffer((uint64_t)d * T), after_attn = b.buffer((uint64_t)d * T);
+        // sharded (T == 1 only): the rank's slice of the full vector; unsharded: dense [T, d]
+        b.op(DeviceOp::qmatmul(attn_proj, attn_buf, wo, T, d_loc, d, 0, d, r * d_loc, sharded ? d_loc : d));
         if (sharded) dp.gather_points.push_back({(uint32_t)dp.program.ops.size(), attn_proj, 0, d_loc});
-        b.op(DeviceOp::elementwise(ZGML_OP_ADD, after_attn, x, attn_proj, d));
+        b.op(DeviceOp::elementwise(ZGML_OP_ADD, after_attn, x, attn_proj, d * T));
 
         // ---- SwiGLU half (swigluFfn, llama_transformer.zig:129-133; silu = nn.zig:38-44)
-        const uint16_t norm2 = b.rms_norm(after_attn, g2, d, c.rms_norm_eps);
-        const uint16_t gate = b.buffer(ff_loc), up = b.buffer(ff_loc), silu = b.buffer(ff_loc), act = b.buffer(ff);
-        const uint16_t one = b.leaf(dp.scalar_one), one_rep = b.buffer(ff_loc);
-        b.op(DeviceOp::qmatmul(gate, norm2, wg, 1, ff_loc, d, 0, d, 0, ff_loc));
-        const uint32_t ne1[4] = {1, 1, 1, 1}, st1[4] = {1, 1, 1, 1}, nef[4] = {ff_loc, 1, 1, 1}, stf[4] = {1, ff_loc, ff_loc, ff_loc};
+        const uint16_t norm2 = b.rms_norm(after_attn, g2, d, c.rms_norm_eps, T);
+        const uint32_t nf = ff_loc * T; // elements of one [d_ff, T] activation
+        const uint16_t gate = b.buffer(nf), up = b.buffer(nf), silu = b.buffer(nf), act = b.buffer((uint64_t)ff * T);
+        const uint16_t one = b.leaf(dp.scalar_one), one_rep = b.buffer(nf);
+        b.op(DeviceOp::qmatmul(gate, norm2, wg, T, ff_loc, d, 0, d, 0, ff_loc));
+        const uint32_t ne1[4] = {1, 1, 1, 1}, st1[4] = {1, 1, 1, 1}, nef[4] = {ff_loc, T, 1, 1}, stf[4] = {1, ff_loc, nf, nf};
         if (fused_elementwise) {
-            const uint16_t exp_neg = b.buffer(ff_loc);
-            b.op(DeviceOp::fused_elementwise(b.steps({{ZGML_OP_NEG, 0, 0, 0, 0}, {ZGML_OP_EXP, 0, 0, 0, 0}}), 2, ff_loc, exp_neg, gate));
-            b.op(DeviceOp::repeat(one_rep, one, ff_loc, ne1, nef, st1, stf));
+            const uint16_t exp_neg = b.buffer(nf);
+            b.op(DeviceOp::fused_elementwise(b.steps({{ZGML_OP_NEG, 0, 0, 0, 0}, {ZGML_OP_EXP, 0, 0, 0, 0}}), 2, nf, exp_neg, gate));
+            b.op(DeviceOp::repeat(one_rep, one, nf, ne1, nef, st1, stf));
             b.op(DeviceOp::fused_elementwise(
-                b.steps({{ZGML_OP_ADD, 0, 0, one_rep, 0}, {ZGML_OP_RECIP, 0, 0, 0, 0}, {ZGML_OP_MUL, 1, 0, gate, 0}}), 3, ff_loc,
+                b.steps({{ZGML_OP_ADD, 0, 0, one_rep, 0}, {ZGML_OP_RECIP, 0, 0, 0, 0}, {ZGML_OP_MUL, 1, 0, gate, 0}}), 3, nf,
                 silu, exp_neg));
         } else { // appendElementwiseChainOps (device_inference.zig:373-397)
-            const uint16_t t_neg = b.buffer(ff_loc), t_exp = b.buffer(ff_loc), t_add = b.buffer(ff_loc), t_rec = b.buffer(ff_loc);
-            b.op(DeviceOp::elementwise(ZGML_OP_NEG, t_neg, gate, gate, ff_loc));
-            b.op(DeviceOp::elementwise(ZGML_OP_EXP, t_exp, t_neg, t_neg, ff_loc));
-            b.op(DeviceOp::repeat(one_rep, one, ff_loc, ne1, nef, st1, stf));
-            b.op(DeviceOp::elementwise(ZGML_OP_ADD, t_add, t_exp, one_rep, ff_loc));
-            b.op(DeviceOp::elementwise(ZGML_OP_RECIP, t_rec, t_add, t_add, ff_loc));
-            b.op(DeviceOp::elementwise(ZGML_OP_MUL, silu, gate, t_rec, ff_loc));
+            const uint16_t t_neg = b.buffer(nf), t_exp = b.buffer(nf), t_add = b.buffer(nf), t_rec = b.buffer(nf);
+            b.op(DeviceOp::elementwise(ZGML_OP_NEG, t_neg, gate, gate, nf));
+            b.op(DeviceOp::elementwise(ZGML_OP_EXP, t_exp, t_neg, t_neg, nf));
+            b.op(DeviceOp::repeat(one_rep, one, nf, ne1, nef, st1, stf));
+            b.op(DeviceOp::elementwise(ZGML_OP_ADD, t_add, t_exp, one_rep, nf));
+            b.op(DeviceOp::elementwise(ZGML_OP_RECIP, t_rec, t_add, t_add, nf));
+            b.op(DeviceOp::elementwise(ZGML_OP_MUL, silu, gate, t_rec, nf));
         }
-        b.op(DeviceOp::qmatmul(up, norm2, wu, 1, ff_loc, d, 0, d, 0, ff_loc));
-        b.op(DeviceOp::elementwise(ZGML_OP_MUL, act, silu, up, ff_loc, r * ff_loc, 0, 0));
+        b.op(DeviceOp::qmatmul(up, norm2, wu, T, ff_loc, d, 0, d, 0, ff_loc));
+        b.op(DeviceOp::elementwise(ZGML_OP_MUL, act, silu, up, nf, r * ff_loc, 0, 0));
         if (sharded) dp.gather_points.push_back({(uint32_t)dp.program.ops.size(), act, 0, ff_loc});
-        const uint16_t down = b.buffer(d), out = b.buffer(d);
-        b.op(DeviceOp::qmatmul(down, act, wd, 1, d_loc, ff, 0, ff, r * d_loc, d_loc));
+        const uint16_t down = b.buffer((uint64_t)d * T), out = b.buffer((uint64_t)d * T);
+        b.op(DeviceOp::qmatmul(down, act, wd, T, d_loc, ff, 0, ff, r * d_loc, sharded ? d_loc : d));
         if (sharded) dp.gather_points.push_back({(uint32_t)dp.program.ops.size(), down, 0, d_loc});
-        b.op(DeviceOp::elementwise(ZGML_OP_ADD, out, after_attn, down, d));
+        b.op(DeviceOp::elementwise(ZGML_OP_ADD, out, after_attn, down, d * T));
         x = out;
     }
 
     // final norm + LM head (llama.zig:158-165)
     const uint16_t gf = b.leaf(model.gamma_f);
-    const uint16_t normf = b.rms_norm(x, gf, d, c.rms_norm_eps);
-    dp.buf_logits = b.buffer(c.vocab_size);
+    const uint16_t normf = b.rms_norm(x, gf, d, c.rms_norm_eps, T);
+    dp.buf_logits = b.buffer((uint64_t)c.vocab_size * T);
     if (c.tied_lm_head) { // x.matMul(false, token_embed, true): dense f32, B K-contiguous
         const uint16_t embed = b.leaf(model.token_embed);
         backend::MatMulGeometry g{};
-        g.M = 1, g.N = c.vocab_size, g.K = d, g.a_row_stride = d, g.a_col_stride = 1, g.b_row_stride = 1, g.b_col_stride = d;
+        g.M = T, g.N = c.vocab_size, g.K = d, g.a_row_stride = d, g.a_col_stride = 1, g.b_row_stride = 1, g.b_col_stride = d;
         g.a_offset = 0, g.b_offset = 0, g.dst_offset = 0, g.dst_row_stride = c.vocab_size;
         b.op(DeviceOp::matmul(dp.buf_logits, normf, embed, g));
     } else {
         const uint32_t v_loc = c.vocab_size / ws;
-        b.op(DeviceOp::qmatmul(dp.buf_logits, normf, (uint16_t)model.lm_head_index(), 1, v_loc, d, 0, d, r * v_loc, v_loc));
+        b.op(DeviceOp::qmatmul(dp.buf_logits, normf, (uint16_t)model.lm_head_index(), T, v_loc, d, 0, d, r * v_loc,
+                               sharded ? v_loc : c.vocab_size));
         if (sharded) dp.gather_points.push_back({(uint32_t)dp.program.ops.size(), dp.buf_logits, 0, v_loc});
     }
     dp.program.n_buffers = (uint16_t)dp.program.buffer_sizes.size();
@@ -374,23 +381,35 @@ std::unique_ptr<DecodeProgram> build_decode_program(const LlamaModel& model, boo
     dp.step_inputs.push_back(io(dp.buf_token_input, dp.token_input));
     dp.step_inputs.push_back(io(dp.buf_attn_mask, dp.attn_mask));
     for (uint32_t l = 0; l < c.n_layers; l++) dp.step_inputs.push_back(io(dp.buf_rope[l], dp.rope_leaf[l]));
+    // Last-column logits: [vocab, T] column-major -> last col at offset (T-1)*vocab (llama_inference.zig:463-465)
     dp.logits_host.assign(c.vocab_size, 0.f);
-    dp.step_outputs.push_back(io(dp.buf_logits, dp.logits_host));
+    backend::ProgramIO out_io = io(dp.buf_logits, dp.logits_host);
+    out_io.offset = (uint32_t)((size_t)(T - 1) * c.vocab_size * sizeof(float));
+    dp.step_outputs.push_back(out_io);
     return dpp;
 }
 
-void patch_step(const LlamaModel& model, DecodeProgram& dp, uint32_t token, uint32_t pos) {
+void patch_step(const LlamaModel& model, DecodeProgram& dp, uint32_t token, uint32_t pos) { patch_tokens(model, dp, &token, pos); }
+
+// LlamaInferencePlan.execute steps 1-4 for token_len tokens at positions [pos, pos + T)
+void patch_tokens(const LlamaModel& model, DecodeProgram& dp, const uint32_t* tokens, uint32_t pos) {
     const LlamaConfig& c = model.cfg;
-    const uint32_t d = c.d_model, dh = c.d_head(), S = c.max_seq_len;
-    std::memcpy(dp.token_input.data(), model.token_embed.data() + (size_t)token * d, d * sizeof(float));
-    std::fill(dp.attn_mask.begin(), dp.attn_mask.begin() + pos + 1, 0.f);
-    if (pos + 1 < S) std::fill(dp.attn_mask.begin() + pos + 1, dp.attn_mask.end(), -std::numeric_limits<float>::infinity());
-    for (auto& leaf : dp.rope_leaf) {
-        std::memcpy(leaf.data(), model.cos_table.data() + (size_t)pos * dh, dh * sizeof(float));
-        std::memcpy(leaf.data() + dh, model.sin_table.data() + (size_t)pos * dh, dh * sizeof(float));
+    const uint32_t d = c.d_model, dh = c.d_head(), S = c.max_seq_len, T = dp.token_len;
+    const float ninf = -std::numeric_limits<float>::infinity();
+    for (uint32_t j = 0; j < T; j++) {
+        std::memcpy(dp.token_input.data() + (size_t)j * d, model.token_embed.data() + (size_t)tokens[j] * d, d * sizeof(float));
+        float* col = dp.attn_mask.data() + (size_t)j * S;
+        const uint32_t valid_upto = pos + j + 1;
+        std::fill(col, col + valid_upto, 0.f);
+        if (valid_upto < S) std::fill(col + valid_upto, col + S, ninf);
     }
+    for (auto& leaf : dp.rope_leaf)
+        for (uint32_t j = 0; j < T; j++) {
+            std::memcpy(leaf.data() + (size_t)j * 2 * dh, model.cos_table.data() + (size_t)(pos + j) * dh, dh * sizeof(float));
+            std::memcpy(leaf.data() + (size_t)j * 2 * dh + dh, model.sin_table.data() + (size_t)(pos + j) * dh, dh * sizeof(float));
+        }
     dp.patchSliceAssignOffset(pos);
-    dp.patchAttentionSeqKV(pos + 1);
+    dp.patchAttentionSeqKV(pos + T);
 }
 
 bool LlamaDeviceSession::init(const LlamaModel& m, const backend::Backend& backend, bool include_dead_f32) {
@@ -398,7 +417,7 @@ bool LlamaDeviceSession::init(const LlamaModel& m, const backend::Backend& backe
     be = backend;
     const bool fuse = be.capabilities.fused_elementwise &&
                       (!be.capabilities.max_fused_elementwise_steps || *be.capabilities.max_fused_elementwise_steps >= 3);
-    dp = build_decode_program(m, fuse, include_dead_f32);
+    dp = build_decode_program(m, fuse, include_dead_f32, 1);
     if (!be.supportsProgram(dp->program)) return false; // error.UnsupportedDeviceOp
     handle = be.compileProgram(dp->program);
     return handle != nullptr; // error.CompileFailed

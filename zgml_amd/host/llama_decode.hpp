@@ -72,6 +72,7 @@ struct DecodeProgram {
     std::vector<std::vector<float>> rope_leaf; // per layer [2*d_head]
     std::vector<std::vector<float>> dead_f32;  // optional f32 master copies (never read by an op)
     std::vector<float> kv_zero;                 // zero initial KV (not uploaded: buffers start zeroed)
+    uint32_t token_len = 1; // tokens per execution (1 = decode plan, N = prefill plan)
     uint16_t buf_token_input = 0, buf_attn_mask = 0, buf_logits = 0;
     std::vector<uint16_t> buf_rope, buf_k_cache, buf_v_cache;
     std::vector<uint32_t> slice_assign_op_indices, attention_op_indices;
@@ -92,12 +93,15 @@ struct DecodeProgram {
 
 // include_dead_f32: also register the f32 master copy of every quantized weight as a buffer with
 // an initial upload, exactly as DeviceInference does; the backend elides them.
+// token_len: 1 builds the decode plan; N > 1 builds the fixed-width prefill plan
+// (LlamaInferencePlan with token_len = N, src/llama_inference.zig:405-466; src/llm/device_prefill.zig).
 std::unique_ptr<DecodeProgram> build_decode_program(const LlamaModel& model, bool fused_elementwise,
-                                                    bool include_dead_f32);
+                                                    bool include_dead_f32, uint32_t token_len = 1);
 
 // Patch the plan's host leaves for (token, pos): embedding row, causal mask column, RoPE row
 // (llama_smollm_bench.zig:299-309), then the dynamic op fields.
 void patch_step(const LlamaModel& model, DecodeProgram& dp, uint32_t token, uint32_t pos);
+void patch_tokens(const LlamaModel& model, DecodeProgram& dp, const uint32_t* tokens, uint32_t pos);
 
 struct LlamaDeviceSession {
     const LlamaModel* model = nullptr;

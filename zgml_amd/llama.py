@@ -48,6 +48,10 @@ def load_host() -> C.CDLL:
         vp, u32, u64 = C.c_void_p, C.c_uint32, C.c_uint64
         lib.zh_preset.argtypes, lib.zh_preset.restype = [C.c_char_p, u32, C.POINTER(Config)], None
         lib.zh_model_create.argtypes, lib.zh_model_create.restype = [C.POINTER(Config), C.c_int, C.c_int, C.c_int, C.c_int], vp
+        lib.zh_model_create_ex.argtypes = [C.POINTER(Config), C.c_int, C.c_int, C.c_int, C.c_int, u32]
+        lib.zh_model_create_ex.restype = vp
+        lib.zh_model_patch_tokens.argtypes, lib.zh_model_patch_tokens.restype = [vp, vp, u32], None
+        lib.zh_session_prefill.argtypes, lib.zh_session_prefill.restype = [vp, vp, u32, vp], C.c_int64
         lib.zh_model_free.argtypes, lib.zh_model_free.restype = [vp], None
         lib.zh_model_program.argtypes, lib.zh_model_program.restype = [vp], C.POINTER(capi.DeviceProgramC)
         lib.zh_model_patch.argtypes, lib.zh_model_patch.restype = [vp, u32, u32], None
@@ -89,10 +93,12 @@ class Model:
     """Synthetic LLaMA weights + the decode DeviceProgram (`DeviceInference.init`, token_len = 1)."""
 
     def __init__(self, cfg: Config, weight_kind: int = Q4_0, fused_elementwise: bool = True,
-                 include_dead_f32: bool = False, threads: int = 8):
+                 include_dead_f32: bool = False, threads: int = 8, token_len: int = 1):
         self.lib = load_host()
         self.cfg = cfg
-        self.ptr = self.lib.zh_model_create(C.byref(cfg), weight_kind, int(fused_elementwise), int(include_dead_f32), threads)
+        self.token_len = token_len
+        self.ptr = self.lib.zh_model_create_ex(C.byref(cfg), weight_kind, int(fused_elementwise), int(include_dead_f32),
+                                               threads, token_len)
         if not self.ptr:
             raise ValueError("invalid LlamaConfig / shard spec")
 
@@ -149,6 +155,14 @@ class Session:
     def step(self, token: int, pos: int, want_logits: bool = True):
         logits = np.zeros(self.model.cfg.vocab_size, np.float32) if want_logits else None
         nxt = self.lib.zh_session_step(self.ptr, token, pos, logits.ctypes.data if want_logits else None)
+        return int(nxt), logits
+
+    def prefill(self, tokens, pos: int, want_logits: bool = True):
+        """One execution of a token_len = N plan: returns (greedy token, logits of the last position)."""
+        toks = np.ascontiguousarray(tokens, dtype=np.uint32)
+        assert toks.size == self.model.token_len
+        logits = np.zeros(self.model.cfg.vocab_size, np.float32) if want_logits else None
+        nxt = self.lib.zh_session_prefill(self.ptr, toks.ctypes.data, pos, logits.ctypes.data if want_logits else None)
         return int(nxt), logits
 
     def decode(self, first_token: int, start_pos: int, n_steps: int):
