@@ -384,6 +384,10 @@ double zgml_hip_qmatvec_bench(zgml_hip_ctx* ctx, uint32_t K, uint32_t N, int q4,
  * bytes = weights + 4*M*K + 4*M*N, flops = 2*M*K*N. */
 double zgml_hip_qmatmul_bench(zgml_hip_ctx* ctx, uint32_t M, uint32_t K, uint32_t N, int q4, uint32_t n_matrices,
                               uint32_t warmup, uint32_t iters, uint64_t* bytes_per_launch);
+/* Ring benchmark of the f16-promoted dense matmul (M == 1: f32 x times f16 weights; M > 1: f16
+ * MFMA); bytes = 2*K*N + 4*M*K + 4*M*N. N % 16 == 0. */
+double zgml_hip_dense_f16_bench(zgml_hip_ctx* ctx, uint32_t M, uint32_t K, uint32_t N, uint32_t n_matrices,
+                                uint32_t warmup, uint32_t iters, uint64_t* bytes_per_launch);
 /* One mat-vec y = x^T W with synthetic matrix `matrix_id` of the same generator (parity tests
  * rebuild that matrix on the host in int8 + f32-scale form and check y against the oracle).
  * Returns 0 on success. */

@@ -33,6 +33,7 @@ def load() -> C.CDLL:
     lib = C.CDLL(str(LIB_PATH))
     vp, u64, i32, f32 = C.c_void_p, C.c_uint64, C.c_int, C.c_float
     lib.zo_set_threads.argtypes, lib.zo_set_threads.restype = [i32], None
+    lib.zo_set_f16_dense.argtypes, lib.zo_set_f16_dense.restype = [i32], None
     lib.zo_get_threads.argtypes, lib.zo_get_threads.restype = [], i32
     lib.zo_compile_program.argtypes, lib.zo_compile_program.restype = [C.POINTER(capi.DeviceProgramC)], vp
     lib.zo_refresh_program.argtypes, lib.zo_refresh_program.restype = [vp, C.POINTER(capi.DeviceOpC), u64], None
@@ -65,6 +66,11 @@ def load() -> C.CDLL:
 
 def set_threads(n: int) -> None:
     load().zo_set_threads(n)
+
+
+def set_f16_dense(on: bool) -> None:
+    """Programs compiled afterwards promote uploaded matmul B operands to f16 (wgpu.zig:1071-1104)."""
+    load().zo_set_f16_dense(int(on))
 
 
 class OracleBackend:

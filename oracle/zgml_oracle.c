@@ -432,6 +432,44 @@ static void zo_mm_range(void* vctx, uint64_t n0, uint64_t n1) {
     }
 }
 
+/* f16 weight promotion (src/backend/wgpu.zig:1071-1104: B operands of `matmul` ops with an initial
+ * upload are packed to f16 [K,N]; kernels src/backend/metal.zig:680-760):
+ *   matvec_f16 (M == 1): sum += A[k] * float(B16[k*N + n])            — A stays f32
+ *   matmul_f16 (M  > 1): A is staged as half(A[...]), f32 accumulate (simdgroup_float8x8)
+ * `shadow` is that packed f16 image held as f32 values. k-sequential here; orders differ. */
+float zo_f16_to_f32(uint16_t h);
+uint16_t zo_f32_to_f16(float f);
+typedef struct {
+    const float *a, *shadow;
+    float* dst;
+    const zgml_matmul_geom* g;
+} zo_mm16_ctx;
+
+static void zo_mm16_range(void* vctx, uint64_t n0, uint64_t n1) {
+    zo_mm16_ctx* c = (zo_mm16_ctx*)vctx;
+    const zgml_matmul_geom* g = c->g;
+    for (uint64_t m = 0; m < g->M; m++) {
+        const float* ap = c->a + g->a_offset + m * g->a_row_stride;
+        for (uint64_t n = n0; n < n1; n++) {
+            float acc = 0;
+            for (uint64_t k = 0; k < g->K; k++) {
+                float av = ap[k * g->a_col_stride];
+                if (g->M > 1) av = zo_f16_to_f32(zo_f32_to_f16(av));
+                acc += av * c->shadow[k * g->N + n];
+            }
+            c->dst[g->dst_offset + m * g->dst_row_stride + n] = acc;
+        }
+    }
+}
+
+static void zo_matmul_f16(const zo_buffer* b, const zgml_op_matmul* m, const float* shadow) {
+    zo_mm16_ctx c = {b[m->a].ptr, shadow, b[m->dst].ptr, &m->geom};
+    if (m->geom.N * m->geom.K * m->geom.M >= (1u << 16))
+        zo_parallel_for(m->geom.N, 1, 0, zo_mm16_range, &c);
+    else
+        zo_mm16_range(&c, 0, m->geom.N);
+}
+
 static void zo_matmul(const zo_buffer* b, const zgml_op_matmul* m) {
     zo_mm_ctx c = {b[m->a].ptr, b[m->b].ptr, b[m->dst].ptr, &m->geom};
     if (m->geom.N * m->geom.K * m->geom.M >= (1u << 16))
@@ -581,7 +619,21 @@ struct zo_program {
     uint64_t n_ops;
     zgml_device_op* ops;
     zgml_fused_step** steps; /* owned copies, one per op (NULL unless fused) */
+    float** f16_shadow;      /* per buffer: packed f16 [K,N] image of a promoted matmul B (else NULL) */
 };
+
+static int g_f16_dense = 0;
+void zo_set_f16_dense(int on) { g_f16_dense = on; } /* consulted by zo_compile_program */
+
+static void zo_program_run(zo_program* p, const zgml_device_op* ops, uint64_t n_ops) {
+    for (uint64_t i = 0; i < n_ops; i++) {
+        const zgml_device_op* op = &ops[i];
+        if (op->kind == ZGML_DOP_MATMUL && p->f16_shadow[op->u.matmul.b])
+            zo_matmul_f16(p->buffers, &op->u.matmul, p->f16_shadow[op->u.matmul.b]);
+        else
+            zo_execute_op(p->buffers, p->qweights, op);
+    }
+}
 
 static void zo_copy_ops(zo_program* p, const zgml_device_op* ops, uint64_t n_ops) {
     for (uint64_t i = 0; i < p->n_ops; i++) free(p->steps[i]);
@@ -638,6 +690,24 @@ zo_program* zo_compile_program(const zgml_device_program* prog) {
     }
     zo_copy_ops(p, prog->ops, prog->n_ops);
     zo_upload(p, prog->initial_uploads, prog->n_initial_uploads);
+    p->f16_shadow = (float**)calloc(p->n_buffers ? p->n_buffers : 1, sizeof(float*));
+    if (g_f16_dense) { /* wgpu.zig:1071-1104: first matmul user's geometry packs the buffer */
+        for (uint64_t i = 0; i < prog->n_ops; i++) {
+            if (prog->ops[i].kind != ZGML_DOP_MATMUL) continue;
+            const zgml_op_matmul* m = &prog->ops[i].u.matmul;
+            int has_upload = 0;
+            for (uint64_t u = 0; u < prog->n_initial_uploads; u++)
+                if (prog->initial_uploads[u].buf_idx == m->b) has_upload = 1;
+            if (!has_upload || p->f16_shadow[m->b]) continue;
+            const zgml_matmul_geom* g = &m->geom;
+            float* sh = (float*)malloc(sizeof(float) * (g->K * g->N ? g->K * g->N : 1));
+            const float* src = p->buffers[m->b].ptr;
+            for (uint64_t k = 0; k < g->K; k++)
+                for (uint64_t n = 0; n < g->N; n++)
+                    sh[k * g->N + n] = zo_f16_to_f32(zo_f32_to_f16(src[g->b_offset + k * g->b_row_stride + n * g->b_col_stride]));
+            p->f16_shadow[m->b] = sh;
+        }
+    }
     return p;
 }
 
@@ -646,14 +716,14 @@ void zo_refresh_program(zo_program* p, const zgml_device_op* ops, uint64_t n_ops
 void zo_execute_program(zo_program* p, const zgml_program_io* inputs, uint64_t n_inputs,
                         const zgml_program_io* outputs, uint64_t n_outputs) {
     zo_upload(p, inputs, n_inputs);
-    zo_execute_ops(p->buffers, p->qweights, p->ops, p->n_ops);
+    zo_program_run(p, p->ops, p->n_ops);
     zo_download(p, outputs, n_outputs);
 }
 
 void zo_program_execute_range(zo_program* p, uint64_t first, uint64_t count) {
     if (first > p->n_ops) return;
     if (first + count > p->n_ops) count = p->n_ops - first;
-    zo_execute_ops(p->buffers, p->qweights, p->ops + first, count);
+    zo_program_run(p, p->ops + first, count);
 }
 
 void zo_program_upload(zo_program* p, const zgml_program_io* io, uint64_t n) { zo_upload(p, io, n); }
@@ -662,6 +732,9 @@ void zo_program_download(zo_program* p, const zgml_program_io* io, uint64_t n) {
 void zo_free_program(zo_program* p) {
     if (!p) return;
     for (uint64_t i = 0; i < p->n_buffers; i++) free(p->buffers[i].ptr);
+    if (p->f16_shadow)
+        for (uint64_t i = 0; i < p->n_buffers; i++) free(p->f16_shadow[i]);
+    free(p->f16_shadow);
     free(p->buffers);
     for (uint64_t i = 0; i < p->n_qweights; i++) {
         free(p->q_data[i]);

@@ -119,3 +119,33 @@ def test_prefill_plan_matches_oracle_and_sequential(hip_backend, oracle, kind, T
         t_seq, l_seq = s1.step(t, p)
     assert np.abs(l_seq - l_hip2).max() / np.abs(l_seq).max() < 2e-4 and t_seq == t_hip2
     s1.close(), m1.close()
+
+
+@pytest.mark.parametrize("T", [1, 32])
+@pytest.mark.parametrize("promote", [False, True])
+def test_dense_model_f32_and_f16_promoted(hip_backend, oracle, T, promote):
+    """BASELINE config 5's dense variant: the same model with dequantised f32 weights as `matmul`
+    ops. promote=False: exact-f32 path (2e-4 of the logit range, as the quantized tests);
+    promote=True: weights promoted to f16 on both sides (wgpu.zig:1071-1104) — A is rounded to f16
+    for T > 1, and a 1-ulp f32 difference in A can flip that rounding (2^-11 relative on one term),
+    so the bound is 2e-3 of the logit range; greedy tokens must agree."""
+    cfg = llama.preset("tiny")
+    toks = [(7 * i + 3) % cfg.vocab_size for i in range(T)]
+    hip_backend.set_option(capi.OPT_F16_DENSE_WEIGHTS, int(promote))
+    oracle.set_f16_dense(promote)
+    try:
+        m = llama.Model(cfg, llama.F32_DENSE, token_len=T)
+        s_ref = llama.Session(m, oracle.backend_fns())
+        s_hip = llama.Session(m, llama.hip_backend_fns(hip_backend))
+        worst = 0.0
+        for chunk in range(2):
+            t_ref, l_ref = s_ref.prefill(toks, chunk * T)
+            t_hip, l_hip = s_hip.prefill(toks, chunk * T)
+            assert not hip_backend.last_error(), hip_backend.last_error()
+            worst = max(worst, float(np.abs(l_hip - l_ref).max() / np.abs(l_ref).max()))
+            assert t_hip == t_ref
+        assert worst < (2e-3 if promote else 2e-4), worst
+        s_ref.close(), s_hip.close(), m.close()
+    finally:
+        hip_backend.set_option(capi.OPT_F16_DENSE_WEIGHTS, 0)
+        oracle.set_f16_dense(False)

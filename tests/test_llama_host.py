@@ -159,3 +159,29 @@ def test_prefill_plan_equals_sequential_on_oracle():
     assert nxt2 == nxt
     np.testing.assert_allclose(lg2, lg, atol=1e-4)
     s1.close(), sN.close(), m1.close(), mN.close()
+
+
+def test_dense_model_is_the_dequantised_q4_model():
+    """weight_kind F32_DENSE lowers every projection to a `matmul` over the dequantised [K, N]
+    weights: same op count, logits equal to the Q4_0 model's up to f32 rounding; with the f16
+    promotion (wgpu.zig:1071-1104) restated in the oracle they move by ~1e-4 of the range."""
+    from oracle import oracle as O
+    cfg = llama.preset("tiny")
+    mq, md = llama.Model(cfg, llama.Q4_0), llama.Model(cfg, llama.F32_DENSE)
+    assert mq.program.n_ops == md.program.n_ops
+    assert md.program.n_qweights == 0
+    sq, sd = llama.Session(mq, O.backend_fns()), llama.Session(md, O.backend_fns())
+    tq, lq = sq.step(3, 0)
+    td, ld = sd.step(3, 0)
+    assert tq == td
+    np.testing.assert_allclose(ld, lq, atol=1e-5)
+    O.set_f16_dense(True)
+    try:
+        sh = llama.Session(md, O.backend_fns())
+        th, lh = sh.step(3, 0)
+    finally:
+        O.set_f16_dense(False)
+    assert th == td and 0 < np.abs(lh - ld).max() < 2e-3
+    for s in (sq, sd, sh):
+        s.close()
+    mq.close(), md.close()

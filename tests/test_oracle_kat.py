@@ -215,3 +215,34 @@ def test_attention_fully_masked_row_is_zero(oracle):
         return (w / w.sum()) @ v.reshape(skv, dh)[:n].astype(np.float64)
     np.testing.assert_allclose(out4[:dh], dense(4), atol=1e-5)
     np.testing.assert_allclose(out2[:dh], dense(2), atol=1e-5)
+
+
+def test_f16_promotion_known_answer_and_rounding():
+    """src/backend/wgpu.zig:1276-1318 (auto-promoted f16 matmul, small integers exact) plus the two
+    kernels' A handling (src/backend/metal.zig:680-760): M == 1 keeps A in f32, M > 1 rounds it."""
+    from zgml_amd import DeviceOp, DeviceProgram, MatMulGeometry, ProgramIO
+    from oracle import oracle as O
+    f32 = np.float32
+    O.set_f16_dense(True)
+    try:
+        g = MatMulGeometry(M=2, N=2, K=3, a_row_stride=3, a_col_stride=1, b_row_stride=2, b_col_stride=1,
+                           a_offset=0, b_offset=0, dst_offset=0, dst_row_stride=2)
+        prog = DeviceProgram(ops=[DeviceOp.matmul(2, 0, 1, g)], buffer_sizes=[6, 6, 4],
+                             initial_uploads=[ProgramIO(0, np.array([1, 2, 3, 4, 5, 6], f32)),
+                                              ProgramIO(1, np.array([7, 8, 9, 10, 11, 12], f32))])
+        assert np.array_equal(O.run_program(prog, 2, 4), np.array([58, 64, 139, 154], f32))
+        x = f32(1 + 2.0 ** -12)  # not representable in f16
+        for M, want in ((1, x), (2, f32(1.0))):
+            g = MatMulGeometry(M=M, N=1, K=1, a_row_stride=1, a_col_stride=1, b_row_stride=1, b_col_stride=1,
+                               a_offset=0, b_offset=0, dst_offset=0, dst_row_stride=1)
+            prog = DeviceProgram(ops=[DeviceOp.matmul(2, 0, 1, g)], buffer_sizes=[M, 1, M],
+                                 initial_uploads=[ProgramIO(0, np.full(M, x, f32)), ProgramIO(1, np.array([1.0], f32))])
+            assert O.run_program(prog, 2, M)[0] == want
+        # B is rounded: 1 + 2^-12 -> 1.0
+        g = MatMulGeometry(M=1, N=1, K=1, a_row_stride=1, a_col_stride=1, b_row_stride=1, b_col_stride=1,
+                           a_offset=0, b_offset=0, dst_offset=0, dst_row_stride=1)
+        prog = DeviceProgram(ops=[DeviceOp.matmul(2, 0, 1, g)], buffer_sizes=[1, 1, 1],
+                             initial_uploads=[ProgramIO(0, np.array([3.0], f32)), ProgramIO(1, np.array([x], f32))])
+        assert O.run_program(prog, 2, 1)[0] == f32(3.0)
+    finally:
+        O.set_f16_dense(False)

@@ -1,0 +1,273 @@
+// dense_f16.hip — dense matmul with f16-promoted weights (the one place the path is a real
+// contraction on 16-bit data, so the one place the XDL matrix cores are used).
+//
+// Semantics (the reference's f16 weight promotion: src/backend/wgpu.zig:1071-1104 packs the B
+// operand of a `matmul` op that has an initial upload to f16 [K,N]; src/backend/metal.zig:680-760
+// `matvec_f16` / `matmul_f16` then compute
+//     M == 1:  C[n]   = sum_k A[k]            * f32(B16[k,n])      (A stays f32)
+//     M  > 1:  C[m,n] = sum_k f16(A[m,k])     * B16[k,n]           (A rounded to half, f32 accumulate)
+// Same here; only the summation order differs.
+//
+// Device layout of a promoted weight ("MFMA-packed", chosen at compile_program time):
+//   Bp: half[N/16][KC][64][8],  KC = ceil(K/32), item (g, c, lane = 16r+i) = the 8 values
+//       B[k = 32c + 8r + e][n = 16g + i], e = 0..7 (zero for k >= K)
+// which is exactly the B operand of v_mfma_f32_16x16x32_f16 for lane (i, r): one 16-byte load per
+// lane, 1 KiB contiguous per wave, and no LDS or shuffles on the weight stream.
+//
+// Thread mapping (same shape as the quantized mat-vec): a workgroup owns one 16-column group and all
+// of K; its waves split K. Per step a wave takes DEPTH consecutive 32-k chunks (4 KiB of weights in
+// flight per wave, next step prefetched), x for the step is staged through LDS by row-contiguous
+// loads — as f16 [16R rows][chunk] for the MFMA form (ds_read_b128 = one A operand), as f32 for the
+// M == 1 form (v_fma_mix_f32: f32 x times the f16 weight, no rounding of x).
+#include "kernels.h"
+
+#include <hip/hip_fp16.h>
+#include <stdlib.h>
+
+namespace zgml {
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kDepth = 4; // 32-k chunks per wave per step
+
+typedef float mfma_f4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+struct F16Args {
+    const uint4* bp;
+    const float* a;
+    float* out;
+    uint32_t M, K, KC, a_rs, out_rs, NB2;
+};
+
+inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+__device__ __forceinline__ uint32_t column_group(uint32_t b, uint32_t NB2) {
+    // groups b and b+8 land on the same XCD (round-robin dispatch); nothing to share here, keep it linear
+    (void)NB2;
+    return b;
+}
+
+template <bool XVEC>
+__device__ __forceinline__ float4 load_a4(const float* x, uint32_t i, uint32_t K) {
+    if (XVEC) return *(const float4*)(x + (i < K ? i : 0));
+    const uint32_t last = K - 1;
+    return make_float4(x[min(i, last)], x[min(i + 1, last)], x[min(i + 2, last)], x[min(i + 3, last)]);
+}
+__device__ __forceinline__ float4 zero_tail(float4 v, uint32_t i, uint32_t K) {
+    return make_float4(i < K ? v.x : 0.f, i + 1 < K ? v.y : 0.f, i + 2 < K ? v.z : 0.f, i + 3 < K ? v.w : 0.f);
+}
+
+__device__ __forceinline__ uint2 pack_half4(float4 v) {
+    const __half2 lo = __floats2half2_rn(v.x, v.y), hi = __floats2half2_rn(v.z, v.w);
+    uint2 r;
+    r.x = *(const uint32_t*)&lo, r.y = *(const uint32_t*)&hi;
+    return r;
+}
+
+// R m-tiles of 16 rows (MFMA form), or R == 0: the M == 1 mat-vec form.
+template <int R, bool XVEC>
+__global__ void __launch_bounds__(512) dense_f16_kernel(F16Args a) {
+    constexpr bool MV = R == 0;
+    constexpr int ROWS = MV ? 1 : 16 * R;
+    constexpr int NX = MV ? 1 : 8 * R; // float4 of x each thread stages per step (4 waves: 512 k per step)
+    extern __shared__ float smem[];
+    const uint32_t g = column_group(blockIdx.x, a.NB2), m0 = blockIdx.y * ROWS;
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    const uint32_t row = lane >> 4, i = lane & 15;
+    const uint32_t step_chunks = n_waves * kDepth, chf = step_chunks * 32;
+    // LDS row: f16 form chf halves + 8 pad (= (chf + 8) / 2 floats); f32 form chf floats
+    const uint32_t row_floats = MV ? chf : (chf + 8) / 2;
+    const uint32_t buf_floats = ROWS * row_floats;
+    const uint4* bp = a.bp + ((uint64_t)g * a.KC) * 64 + lane;
+    const uint32_t n_steps = (a.KC + step_chunks - 1) / step_chunks;
+
+    const uint32_t f4_per_row = chf / 4;
+    uint32_t st_col[NX], st_lds[NX];
+    const float* st_src[NX];
+    bool st_on[NX];
+#pragma unroll
+    for (int j = 0; j < NX; j++) {
+        const uint32_t f = threadIdx.x + j * blockDim.x, r = f / f4_per_row;
+        st_on[j] = r < (uint32_t)ROWS; // mat-vec form: only chf/4 threads stage
+        st_col[j] = 4 * (f % f4_per_row);
+        st_lds[j] = MV ? st_col[j] : r * row_floats + st_col[j] / 2;
+        st_src[j] = a.a + (uint64_t)min(m0 + min(r, (uint32_t)ROWS - 1), a.M - 1) * a.a_rs;
+    }
+    float4 stage[NX];
+    auto stage_load = [&](uint32_t step) {
+#pragma unroll
+        for (int j = 0; j < NX; j++) stage[j] = load_a4<XVEC>(st_src[j], step * chf + st_col[j], a.K);
+    };
+    auto stage_store = [&](uint32_t step) {
+        float* dst = smem + (step & 1) * buf_floats;
+        const bool full = (step + 1) * chf <= a.K; // whole chunk inside K (uniform): no selects
+#pragma unroll
+        for (int j = 0; j < NX; j++) {
+            const float4 v = full ? stage[j] : zero_tail(stage[j], step * chf + st_col[j], a.K);
+            if (MV) {
+                if (st_on[j]) *(float4*)(dst + st_lds[j]) = v;
+            } else {
+                *(uint2*)(dst + st_lds[j]) = pack_half4(v); // f16(A), round to nearest even
+            }
+        }
+    };
+    auto load_b = [&](uint4 (&b)[kDepth], uint32_t step) {
+#pragma unroll
+        for (int d = 0; d < kDepth; d++) { // clamped, unconditional; x of chunks >= KC is staged as zero
+            const uint32_t c = min(step * step_chunks + w * kDepth + d, a.KC - 1);
+            b[d] = bp[(uint64_t)c * 64];
+        }
+    };
+
+    mfma_f4 acc[MV ? 1 : R];
+#pragma unroll
+    for (int t = 0; t < (MV ? 1 : R); t++) acc[t] = mfma_f4{0.f, 0.f, 0.f, 0.f};
+    float acc_mv = 0.f;
+
+    auto compute = [&](const uint4 (&b)[kDepth], uint32_t step) {
+        const float* xs = smem + (step & 1) * buf_floats;
+#pragma unroll
+        for (int d = 0; d < kDepth; d++) {
+            const uint32_t k_local = (w * kDepth + d) * 32 + 8 * row; // this lane's 8 k within the step
+            if (MV) {
+                const float4 x0 = *(const float4*)(xs + k_local), x1 = *(const float4*)(xs + k_local + 4);
+                const __half2* h = (const __half2*)&b[d];
+                // fmaf(f32, f32(f16), f32) -> v_fma_mix_f32
+                acc_mv = fmaf(x0.x, __low2float(h[0]), acc_mv);
+                acc_mv = fmaf(x0.y, __high2float(h[0]), acc_mv);
+                acc_mv = fmaf(x0.z, __low2float(h[1]), acc_mv);
+                acc_mv = fmaf(x0.w, __high2float(h[1]), acc_mv);
+                acc_mv = fmaf(x1.x, __low2float(h[2]), acc_mv);
+                acc_mv = fmaf(x1.y, __high2float(h[2]), acc_mv);
+                acc_mv = fmaf(x1.z, __low2float(h[3]), acc_mv);
+                acc_mv = fmaf(x1.w, __high2float(h[3]), acc_mv);
+            } else {
+                const half8 bv = *(const half8*)&b[d];
+#pragma unroll
+                for (int t = 0; t < (MV ? 1 : R); t++) {
+                    const half8 av = *(const half8*)(xs + (t * 16 + i) * row_floats + k_local / 2);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    uint4 cur[kDepth];
+    stage_load(0);
+    load_b(cur, 0);
+    stage_store(0);
+    __syncthreads();
+    for (uint32_t st = 1; st < n_steps; st++) {
+        uint4 nxt[kDepth];
+        stage_load(st);
+        load_b(nxt, st);
+        __builtin_amdgcn_sched_barrier(0); // keep the prefetch ahead of the compute block
+        compute(cur, st - 1);
+        __builtin_amdgcn_sched_barrier(0);
+        stage_store(st);
+        __syncthreads();
+#pragma unroll
+        for (int d = 0; d < kDepth; d++) cur[d] = nxt[d];
+    }
+    compute(cur, n_steps - 1);
+    __syncthreads();
+
+    if (MV) {
+        // fold the 4 k-rows of the wave, then the waves, in fixed order
+        acc_mv += __shfl_xor(acc_mv, 16, 64);
+        acc_mv += __shfl_xor(acc_mv, 32, 64);
+        if (lane < 16) smem[w * 16 + lane] = acc_mv;
+        __syncthreads();
+        if (threadIdx.x < 16) {
+            float v = smem[threadIdx.x];
+            for (uint32_t ww = 1; ww < n_waves; ww++) v += smem[ww * 16 + threadIdx.x];
+            a.out[(uint64_t)m0 * a.out_rs + g * 16 + threadIdx.x] = v;
+        }
+    } else {
+        constexpr int RT = MV ? 1 : R;
+#pragma unroll
+        for (int t = 0; t < RT; t++)
+#pragma unroll
+            for (int v = 0; v < 4; v++) smem[((w * RT + t) * 4 + v) * 64 + lane] = acc[t][v];
+        __syncthreads();
+        for (uint32_t idx = threadIdx.x; idx < (uint32_t)RT * 256; idx += blockDim.x) {
+            const uint32_t t = idx >> 8, v = (idx >> 6) & 3, l = idx & 63;
+            float sum = smem[(t * 4 + v) * 64 + l];
+            for (uint32_t ww = 1; ww < n_waves; ww++) sum += smem[((ww * RT + t) * 4 + v) * 64 + l];
+            const uint32_t m = m0 + t * 16 + 4 * (l >> 4) + v, n = g * 16 + (l & 15);
+            if (m < a.M) a.out[(uint64_t)m * a.out_rs + n] = sum;
+        }
+    }
+}
+
+// f32 B (any strides, device memory) -> MFMA-packed f16. One thread per 16-byte item.
+__global__ void __launch_bounds__(kBlock) pack_f16_kernel(const float* __restrict__ b, uint32_t b_rs, uint32_t b_cs,
+                                                          uint32_t K, uint32_t N, uint32_t KC, uint4* __restrict__ out) {
+    const uint64_t n_items = (uint64_t)(N / 16) * KC * 64;
+    for (uint64_t it = (uint64_t)blockIdx.x * kBlock + threadIdx.x; it < n_items; it += (uint64_t)gridDim.x * kBlock) {
+        const uint32_t lane = it & 63, i = lane & 15, r = lane >> 4;
+        const uint64_t gc = it >> 6;
+        const uint32_t c = gc % KC, g = gc / KC;
+        const uint32_t n = g * 16 + i;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const uint32_t k = c * 32 + 8 * r + e;
+            v[e] = k < K ? b[(uint64_t)k * b_rs + (uint64_t)n * b_cs] : 0.f;
+        }
+        const uint2 lo = pack_half4(make_float4(v[0], v[1], v[2], v[3])), hi = pack_half4(make_float4(v[4], v[5], v[6], v[7]));
+        out[it] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    }
+}
+
+} // namespace
+
+uint64_t f16_packed_bytes(uint64_t K, uint64_t N) { return (N / 16) * ((K + 31) / 32) * 64 * 16; }
+
+bool f16_packable(uint64_t K, uint64_t N) { return K > 0 && N > 0 && N % 16 == 0; }
+
+void launch_pack_f16(hipStream_t s, const float* b, uint32_t b_rs, uint32_t b_cs, uint32_t K, uint32_t N, void* out) {
+    pack_f16_kernel<<<2048, kBlock, 0, s>>>(b, b_rs, b_cs, K, N, (K + 31) / 32, (uint4*)out);
+}
+
+void launch_dense_f16(hipStream_t s, const DenseF16Params& p) {
+    if (p.M == 0 || p.N == 0) return;
+    F16Args a{(const uint4*)p.bp, p.a, p.dst, p.M, p.K, (p.K + 31) / 32, p.a_rs, p.dst_rs, p.N / 16};
+    uint32_t waves = cdiv(a.KC, kDepth);
+    static const int max_waves = getenv("ZGML_F16_WAVES") ? atoi(getenv("ZGML_F16_WAVES")) : 4;
+    if (waves > (uint32_t)max_waves) waves = max_waves;
+    const bool xvec = ((uintptr_t)p.a % 16 == 0) && (p.K % 4 == 0) && (p.M == 1 || p.a_rs % 4 == 0);
+    const uint32_t chf = waves * kDepth * 32;
+    if (p.M == 1) {
+        const size_t lds = 2ull * chf * sizeof(float);
+        if (xvec)
+            dense_f16_kernel<0, true><<<dim3(a.NB2, 1), waves * 64, lds, s>>>(a);
+        else
+            dense_f16_kernel<0, false><<<dim3(a.NB2, 1), waves * 64, lds, s>>>(a);
+        return;
+    }
+    const uint32_t R = p.M > 16 ? 2 : 1;
+    size_t lds = 2ull * 16 * R * ((chf + 8) / 2) * sizeof(float);
+    const size_t red = (size_t)waves * R * 256 * sizeof(float);
+    if (red > lds) lds = red;
+    const dim3 grid(a.NB2, cdiv(p.M, 16 * R));
+    if (lds > 64 * 1024) {
+        hipFuncSetAttribute((const void*)dense_f16_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)dense_f16_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
+    if (R == 2) {
+        if (xvec)
+            dense_f16_kernel<2, true><<<grid, waves * 64, lds, s>>>(a);
+        else
+            dense_f16_kernel<2, false><<<grid, waves * 64, lds, s>>>(a);
+    } else {
+        if (xvec)
+            dense_f16_kernel<1, true><<<grid, waves * 64, lds, s>>>(a);
+        else
+            dense_f16_kernel<1, false><<<grid, waves * 64, lds, s>>>(a);
+    }
+}
+
+} // namespace zgml

@@ -89,6 +89,19 @@ struct DenseMatmulParams {
     uint32_t b_f16;
 };
 
+// dense matmul against an f16-promoted, MFMA-packed B (dense_f16.hip)
+struct DenseF16Params {
+    float* dst;      // dst_offset applied
+    const float* a;  // a_offset applied, a_col_stride == 1
+    const void* bp;  // packed half[N/16][ceil(K/32)][64][8]
+    uint32_t M, N, K;
+    uint32_t a_rs, dst_rs;
+};
+bool f16_packable(uint64_t K, uint64_t N);
+uint64_t f16_packed_bytes(uint64_t K, uint64_t N);
+void launch_pack_f16(hipStream_t s, const float* b, uint32_t b_rs, uint32_t b_cs, uint32_t K, uint32_t N, void* out);
+void launch_dense_f16(hipStream_t s, const DenseF16Params& p);
+
 // ── quantized weights on the device ──────────────────────────────────────────
 enum QWFormat : uint32_t {
     QW_RAW = 0, // int8 [K*N] + f32 scale per `bs` flat elements (any bs, any N)

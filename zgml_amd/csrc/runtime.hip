@@ -97,6 +97,7 @@ struct zgml_hip_program {
     std::vector<float*> bufs;                         // device pointers (nullptr = elided)
     void* arena = nullptr;
     std::vector<QWeightDev> qweights;
+    std::vector<void*> f16_weights; // per buffer: MFMA-packed f16 copy of a promoted matmul B operand (else nullptr)
     std::vector<void*> owned; // other device allocations
     float* scratch = nullptr;
     uint64_t scratch_bytes = 0;
@@ -291,8 +292,8 @@ bool prepare_io(zgml_hip_program* p, IoPlan& plan, const zgml_program_io* ios, u
         }
         if (!p->bufs[io.buf_idx]) {
             ctx->fail("program I/O names buffer " + std::to_string(io.buf_idx) +
-                      " which no op references and was elided at compile time "
-                      "(set ZGML_HIP_OPT_SKIP_DEAD_UPLOADS=0 before compile to keep it)");
+                      " which has no f32 image on the device: no op references it and it was elided at compile"
+                      " time (ZGML_HIP_OPT_SKIP_DEAD_UPLOADS=0 keeps it), or it is a matmul weight promoted to f16");
             return false;
         }
         if ((uint64_t)io.offset + io.size > p->sizes[io.buf_idx] * sizeof(float)) {
@@ -420,6 +421,11 @@ bool make_single(zgml_hip_program* p, size_t i, Launch& L) {
             dp.b_rs = (uint32_t)m.geom.b_row_stride, dp.b_cs = (uint32_t)m.geom.b_col_stride;
             dp.dst_rs = (uint32_t)m.geom.dst_row_stride;
             dp.b_f16 = 0;
+            if (m.b < p->f16_weights.size() && p->f16_weights[m.b]) { // promoted at compile time
+                DenseF16Params fp{dp.dst, dp.a, p->f16_weights[m.b], dp.M, dp.N, dp.K, dp.a_rs, dp.dst_rs};
+                L.run = [=](hipStream_t s) { launch_dense_f16(s, fp); };
+                return true;
+            }
             L.run = [=](hipStream_t s) { launch_dense_matmul(s, dp); };
             return true;
         }
@@ -1432,6 +1438,44 @@ zgml_hip_program* zgml_hip_compile_program(zgml_hip_ctx* ctx, const zgml_device_
         if (op.kind == ZGML_DOP_QMATMUL) qw_live[op.u.qmatmul.weight_idx] = 1;
     }
 
+    // f16 weight promotion (opt-in; src/backend/wgpu.zig:1071-1104): the B operand of `matmul` ops
+    // that has an initial upload is kept only as an MFMA-packed f16 copy. Stricter than the
+    // reference, which trusts the first user's geometry: every reader of the buffer must be a
+    // matmul using it as B with the same geometry, and no op may write it.
+    p->f16_weights.assign(nb, nullptr);
+    struct Promo {
+        uint64_t K, N, b_off, b_rs, b_cs;
+    };
+    std::vector<int> promo_state(nb, 0); // 0 unseen, 1 candidate, -1 rejected
+    std::vector<Promo> promo(nb);
+    if (ctx->opt_f16_dense) {
+        std::vector<char> has_upload(nb, 0);
+        for (uint64_t i = 0; i < prog->n_initial_uploads; i++)
+            if (prog->initial_uploads[i].buf_idx < nb) has_upload[prog->initial_uploads[i].buf_idx] = 1;
+        const Schedule acc = build_schedule(p->ops, p->sizes, {});
+        for (size_t oi = 0; oi < p->ops.size(); oi++) {
+            const auto& op = p->ops[oi];
+            for (const Span& sp : acc.access[oi].writes) promo_state[sp.buf] = -1;
+            if (op.kind == ZGML_DOP_MATMUL) {
+                const auto& m = op.u.matmul;
+                const Promo g{m.geom.K, m.geom.N, m.geom.b_offset, m.geom.b_row_stride, m.geom.b_col_stride};
+                if (m.a == m.b || m.dst == m.b || !has_upload[m.b] || m.geom.a_col_stride != 1 || !f16_packable(g.K, g.N)) {
+                    promo_state[m.b] = -1;
+                } else if (promo_state[m.b] == 0) {
+                    promo_state[m.b] = 1, promo[m.b] = g;
+                } else if (promo_state[m.b] == 1) {
+                    const Promo& q = promo[m.b];
+                    if (q.K != g.K || q.N != g.N || q.b_off != g.b_off || q.b_rs != g.b_rs || q.b_cs != g.b_cs) promo_state[m.b] = -1;
+                }
+                promo_state[m.a] = -1;
+            } else {
+                for (const Span& sp : acc.access[oi].reads) promo_state[sp.buf] = -1;
+            }
+        }
+        for (size_t i = 0; i < nb; i++)
+            if (promo_state[i] == 1) live[i] = 0; // no f32 copy on the device
+    }
+
     // one arena for all live buffers, 256-byte aligned slots, zero-initialised like
     // OwnedBufferTable.init (src/backend/reference.zig:81-97)
     uint64_t total = 0;
@@ -1466,6 +1510,42 @@ zgml_hip_program* zgml_hip_compile_program(zgml_hip_ctx* ctx, const zgml_device_
         }
         ok = CTX_CHECK(ctx, hipMemcpyAsync((char*)p->bufs[io.buf_idx] + io.offset, io.host_ptr, io.size,
                                            hipMemcpyHostToDevice, ctx->stream));
+    }
+
+    // promoted weights: stage the f32 image, pack to f16 on the device, drop the f32 image
+    for (size_t b = 0; ok && b < nb; b++) {
+        if (promo_state[b] != 1) continue;
+        const Promo& g = promo[b];
+        float* tmp = nullptr;
+        void* packed = nullptr;
+        const uint64_t bytes = p->sizes[b] * sizeof(float);
+        ok = CTX_CHECK(ctx, hipMalloc((void**)&tmp, bytes)) && CTX_CHECK(ctx, hipMemsetAsync(tmp, 0, bytes, ctx->stream)) &&
+             CTX_CHECK(ctx, hipMalloc(&packed, f16_packed_bytes(g.K, g.N)));
+        if (ok && (g.b_off + (g.K - 1) * g.b_rs + (g.N - 1) * g.b_cs >= p->sizes[b])) {
+            ctx->fail("matmul B geometry exceeds its buffer");
+            ok = false;
+        }
+        for (uint64_t i = 0; ok && i < prog->n_initial_uploads; i++) {
+            const zgml_program_io& io = prog->initial_uploads[i];
+            if (io.buf_idx != b) continue;
+            if ((uint64_t)io.offset + io.size > bytes) {
+                ctx->fail("initial upload out of range");
+                ok = false;
+                break;
+            }
+            ok = CTX_CHECK(ctx, hipMemcpyAsync((char*)tmp + io.offset, io.host_ptr, io.size, hipMemcpyHostToDevice, ctx->stream));
+        }
+        if (ok) {
+            launch_pack_f16(ctx->stream, tmp + g.b_off, (uint32_t)g.b_rs, (uint32_t)g.b_cs, (uint32_t)g.K, (uint32_t)g.N, packed);
+            ok = CTX_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        hipFree(tmp);
+        if (ok) {
+            p->f16_weights[b] = packed;
+            p->owned.push_back(packed);
+        } else {
+            hipFree(packed);
+        }
     }
 
     // quantized weights: upload raw, classify and re-pack on the device
@@ -1741,6 +1821,69 @@ static bool make_synth_weight(zgml_hip_ctx* ctx, uint32_t K, uint32_t N, int q4,
     if (!CTX_CHECK(ctx, hipMalloc(&w->qs, w->qs_bytes)) || !CTX_CHECK(ctx, hipMalloc(&w->sc, w->sc_bytes))) return false;
     launch_synth_packed(ctx->stream, *w, id);
     return true;
+}
+
+double zgml_hip_dense_f16_bench(zgml_hip_ctx* ctx, uint32_t M, uint32_t K, uint32_t N, uint32_t n_matrices, uint32_t warmup,
+                                uint32_t iters, uint64_t* bytes_per_launch) {
+    if (!ctx || !f16_packable(K, N) || !n_matrices || !iters || !M) return -1.0;
+    hipSetDevice(ctx->device);
+    std::vector<void*> ring(n_matrices, nullptr);
+    float *b32 = nullptr, *x = nullptr, *y = nullptr;
+    std::vector<float> bh((size_t)K * N), xh((size_t)M * K);
+    for (size_t i = 0; i < bh.size(); i++) bh[i] = ((int)((i * 7 + (i >> 5) * 3) % 31) - 15) * 0.00390625f;
+    for (size_t i = 0; i < xh.size(); i++) xh[i] = ((int)(i % 17) - 8) * 0.03125f;
+    bool ok = CTX_CHECK(ctx, hipMalloc((void**)&b32, bh.size() * 4)) && CTX_CHECK(ctx, hipMalloc((void**)&x, xh.size() * 4)) &&
+              CTX_CHECK(ctx, hipMalloc((void**)&y, (size_t)M * N * 4)) &&
+              CTX_CHECK(ctx, hipMemcpy(b32, bh.data(), bh.size() * 4, hipMemcpyHostToDevice)) &&
+              CTX_CHECK(ctx, hipMemcpy(x, xh.data(), xh.size() * 4, hipMemcpyHostToDevice));
+    for (uint32_t i = 0; ok && i < n_matrices; i++) {
+        ok = CTX_CHECK(ctx, hipMalloc(&ring[i], f16_packed_bytes(K, N)));
+        if (ok) launch_pack_f16(ctx->stream, b32, N, 1, K, N, ring[i]);
+    }
+    double us = -1.0;
+    if (ok) {
+        DenseF16Params fp{y, x, nullptr, M, N, K, K, N};
+        for (uint32_t i = 0; i < warmup; i++) {
+            fp.bp = ring[i % n_matrices];
+            launch_dense_f16(ctx->stream, fp);
+        }
+        hipGraph_t g = nullptr;
+        hipGraphExec_t ge = nullptr;
+        ok = CTX_CHECK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+        if (ok) {
+            for (uint32_t i = 0; i < n_matrices; i++) {
+                fp.bp = ring[i];
+                launch_dense_f16(ctx->stream, fp);
+            }
+            ok = CTX_CHECK(ctx, hipStreamEndCapture(ctx->stream, &g)) &&
+                 CTX_CHECK(ctx, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        }
+        if (ok) {
+            const uint32_t reps = (iters + n_matrices - 1) / n_matrices;
+            hipGraphLaunch(ge, ctx->stream);
+            hipEvent_t e0, e1;
+            hipEventCreate(&e0);
+            hipEventCreate(&e1);
+            hipEventRecord(e0, ctx->stream);
+            for (uint32_t r = 0; r < reps; r++) hipGraphLaunch(ge, ctx->stream);
+            hipEventRecord(e1, ctx->stream);
+            if (CTX_CHECK(ctx, hipEventSynchronize(e1))) {
+                float ms = 0;
+                hipEventElapsedTime(&ms, e0, e1);
+                us = (double)ms * 1000.0 / ((double)reps * n_matrices);
+            }
+            hipEventDestroy(e0);
+            hipEventDestroy(e1);
+        }
+        if (ge) hipGraphExecDestroy(ge);
+        if (g) hipGraphDestroy(g);
+    }
+    if (bytes_per_launch) *bytes_per_launch = 2ull * K * N + 4ull * M * K + 4ull * M * N;
+    for (void* r : ring) hipFree(r);
+    hipFree(b32);
+    hipFree(x);
+    hipFree(y);
+    return us;
 }
 
 double zgml_hip_qmatvec_bench(zgml_hip_ctx* ctx, uint32_t K, uint32_t N, int q4, uint32_t n_matrices, uint32_t warmup,

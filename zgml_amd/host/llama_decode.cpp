@@ -64,12 +64,13 @@ float f16_round(float f) {
 // element (k, n_global) of weight `id` with full width N_full; Q4_0: stored nibble - 8 (values
 // in [-8,7], what quantizedWeightFromInfo's .q4_0 arm yields), Q8_0: int8.
 inline int8_t synth_q(uint64_t flat, uint32_t id, WeightKind kind) {
-    if (kind == WeightKind::q4_0) return (int8_t)((int)((flat * 7 + (flat >> 5) * 3 + (uint64_t)id * 5) & 15) - 8);
+    if (kind != WeightKind::q8_0) // dense models are the dequantised Q4_0 model
+        return (int8_t)((int)((flat * 7 + (flat >> 5) * 3 + (uint64_t)id * 5) & 15) - 8);
     return (int8_t)((int)((flat * 13 + (uint64_t)id * 29) % 255) - 127);
 }
 // block scale: small enough that a 30-layer random-ish stack stays finite; exact in f16
 inline float synth_scale(uint64_t block, uint32_t id, WeightKind kind) {
-    const float base = kind == WeightKind::q4_0 ? 1.0f / 512.0f : 1.0f / 8192.0f;
+    const float base = kind != WeightKind::q8_0 ? 1.0f / 512.0f : 1.0f / 8192.0f;
     return f16_round(base * (1.0f + (float)((block + id) % 7) * 0.125f));
 }
 
@@ -151,6 +152,17 @@ std::unique_ptr<LlamaModel> make_synthetic_model(const LlamaConfig& cfg, WeightK
         auto [n0, nl] = shard(cfg.vocab_size);
         m->qweights.push_back(make_qweight(d, cfg.vocab_size, n0, nl, cfg.n_layers * 8, kind, threads));
     }
+    if (kind == WeightKind::f32_dense) { // the same model, dequantised: f32 [K, N] per weight; int8 form dropped
+        for (auto& q : m->qweights) {
+            std::vector<float> w(q.K * q.N);
+            parallel_rows(q.K, threads, [&](size_t k0, size_t k1) {
+                for (size_t i = k0 * q.N; i < k1 * q.N; i++) w[i] = (float)q.data[i] * q.scales[i / 32];
+            });
+            m->dense.push_back(std::move(w));
+            std::vector<int8_t>().swap(q.data);
+            std::vector<float>().swap(q.scales);
+        }
+    }
     // RoPE tables (src/nn.zig:297-310), f32 math
     m->cos_table.resize((size_t)cfg.max_seq_len * dh);
     m->sin_table.resize((size_t)cfg.max_seq_len * dh);
@@ -196,6 +208,21 @@ struct Builder {
         return b;
     }
     void op(const DeviceOp& o) { dp.program.ops.push_back(o); }
+    // x.matMul(false, w, false) of one projection: qmatmul against the quantized weight table, or —
+    // dense model — a `matmul` whose B is the [K, N] f32 weight leaf (N contiguous, same flat k*N+n
+    // order as the quantized form; a backend may promote it to f16, src/backend/wgpu.zig:1071-1104)
+    std::vector<uint16_t> dense_buf; // weight index -> buffer id (dense models)
+    void proj(uint16_t dst, uint16_t input, uint16_t widx, uint32_t M, uint32_t N, uint32_t K, uint32_t in_off, uint32_t in_rs,
+              uint32_t dst_off, uint32_t dst_rs) {
+        if (dense_buf.empty()) {
+            op(DeviceOp::qmatmul(dst, input, widx, M, N, K, in_off, in_rs, dst_off, dst_rs));
+            return;
+        }
+        backend::MatMulGeometry g{};
+        g.M = M, g.N = N, g.K = K, g.a_row_stride = in_rs, g.a_col_stride = 1, g.b_row_stride = N, g.b_col_stride = 1;
+        g.a_offset = in_off, g.b_offset = 0, g.dst_offset = dst_off, g.dst_row_stride = dst_rs;
+        op(DeviceOp::matmul(dst, input, dense_buf[widx], g));
+    }
     // rmsnorm -> repeat(gamma) -> mul  (applyRmsNorm, llama_transformer.zig:120-127)
     uint16_t rms_norm(uint16_t x, uint16_t gamma, uint32_t d, float eps, uint32_t T) {
         const uint16_t bare = buffer((uint64_t)d * T), rep = buffer((uint64_t)d * T), out = buffer((uint64_t)d * T);
@@ -228,9 +255,12 @@ std::unique_ptr<DecodeProgram> build_decode_program(const LlamaModel& model, boo
     const uint32_t T = token_len ? token_len : 1; // tokens per execution: 1 = decode plan, N = prefill plan
     dp.token_len = T;
 
-    // quantized weight table (all borrowed from the model)
+    // quantized weight table (all borrowed from the model), or dense f32 weight leaves
     for (const auto& qw : model.qweights)
-        dp.program.qweights.push_back({qw.data.data(), qw.data.size(), qw.scales.data(), qw.scales.size(), qw.K, qw.N, 32});
+        if (model.kind != WeightKind::f32_dense)
+            dp.program.qweights.push_back({qw.data.data(), qw.data.size(), qw.scales.data(), qw.scales.size(), qw.K, qw.N, 32});
+    if (model.kind == WeightKind::f32_dense)
+        for (const auto& w : model.dense) b.dense_buf.push_back(b.leaf(w));
 
     dp.token_input.assign((size_t)d * T, 0.f);
     dp.attn_mask.assign((size_t)S * T, -std::numeric_limits<float>::infinity()); // [max_seq, T], column per query
@@ -252,7 +282,7 @@ std::unique_ptr<DecodeProgram> build_decode_program(const LlamaModel& model, boo
         const uint16_t k_cache = b.buffer((uint64_t)dh * S * KV_loc), v_cache = b.buffer((uint64_t)dh * S * KV_loc);
         dp.buf_k_cache.push_back(k_cache);
         dp.buf_v_cache.push_back(v_cache);
-        if (include_dead_f32) { // f32 master copies: buffers + uploads, never referenced by an op (F8)
+        if (include_dead_f32 && model.kind != WeightKind::f32_dense) { // f32 master copies: buffers + uploads, never referenced by an op (F8)
             for (int j = 0; j < 7; j++) {
                 const auto& qw = model.qweights[l * 7 + j];
                 dp.dead_f32.emplace_back(qw.K * qw.N);
@@ -276,7 +306,7 @@ std::unique_ptr<DecodeProgram> build_decode_program(const LlamaModel& model, boo
         for (int hl = (int)H_loc - 1; hl >= 0; hl--) {
             const uint32_t h = h0 + hl, kvh = h / n_rep, kvl = kvh - kv0;
             if (!q_done) {
-                b.op(DeviceOp::qmatmul(q_proj, norm1, wq, T, d_loc, d, 0, d, 0, d_loc));
+                b.proj(q_proj, norm1, wq, T, d_loc, d, 0, d, 0, d_loc);
                 q_done = true;
             }
             const uint16_t q_rot = b.buffer((uint64_t)dh * T);
@@ -284,7 +314,7 @@ std::unique_ptr<DecodeProgram> build_decode_program(const LlamaModel& model, boo
             if (!kv_done[kvl]) {
                 kv_done[kvl] = 1;
                 if (!k_proj_done) {
-                    b.op(DeviceOp::qmatmul(k_proj, norm1, wk, T, kvd_loc, d, 0, d, 0, kvd_loc));
+                    b.proj(k_proj, norm1, wk, T, kvd_loc, d, 0, d, 0, kvd_loc);
                     k_proj_done = true;
                 }
                 const uint16_t k_rot = b.buffer((uint64_t)dh * T);
@@ -293,7 +323,7 @@ std::unique_ptr<DecodeProgram> build_decode_program(const LlamaModel& model, boo
                 dp.slice_assign_op_indices.push_back((uint32_t)dp.program.ops.size());
                 b.op(DeviceOp::slice_assign(k_cache, k_rot, dh, T, slab, slab, 1, dh, 0, 1, dh, dh));
                 if (!v_proj_done) {
-                    b.op(DeviceOp::qmatmul(v_proj, norm1, wv, T, kvd_loc, d, 0, d, 0, kvd_loc));
+                    b.proj(v_proj, norm1, wv, T, kvd_loc, d, 0, d, 0, kvd_loc);
                     v_proj_done = true;
                 }
                 dp.slice_assign_op_indices.push_back((uint32_t)dp.program.ops.size());
@@ -317,7 +347,7 @@ std::unique_ptr<DecodeProgram> build_decode_program(const LlamaModel& model, boo
         if (sharded) dp.gather_points.push_back({(uint32_t)dp.program.ops.size(), attn_buf, 0, d_loc});
         const uint16_t attn_proj = b.buffer((uint64_t)d * T), after_attn = b.buffer((uint64_t)d * T);
         // sharded (T == 1 only): the rank's slice of the full vector; unsharded: dense [T, d]
-        b.op(DeviceOp::qmatmul(attn_proj, attn_buf, wo, T, d_loc, d, 0, d, r * d_loc, sharded ? d_loc : d));
+        b.proj(attn_proj, attn_buf, wo, T, d_loc, d, 0, d, r * d_loc, sharded ? d_loc : d);
         if (sharded) dp.gather_points.push_back({(uint32_t)dp.program.ops.size(), attn_proj, 0, d_loc});
         b.op(DeviceOp::elementwise(ZGML_OP_ADD, after_attn, x, attn_proj, d * T));
 
@@ -326,7 +356,7 @@ std::unique_ptr<DecodeProgram> build_decode_program(const LlamaModel& model, boo
         const uint32_t nf = ff_loc * T; // elements of one [d_ff, T] activation
         const uint16_t gate = b.buffer(nf), up = b.buffer(nf), silu = b.buffer(nf), act = b.buffer((uint64_t)ff * T);
         const uint16_t one = b.leaf(dp.scalar_one), one_rep = b.buffer(nf);
-        b.op(DeviceOp::qmatmul(gate, norm2, wg, T, ff_loc, d, 0, d, 0, ff_loc));
+        b.proj(gate, norm2, wg, T, ff_loc, d, 0, d, 0, ff_loc);
         const uint32_t ne1[4] = {1, 1, 1, 1}, st1[4] = {1, 1, 1, 1}, nef[4] = {ff_loc, T, 1, 1}, stf[4] = {1, ff_loc, nf, nf};
         if (fused_elementwise) {
             const uint16_t exp_neg = b.buffer(nf);
@@ -344,11 +374,11 @@ std::unique_ptr<DecodeProgram> build_decode_program(const LlamaModel& model, boo
             b.op(DeviceOp::elementwise(ZGML_OP_RECIP, t_rec, t_add, t_add, nf));
             b.op(DeviceOp::elementwise(ZGML_OP_MUL, silu, gate, t_rec, nf));
         }
-        b.op(DeviceOp::qmatmul(up, norm2, wu, T, ff_loc, d, 0, d, 0, ff_loc));
+        b.proj(up, norm2, wu, T, ff_loc, d, 0, d, 0, ff_loc);
         b.op(DeviceOp::elementwise(ZGML_OP_MUL, act, silu, up, nf, r * ff_loc, 0, 0));
         if (sharded) dp.gather_points.push_back({(uint32_t)dp.program.ops.size(), act, 0, ff_loc});
         const uint16_t down = b.buffer((uint64_t)d * T), out = b.buffer((uint64_t)d * T);
-        b.op(DeviceOp::qmatmul(down, act, wd, T, d_loc, ff, 0, ff, r * d_loc, sharded ? d_loc : d));
+        b.proj(down, act, wd, T, d_loc, ff, 0, ff, r * d_loc, sharded ? d_loc : d);
         if (sharded) dp.gather_points.push_back({(uint32_t)dp.program.ops.size(), down, 0, d_loc});
         b.op(DeviceOp::elementwise(ZGML_OP_ADD, out, after_attn, down, d * T));
         x = out;
@@ -366,8 +396,8 @@ std::unique_ptr<DecodeProgram> build_decode_program(const LlamaModel& model, boo
         b.op(DeviceOp::matmul(dp.buf_logits, normf, embed, g));
     } else {
         const uint32_t v_loc = c.vocab_size / ws;
-        b.op(DeviceOp::qmatmul(dp.buf_logits, normf, (uint16_t)model.lm_head_index(), T, v_loc, d, 0, d, r * v_loc,
-                               sharded ? v_loc : c.vocab_size));
+        b.proj(dp.buf_logits, normf, (uint16_t)model.lm_head_index(), T, v_loc, d, 0, d, r * v_loc,
+                               sharded ? v_loc : c.vocab_size);
         if (sharded) dp.gather_points.push_back({(uint32_t)dp.program.ops.size(), dp.buf_logits, 0, v_loc});
     }
     dp.program.n_buffers = (uint16_t)dp.program.buffer_sizes.size();

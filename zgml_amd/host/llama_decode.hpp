@@ -41,7 +41,7 @@ LlamaConfig smollm_135m();               // benchmarks/llama_smollm_bench.zig:31
 LlamaConfig llama2_7b(uint32_t max_seq); // SURVEY §8(a) "L7"
 LlamaConfig tiny_test();                 // small GQA config for parity tests
 
-enum class WeightKind : int { q4_0 = 0, q8_0 = 1 };
+enum class WeightKind : int { q4_0 = 0, q8_0 = 1, f32_dense = 2 };
 
 struct QWeightHost {
     std::vector<int8_t> data;
@@ -57,6 +57,8 @@ struct LlamaModel {
     std::vector<float> gamma_f;
     // per layer: q,k,v,o,gate,up,down; then (untied) the LM head
     std::vector<QWeightHost> qweights;
+    // kind == f32_dense: the same weights dequantised to f32 [K, N] (qweights keep only K and N)
+    std::vector<std::vector<float>> dense;
     std::vector<float> cos_table, sin_table; // [max_seq][d_head], RoPE.init src/nn.zig:286-311
     size_t lm_head_index() const { return (size_t)cfg.n_layers * 7; }
 };
