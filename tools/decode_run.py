@@ -16,3 +16,6 @@ t0 = time.perf_counter()
 s.resident_decode(int(w[-1]), 4, steps)
 dt = time.perf_counter() - t0
 print(f"{name}: {steps / dt:.1f} tok/s, {1e3 * dt / steps:.3f} ms/token")
+s.close()
+m.close()
+be.close()

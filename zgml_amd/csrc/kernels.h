@@ -80,6 +80,30 @@ struct AttentionParams {
     uint32_t d2_rs, d2_cs;
 };
 
+// Decode-shaped attention of one head with everything that feeds it folded in (seq_q == 1):
+// rope of the head's query, rope of its kv head's new key + K-cache store, V-cache store, the
+// attention itself and (via att.dst2) the head-output row store. Heads that share a kv head each
+// recompute the new key/value from the projections; `owner` marks the one that writes the cache
+// and the k_rot side output. The new column is taken from registers, never re-read from memory.
+struct AttnDecodeParams {
+    AttentionParams att;      // att.q = q_rot (side output), att.k / att.v = the kv head's slabs
+    float* q_rot;             // == att.q, writable
+    const float* q_src;       // q projection slice, unit stride
+    const float* q_cs;        // cos | sin row of the query rope (sin at + half_d)
+    const float* k_src;       // k projection slice, unit stride
+    const float* k_cs;        // cos | sin row of the key rope
+    const float* v_src;       // v projection slice, unit stride
+    float* k_rot;             // the key rope's dense output (owner writes it)
+    float* k_cache;           // base of the K cache buffer (store offset is relative to it)
+    float* v_cache;
+    const uint32_t* dyn_k_off; // current K store offset (elements)
+    const uint32_t* dyn_v_off;
+    uint32_t k_off, v_off;    // att.k - k_cache, att.v - v_cache (elements)
+    uint32_t owner;
+    uint32_t max_kv;          // compile-time seq_kv bound: rows [0, max_kv) of the slabs are readable
+    unsigned long long* trace; // diagnostics (ZGML_HIP_ATTN_TRACE=1): 8 wall-clock stamps, else nullptr
+};
+
 struct DenseMatmulParams {
     float* dst;       // dst_offset applied
     const float* a;   // a_offset applied
@@ -182,6 +206,7 @@ void launch_reduce(hipStream_t s, uint32_t op, float* dst, const float* src, uin
 void launch_repeat_batch(hipStream_t s, const RepeatParams* dev_params, uint32_t n_ops, uint32_t max_elems);
 void launch_move_batch(hipStream_t s, const MoveParams* dev_params, uint32_t n_ops, uint32_t max_elems);
 // all_dense: every op has unit row strides, 16-byte aligned q/k/v rows, d_head a power of two in [4, 256]
+void launch_attention_decode_batch(hipStream_t s, const AttnDecodeParams* dev_params, uint32_t n_heads, uint32_t d_head);
 void launch_attention_batch(hipStream_t s, const AttentionParams* dev_params, uint32_t n_ops, uint32_t max_seq_q,
                             bool all_dense);
 void launch_dense_matmul(hipStream_t s, const DenseMatmulParams& p);

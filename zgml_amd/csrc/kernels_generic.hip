@@ -472,6 +472,199 @@ __global__ void __launch_bounds__(kAttnBlock) attention_dense_kernel(const Atten
     }
 }
 
+// rope of 4 consecutive dims [d0, d0+4) of a head vector (reference.zig:457-478, DeviceOp
+// convention: sin at cs + pair + half_d); `own` = x[d0..], `par` = x[(d0 ^ half)..]. Same
+// expressions as rope_body so the fused path is bit-identical to the op-by-op one.
+__device__ __forceinline__ float4 rope4(float4 own, float4 par, float4 c, float4 s, bool is_hi) {
+    if (is_hi) // own = x_hi, par = x_lo: hi = x_hi * c + x_lo * s
+        return make_float4(own.x * c.x + par.x * s.x, own.y * c.y + par.y * s.y, own.z * c.z + par.z * s.z,
+                           own.w * c.w + par.w * s.w);
+    return make_float4(own.x * c.x - par.x * s.x, own.y * c.y - par.y * s.y, own.z * c.z - par.z * s.z,
+                       own.w * c.w - par.w * s.w); // lo = x_lo * c - x_hi * s
+}
+
+__device__ __forceinline__ float score_of(float dot, float mk, float scale) {
+    float score = -INFINITY;
+    if (isfinite(mk)) {
+        score = dot * scale + mk;
+        if (!isfinite(score)) score = -INFINITY;
+    }
+    return score;
+}
+
+// ── decode attention, one workgroup per head (seq_q == 1) ───────────────────────────────────
+// At decode lengths this kernel is not bandwidth: a launch keeps only n_heads CUs busy, so what
+// it costs is (a) the chain of dependent memory round trips and (b) the instruction stream of ONE
+// wave (a CU issues ~1 wave-instruction per 4-5 cycles per SIMD: 1000 instructions are ~2 us).
+// So: every load of a phase is issued back to back without branches (a conditional load makes
+// hipcc wait for everything before it), reductions inside a key's lane group use DPP instead of
+// LDS shuffles, there is no score buffer and a single barrier — each key slot (LPK lanes) runs its
+// own online softmax (m, l, acc) over the keys it streams, slots are merged at the end (within
+// the wave by shuffles, across waves through LDS) — and waves the context does not need retire at
+// the top (a retired wave no longer counts at s_barrier).
+// Lane layout: a key is handled by LPK = d_head/4 adjacent lanes holding one float4 of the head
+// dimension each (one coalesced row read per key); a wave streams 64/LPK keys per step.
+
+// allreduce (sum) over groups of LPK adjacent lanes; DPP inside a 16-lane row, ds_bpermute above
+template <int LPK>
+__device__ __forceinline__ float group_sum(float v) {
+    if (LPK >= 2) v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
+    if (LPK >= 4) v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));  // quad_perm [2,3,0,1]
+    if (LPK >= 8) v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xF, 0xF, true)); // row_half_mirror
+    if (LPK >= 16) v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xF, 0xF, true)); // row_mirror
+    if (LPK >= 32) v += __shfl_xor(v, 16, 64);
+    if (LPK >= 64) v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+struct SoftState { // online softmax of one key stream: running max, sum of weights, weighted V (4 dims)
+    float m, l;
+    float4 acc;
+};
+// merge stream `o` into `s` (either may be empty: m == -inf)
+__device__ __forceinline__ void soft_merge(SoftState& s, float om, float ol, float4 oacc) {
+    const float nm = fmaxf(s.m, om);
+    const float a = s.m > -INFINITY ? expf(s.m - nm) : 0.0f, b = om > -INFINITY ? expf(om - nm) : 0.0f;
+    s.l = s.l * a + ol * b;
+    s.acc = make_float4(s.acc.x * a + oacc.x * b, s.acc.y * a + oacc.y * b, s.acc.z * a + oacc.z * b, s.acc.w * a + oacc.w * b);
+    s.m = nm;
+}
+
+template <int LPK>
+__global__ void __launch_bounds__(kAttnBlock) attention_decode_kernel(const AttnDecodeParams* __restrict__ params) {
+    constexpr int DH = 4 * LPK, KPW = 64 / LPK, U = kAttnUnroll, HALF = DH / 2;
+    const unsigned long long ts0 = wall_clock64();
+    const AttnDecodeParams& P = params[blockIdx.y];
+    const AttentionParams& p = P.att;
+    unsigned long long* const trace = P.trace;
+#define ATTN_STAMP(i) do { if (trace && threadIdx.x == 0) trace[i] = wall_clock64(); } while (0)
+    if (trace && threadIdx.x == 0) trace[0] = ts0;
+    __shared__ float part_ml[2 * (kAttnBlock / 64)];
+    __shared__ float4 part_acc[(kAttnBlock / 64) * LPK];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t slot = lane / LPK, li = lane % LPK, d0 = 4 * li, pair = d0 & (HALF - 1);
+    const bool is_hi = d0 >= (uint32_t)HALF;
+    // ---- phase A: dynamic words (scalar) and everything the ropes need (vector), one round
+    const uint32_t seq_kv = *p.dyn_seq_kv, dk = *P.dyn_k_off, dv = *P.dyn_v_off;
+    const uint32_t d2_off = p.dst2 ? *p.dyn_dst2_off : 0; // scalar, with the other dynamic words
+    const float4 q_own = *(const float4*)(P.q_src + d0), q_par = *(const float4*)(P.q_src + (d0 ^ HALF));
+    const float4 q_c = *(const float4*)(P.q_cs + pair), q_s = *(const float4*)(P.q_cs + HALF + pair);
+    const float4 k_own = *(const float4*)(P.k_src + d0), k_par = *(const float4*)(P.k_src + (d0 ^ HALF));
+    const float4 k_c = *(const float4*)(P.k_cs + pair), k_s = *(const float4*)(P.k_cs + HALF + pair);
+    const float4 v_new = *(const float4*)(P.v_src + d0);
+    ATTN_STAMP(1);
+    // waves the context needs: one step of a wave covers KPW * U keys
+    uint32_t NW = (seq_kv + KPW * U - 1) / (KPW * U);
+    NW = NW < 1 ? 1 : (NW > (uint32_t)(kAttnBlock / 64) ? (uint32_t)(kAttnBlock / 64) : NW);
+    if (w >= NW) return;
+    const uint32_t keys_per_iter = KPW * NW, step_keys = keys_per_iter * U, last = seq_kv ? seq_kv - 1 : 0;
+    // ---- phase B: first step's K / V / mask rows (clamped to live rows, unconditional)
+    float4 kv[U], vv[U];
+    float mk[U];
+#pragma unroll
+    for (int j = 0; j < U; j++) {
+        const uint32_t s = min(j * keys_per_iter + w * KPW + slot, last);
+        kv[j] = *(const float4*)(p.k + (uint64_t)s * p.k_cs + d0);
+        vv[j] = *(const float4*)(p.v + (uint64_t)s * p.v_cs + d0);
+        mk[j] = p.mask[(uint64_t)s * p.mask_rs]; // host passes a zero word with stride 0 when there is no mask
+    }
+    ATTN_STAMP(2);
+    // ---- ropes; side outputs and the cache stores (one lane group writes each value)
+    const float4 qv = rope4(q_own, q_par, q_c, q_s, is_hi);
+    const float4 k_new = rope4(k_own, k_par, k_c, k_s, is_hi);
+    const uint32_t col_k = (dk - P.k_off) / p.k_cs, col_v = (dv - P.v_off) / p.v_cs;
+    if (w == 0 && slot == 0) {
+        *(float4*)(P.q_rot + d0) = qv;
+        if (P.owner) {
+            *(float4*)(P.k_rot + d0) = k_new;
+            *(float4*)(P.k_cache + dk + d0) = k_new;
+            *(float4*)(P.v_cache + dv + d0) = v_new;
+        }
+    }
+    ATTN_STAMP(3);
+    SoftState st{-INFINITY, 0.f, make_float4(0.f, 0.f, 0.f, 0.f)};
+    // one step: scores of the slot's U keys, then the online-softmax update
+    auto step = [&](uint32_t base) {
+        float sc[U];
+        float bm = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < U; j++) {
+            const uint32_t t = base + j * keys_per_iter + w * KPW + slot;
+            const float4 kk = t == col_k ? k_new : kv[j];
+            const float dot = group_sum<LPK>(qv.x * kk.x + qv.y * kk.y + qv.z * kk.z + qv.w * kk.w);
+            sc[j] = t < seq_kv ? score_of(dot, mk[j], p.scale) : -INFINITY;
+            bm = fmaxf(bm, sc[j]);
+        }
+        const float nm = fmaxf(st.m, bm);
+        if (nm > -INFINITY) { // per key slot; lanes of a slot agree
+            const float alpha = st.m > -INFINITY ? expf(st.m - nm) : 0.0f;
+            st.l *= alpha;
+            st.acc = make_float4(st.acc.x * alpha, st.acc.y * alpha, st.acc.z * alpha, st.acc.w * alpha);
+#pragma unroll
+            for (int j = 0; j < U; j++) {
+                const uint32_t t = base + j * keys_per_iter + w * KPW + slot;
+                const float wgt = sc[j] > -INFINITY ? expf(sc[j] - nm) : 0.0f;
+                const float4 x = t == col_v ? v_new : vv[j];
+                st.l += wgt;
+                if (sc[j] > -INFINITY) { // rows of dead slots are never touched
+                    st.acc.x += wgt * x.x;
+                    st.acc.y += wgt * x.y;
+                    st.acc.z += wgt * x.z;
+                    st.acc.w += wgt * x.w;
+                }
+            }
+            st.m = nm;
+        }
+    };
+    if (seq_kv <= step_keys) { // the usual decode case: everything is already in registers
+        if (seq_kv) step(0);
+    } else {
+        for (uint32_t base = 0; base < seq_kv; base += step_keys) {
+            // prefetch the next step (clamped: the last step re-reads live rows, L2 hits)
+            float4 kn[U], vn[U];
+            float mn[U];
+#pragma unroll
+            for (int j = 0; j < U; j++) {
+                const uint32_t s = min(base + step_keys + j * keys_per_iter + w * KPW + slot, last);
+                kn[j] = *(const float4*)(p.k + (uint64_t)s * p.k_cs + d0);
+                vn[j] = *(const float4*)(p.v + (uint64_t)s * p.v_cs + d0);
+                mn[j] = p.mask[(uint64_t)s * p.mask_rs];
+            }
+            step(base);
+#pragma unroll
+            for (int j = 0; j < U; j++) kv[j] = kn[j], vv[j] = vn[j], mk[j] = mn[j];
+        }
+    }
+    ATTN_STAMP(4);
+    // ---- merge the key slots of the wave, then the waves
+#pragma unroll
+    for (int off = LPK; off < 64; off <<= 1) {
+        const float om = __shfl_xor(st.m, off, 64), ol = __shfl_xor(st.l, off, 64);
+        const float4 oa = make_float4(__shfl_xor(st.acc.x, off, 64), __shfl_xor(st.acc.y, off, 64), __shfl_xor(st.acc.z, off, 64),
+                                      __shfl_xor(st.acc.w, off, 64));
+        soft_merge(st, om, ol, oa);
+    }
+    if (lane < LPK) {
+        part_acc[w * LPK + lane] = st.acc;
+        if (lane == 0) part_ml[2 * w] = st.m, part_ml[2 * w + 1] = st.l;
+    }
+    ATTN_STAMP(5);
+    __syncthreads();
+    ATTN_STAMP(6);
+    if (tid < LPK) {
+        SoftState r{part_ml[0], part_ml[1], part_acc[tid]};
+        for (uint32_t ww = 1; ww < NW; ww++) soft_merge(r, part_ml[2 * ww], part_ml[2 * ww + 1], part_acc[ww * LPK + tid]);
+        const float inv_l = r.l > 0.f ? 1.0f / r.l : 0.0f;
+        const float o[4] = {r.acc.x * inv_l, r.acc.y * inv_l, r.acc.z * inv_l, r.acc.w * inv_l};
+        *(float4*)(p.dst + 4 * tid) = make_float4(o[0], o[1], o[2], o[3]); // dst_rs == 1, 16-byte aligned (planner)
+        if (p.dst2)
+#pragma unroll
+            for (int e = 0; e < 4; e++) p.dst2[(uint64_t)d2_off + (uint64_t)(4 * tid + e) * p.d2_rs] = o[e];
+    }
+    ATTN_STAMP(7);
+#undef ATTN_STAMP
+}
+
 // ── dense f32 matmul (reference.zig:480-497 -> forward.blasSgemm index contract) ───────────
 // C[m*dst_rs + n] = sum_k A[m*a_rs + k*a_cs] * B[k*b_rs + n*b_cs]
 
@@ -661,6 +854,20 @@ void launch_repeat_batch(hipStream_t s, const RepeatParams* dev_params, uint32_t
 void launch_move_batch(hipStream_t s, const MoveParams* dev_params, uint32_t n_ops, uint32_t max_elems) {
     if (!n_ops || !max_elems) return;
     move_kernel<<<dim3(cdiv(max_elems, kBlock), n_ops), kBlock, 0, s>>>(dev_params);
+}
+
+void launch_attention_decode_batch(hipStream_t s, const AttnDecodeParams* dev_params, uint32_t n_heads, uint32_t d_head) {
+    if (!n_heads) return;
+    const dim3 grid(1, n_heads);
+    switch (d_head) { // all heads of a launch share d_head (checked by the planner)
+        case 8: attention_decode_kernel<2><<<grid, kAttnBlock, 0, s>>>(dev_params); break;
+        case 16: attention_decode_kernel<4><<<grid, kAttnBlock, 0, s>>>(dev_params); break;
+        case 32: attention_decode_kernel<8><<<grid, kAttnBlock, 0, s>>>(dev_params); break;
+        case 64: attention_decode_kernel<16><<<grid, kAttnBlock, 0, s>>>(dev_params); break;
+        case 128: attention_decode_kernel<32><<<grid, kAttnBlock, 0, s>>>(dev_params); break;
+        case 256: attention_decode_kernel<64><<<grid, kAttnBlock, 0, s>>>(dev_params); break;
+        default: break;
+    }
 }
 
 void launch_attention_batch(hipStream_t s, const AttentionParams* dev_params, uint32_t n_ops, uint32_t max_seq_q,

@@ -22,6 +22,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -97,6 +98,8 @@ struct zgml_hip_program {
     std::vector<float*> bufs;                         // device pointers (nullptr = elided)
     void* arena = nullptr;
     std::vector<QWeightDev> qweights;
+    std::vector<unsigned long long*> attn_traces; // diagnostics (ZGML_HIP_ATTN_TRACE)
+    float* zero_word = nullptr;                   // a device 0.0f: mask operand of unmasked decode attention
     std::vector<void*> f16_weights; // per buffer: MFMA-packed f16 copy of a promoted matmul B operand (else nullptr)
     std::vector<void*> owned; // other device allocations
     float* scratch = nullptr;
@@ -616,6 +619,14 @@ struct Macro {
     uint32_t n_epi = 0;
     QmvEpiStep epi[kMaxEpiSteps];
     OpAccess access;
+    // decode attention of one kv group: rope k + K store + V store, and per head rope q +
+    // attention (+ row store), all in one launch record per head
+    struct Head {
+        uint32_t rq, att;
+        int row_store;
+    };
+    std::vector<Head> heads;
+    uint32_t rk = 0, sk = 0, sv = 0;
 };
 
 bool ops_conflict(const OpAccess& x, const OpAccess& c) {
@@ -913,6 +924,105 @@ void build_fused_plan(zgml_hip_program* p) {
             m.access = OpAccess{};
             for (uint32_t x : m.members) add_access(m.access, s0.access[x]);
         }
+    // ---- decode attention (seq_q == 1): per kv group {rope k, K store, V store} + per head
+    // {rope q, attention, row store} become one launch record per head (AttnDecodeParams). The new
+    // K/V column is recomputed by every head of the group from the projections and never re-read
+    // from the cache, so the heads of a group need no ordering among themselves.
+    {
+        auto last_writer_span = [&](const Span& q, uint32_t before) -> int {
+            for (int j = (int)before - 1; j >= 0; j--)
+                for (const Span& w : s0.access[j].writes)
+                    if (spans_overlap(w, q)) return j;
+            return -1;
+        };
+        auto pow2 = [](uint32_t v) { return v && (v & (v - 1)) == 0; };
+        auto aligned4 = [&](uint16_t buf, uint64_t off) { return ((uintptr_t)buf_at(p, buf, off) % 16) == 0; };
+        struct Cand {
+            uint32_t rq, att, rk, sk, sv;
+            int row_store;
+        };
+        std::map<uint32_t, std::vector<Cand>> groups; // by K store op
+        static const bool enabled = !(getenv("ZGML_HIP_ATTN_DECODE") && atoi(getenv("ZGML_HIP_ATTN_DECODE")) == 0);
+        for (uint32_t i = 0; enabled && i < n; i++) {
+            if (in_macro[i] || ops[i].kind != ZGML_DOP_ATTENTION) continue;
+            const auto& t = ops[i].u.attention;
+            const uint32_t dh = t.d_head;
+            if (t.seq_q != 1 || !pow2(dh) || dh < 8 || dh > 256 || t.q_rs != 1 || t.k_rs != 1 || t.v_rs != 1 || t.dst_rs != 1 ||
+                t.k_cs % 4 || t.v_cs % 4 || t.seq_kv == 0 || !aligned4(t.q, t.q_off) || !aligned4(t.k, t.k_off) ||
+                !aligned4(t.v, t.v_off) || !aligned4(t.dst, t.dst_off))
+                continue;
+            // query rope
+            const int rq = last_writer(ExactSpan{t.q, t.q_off, dh}, i);
+            if (rq < 0 || in_macro[rq] || ops[rq].kind != ZGML_DOP_ROPE) continue;
+            const auto& q = ops[rq].u.rope;
+            if (q.dst != t.q || q.dst_off != t.q_off || 2 * q.half_d != dh || q.seq_len != 1 || q.src_rs != 1 ||
+                !aligned4(q.src, q.src_off) || !aligned4(q.cos_sin, q.cs_off))
+                continue;
+            // K store (dynamic column) fed by the key rope
+            const int sk = last_writer_span(Span{t.k, t.k_off, t.k_off + (uint64_t)(t.seq_kv - 1) * t.k_cs + dh}, i);
+            if (sk < 0 || in_macro[sk] || ops[sk].kind != ZGML_DOP_SLICE_ASSIGN) continue;
+            const auto& ks = ops[sk].u.slice_assign;
+            if (ks.dst != t.k || !ks.patch_stride || ks.patch_stride != t.k_cs || ks.dst_base_offset != t.k_off || ks.rows != dh ||
+                ks.cols != 1 || ks.dst_row_stride != 1 || ks.src_row_stride != 1)
+                continue;
+            const int rk = last_writer(ExactSpan{ks.src, ks.src_offset, dh}, sk);
+            if (rk < 0 || in_macro[rk] || ops[rk].kind != ZGML_DOP_ROPE) continue;
+            const auto& kr = ops[rk].u.rope;
+            if (kr.dst != ks.src || kr.dst_off != ks.src_offset || 2 * kr.half_d != dh || kr.seq_len != 1 || kr.src_rs != 1 ||
+                !aligned4(kr.src, kr.src_off) || !aligned4(kr.cos_sin, kr.cs_off) || !aligned4(kr.dst, kr.dst_off))
+                continue;
+            // V store
+            const int sv = last_writer_span(Span{t.v, t.v_off, t.v_off + (uint64_t)(t.seq_kv - 1) * t.v_cs + dh}, i);
+            if (sv < 0 || in_macro[sv] || ops[sv].kind != ZGML_DOP_SLICE_ASSIGN) continue;
+            const auto& vs = ops[sv].u.slice_assign;
+            if (vs.dst != t.v || !vs.patch_stride || vs.patch_stride != t.v_cs || vs.dst_base_offset != t.v_off || vs.rows != dh ||
+                vs.cols != 1 || vs.dst_row_stride != 1 || vs.src_row_stride != 1 || !aligned4(vs.src, vs.src_offset))
+                continue;
+            // the slabs must hold seq_kv (compile-time bound) whole columns: speculative reads stay inside
+            if (t.k_off + (uint64_t)(t.seq_kv - 1) * t.k_cs + dh > p->sizes[t.k] || t.v_off + (uint64_t)(t.seq_kv - 1) * t.v_cs + dh > p->sizes[t.v])
+                continue;
+            // optional row store of the dense head output
+            int row_store = -1;
+            if (t.dst_cs == dh) {
+                std::vector<uint32_t> readers;
+                readers_until_overwrite(ExactSpan{t.dst, t.dst_off, dh}, i, readers);
+                for (uint32_t r : readers) {
+                    if (in_macro[r] || ops[r].kind != ZGML_DOP_SLICE_ASSIGN) continue;
+                    const auto& sa = ops[r].u.slice_assign;
+                    if (sa.src != t.dst || sa.src_offset != t.dst_off || sa.rows != dh || sa.cols != 1 || sa.src_row_stride != 1) continue;
+                    row_store = (int)r;
+                    break;
+                }
+            }
+            groups[(uint32_t)sk].push_back({(uint32_t)rq, i, (uint32_t)rk, (uint32_t)sk, (uint32_t)sv, row_store});
+        }
+        for (auto& kv : groups) {
+            const std::vector<Cand>& hs = kv.second;
+            bool same = true;
+            for (const Cand& c : hs) same = same && c.rk == hs[0].rk && c.sv == hs[0].sv;
+            if (!same) continue;
+            Macro m;
+            m.rk = hs[0].rk, m.sk = hs[0].sk, m.sv = hs[0].sv;
+            m.members = {m.rk, m.sk, m.sv};
+            for (const Cand& c : hs) {
+                m.members.push_back(c.rq);
+                m.members.push_back(c.att);
+                if (c.row_store >= 0) m.members.push_back((uint32_t)c.row_store);
+                m.heads.push_back({c.rq, c.att, c.row_store});
+            }
+            std::sort(m.members.begin(), m.members.end());
+            if (std::adjacent_find(m.members.begin(), m.members.end()) != m.members.end()) continue; // an op claimed twice
+            m.position = m.members.back();
+            if (!delay_legal(m.members, m.position)) continue;
+            for (uint32_t x : m.members) {
+                add_access(m.access, s0.access[x]);
+                in_macro[x] = 1;
+            }
+            m.anchor = hs[0].att;
+            macros.push_back(std::move(m));
+        }
+    }
+
     // rope -> slice_assign (K into the cache) and attention -> slice_assign (head output into the
     // concatenated buffer): the copy of the anchor's dense output is done by the anchor itself
     for (uint32_t i = 0; i < n; i++) {
@@ -971,7 +1081,55 @@ void build_fused_plan(zgml_hip_program* p) {
     for (const auto& lv : levels) {
         std::vector<PlanItem> plain_ops;
         std::vector<const Macro*> qmvs;
+        std::map<uint32_t, std::vector<AttnDecodeParams>> adec_by_dh; // one launch per head size
+        uint32_t adec_lo = UINT32_MAX, adec_hi = 0, adec_ops = 0;
         for (uint32_t mi : lv) {
+            if (!macros[mi].heads.empty()) {
+                const Macro& m = macros[mi];
+                const auto& kr = ops[m.rk].u.rope;
+                const auto& ks = ops[m.sk].u.slice_assign;
+                const auto& vs = ops[m.sv].u.slice_assign;
+                bool first_head = true;
+                for (const Macro::Head& h : m.heads) {
+                    const auto& t = ops[h.att].u.attention;
+                    const auto& qr = ops[h.rq].u.rope;
+                    AttnDecodeParams a{};
+                    a.att = make_attention(p, t, h.att);
+                    if (!a.att.mask) a.att.mask = p->zero_word, a.att.mask_rs = 0, a.att.mask_cs = 0;
+                    if (h.row_store >= 0) {
+                        const auto& sa = ops[h.row_store].u.slice_assign;
+                        a.att.dst2 = p->bufs[sa.dst];
+                        a.att.dyn_dst2_off = p->dyn_dev + h.row_store;
+                        a.att.d2_rs = sa.dst_row_stride, a.att.d2_cs = sa.dst_col_stride;
+                    }
+                    a.q_rot = buf_at(p, t.q, t.q_off);
+                    a.q_src = buf_at(p, qr.src, qr.src_off);
+                    a.q_cs = buf_at(p, qr.cos_sin, qr.cs_off);
+                    a.k_src = buf_at(p, kr.src, kr.src_off);
+                    a.k_cs = buf_at(p, kr.cos_sin, kr.cs_off);
+                    a.v_src = buf_at(p, vs.src, vs.src_offset);
+                    a.k_rot = buf_at(p, kr.dst, kr.dst_off);
+                    a.k_cache = p->bufs[ks.dst], a.v_cache = p->bufs[vs.dst];
+                    a.dyn_k_off = p->dyn_dev + m.sk, a.dyn_v_off = p->dyn_dev + m.sv;
+                    a.k_off = t.k_off, a.v_off = t.v_off;
+                    a.owner = first_head ? 1 : 0;
+                    a.max_kv = p->sched.bounds[h.att].max_seq_kv ? p->sched.bounds[h.att].max_seq_kv : t.seq_kv;
+                    static const bool want_trace = getenv("ZGML_HIP_ATTN_TRACE") && atoi(getenv("ZGML_HIP_ATTN_TRACE"));
+                    if (want_trace && first_head) { // one record per launch (the group's owner head)
+                        unsigned long long* t = nullptr;
+                        if (hipHostMalloc((void**)&t, 8 * sizeof(unsigned long long), hipHostMallocMapped) == hipSuccess) {
+                            memset(t, 0, 8 * sizeof(unsigned long long));
+                            a.trace = t;
+                            p->attn_traces.push_back(t);
+                        }
+                    }
+                    first_head = false;
+                    adec_by_dh[t.d_head].push_back(a);
+                }
+                adec_lo = std::min(adec_lo, m.members.front()), adec_hi = std::max(adec_hi, m.members.back());
+                adec_ops += (uint32_t)m.members.size();
+                continue;
+            }
             if (macros[mi].qmv)
                 qmvs.push_back(&macros[mi]);
             else if (macros[mi].store >= 0)
@@ -980,6 +1138,12 @@ void build_fused_plan(zgml_hip_program* p) {
                 plain_ops.push_back({macros[mi].members[0], -1});
         }
         emit_batches(p, plain_ops);
+        for (auto& kv : adec_by_dh) {
+            const AttnDecodeParams* d = upload_params(p, kv.second);
+            const uint32_t nh = (uint32_t)kv.second.size(), dh = kv.first;
+            p->plan.push_back({ZGML_DOP_ATTENTION, adec_ops, adec_lo, adec_hi, [=](hipStream_t s) { launch_attention_decode_batch(s, d, nh, dh); }});
+            adec_ops = 0; // profile accounting: ops counted once
+        }
         // group mat-vecs that stage the same vector
         std::vector<char> used(qmvs.size(), 0);
         for (size_t i = 0; i < qmvs.size(); i++) {
@@ -1489,6 +1653,7 @@ zgml_hip_program* zgml_hip_compile_program(zgml_hip_ctx* ctx, const zgml_device_
     if (total) {
         ok = CTX_CHECK(ctx, hipMalloc(&p->arena, total)) && CTX_CHECK(ctx, hipMemsetAsync(p->arena, 0, total, ctx->stream));
     }
+    if (ok) ok = CTX_CHECK(ctx, hipMalloc((void**)&p->zero_word, 256)) && CTX_CHECK(ctx, hipMemsetAsync(p->zero_word, 0, 256, ctx->stream));
     p->bufs.assign(nb, nullptr);
     if (ok)
         for (size_t i = 0; i < nb; i++)
@@ -1737,10 +1902,23 @@ void zgml_hip_free_program(zgml_hip_ctx* ctx, zgml_hip_program* p) {
         hipSetDevice(ctx->device);
         hipStreamSynchronize(ctx->stream);
     }
+    if (!p->attn_traces.empty()) { // stamps of the last execution, 100 MHz wall clock -> ns
+        fprintf(stderr, "[zgml_hip] attention trace (ns since previous launch's end | start->params | ->dyn | ->rope | ->scores | ->max | ->pv | ->end)\n");
+        unsigned long long prev_end = 0;
+        for (size_t i = 0; i < p->attn_traces.size(); i++) {
+            const unsigned long long* t = p->attn_traces[i];
+            fprintf(stderr, "  L%02zu gap %6lld |", i, prev_end ? (long long)(t[0] - prev_end) * 10 : -1);
+            for (int k = 1; k < 8; k++) fprintf(stderr, " %5lld", (long long)(t[k] - t[k - 1]) * 10);
+            fprintf(stderr, "\n");
+            prev_end = t[7];
+        }
+        for (auto* t : p->attn_traces) hipHostFree(t);
+    }
     free_graph(p);
     free_resident(p);
     free_param_blobs(p);
     if (p->arena) hipFree(p->arena);
+    if (p->zero_word) hipFree(p->zero_word);
     for (void* d : p->owned) hipFree(d);
     if (p->scratch) hipFree(p->scratch);
     if (p->dyn_dev) hipFree(p->dyn_dev);

@@ -23,7 +23,10 @@ namespace zgml {
 
 struct Span {
     uint16_t buf;
-    uint64_t lo, hi; // [lo, hi) in f32 elements
+    uint64_t lo, hi; // bounding interval [lo, hi) in f32 elements
+    // strided 2-D accesses (a run of `width` elements every `period` elements starting at lo), 0 = the
+    // whole interval: lets the row stores of different heads into one [d, T] buffer commute for T > 1
+    uint64_t period = 0, width = 0;
 };
 
 struct OpAccess {
@@ -55,7 +58,16 @@ void levels_from_access(const std::vector<OpAccess>& access, const std::vector<u
                         const std::vector<uint64_t>& barriers, std::vector<uint32_t>& level,
                         std::vector<std::vector<uint32_t>>& levels);
 
-inline bool spans_overlap(const Span& x, const Span& y) { return x.buf == y.buf && x.lo < y.hi && y.lo < x.hi; }
+inline bool spans_overlap(const Span& x, const Span& y) {
+    if (x.buf != y.buf || !(x.lo < y.hi && y.lo < x.hi)) return false;
+    if (x.period && x.period == y.period && x.width <= x.period && y.width <= y.period) {
+        // both touch residues [lo % P, lo % P + width) modulo the same period: disjoint residue sets never meet
+        const uint64_t P = x.period, a = x.lo % P, b = y.lo % P;
+        const bool a_wraps = a + x.width > P, b_wraps = b + y.width > P;
+        if (!a_wraps && !b_wraps && (a + x.width <= b || b + y.width <= a)) return false;
+    }
+    return true;
+}
 
 // true when every dynamic field of `ops` respects the bounds assumed by `s`
 bool dynamic_fields_in_bounds(const Schedule& s, const std::vector<zgml_device_op>& ops);

@@ -16,6 +16,15 @@ inline uint64_t ext2(uint64_t n0, uint64_t s0, uint64_t n1, uint64_t s1) {
     return (n0 - 1) * s0 + (n1 - 1) * s1 + 1;
 }
 
+// strided 2-D access n0 x n1 with strides s0, s1 from `off`: bounding interval plus, when one
+// dimension is a dense run repeated at a larger stride, the (period, width) form
+inline Span span2(uint16_t buf, uint64_t off, uint64_t n0, uint64_t s0, uint64_t n1, uint64_t s1) {
+    Span sp = span(buf, off, ext2(n0, s0, n1, s1));
+    if (n0 > 0 && n1 > 1 && s0 == 1 && s1 >= n0) sp.period = s1, sp.width = n0;
+    else if (n1 > 0 && n0 > 1 && s1 == 1 && s0 >= n1) sp.period = s0, sp.width = n1;
+    return sp;
+}
+
 OpAccess op_access(const zgml_device_op& op, const DynBound& b) {
     OpAccess a;
     switch (op.kind) {
@@ -46,8 +55,8 @@ OpAccess op_access(const zgml_device_op& op, const DynBound& b) {
         case ZGML_DOP_QMATMUL: {
             const auto& q = op.u.qmatmul;
             const uint64_t irs = q.input_row_stride ? q.input_row_stride : q.K, drs = q.dst_row_stride ? q.dst_row_stride : q.N;
-            a.writes.push_back(span(q.dst, q.dst_offset, ext2(q.M, drs, q.N, 1)));
-            a.reads.push_back(span(q.input, q.input_offset, ext2(q.M, irs, q.K, 1)));
+            a.writes.push_back(span2(q.dst, q.dst_offset, q.M, drs, q.N, 1));
+            a.reads.push_back(span2(q.input, q.input_offset, q.M, irs, q.K, 1));
             break;
         }
         case ZGML_DOP_SOFTMAX:
@@ -75,25 +84,25 @@ OpAccess op_access(const zgml_device_op& op, const DynBound& b) {
         }
         case ZGML_DOP_SLICE_ASSIGN: {
             const auto& s = op.u.slice_assign;
-            a.reads.push_back(span(s.src, s.src_offset, ext2(s.rows, s.src_row_stride, s.cols, s.src_col_stride)));
+            a.reads.push_back(span2(s.src, s.src_offset, s.rows, s.src_row_stride, s.cols, s.src_col_stride));
             if (b.kind == 1)
                 a.writes.push_back({s.dst, b.lo, b.hi});
             else
-                a.writes.push_back(span(s.dst, s.dst_offset, ext2(s.rows, s.dst_row_stride, s.cols, s.dst_col_stride)));
+                a.writes.push_back(span2(s.dst, s.dst_offset, s.rows, s.dst_row_stride, s.cols, s.dst_col_stride));
             break;
         }
         case ZGML_DOP_ROPE: {
             const auto& r = op.u.rope;
             a.writes.push_back(span(r.dst, r.dst_off, (uint64_t)r.seq_len * 2 * r.half_d));
-            a.reads.push_back(span(r.src, r.src_off, ext2(2 * r.half_d, r.src_rs, r.seq_len, r.src_cs)));
+            a.reads.push_back(span2(r.src, r.src_off, 2 * r.half_d, r.src_rs, r.seq_len, r.src_cs));
             a.reads.push_back(span(r.cos_sin, r.cs_off, ext2(2 * r.half_d, 1, r.seq_len, r.cs_cs)));
             break;
         }
         case ZGML_DOP_ATTENTION: {
             const auto& t = op.u.attention;
             const uint64_t skv = b.max_seq_kv;
-            a.writes.push_back(span(t.dst, t.dst_off, ext2(t.d_head, t.dst_rs, t.seq_q, t.dst_cs)));
-            a.reads.push_back(span(t.q, t.q_off, ext2(t.d_head, t.q_rs, t.seq_q, t.q_cs)));
+            a.writes.push_back(span2(t.dst, t.dst_off, t.d_head, t.dst_rs, t.seq_q, t.dst_cs));
+            a.reads.push_back(span2(t.q, t.q_off, t.d_head, t.q_rs, t.seq_q, t.q_cs));
             a.reads.push_back(span(t.k, t.k_off, ext2(t.d_head, t.k_rs, skv, t.k_cs)));
             a.reads.push_back(span(t.v, t.v_off, ext2(t.d_head, t.v_rs, skv, t.v_cs)));
             if (t.has_mask) a.reads.push_back(span(t.mask, t.mask_off, ext2(skv, t.mask_rs, t.seq_q, t.mask_cs)));
@@ -104,7 +113,7 @@ OpAccess op_access(const zgml_device_op& op, const DynBound& b) {
     return a;
 }
 
-inline bool overlap(const Span& x, const Span& y) { return x.buf == y.buf && x.lo < y.hi && y.lo < x.hi; }
+inline bool overlap(const Span& x, const Span& y) { return spans_overlap(x, y); }
 
 } // namespace
 
