@@ -186,6 +186,7 @@ struct QmvLaunch {
     QmvPart parts[kMaxQmvParts];
     QmvPrologue pro;
     uint32_t K = 0;
+    unsigned long long* trace = nullptr; // diagnostics (ZGML_HIP_QMV_TRACE=1): 8 wall-clock stamps of block 0
 };
 
 struct QMatmulParams {

@@ -533,12 +533,15 @@ __device__ __forceinline__ void soft_merge(SoftState& s, float om, float ol, flo
 template <int LPK>
 __global__ void __launch_bounds__(kAttnBlock) attention_decode_kernel(const AttnDecodeParams* __restrict__ params) {
     constexpr int DH = 4 * LPK, KPW = 64 / LPK, U = kAttnUnroll, HALF = DH / 2;
-    const unsigned long long ts0 = wall_clock64();
     const AttnDecodeParams& P = params[blockIdx.y];
     const AttentionParams& p = P.att;
+#ifdef ZGML_TRACE // build with -DZGML_TRACE (ZGML_HIP_ATTN_TRACE=1 then prints the stamps)
     unsigned long long* const trace = P.trace;
 #define ATTN_STAMP(i) do { if (trace && threadIdx.x == 0) trace[i] = wall_clock64(); } while (0)
-    if (trace && threadIdx.x == 0) trace[0] = ts0;
+#else
+#define ATTN_STAMP(i) do { } while (0)
+#endif
+    ATTN_STAMP(0);
     __shared__ float part_ml[2 * (kAttnBlock / 64)];
     __shared__ float4 part_acc[(kAttnBlock / 64) * LPK];
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;

@@ -133,6 +133,7 @@ struct QMVArgs {
     uint32_t M, K;
     uint32_t U;      // k-units per column group (Q4: KC, Q8: 2*KC)
     uint32_t in_rs;
+    unsigned long long* trace; // diagnostics: stamps of workgroup (0,0), else nullptr
 };
 
 // x staging in two halves so the weight loads can sit between them: x_fetch() issues this thread's
@@ -373,25 +374,39 @@ struct Q8Group {
 
 // Q4: unit = 32 k, UNIT_X = 32 floats of x per unit; Q8: unit = 16 k.
 // PRO: the launch has a prologue (second vector b, optional rmsnorm); GROUPED: more than one matrix.
+// The first 16 argument dwords are what the kernel needs before it can issue its first loads; the
+// build preloads them into SGPRs (-amdgpu-kernarg-preload-count=16), so the x and weight streams
+// start without waiting for an s_load round trip to the argument block. Part 0's fields are
+// repeated there; `a` carries the rest (further parts, prologue, epilogues).
+#define QMV_HEAD_PARAMS                                                                                                  \
+    const uint4 *__restrict__ qs0, const void *__restrict__ sc0, float *__restrict__ out0, const float *__restrict__ xa_base, \
+        const float *__restrict__ xb_base, uint32_t U, uint32_t K, uint32_t NB2_0, uint32_t out_rs0, uint32_t in_rs,         \
+        uint32_t n_parts
 template <typename ST, bool XVEC, int DEPTH, bool Q4, bool PRO, bool GROUPED>
-__global__ void __launch_bounds__(1024) qmatvec_kernel(QMVArgs a) {
+__global__ void __launch_bounds__(1024) qmatvec_kernel(QMV_HEAD_PARAMS, QMVArgs a) {
     constexpr uint32_t UNIT_X = Q4 ? 32 : 16;
     using ScaleT = typename std::conditional<Q4, Pair<ST>, ST>::type;
     using Group = typename std::conditional<Q4, Q4Group<ST, DEPTH>, Q8Group<ST, DEPTH>>::type;
     extern __shared__ float smem[];
+#ifdef ZGML_TRACE // build with -DZGML_TRACE: the stamps serialise the kernel-argument loads, so never in product builds
+#define QMV_STAMP(i) do { if (a.trace && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.trace[i] = wall_clock64(); } while (0)
+#else
+#define QMV_STAMP(i) do { } while (0)
+#endif
+    QMV_STAMP(0);
     float* xs = smem;                     // U * UNIT_X floats (+4 spare)
-    float* red = smem + a.U * UNIT_X + 4; // waves * 16 floats
+    float* red = smem + U * UNIT_X + 4; // waves * 16 floats
     // which matrix of the group this workgroup belongs to (wave-uniform); fields are selected from
     // statically indexed argument loads
     uint32_t pi = 0;
-    const uint4* qs_base = a.parts[0].qs;
-    const void* sc_base = a.parts[0].sc;
-    float* out = a.parts[0].out;
-    uint32_t NB2 = a.parts[0].NB2, block_begin = 0, out_rs = a.parts[0].out_rs;
+    const uint4* qs_base = qs0;
+    const void* sc_base = sc0;
+    float* out = out0;
+    uint32_t NB2 = NB2_0, block_begin = 0, out_rs = out_rs0;
     if (GROUPED) {
 #pragma unroll
         for (uint32_t t = 1; t < (uint32_t)kMaxQmvParts; t++) {
-            const bool take = t < a.n_parts && blockIdx.x >= a.parts[t].block_begin;
+            const bool take = t < n_parts && blockIdx.x >= a.parts[t].block_begin;
             pi = take ? t : pi;
             qs_base = take ? a.parts[t].qs : qs_base;
             sc_base = take ? a.parts[t].sc : sc_base;
@@ -405,35 +420,41 @@ __global__ void __launch_bounds__(1024) qmatvec_kernel(QMVArgs a) {
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint32_t row = lane >> 4, i = lane & 15;
     const uint32_t stride = (blockDim.x >> 6) * 4; // units per step (4 rows per wave)
-    const uint4* qs = qs_base + (uint64_t)g * a.U * 16 + i;
-    const ScaleT* sc = (const ScaleT*)sc_base + (uint64_t)(g >> 1) * a.U * 16 + i;
-    const uint32_t n_groups = (a.U + stride * DEPTH - 1) / (stride * DEPTH);
-    const uint32_t u_last = a.U - 1;
+    const uint4* qs = qs_base + (uint64_t)g * U * 16 + i;
+    const ScaleT* sc = (const ScaleT*)sc_base + (uint64_t)(g >> 1) * U * 16 + i;
+    const uint32_t n_groups = (U + stride * DEPTH - 1) / (stride * DEPTH);
+    const uint32_t u_last = U - 1;
 
-    const float* xa_row = a.pro.a + (uint64_t)m * a.in_rs;
-    const XRegs xa = x_fetch<XVEC>(xa_row, a.K);
-    const XRegs xb = PRO ? x_fetch<XVEC>(a.pro.b, a.K) : xa;
+    const float* xa_row = xa_base + (uint64_t)m * in_rs;
+    const XRegs xa = x_fetch<XVEC>(xa_row, K);
+    const XRegs xb = PRO ? x_fetch<XVEC>(xb_base, K) : xa;
     uint32_t u = 4 * w + row; // this row's unit in step 0
     Group cur;
     cur.load(qs, sc, u, stride, u_last);
+    QMV_STAMP(1); // loads issued
     float inv = 1.0f;
     if (PRO && a.pro.kind == QMV_PRO_RMSNORM_MUL) {
-        const float ss = block_sumsq(xa, a.K, red);
-        inv = 1.0f / sqrtf(ss / (float)a.K + a.pro.eps); // reference.zig:365
+        const float ss = block_sumsq(xa, K, red);
+        inv = 1.0f / sqrtf(ss / (float)K + a.pro.eps); // reference.zig:365
     }
-    x_commit<XVEC, PRO>(xs, xa, xb, a.pro, inv, a.U * UNIT_X, a.K, xa_row);
+    QMV_STAMP(2); // x arrived (+ sum of squares)
+    x_commit<XVEC, PRO>(xs, xa, xb, a.pro, inv, U * UNIT_X, K, xa_row);
     __syncthreads();
+    QMV_STAMP(3); // x staged
 
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
     for (uint32_t gi = 1; gi < n_groups; gi++) {
         Group nxt;
         nxt.load(qs, sc, u + DEPTH * stride, stride, u_last);
-        cur.compute(xs, u, stride, a.U, i, acc0, acc1, acc2, acc3);
+        cur.compute(xs, u, stride, U, i, acc0, acc1, acc2, acc3);
         cur = nxt;
         u += DEPTH * stride;
     }
-    cur.compute(xs, u, stride, a.U, i, acc0, acc1, acc2, acc3);
+    cur.compute(xs, u, stride, U, i, acc0, acc1, acc2, acc3);
+    QMV_STAMP(4); // weights streamed
     reduce_store<GROUPED>((acc0 + acc1) + (acc2 + acc3), red, a, pi, out, out_rs, g, m);
+    QMV_STAMP(5);
+#undef QMV_STAMP
 }
 
 // ── M > 1 (prefill): tile kernel on the f32 matrix cores ─────────────────────────────────────
@@ -821,7 +842,7 @@ uint32_t qmv_waves(const QWeightDev& w, uint32_t total_blocks = 0) {
     return waves < 1 ? 1 : waves;
 }
 
-using KernelFn = void (*)(QMVArgs);
+using KernelFn = void (*)(QMV_HEAD_PARAMS, QMVArgs);
 
 template <typename ST, bool XV, bool Q, bool PRO, bool GRP>
 KernelFn pick_depth(int depth_sel) {
@@ -856,7 +877,8 @@ void launch_packed(hipStream_t s, QMVArgs& a, const QWeightDev& w0, uint32_t tot
                                      : pick_kernel<float>(xvec, q4, pro, grp, depth_sel);
     if (lds > 64 * 1024) // > 64 KiB of dynamic LDS needs an explicit opt-in per kernel (idempotent)
         hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
-    hipLaunchKernelGGL(fn, grid, dim3(waves * 64), lds, s, a);
+    hipLaunchKernelGGL(fn, grid, dim3(waves * 64), lds, s, a.parts[0].qs, a.parts[0].sc, a.parts[0].out, a.pro.a, a.pro.b, a.U, a.K,
+                       a.parts[0].NB2, a.parts[0].out_rs, a.in_rs, a.n_parts, a);
 }
 
 using TileFn = void (*)(QMMArgs);
@@ -915,6 +937,7 @@ void launch_qmatmul(hipStream_t s, const QWeightDev& w, const QMatmulParams& p, 
     a.M = p.M, a.K = p.K;
     a.U = w.format == QW_Q4 ? w.KC : 2 * w.KC;
     a.in_rs = p.in_rs;
+    a.trace = nullptr;
     launch_packed(s, a, w, a.parts[0].NB2, p.M, xvec);
 }
 
@@ -944,6 +967,7 @@ void launch_qmatvec_fused(hipStream_t s, const QmvLaunch& L) {
     a.in_rs = L.K;
     bool xvec = ((uintptr_t)L.pro.a % 16 == 0) && (L.K % 4 == 0);
     if (L.pro.kind != QMV_PRO_NONE) xvec = xvec && ((uintptr_t)L.pro.b % 16 == 0);
+    a.trace = L.trace;
     launch_packed(s, a, w0, blocks, 1, xvec);
 }
 

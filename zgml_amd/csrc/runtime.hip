@@ -99,6 +99,11 @@ struct zgml_hip_program {
     void* arena = nullptr;
     std::vector<QWeightDev> qweights;
     std::vector<unsigned long long*> attn_traces; // diagnostics (ZGML_HIP_ATTN_TRACE)
+    struct QmvTrace {
+        unsigned long long* t;
+        uint32_t parts, pro, K, N;
+    };
+    std::vector<QmvTrace> qmv_traces; // diagnostics (ZGML_HIP_QMV_TRACE)
     float* zero_word = nullptr;                   // a device 0.0f: mask operand of unmasked decode attention
     std::vector<void*> f16_weights; // per buffer: MFMA-packed f16 copy of a promoted matmul B operand (else nullptr)
     std::vector<void*> owned; // other device allocations
@@ -1178,6 +1183,15 @@ void build_fused_plan(zgml_hip_program* p) {
                 hi = std::max(hi, c->members.back());
                 n_ops += (uint32_t)c->members.size();
             }
+            static const bool want_qmv_trace = getenv("ZGML_HIP_QMV_TRACE") && atoi(getenv("ZGML_HIP_QMV_TRACE"));
+            if (want_qmv_trace) {
+                unsigned long long* t = nullptr;
+                if (hipHostMalloc((void**)&t, 8 * sizeof(unsigned long long), hipHostMallocMapped) == hipSuccess) {
+                    memset(t, 0, 8 * sizeof(unsigned long long));
+                    L.trace = t;
+                    p->qmv_traces.push_back({t, L.n_parts, L.pro.kind, (uint32_t)w0.K, (uint32_t)w0.N});
+                }
+            }
             p->plan.push_back({ZGML_DOP_QMATMUL, n_ops, lo, hi, [=](hipStream_t s) { launch_qmatvec_fused(s, L); }});
         }
     }
@@ -1913,6 +1927,19 @@ void zgml_hip_free_program(zgml_hip_ctx* ctx, zgml_hip_program* p) {
             prev_end = t[7];
         }
         for (auto* t : p->attn_traces) hipHostFree(t);
+    }
+    if (!p->qmv_traces.empty()) {
+        fprintf(stderr, "[zgml_hip] mat-vec trace, workgroup 0 (ns: gap since previous mat-vec end | ->loads issued | ->x arrived(+sumsq) | ->x staged | ->streamed | ->reduced+epilogue)\n");
+        unsigned long long prev_end = 0;
+        for (size_t i = 0; i < p->qmv_traces.size() && i < 24; i++) {
+            const auto& q = p->qmv_traces[i];
+            fprintf(stderr, "  #%02zu K=%5u N0=%5u parts=%u pro=%u gap %6lld |", i, q.K, q.N, q.parts, q.pro,
+                    prev_end ? (long long)(q.t[0] - prev_end) * 10 : -1);
+            for (int k = 1; k < 6; k++) fprintf(stderr, " %5lld", (long long)(q.t[k] - q.t[k - 1]) * 10);
+            fprintf(stderr, "\n");
+            prev_end = q.t[5];
+        }
+        for (auto& q : p->qmv_traces) hipHostFree(q.t);
     }
     free_graph(p);
     free_resident(p);
