@@ -219,8 +219,13 @@ __device__ __forceinline__ float block_sumsq(const XRegs& r, uint32_t K, float* 
         ss += v.z * v.z;
         ss += v.w * v.w;
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    // row of 16 by DPP (quad swaps, half mirror, mirror), then the 4 rows by two LDS shuffles
+    ss += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(ss), 0xB1, 0xF, 0xF, true));
+    ss += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(ss), 0x4E, 0xF, 0xF, true));
+    ss += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(ss), 0x141, 0xF, 0xF, true));
+    ss += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(ss), 0x140, 0xF, 0xF, true));
+    ss += __shfl_xor(ss, 16, 64);
+    ss += __shfl_xor(ss, 32, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
     __syncthreads();
     float t = 0.f;
@@ -259,14 +264,15 @@ __device__ __forceinline__ uint32_t column_group(uint32_t b, uint32_t NB2) {
 }
 
 // the part's elementwise epilogue on one output value (residual add, SiLU chain, ...)
-__device__ __forceinline__ void run_epilogue(const QMVPartDev& part, uint32_t n, float v) {
+__device__ __forceinline__ void run_epilogue(const QMVPartDev& part, uint32_t n, float v, const float* out_row) {
+    const float raw = v; // an operand that is this part's own output (SiLU's final gate * sigmoid) stays in the register
     for (uint32_t e = 0; e < part.n_epi; e++) { // M == 1 whenever n_epi != 0
         const QmvEpiStep st = part.epi[e];
         if (st.op == ZGML_OP_ADD) {
-            const float o = st.operand[n];
+            const float o = st.operand == out_row ? raw : st.operand[n];
             v = st.swapped ? o + v : v + o;
         } else if (st.op == ZGML_OP_MUL) {
-            const float o = st.operand[n];
+            const float o = st.operand == out_row ? raw : st.operand[n];
             v = st.swapped ? o * v : v * o;
         } else {
             v = epi_unary(st.op, v);
@@ -292,15 +298,16 @@ __device__ __forceinline__ void reduce_store(float acc, float* red, const QMVArg
         float v = red[threadIdx.x];
         for (uint32_t ww = 1; ww < n_waves; ww++) v += red[ww * 16 + threadIdx.x];
         const uint32_t n = g * 16 + threadIdx.x;
-        out[(uint64_t)m * out_rs + n] = v;
+        float* const out_row = out + (uint64_t)m * out_rs;
+        out_row[n] = v;
         if (!GROUPED || pi == 0)
-            run_epilogue(a.parts[0], n, v);
+            run_epilogue(a.parts[0], n, v, out_row);
         else if (pi == 1)
-            run_epilogue(a.parts[1], n, v);
+            run_epilogue(a.parts[1], n, v, out_row);
         else if (pi == 2)
-            run_epilogue(a.parts[2], n, v);
+            run_epilogue(a.parts[2], n, v, out_row);
         else
-            run_epilogue(a.parts[3], n, v);
+            run_epilogue(a.parts[3], n, v, out_row);
     }
 }
 
