@@ -316,31 +316,60 @@ __device__ __forceinline__ void reduce_store(float acc, float* red, const QMVArg
 // {load next; compute current}; compute last — the prefetch is unconditional inside the loop so
 // hipcc can keep counted vmcnt waits (a prefetch under a branch would degrade them to vmcnt(0)).
 
-template <typename ST, int DEPTH>
+// XD ("x direct"): x is not staged through LDS; each lane loads the x value(s) of "its" k of the
+// unit together with the unit's weights (dword loads, L2-resident vector), so the kernel has no
+// x round trip + LDS store + barrier before its first FMA. PROMUL: x = a * b (the absorbed
+// elementwise mul), computed per lane; workgroup (0,0) stores it.
+struct XDirect {
+    const float* a;
+    const float* b;
+    float* store_x; // nullptr unless this workgroup owns the prologue's side output
+    uint32_t K;
+};
+
+template <typename ST, int DEPTH, bool XD, bool PROMUL>
 struct Q4Group {
     uint4 wq[DEPTH];
     Pair<ST> s2[DEPTH];
-    __device__ __forceinline__ void load(const uint4* qs, const Pair<ST>* sc, uint32_t u, uint32_t stride, uint32_t u_last) {
+    float xa[XD ? DEPTH : 1], xb[XD ? DEPTH : 1], ya[XD && PROMUL ? DEPTH : 1], yb[XD && PROMUL ? DEPTH : 1];
+    __device__ __forceinline__ void load(const uint4* qs, const Pair<ST>* sc, uint32_t u, uint32_t stride, uint32_t u_last,
+                                         const XDirect& xd, uint32_t i) {
 #pragma unroll
         for (int d = 0; d < DEPTH; d++) { // clamped, unconditional
             const uint32_t ud = min(u + d * stride, u_last);
+            if (XD) {
+                const uint32_t ka = min(ud * 32 + i, xd.K - 1), kb = min(ud * 32 + 16 + i, xd.K - 1);
+                xa[d] = xd.a[ka], xb[d] = xd.a[kb];
+                if (PROMUL) ya[d] = xd.b[ka], yb[d] = xd.b[kb];
+            }
             wq[d] = qs[(uint64_t)ud * 16];
             s2[d] = sc[(uint64_t)ud * 16];
         }
     }
     __device__ __forceinline__ void compute(const float* xs, uint32_t u, uint32_t stride, uint32_t U, uint32_t i,
-                                            float& acc0, float& acc1, float& acc2, float& acc3) const {
+                                            float& acc0, float& acc1, float& acc2, float& acc3, const XDirect& xd) const {
 #pragma unroll
         for (int d = 0; d < DEPTH; d++) {
             const uint32_t ud = u + d * stride;
             const bool ok = ud < U;
             const uint32_t uc = min(ud, U - 1);
-            const float xa = xs[uc * 32 + i], xb = xs[uc * 32 + 16 + i];
+            float va, vb;
+            if (XD) {
+                const uint32_t ka = ud * 32 + i, kb = ka + 16;
+                va = PROMUL ? xa[d] * ya[d] : xa[d], vb = PROMUL ? xb[d] * yb[d] : xb[d];
+                va = ka < xd.K ? va : 0.f, vb = kb < xd.K ? vb : 0.f;
+                if (PROMUL && xd.store_x && ok) {
+                    if (ka < xd.K) xd.store_x[ka] = va;
+                    if (kb < xd.K) xd.store_x[kb] = vb;
+                }
+            } else {
+                va = xs[uc * 32 + i], vb = xs[uc * 32 + 16 + i];
+            }
             // all 64 lanes run the DPP section (row_newbcast reads need their source lanes live);
             // out-of-range units get t = 0 (their clamped weights are finite, so 0 * q = 0).
             // cvt_nib yields q/16: the 16 is folded into t (exact power of two)
-            float tA = ok ? (to_f32(s2[d].a) * 16.0f) * xa : 0.f;
-            float tB = ok ? (to_f32(s2[d].b) * 16.0f) * xb : 0.f;
+            float tA = ok ? (to_f32(s2[d].a) * 16.0f) * va : 0.f;
+            float tB = ok ? (to_f32(s2[d].b) * 16.0f) * vb : 0.f;
             dpp_fence(tA, tB);
             q4_dword<0>(acc0, acc1, wq[d].x, tA);
             q4_dword<8>(acc2, acc3, wq[d].y, tA);
@@ -350,26 +379,41 @@ struct Q4Group {
     }
 };
 
-template <typename ST, int DEPTH>
+template <typename ST, int DEPTH, bool XD, bool PROMUL>
 struct Q8Group {
     uint4 wq[DEPTH];
     ST s1[DEPTH];
-    __device__ __forceinline__ void load(const uint4* qs, const ST* sc, uint32_t u, uint32_t stride, uint32_t u_last) {
+    float xa[XD ? DEPTH : 1], ya[XD && PROMUL ? DEPTH : 1];
+    __device__ __forceinline__ void load(const uint4* qs, const ST* sc, uint32_t u, uint32_t stride, uint32_t u_last,
+                                         const XDirect& xd, uint32_t i) {
 #pragma unroll
         for (int d = 0; d < DEPTH; d++) {
             const uint32_t ud = min(u + d * stride, u_last);
+            if (XD) {
+                const uint32_t ka = min(ud * 16 + i, xd.K - 1);
+                xa[d] = xd.a[ka];
+                if (PROMUL) ya[d] = xd.b[ka];
+            }
             wq[d] = qs[(uint64_t)ud * 16];
             s1[d] = sc[(uint64_t)ud * 16];
         }
     }
     __device__ __forceinline__ void compute(const float* xs, uint32_t u, uint32_t stride, uint32_t U, uint32_t i,
-                                            float& acc0, float& acc1, float& acc2, float& acc3) const {
+                                            float& acc0, float& acc1, float& acc2, float& acc3, const XDirect& xd) const {
 #pragma unroll
         for (int d = 0; d < DEPTH; d++) {
             const uint32_t ud = u + d * stride;
             const bool ok = ud < U;
-            const float xa = xs[min(ud, U - 1) * 16 + i];
-            float t = ok ? to_f32(s1[d]) * xa : 0.f;
+            float va;
+            if (XD) {
+                const uint32_t ka = ud * 16 + i;
+                va = PROMUL ? xa[d] * ya[d] : xa[d];
+                va = ka < xd.K ? va : 0.f;
+                if (PROMUL && xd.store_x && ok && ka < xd.K) xd.store_x[ka] = va;
+            } else {
+                va = xs[min(ud, U - 1) * 16 + i];
+            }
+            float t = ok ? to_f32(s1[d]) * va : 0.f;
             dpp_fence(t);
             q8_dword<0>(acc0, acc1, wq[d].x, t);
             q8_dword<4>(acc2, acc3, wq[d].y, t);
@@ -389,11 +433,11 @@ struct Q8Group {
     const uint4 *__restrict__ qs0, const void *__restrict__ sc0, float *__restrict__ out0, const float *__restrict__ xa_base, \
         const float *__restrict__ xb_base, uint32_t U, uint32_t K, uint32_t NB2_0, uint32_t out_rs0, uint32_t in_rs,         \
         uint32_t n_parts
-template <typename ST, bool XVEC, int DEPTH, bool Q4, bool PRO, bool GROUPED>
+template <typename ST, bool XVEC, int DEPTH, bool Q4, bool PRO, bool GROUPED, bool XD>
 __global__ void __launch_bounds__(1024) qmatvec_kernel(QMV_HEAD_PARAMS, QMVArgs a) {
     constexpr uint32_t UNIT_X = Q4 ? 32 : 16;
     using ScaleT = typename std::conditional<Q4, Pair<ST>, ST>::type;
-    using Group = typename std::conditional<Q4, Q4Group<ST, DEPTH>, Q8Group<ST, DEPTH>>::type;
+    using Group = typename std::conditional<Q4, Q4Group<ST, DEPTH, XD, PRO>, Q8Group<ST, DEPTH, XD, PRO>>::type;
     extern __shared__ float smem[];
 #ifdef ZGML_TRACE // build with -DZGML_TRACE: the stamps serialise the kernel-argument loads, so never in product builds
 #define QMV_STAMP(i) do { if (a.trace && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.trace[i] = wall_clock64(); } while (0)
@@ -402,7 +446,7 @@ __global__ void __launch_bounds__(1024) qmatvec_kernel(QMV_HEAD_PARAMS, QMVArgs 
 #endif
     QMV_STAMP(0);
     float* xs = smem;                     // U * UNIT_X floats (+4 spare)
-    float* red = smem + U * UNIT_X + 4; // waves * 16 floats
+    float* red = XD ? smem : smem + U * UNIT_X + 4; // waves * 16 floats
     // which matrix of the group this workgroup belongs to (wave-uniform); fields are selected from
     // statically indexed argument loads
     uint32_t pi = 0;
@@ -433,31 +477,36 @@ __global__ void __launch_bounds__(1024) qmatvec_kernel(QMV_HEAD_PARAMS, QMVArgs 
     const uint32_t u_last = U - 1;
 
     const float* xa_row = xa_base + (uint64_t)m * in_rs;
-    const XRegs xa = x_fetch<XVEC>(xa_row, K);
-    const XRegs xb = PRO ? x_fetch<XVEC>(xb_base, K) : xa;
     uint32_t u = 4 * w + row; // this row's unit in step 0
+    const XDirect xd{xa_row, xb_base, (XD && PRO && blockIdx.x == 0 && blockIdx.y == 0) ? a.pro.store_x : nullptr, K};
     Group cur;
-    cur.load(qs, sc, u, stride, u_last);
-    QMV_STAMP(1); // loads issued
-    float inv = 1.0f;
-    if (PRO && a.pro.kind == QMV_PRO_RMSNORM_MUL) {
-        const float ss = block_sumsq(xa, K, red);
-        inv = 1.0f / sqrtf(ss / (float)K + a.pro.eps); // reference.zig:365
+    if (XD) { // XD with PRO means the MUL prologue (the host never pairs XD with the rmsnorm one)
+        cur.load(qs, sc, u, stride, u_last, xd, i);
+    } else {
+        const XRegs xa = x_fetch<XVEC>(xa_row, K);
+        const XRegs xb = PRO ? x_fetch<XVEC>(xb_base, K) : xa;
+        cur.load(qs, sc, u, stride, u_last, xd, i);
+        QMV_STAMP(1); // loads issued
+        float inv = 1.0f;
+        if (PRO && a.pro.kind == QMV_PRO_RMSNORM_MUL) {
+            const float ss = block_sumsq(xa, K, red);
+            inv = 1.0f / sqrtf(ss / (float)K + a.pro.eps); // reference.zig:365
+        }
+        QMV_STAMP(2); // x arrived (+ sum of squares)
+        x_commit<XVEC, PRO>(xs, xa, xb, a.pro, inv, U * UNIT_X, K, xa_row);
+        __syncthreads();
+        QMV_STAMP(3); // x staged
     }
-    QMV_STAMP(2); // x arrived (+ sum of squares)
-    x_commit<XVEC, PRO>(xs, xa, xb, a.pro, inv, U * UNIT_X, K, xa_row);
-    __syncthreads();
-    QMV_STAMP(3); // x staged
 
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
     for (uint32_t gi = 1; gi < n_groups; gi++) {
         Group nxt;
-        nxt.load(qs, sc, u + DEPTH * stride, stride, u_last);
-        cur.compute(xs, u, stride, U, i, acc0, acc1, acc2, acc3);
+        nxt.load(qs, sc, u + DEPTH * stride, stride, u_last, xd, i);
+        cur.compute(xs, u, stride, U, i, acc0, acc1, acc2, acc3, xd);
         cur = nxt;
         u += DEPTH * stride;
     }
-    cur.compute(xs, u, stride, U, i, acc0, acc1, acc2, acc3);
+    cur.compute(xs, u, stride, U, i, acc0, acc1, acc2, acc3, xd);
     QMV_STAMP(4); // weights streamed
     reduce_store<GROUPED>((acc0 + acc1) + (acc2 + acc3), red, a, pi, out, out_rs, g, m);
     QMV_STAMP(5);
@@ -851,37 +900,41 @@ uint32_t qmv_waves(const QWeightDev& w, uint32_t total_blocks = 0) {
 
 using KernelFn = void (*)(QMV_HEAD_PARAMS, QMVArgs);
 
-template <typename ST, bool XV, bool Q, bool PRO, bool GRP>
+template <typename ST, bool XV, bool Q, bool PRO, bool GRP, bool XD>
 KernelFn pick_depth(int depth_sel) {
     switch (depth_sel) {
-        case 0: return qmatvec_kernel<ST, XV, 1, Q, PRO, GRP>;
-        case 1: return qmatvec_kernel<ST, XV, 2, Q, PRO, GRP>;
-        default: return qmatvec_kernel<ST, XV, 4, Q, PRO, GRP>;
+        case 0: return qmatvec_kernel<ST, XV, 1, Q, PRO, GRP, XD>;
+        case 1: return qmatvec_kernel<ST, XV, 2, Q, PRO, GRP, XD>;
+        default: return qmatvec_kernel<ST, XV, 4, Q, PRO, GRP, XD>;
     }
 }
-template <typename ST, bool XV, bool Q>
+template <typename ST, bool XV, bool Q, bool XD>
 KernelFn pick_mode(bool pro, bool grp, int depth_sel) {
-    if (pro) return grp ? pick_depth<ST, XV, Q, true, true>(depth_sel) : pick_depth<ST, XV, Q, true, false>(depth_sel);
-    return grp ? pick_depth<ST, XV, Q, false, true>(depth_sel) : pick_depth<ST, XV, Q, false, false>(depth_sel);
+    if (pro) return grp ? pick_depth<ST, XV, Q, true, true, XD>(depth_sel) : pick_depth<ST, XV, Q, true, false, XD>(depth_sel);
+    return grp ? pick_depth<ST, XV, Q, false, true, XD>(depth_sel) : pick_depth<ST, XV, Q, false, false, XD>(depth_sel);
 }
 template <typename ST>
-KernelFn pick_kernel(bool xvec, bool q4, bool pro, bool grp, int depth_sel) {
-    if (xvec) return q4 ? pick_mode<ST, true, true>(pro, grp, depth_sel) : pick_mode<ST, true, false>(pro, grp, depth_sel);
-    return q4 ? pick_mode<ST, false, true>(pro, grp, depth_sel) : pick_mode<ST, false, false>(pro, grp, depth_sel);
+KernelFn pick_kernel(bool xvec, bool q4, bool pro, bool grp, int depth_sel, bool xd) {
+    if (xd) return q4 ? pick_mode<ST, false, true, true>(pro, grp, depth_sel) : pick_mode<ST, false, false, true>(pro, grp, depth_sel);
+    if (xvec) return q4 ? pick_mode<ST, true, true, false>(pro, grp, depth_sel) : pick_mode<ST, true, false, false>(pro, grp, depth_sel);
+    return q4 ? pick_mode<ST, false, true, false>(pro, grp, depth_sel) : pick_mode<ST, false, false, false>(pro, grp, depth_sel);
 }
 
 void launch_packed(hipStream_t s, QMVArgs& a, const QWeightDev& w0, uint32_t total_blocks, uint32_t M, bool xvec) {
     const bool q4 = w0.format == QW_Q4;
+    // x direct (no LDS staging) unless the prologue needs the whole vector first (rmsnorm)
+    static const bool xd_enabled = !(getenv("ZGML_QMV_XDIRECT") && atoi(getenv("ZGML_QMV_XDIRECT")) == 0);
+    const bool xd = xd_enabled && a.pro.kind != QMV_PRO_RMSNORM_MUL;
     uint32_t waves = qmv_waves(w0, total_blocks);
-    if (a.pro.kind != QMV_PRO_NONE) // a prologue keeps all of x in the register window: 16 floats per thread
+    if (!xd && a.pro.kind != QMV_PRO_NONE) // a staged prologue keeps all of x in the register window: 16 floats per thread
         while (waves < (uint32_t)kMaxWaves && waves * 64 * 4 * kXRegs < a.K) waves++;
     dim3 grid(total_blocks, M);
-    const size_t lds = qmv_lds_bytes(w0);
+    const size_t lds = xd ? (size_t)kMaxWaves * 16 * sizeof(float) : qmv_lds_bytes(w0);
     const uint32_t n_steps = cdiv(a.U, waves * 4);
     const int depth_sel = n_steps >= 4 ? 2 : (n_steps >= 2 ? 1 : 0); // DEPTH 4 / 2 / 1
     const bool pro = a.pro.kind != QMV_PRO_NONE, grp = a.n_parts > 1;
-    const KernelFn fn = w0.scale_f16 ? pick_kernel<__half>(xvec, q4, pro, grp, depth_sel)
-                                     : pick_kernel<float>(xvec, q4, pro, grp, depth_sel);
+    const KernelFn fn = w0.scale_f16 ? pick_kernel<__half>(xvec, q4, pro, grp, depth_sel, xd)
+                                     : pick_kernel<float>(xvec, q4, pro, grp, depth_sel, xd);
     if (lds > 64 * 1024) // > 64 KiB of dynamic LDS needs an explicit opt-in per kernel (idempotent)
         hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
     hipLaunchKernelGGL(fn, grid, dim3(waves * 64), lds, s, a.parts[0].qs, a.parts[0].sc, a.parts[0].out, a.pro.a, a.pro.b, a.U, a.K,
