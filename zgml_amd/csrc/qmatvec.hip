@@ -133,6 +133,7 @@ struct QMVArgs {
     uint32_t M, K;
     uint32_t U;      // k-units per column group (Q4: KC, Q8: 2*KC)
     uint32_t in_rs;
+    uint32_t x_vec; // x rows are 16-byte aligned and K % 4 == 0
     unsigned long long* trace; // diagnostics: stamps of workgroup (0,0), else nullptr
 };
 
@@ -323,9 +324,63 @@ __device__ __forceinline__ void reduce_store(float acc, float* red, const QMVArg
 struct XDirect {
     const float* a;
     const float* b;
-    float* store_x; // nullptr unless this workgroup owns the prologue's side output
+    float* store_x;   // nullptr unless this workgroup owns the prologue's side outputs
+    float* store_mid; // rmsnorm prologue: the normalised vector before the gain
     uint32_t K;
+    float inv;        // rmsnorm factor (norm == true)
+    bool norm;
+    // x of one k under the prologue: a * b, or (a * inv) * b for rmsnorm -> repeat(gamma) -> mul
+    __device__ __forceinline__ float pro_value(float av, float bv, uint32_t k, bool live) const {
+        float v = av;
+        if (norm) {
+            v = av * inv;
+            if (store_mid && live) store_mid[k] = v;
+        }
+        v = v * bv;
+        if (store_x && live) store_x[k] = v;
+        return v;
+    }
 };
+
+// sum of squares of x[0, K) over the whole workgroup, fixed order. `vec`: x is 16-byte aligned and
+// K % 4 == 0 (host-checked), then 4 float4 loads per thread are in flight per batch of 16*T
+// elements (one batch for K <= 4096 with 4 waves); else coalesced dword loads, 4 in flight.
+__device__ __forceinline__ float block_sumsq_direct(const float* x, uint32_t K, float* red, bool vec) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const uint32_t T = blockDim.x;
+    if (vec) {
+        for (uint32_t k = 4 * threadIdx.x; k < K; k += 16 * T) {
+            const uint32_t k1 = k + 4 * T, k2 = k + 8 * T, k3 = k + 12 * T;
+            const float4 v0 = *(const float4*)(x + k), v1 = *(const float4*)(x + (k1 < K ? k1 : 0)),
+                         v2 = *(const float4*)(x + (k2 < K ? k2 : 0)), v3 = *(const float4*)(x + (k3 < K ? k3 : 0));
+            s0 += (v0.x * v0.x + v0.y * v0.y) + (v0.z * v0.z + v0.w * v0.w);
+            s1 += k1 < K ? (v1.x * v1.x + v1.y * v1.y) + (v1.z * v1.z + v1.w * v1.w) : 0.f;
+            s2 += k2 < K ? (v2.x * v2.x + v2.y * v2.y) + (v2.z * v2.z + v2.w * v2.w) : 0.f;
+            s3 += k3 < K ? (v3.x * v3.x + v3.y * v3.y) + (v3.z * v3.z + v3.w * v3.w) : 0.f;
+        }
+    } else {
+        for (uint32_t k = threadIdx.x; k < K; k += 4 * T) {
+            const float v0 = x[k], v1 = x[min(k + T, K - 1)], v2 = x[min(k + 2 * T, K - 1)], v3 = x[min(k + 3 * T, K - 1)];
+            s0 += v0 * v0;
+            s1 += k + T < K ? v1 * v1 : 0.f;
+            s2 += k + 2 * T < K ? v2 * v2 : 0.f;
+            s3 += k + 3 * T < K ? v3 * v3 : 0.f;
+        }
+    }
+    float ss = (s0 + s1) + (s2 + s3);
+    ss += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(ss), 0xB1, 0xF, 0xF, true));
+    ss += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(ss), 0x4E, 0xF, 0xF, true));
+    ss += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(ss), 0x141, 0xF, 0xF, true));
+    ss += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(ss), 0x140, 0xF, 0xF, true));
+    ss += __shfl_xor(ss, 16, 64);
+    ss += __shfl_xor(ss, 32, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    float t = 0.f;
+    for (uint32_t w = 0; w < (blockDim.x >> 6); w++) t += red[w];
+    __syncthreads();
+    return t;
+}
 
 template <typename ST, int DEPTH, bool XD, bool PROMUL>
 struct Q4Group {
@@ -356,12 +411,9 @@ struct Q4Group {
             float va, vb;
             if (XD) {
                 const uint32_t ka = ud * 32 + i, kb = ka + 16;
-                va = PROMUL ? xa[d] * ya[d] : xa[d], vb = PROMUL ? xb[d] * yb[d] : xb[d];
+                va = PROMUL ? xd.pro_value(xa[d], ya[d], ka, ok && ka < xd.K) : xa[d];
+                vb = PROMUL ? xd.pro_value(xb[d], yb[d], kb, ok && kb < xd.K) : xb[d];
                 va = ka < xd.K ? va : 0.f, vb = kb < xd.K ? vb : 0.f;
-                if (PROMUL && xd.store_x && ok) {
-                    if (ka < xd.K) xd.store_x[ka] = va;
-                    if (kb < xd.K) xd.store_x[kb] = vb;
-                }
             } else {
                 va = xs[uc * 32 + i], vb = xs[uc * 32 + 16 + i];
             }
@@ -407,9 +459,8 @@ struct Q8Group {
             float va;
             if (XD) {
                 const uint32_t ka = ud * 16 + i;
-                va = PROMUL ? xa[d] * ya[d] : xa[d];
+                va = PROMUL ? xd.pro_value(xa[d], ya[d], ka, ok && ka < xd.K) : xa[d];
                 va = ka < xd.K ? va : 0.f;
-                if (PROMUL && xd.store_x && ok && ka < xd.K) xd.store_x[ka] = va;
             } else {
                 va = xs[min(ud, U - 1) * 16 + i];
             }
@@ -478,10 +529,16 @@ __global__ void __launch_bounds__(1024) qmatvec_kernel(QMV_HEAD_PARAMS, QMVArgs 
 
     const float* xa_row = xa_base + (uint64_t)m * in_rs;
     uint32_t u = 4 * w + row; // this row's unit in step 0
-    const XDirect xd{xa_row, xb_base, (XD && PRO && blockIdx.x == 0 && blockIdx.y == 0) ? a.pro.store_x : nullptr, K};
+    const bool pro_owner = XD && PRO && blockIdx.x == 0 && blockIdx.y == 0;
+    XDirect xd{xa_row, xb_base, pro_owner ? a.pro.store_x : nullptr, pro_owner ? a.pro.store_mid : nullptr, K, 1.0f, false};
     Group cur;
-    if (XD) { // XD with PRO means the MUL prologue (the host never pairs XD with the rmsnorm one)
+    if (XD) {
         cur.load(qs, sc, u, stride, u_last, xd, i);
+        if (PRO && a.pro.kind == QMV_PRO_RMSNORM_MUL) { // the weights are in flight while the vector is reduced
+            const float ss = block_sumsq_direct(xa_row, K, red, a.x_vec != 0);
+            xd.inv = 1.0f / sqrtf(ss / (float)K + a.pro.eps); // reference.zig:365
+            xd.norm = true;
+        }
     } else {
         const XRegs xa = x_fetch<XVEC>(xa_row, K);
         const XRegs xb = PRO ? x_fetch<XVEC>(xb_base, K) : xa;
@@ -922,9 +979,13 @@ KernelFn pick_kernel(bool xvec, bool q4, bool pro, bool grp, int depth_sel, bool
 
 void launch_packed(hipStream_t s, QMVArgs& a, const QWeightDev& w0, uint32_t total_blocks, uint32_t M, bool xvec) {
     const bool q4 = w0.format == QW_Q4;
-    // x direct (no LDS staging) unless the prologue needs the whole vector first (rmsnorm)
+    a.x_vec = xvec ? 1 : 0;
+    // x direct (no LDS staging); the rmsnorm prologue reduces the vector while the weights fly
     static const bool xd_enabled = !(getenv("ZGML_QMV_XDIRECT") && atoi(getenv("ZGML_QMV_XDIRECT")) == 0);
-    const bool xd = xd_enabled && a.pro.kind != QMV_PRO_RMSNORM_MUL;
+    static const bool xd_norm = !(getenv("ZGML_QMV_XDIRECT_NORM") && atoi(getenv("ZGML_QMV_XDIRECT_NORM")) == 0);
+    // (measured: with the rmsnorm prologue the extra per-lane dword loads of x and gamma cost more than the
+    // LDS round trip they replace once K is large: Llama-2-7B -5 %, SmolLM-135M +2.7 %)
+    const bool xd = xd_enabled && (a.pro.kind != QMV_PRO_RMSNORM_MUL || (xd_norm && a.K <= 2048));
     uint32_t waves = qmv_waves(w0, total_blocks);
     if (!xd && a.pro.kind != QMV_PRO_NONE) // a staged prologue keeps all of x in the register window: 16 floats per thread
         while (waves < (uint32_t)kMaxWaves && waves * 64 * 4 * kXRegs < a.K) waves++;
