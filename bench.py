@@ -152,6 +152,37 @@ def bench_single(args):
     print(json.dumps(out), flush=True)
 
 
+def prefill_leg(be, llama, kind, T=32, reps=8, max_seq=512):
+    """BASELINE configs[4]: Llama-2-7B prefill of one token_len = 32 chunk, Q4_0 (f32-MFMA tile kernel over the
+    packed 4-bit weights) or dense f16 (weights promoted to f16, v_mfma_f32_16x16x32_f16). Timed region:
+    resident replays of the chunk's program (inputs already in HBM), HIP work only."""
+    import numpy as np
+    from zgml_amd import capi
+    dense = kind == "f16"
+    be.set_option(capi.OPT_F16_DENSE_WEIGHTS, int(dense))
+    try:
+        t0 = time.perf_counter()
+        m = llama.Model(llama.preset("llama2-7b", max_seq), llama.F32_DENSE if dense else llama.Q4_0, threads=16, token_len=T)
+        s = llama.Session(m, llama.hip_backend_fns(be))
+        build_s = time.perf_counter() - t0
+        toks = [(7 * i + 3) % m.cfg.vocab_size for i in range(T)]
+        nxt, logits = s.prefill(toks, 0)  # through the vtable once (uploads + logits download)
+        finite = bool(np.isfinite(logits).all())
+        be._lib.zgml_hip_enqueue_program(be.ctx, s.handle)
+        be.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            be._lib.zgml_hip_enqueue_program(be.ctx, s.handle)
+        be.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        s.close()
+        m.close()
+        return {"prefill_tok_s": round(T / dt, 1), "ms_per_chunk": round(dt * 1e3, 3), "token_len": T, "first_token": int(nxt),
+                "logits_finite": finite, "build_s": round(build_s, 1)}
+    finally:
+        be.set_option(capi.OPT_F16_DENSE_WEIGHTS, 0)
+
+
 def bench_llama7b_single(be, llama, args):
     cfg = llama.preset("llama2-7b", 2048)
     t0 = time.perf_counter()
@@ -170,7 +201,15 @@ def bench_llama7b_single(be, llama, args):
     sess.close()
     model.close()
     tok_s = K / dt
-    return {"tok_s": round(tok_s, 1), "ms_per_token": round(1e3 * dt / K, 3), "steps": K, "build_s": round(build_s, 1),
+    prefill = {}
+    if not args.skip_prefill:
+        for kind in ("q4_0", "f16"):
+            try:
+                prefill[kind] = prefill_leg(be, llama, kind)
+            except Exception as e:
+                prefill[kind] = {"error": str(e)[:200]}
+        prefill["workload"] = "Llama-2-7B prefill, one chunk of 32 tokens, Q4_0 vs dense f16 (BASELINE configs[4])"
+    return {"prefill_batch32": prefill, "tok_s": round(tok_s, 1), "ms_per_token": round(1e3 * dt / K, 3), "steps": K, "build_s": round(build_s, 1),
             "q4_0_weight_bytes": qb, "weight_stream_GBps": round(qb * tok_s / 1e9, 1),
             "frac_of_hbm_peak": round(qb * tok_s / 1e9 / HBM_PEAK_GBPS, 4),
             "workload": "Llama-2-7B Q4_0 greedy decode, batch 1, 1xMI355X (BASELINE configs[2])"}
@@ -257,6 +296,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--skip-cpu", action="store_true", help="omit the cpu_baseline leg")
     ap.add_argument("--skip-llama7b", action="store_true", help="omit the Llama-2-7B @ 1 GPU extra leg")
+    ap.add_argument("--skip-prefill", action="store_true", help="omit the Llama-2-7B prefill (configs[4]) leg")
     args = ap.parse_args()
     if not (ROOT / "zgml_amd" / "lib" / "libzgml_hip.so").exists():
         import __graft_entry__ as g
