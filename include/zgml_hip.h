@@ -206,7 +206,20 @@ typedef struct zgml_program_io {
 } zgml_program_io;
 
 /* QuantizedWeightUpload, src/backend.zig:260-266: int8 data in flat [K,N] row-major order
- * (index k*N+n), one f32 scale per `block_size` consecutive FLAT elements. */
+ * (index k*N+n), one f32 scale per `block_size` consecutive FLAT elements.
+ *
+ * Extension (no reference counterpart yet): the packed-GGUF pass-through form. With
+ * `scales == NULL && scales_len == 0 && block_size == 32`, `data` holds the tensor's GGUF blocks exactly
+ * as they sit in the file — block b covers flat elements [32b, 32b+32) —
+ *     data_len == rows*cols/32 * 18  ->  Q4_0 blocks {f16 scale, 16 bytes}; element j of the block is the
+ *                                        low (j even) / high (j odd) nibble of byte j/2, value = nibble - 8
+ *                                        — the reference loader's interleaved order (gguf_loader.zig:137-141)
+ *     data_len == rows*cols/32 * 34  ->  Q8_0 blocks {f16 scale, 32 int8}
+ * i.e. what quantizedWeightFromInfo (src/models/gguf_loader.zig:99-154) expands on the host; here the
+ * expansion and the re-pack happen on the device and half (Q4_0) of the bytes cross PCIe.
+ * Requires rows*cols % 32 == 0 and cols % 32 == 0. */
+#define ZGML_QW_GGUF_Q4_0_BLOCK_BYTES 18
+#define ZGML_QW_GGUF_Q8_0_BLOCK_BYTES 34
 typedef struct zgml_qweight_upload {
     const int8_t* data;
     uint64_t data_len;

@@ -609,6 +609,18 @@ void zo_execute_ops(const zo_buffer* buffers, const zo_qweight* qweights, const 
 
 /* ───────────────────────────── compiled program (CpuBackend) ───────────────────────────── */
 
+void zo_gguf_q4_0_to_int8(const uint8_t* raw, uint64_t n_elems, int8_t* data, float* scales);
+void zo_gguf_q8_0_to_int8(const uint8_t* raw, uint64_t n_elems, int8_t* data, float* scales);
+/* packed-GGUF pass-through form of a QuantizedWeightUpload (include/zgml_hip.h): 1 = Q4_0, 2 = Q8_0 */
+static int zo_gguf_form(const zgml_qweight_upload* qw) {
+    if (qw->scales || qw->scales_len || qw->block_size != 32 || !qw->data) return 0;
+    const uint64_t n = qw->rows * qw->cols;
+    if (!n || n % 32) return 0;
+    if (qw->data_len == n / 32 * 18) return 1;
+    if (qw->data_len == n / 32 * 34) return 2;
+    return 0;
+}
+
 struct zo_program {
     uint64_t n_buffers;
     zo_buffer* buffers;
@@ -680,6 +692,20 @@ zo_program* zo_compile_program(const zgml_device_program* prog) {
     p->q_scales = (float**)calloc(p->n_qweights ? p->n_qweights : 1, sizeof(float*));
     for (uint64_t i = 0; i < p->n_qweights; i++) {
         const zgml_qweight_upload* qw = &prog->qweights[i];
+        const int form = zo_gguf_form(qw);
+        if (form) { /* packed pass-through: what the loader would have expanded (gguf_loader.zig:99-154) */
+            const uint64_t n = qw->rows * qw->cols;
+            p->q_data[i] = (int8_t*)malloc(n);
+            p->q_scales[i] = (float*)malloc(sizeof(float) * (n / 32));
+            if (form == 1)
+                zo_gguf_q4_0_to_int8((const uint8_t*)qw->data, n, p->q_data[i], p->q_scales[i]);
+            else
+                zo_gguf_q8_0_to_int8((const uint8_t*)qw->data, n, p->q_data[i], p->q_scales[i]);
+            p->qweights[i].data = p->q_data[i];
+            p->qweights[i].scales = p->q_scales[i];
+            p->qweights[i].block_size = 32;
+            continue;
+        }
         p->q_data[i] = (int8_t*)malloc(qw->data_len ? qw->data_len : 1);
         memcpy(p->q_data[i], qw->data, qw->data_len);
         p->q_scales[i] = (float*)malloc(sizeof(float) * (qw->scales_len ? qw->scales_len : 1));
@@ -782,6 +808,7 @@ int zo_program_supported(const zgml_device_program* pr, int fused_elementwise, i
                 if (qw->rows != q->K || qw->cols != q->N) return 0;
                 uint64_t n_elems = (uint64_t)q->K * q->N;
                 uint64_t n_blocks = (n_elems + qw->block_size - 1) / qw->block_size;
+                if (zo_gguf_form(qw)) break; /* packed-GGUF pass-through (include/zgml_hip.h) */
                 if (qw->data_len < n_elems || qw->scales_len < n_blocks) return 0;
                 break;
             }

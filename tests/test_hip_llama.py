@@ -149,3 +149,23 @@ def test_dense_model_f32_and_f16_promoted(hip_backend, oracle, T, promote):
     finally:
         hip_backend.set_option(capi.OPT_F16_DENSE_WEIGHTS, 0)
         oracle.set_f16_dense(False)
+
+
+def test_gguf_block_model_equals_expanded_model(hip_backend, oracle):
+    """the model handed over as raw Q4_0 file blocks (packed pass-through) decodes
+    bit-identically to the same model uploaded in the reference's expanded int8 + f32-scale form."""
+    cfg = llama.preset("tiny")
+    ma, mb = llama.Model(cfg, llama.Q4_0), llama.Model(cfg, llama.Q4_0_GGUF)
+    sa, sb = llama.Session(ma, llama.hip_backend_fns(hip_backend)), llama.Session(mb, llama.hip_backend_fns(hip_backend))
+    so = llama.Session(mb, oracle.backend_fns())  # the oracle expands the blocks with the loader restatement
+    tok = 3
+    for pos in range(6):
+        ta, la = sa.step(tok, pos)
+        tb, lb = sb.step(tok, pos)
+        to, lo = so.step(tok, pos)
+        assert np.array_equal(la, lb) and ta == tb == to
+        assert np.abs(lb - lo).max() / np.abs(lo).max() < 2e-4
+        tok = ta
+    for s in (sa, sb, so):
+        s.close()
+    ma.close(), mb.close()

@@ -246,3 +246,24 @@ def test_f16_promotion_known_answer_and_rounding():
         assert O.run_program(prog, 2, 1)[0] == f32(3.0)
     finally:
         O.set_f16_dense(False)
+
+
+def test_oracle_accepts_packed_gguf_upload():
+    """The packed-GGUF pass-through form (include/zgml_hip.h) runs through the oracle's CpuBackend
+    restatement with the loader's expansion, and equals the expanded upload bit for bit."""
+    from zgml_amd import DeviceOp, DeviceProgram, ProgramIO, QuantizedWeightUpload
+    from oracle import oracle as O
+    from tests.synth import q4_0_blocks_from_int8
+    rng = np.random.default_rng(3)
+    K, N = 64, 32
+    data = rng.integers(-8, 8, K * N).astype(np.int8)
+    scales = (rng.random(K * N // 32).astype(np.float16) * 0.1 + 0.01).astype(np.float32)
+    raw = q4_0_blocks_from_int8(data, scales)
+    x = rng.standard_normal(K).astype(np.float32)
+
+    def program(qw):
+        return DeviceProgram(ops=[DeviceOp.qmatmul(1, 0, 0, 1, N, K)], buffer_sizes=[K, N],
+                             initial_uploads=[ProgramIO(0, x)], qweights=[qw])
+    a = O.run_program(program(QuantizedWeightUpload(data, scales, K, N, 32)), 1, N)
+    b = O.run_program(program(QuantizedWeightUpload.from_gguf_blocks(raw, K, N, "q4_0")), 1, N)
+    assert np.array_equal(a, b) and np.abs(a).max() > 0

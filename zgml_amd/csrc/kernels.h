@@ -223,6 +223,8 @@ void launch_f32_to_f16(hipStream_t s, void* dst, const float* src, uint64_t n);
 // bit1 = all scales exactly representable in f16.
 uint32_t classify_qweight(hipStream_t s, const int8_t* raw_data, uint64_t n_elems, const float* raw_scales,
                           uint64_t n_blocks, uint32_t* flag_scratch /* 2 device words */);
+// GGUF Q4_0 / Q8_0 blocks (device copy of the file bytes) -> packed layout; out.format selects which.
+void launch_pack_gguf(hipStream_t s, const uint8_t* raw_blocks, const QWeightDev& out);
 // True when (K, N, block size) can use the packed fast path (else QW_RAW).
 bool qweight_packable(uint64_t K, uint64_t N, uint64_t bs);
 void packed_bytes(QWFormat format, uint32_t scale_f16, uint64_t K, uint64_t N, uint64_t* qs_bytes,

@@ -874,6 +874,29 @@ struct RawSrc { // QuantizedWeightUpload as uploaded: int8 [K,N] + one f32 scale
     __device__ float scale(uint32_t k, uint32_t j, uint32_t NB) const { return scales[(uint64_t)k * NB + j]; }
 };
 
+struct GgufSrc { // GGUF Q4_0 / Q8_0 blocks over the flat [K,N] order (gguf_loader.zig:118-151)
+    const uint8_t* raw;
+    uint32_t N;
+    bool q4;
+    __device__ int q(uint32_t k, uint32_t n) const {
+        const uint64_t flat = (uint64_t)k * N + n, blk = flat >> 5;
+        const uint32_t j = flat & 31;
+        if (q4) {
+            const uint8_t b = raw[blk * 18 + 2 + (j >> 1)]; // the reference's interleaved order (F3): elem 2i low, 2i+1 high
+            return (int)((j & 1) ? (b >> 4) : (b & 15)) - 8;
+        }
+        return (int)(int8_t)raw[blk * 34 + 2 + j];
+    }
+    __device__ float scale(uint32_t k, uint32_t j, uint32_t NB) const {
+        const uint8_t* b = raw + ((uint64_t)k * NB + j) * (q4 ? 18 : 34);
+        return __half2float(__ushort_as_half((unsigned short)(b[0] | (b[1] << 8))));
+    }
+};
+
+__global__ void __launch_bounds__(kBlock) pack_gguf_kernel(const uint8_t* __restrict__ raw, QWeightDev w) {
+    write_packed<__half>(w, GgufSrc{raw, w.N, w.format == QW_Q4}); // GGUF scales are f16: always exact
+}
+
 template <typename ST>
 __global__ void __launch_bounds__(kBlock) synth_packed_kernel(QWeightDev w, uint32_t id) {
     write_packed<ST>(w, SynthSrc{w.N, id, w.format == QW_Q4});
@@ -921,6 +944,10 @@ void launch_pack_qweight(hipStream_t s, const int8_t* raw_data, const float* raw
         pack_kernel<__half><<<2048, kBlock, 0, s>>>(raw_data, raw_scales, out);
     else
         pack_kernel<float><<<2048, kBlock, 0, s>>>(raw_data, raw_scales, out);
+}
+
+void launch_pack_gguf(hipStream_t s, const uint8_t* raw_blocks, const QWeightDev& out) {
+    pack_gguf_kernel<<<2048, kBlock, 0, s>>>(raw_blocks, out);
 }
 
 uint64_t qmatmul_scratch_bytes(const QWeightDev&, uint32_t) { return 0; } // single launch: no split-K slabs

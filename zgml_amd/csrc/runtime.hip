@@ -158,6 +158,16 @@ void fill_caps(zgml_capabilities* c) {
     c->attention_max_d_head = 512;
 }
 
+// packed-GGUF pass-through (include/zgml_hip.h): 0 = reference form, 1 = Q4_0 blocks, 2 = Q8_0 blocks
+int gguf_form(const zgml_qweight_upload& qw) {
+    if (qw.scales || qw.scales_len || qw.block_size != 32 || !qw.data) return 0;
+    const uint64_t n = qw.rows * qw.cols;
+    if (!n || n % 32 || qw.cols % 32 || !qweight_packable(qw.rows, qw.cols, 32)) return 0;
+    if (qw.data_len == n / 32 * ZGML_QW_GGUF_Q4_0_BLOCK_BYTES) return 1;
+    if (qw.data_len == n / 32 * ZGML_QW_GGUF_Q8_0_BLOCK_BYTES) return 2;
+    return 0;
+}
+
 bool elementwise_op_ok(uint32_t op) { return op >= ZGML_OP_ADD && op <= ZGML_OP_GELU; }
 
 // buffer ids an op touches (opBuffersValid, src/backend.zig:303-325)
@@ -216,6 +226,7 @@ bool program_supported(const zgml_device_program* pr) {
                 if (qw.rows != q.K || qw.cols != q.N) return false;
                 const uint64_t n_elems = (uint64_t)q.K * q.N;
                 const uint64_t n_blocks = (n_elems + qw.block_size - 1) / qw.block_size;
+                if (gguf_form(qw)) break; // packed-GGUF pass-through, validated by gguf_form()
                 if (qw.data_len < n_elems || qw.scales_len < n_blocks) return false;
                 break;
             }
@@ -1738,6 +1749,24 @@ zgml_hip_program* zgml_hip_compile_program(zgml_hip_ctx* ctx, const zgml_device_
         w.K = (uint32_t)qw.rows, w.N = (uint32_t)qw.cols, w.bs = (uint32_t)qw.block_size;
         const uint64_t n_elems = qw.rows * qw.cols;
         const uint64_t n_blocks = (n_elems + qw.block_size - 1) / qw.block_size;
+        if (const int form = gguf_form(qw)) { // file blocks straight to the device, unpacked + re-packed there
+            uint8_t* raw = nullptr;
+            w.format = form == 1 ? QW_Q4 : QW_Q8;
+            w.scale_f16 = 1;
+            w.KC = (uint32_t)((qw.rows + 31) / 32);
+            packed_bytes(w.format, 1, w.K, w.N, &w.qs_bytes, &w.sc_bytes);
+            ok = CTX_CHECK(ctx, hipMalloc((void**)&raw, qw.data_len)) &&
+                 CTX_CHECK(ctx, hipMemcpyAsync(raw, qw.data, qw.data_len, hipMemcpyHostToDevice, ctx->stream)) &&
+                 CTX_CHECK(ctx, hipMalloc(&w.qs, w.qs_bytes)) && CTX_CHECK(ctx, hipMalloc(&w.sc, w.sc_bytes));
+            if (ok) {
+                p->owned.push_back(w.qs);
+                p->owned.push_back(w.sc);
+                launch_pack_gguf(ctx->stream, raw, w);
+                ok = CTX_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            }
+            hipFree(raw);
+            continue;
+        }
         int8_t* raw_d = nullptr;
         float* raw_s = nullptr;
         ok = CTX_CHECK(ctx, hipMalloc((void**)&raw_d, n_elems ? n_elems : 1)) &&

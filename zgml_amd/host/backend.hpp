@@ -198,6 +198,17 @@ struct QuantizedWeightUpload {
     const float* scales = nullptr;
     size_t scales_len = 0;
     size_t rows = 0, cols = 0, block_size = 0;
+    // Packed-GGUF pass-through (include/zgml_hip.h): the tensor's Q4_0 (18-byte) or
+    // Q8_0 (34-byte) file blocks over the flat [K,N] order, no host expansion. 0 = reference form.
+    static QuantizedWeightUpload ggufBlocks(const uint8_t* blocks, size_t n_bytes, size_t rows, size_t cols) {
+        return {reinterpret_cast<const int8_t*>(blocks), n_bytes, nullptr, 0, rows, cols, 32};
+    }
+    int ggufForm() const {
+        if (scales || scales_len || block_size != 32 || !data) return 0;
+        const size_t n = rows * cols;
+        if (!n || n % 32 || cols % 32) return 0;
+        return data_len == n / 32 * ZGML_QW_GGUF_Q4_0_BLOCK_BYTES ? 1 : data_len == n / 32 * ZGML_QW_GGUF_Q8_0_BLOCK_BYTES ? 2 : 0;
+    }
 };
 
 struct DeviceProgram {
@@ -250,6 +261,7 @@ struct DeviceProgram {
                 if (qw.block_size == 0) return false;
                 if (qw.rows != q.K || qw.cols != q.N) return false;
                 const size_t n_elems = (size_t)q.K * q.N, n_blocks = (n_elems + qw.block_size - 1) / qw.block_size;
+                if (qw.ggufForm()) continue;
                 if (qw.data_len < n_elems || qw.scales_len < n_blocks) return false;
             }
         }

@@ -74,7 +74,8 @@ zh_model* zh_model_create_ex(const zh_config* cfg, int weight_kind, int fused_el
                               (c.d_ff / c.shard_world) % 32 || (c.vocab_size / c.shard_world) % 32 || c.d_ff % c.shard_world ||
                               c.vocab_size % c.shard_world))
         return nullptr; // shard slices must stay whole 32-column scale blocks
-    if ((WeightKind)weight_kind == WeightKind::f32_dense && c.shard_world > 1) return nullptr;
+    if (((WeightKind)weight_kind == WeightKind::f32_dense || (WeightKind)weight_kind == WeightKind::q4_0_gguf) && c.shard_world > 1)
+        return nullptr; // shard slices are cut from the int8 form
     if (token_len > 1 && c.shard_world > 1) return nullptr; // the row-shard driver is decode-only
     auto* m = new zh_model();
     m->model = make_synthetic_model(c, (WeightKind)weight_kind, threads);
@@ -129,7 +130,7 @@ uint64_t zh_model_quant_bytes(zh_model* m, uint64_t* n_weights) { // Q4_0/Q8_0 f
     for (const auto& q : m->model->qweights) elems += q.K * q.N;
     if (n_weights) *n_weights = elems;
     if (m->model->kind == WeightKind::f32_dense) return elems * 2; // f16-promoted bytes
-    return elems / 32 * (m->model->kind == WeightKind::q4_0 ? 18 : 34);
+    return elems / 32 * (m->model->kind == WeightKind::q8_0 ? 34 : 18);
 }
 
 zh_session* zh_session_create(zh_model* m, const zh_backend_fns* fns) {

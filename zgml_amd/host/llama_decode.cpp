@@ -61,10 +61,19 @@ float f16_round(float f) {
     return r;
 }
 
+// bits of an f16-exact f32 in the normal range (the generator's scales): truncation is exact
+inline uint16_t f32_to_f16_bits(float f) {
+    uint32_t x;
+    std::memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    const int32_t exp = (int32_t)((x >> 23) & 0xFF) - 127 + 15;
+    return (uint16_t)(sign | ((uint32_t)exp << 10) | ((x & 0x7FFFFF) >> 13));
+}
+
 // element (k, n_global) of weight `id` with full width N_full; Q4_0: stored nibble - 8 (values
 // in [-8,7], what quantizedWeightFromInfo's .q4_0 arm yields), Q8_0: int8.
 inline int8_t synth_q(uint64_t flat, uint32_t id, WeightKind kind) {
-    if (kind != WeightKind::q8_0) // dense models are the dequantised Q4_0 model
+    if (kind != WeightKind::q8_0) // dense and gguf-block models are the Q4_0 model in another form
         return (int8_t)((int)((flat * 7 + (flat >> 5) * 3 + (uint64_t)id * 5) & 15) - 8);
     return (int8_t)((int)((flat * 13 + (uint64_t)id * 29) % 255) - 127);
 }
@@ -151,6 +160,23 @@ std::unique_ptr<LlamaModel> make_synthetic_model(const LlamaConfig& cfg, WeightK
     if (!cfg.tied_lm_head) {
         auto [n0, nl] = shard(cfg.vocab_size);
         m->qweights.push_back(make_qweight(d, cfg.vocab_size, n0, nl, cfg.n_layers * 8, kind, threads));
+    }
+    if (kind == WeightKind::q4_0_gguf) { // the same model as 18-byte file blocks (gguf_loader.zig:118-141, interleaved nibbles)
+        for (auto& q : m->qweights) {
+            const size_t nb = q.K * q.N / 32;
+            q.gguf.resize(nb * 18);
+            parallel_rows(nb, threads, [&](size_t b0, size_t b1) {
+                for (size_t b = b0; b < b1; b++) {
+                    uint8_t* blk = q.gguf.data() + b * 18;
+                    const uint16_t h = f32_to_f16_bits(q.scales[b]);
+                    blk[0] = (uint8_t)(h & 0xFF), blk[1] = (uint8_t)(h >> 8);
+                    for (int j = 0; j < 16; j++)
+                        blk[2 + j] = (uint8_t)(((q.data[b * 32 + 2 * j] + 8) & 15) | (((q.data[b * 32 + 2 * j + 1] + 8) & 15) << 4));
+                }
+            });
+            std::vector<int8_t>().swap(q.data);
+            std::vector<float>().swap(q.scales);
+        }
     }
     if (kind == WeightKind::f32_dense) { // the same model, dequantised: f32 [K, N] per weight; int8 form dropped
         for (auto& q : m->qweights) {
@@ -256,9 +282,12 @@ std::unique_ptr<DecodeProgram> build_decode_program(const LlamaModel& model, boo
     dp.token_len = T;
 
     // quantized weight table (all borrowed from the model), or dense f32 weight leaves
-    for (const auto& qw : model.qweights)
-        if (model.kind != WeightKind::f32_dense)
+    for (const auto& qw : model.qweights) {
+        if (model.kind == WeightKind::q4_0_gguf)
+            dp.program.qweights.push_back(backend::QuantizedWeightUpload::ggufBlocks(qw.gguf.data(), qw.gguf.size(), qw.K, qw.N));
+        else if (model.kind != WeightKind::f32_dense)
             dp.program.qweights.push_back({qw.data.data(), qw.data.size(), qw.scales.data(), qw.scales.size(), qw.K, qw.N, 32});
+    }
     if (model.kind == WeightKind::f32_dense)
         for (const auto& w : model.dense) b.dense_buf.push_back(b.leaf(w));
 

@@ -41,11 +41,13 @@ LlamaConfig smollm_135m();               // benchmarks/llama_smollm_bench.zig:31
 LlamaConfig llama2_7b(uint32_t max_seq); // SURVEY §8(a) "L7"
 LlamaConfig tiny_test();                 // small GQA config for parity tests
 
-enum class WeightKind : int { q4_0 = 0, q8_0 = 1, f32_dense = 2 };
+// q4_0_gguf: the Q4_0 model handed over as raw 18-byte GGUF blocks (packed pass-through)
+enum class WeightKind : int { q4_0 = 0, q8_0 = 1, f32_dense = 2, q4_0_gguf = 3 };
 
 struct QWeightHost {
     std::vector<int8_t> data;
     std::vector<float> scales;
+    std::vector<uint8_t> gguf; // q4_0_gguf: the file blocks (data / scales dropped)
     size_t K = 0, N = 0; // rows, cols
 };
 

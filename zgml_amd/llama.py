@@ -11,7 +11,7 @@ import numpy as np
 
 from . import capi
 
-Q4_0, Q8_0, F32_DENSE = 0, 1, 2
+Q4_0, Q8_0, F32_DENSE, Q4_0_GGUF = 0, 1, 2, 3
 
 
 class Config(C.Structure):

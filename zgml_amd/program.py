@@ -239,6 +239,16 @@ class QuantizedWeightUpload:
     rows: int           # K
     cols: int           # N
     block_size: int = 32
+    # packed-GGUF pass-through (include/zgml_hip.h): `data` holds the raw uint8 file
+    # blocks (18 B Q4_0 / 34 B Q8_0 per 32 flat elements) and `scales` is empty
+    gguf: Optional[str] = None
+
+    @staticmethod
+    def from_gguf_blocks(raw: np.ndarray, rows: int, cols: int, kind: str) -> "QuantizedWeightUpload":
+        assert kind in ("q4_0", "q8_0") and (rows * cols) % 32 == 0
+        raw = np.ascontiguousarray(raw, dtype=np.uint8).ravel()
+        assert raw.size == rows * cols // 32 * (18 if kind == "q4_0" else 34)
+        return QuantizedWeightUpload(raw, np.zeros(0, np.float32), rows, cols, 32, gguf=kind)
 
 
 @dataclass
@@ -364,6 +374,10 @@ class DeviceProgram:
                     return False
                 n_elems = op.K * op.N
                 n_blocks = (n_elems + qw.block_size - 1) // qw.block_size
+                if qw.gguf is not None:
+                    if n_elems % 32 or op.N % 32 or qw.block_size != 32:
+                        return False
+                    continue
                 if qw.data.size < n_elems or qw.scales.size < n_blocks:
                     return False
         return True
@@ -376,11 +390,17 @@ class DeviceProgram:
         ups = ios_to_c(self.initial_uploads)
         qws = (capi.QWeightUploadC * max(1, len(self.qweights)))()
         for i, qw in enumerate(self.qweights):
-            d = np.ascontiguousarray(qw.data, dtype=np.int8)
-            s = np.ascontiguousarray(qw.scales, dtype=np.float32)
-            keep += [d, s]
-            qws[i].data, qws[i].data_len = d.ctypes.data, d.size
-            qws[i].scales, qws[i].scales_len = s.ctypes.data, s.size
+            if qw.gguf is not None:
+                d = np.ascontiguousarray(qw.data, dtype=np.uint8)
+                keep += [d]
+                qws[i].data, qws[i].data_len = d.ctypes.data, d.size
+                qws[i].scales, qws[i].scales_len = None, 0
+            else:
+                d = np.ascontiguousarray(qw.data, dtype=np.int8)
+                s = np.ascontiguousarray(qw.scales, dtype=np.float32)
+                keep += [d, s]
+                qws[i].data, qws[i].data_len = d.ctypes.data, d.size
+                qws[i].scales, qws[i].scales_len = s.ctypes.data, s.size
             qws[i].rows, qws[i].cols, qws[i].block_size = qw.rows, qw.cols, qw.block_size
         p = capi.DeviceProgramC()
         p.ops, p.n_ops = C.cast(ops_c, C.POINTER(capi.DeviceOpC)), len(self.ops)
