@@ -346,32 +346,48 @@ struct XDirect {
     }
 };
 
-// sum of squares of x[0, K) over the whole workgroup, fixed order. `vec`: x is 16-byte aligned and
-// K % 4 == 0 (host-checked), then 4 float4 loads per thread are in flight per batch of 16*T
-// elements (one batch for K <= 4096 with 4 waves); else coalesced dword loads, 4 in flight.
-__device__ __forceinline__ float block_sumsq_direct(const float* x, uint32_t K, float* red, bool vec) {
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+// sum of squares of x[0, K) over the whole workgroup, fixed order, in two halves so the kernel can
+// issue these loads BEFORE its weight loads (vmcnt is in order: loads issued after the weights would
+// make the reduction wait for the HBM stream). `vec`: x is 16-byte aligned and K % 4 == 0
+// (host-checked): 4 float4 per thread cover 16*T elements; else 4 dwords per thread cover 4*T.
+struct SumsqRegs {
+    float4 v[4];
+};
+__device__ __forceinline__ SumsqRegs sumsq_fetch(const float* x, uint32_t K, bool vec) {
+    SumsqRegs r;
     const uint32_t T = blockDim.x;
     if (vec) {
-        for (uint32_t k = 4 * threadIdx.x; k < K; k += 16 * T) {
-            const uint32_t k1 = k + 4 * T, k2 = k + 8 * T, k3 = k + 12 * T;
-            const float4 v0 = *(const float4*)(x + k), v1 = *(const float4*)(x + (k1 < K ? k1 : 0)),
-                         v2 = *(const float4*)(x + (k2 < K ? k2 : 0)), v3 = *(const float4*)(x + (k3 < K ? k3 : 0));
-            s0 += (v0.x * v0.x + v0.y * v0.y) + (v0.z * v0.z + v0.w * v0.w);
-            s1 += k1 < K ? (v1.x * v1.x + v1.y * v1.y) + (v1.z * v1.z + v1.w * v1.w) : 0.f;
-            s2 += k2 < K ? (v2.x * v2.x + v2.y * v2.y) + (v2.z * v2.z + v2.w * v2.w) : 0.f;
-            s3 += k3 < K ? (v3.x * v3.x + v3.y * v3.y) + (v3.z * v3.z + v3.w * v3.w) : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t k = 4 * (threadIdx.x + j * T);
+            r.v[j] = *(const float4*)(x + (k < K ? k : 0));
         }
     } else {
-        for (uint32_t k = threadIdx.x; k < K; k += 4 * T) {
-            const float v0 = x[k], v1 = x[min(k + T, K - 1)], v2 = x[min(k + 2 * T, K - 1)], v3 = x[min(k + 3 * T, K - 1)];
-            s0 += v0 * v0;
-            s1 += k + T < K ? v1 * v1 : 0.f;
-            s2 += k + 2 * T < K ? v2 * v2 : 0.f;
-            s3 += k + 3 * T < K ? v3 * v3 : 0.f;
-        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) r.v[j] = make_float4(x[min(threadIdx.x + j * T, K - 1)], 0.f, 0.f, 0.f);
     }
-    float ss = (s0 + s1) + (s2 + s3);
+    return r;
+}
+__device__ __forceinline__ float block_sumsq_direct(const SumsqRegs& r, const float* x, uint32_t K, float* red, bool vec) {
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    const uint32_t T = blockDim.x;
+    if (vec) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float4 v = r.v[j];
+            if (4 * (threadIdx.x + j * T) < K) s[j] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        }
+        for (uint32_t k = 4 * threadIdx.x + 16 * T; k < K; k += 4 * T) { // K > 16 * T: the rest, one load at a time
+            const float4 v = *(const float4*)(x + k);
+            s[0] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (threadIdx.x + j * T < K) s[j] += r.v[j].x * r.v[j].x;
+        for (uint32_t k = threadIdx.x + 4 * T; k < K; k += T) s[0] += x[k] * x[k];
+    }
+    float ss = (s[0] + s[1]) + (s[2] + s[3]);
     ss += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(ss), 0xB1, 0xF, 0xF, true));
     ss += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(ss), 0x4E, 0xF, 0xF, true));
     ss += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(ss), 0x141, 0xF, 0xF, true));
@@ -537,10 +553,13 @@ __global__ void __launch_bounds__(1024) qmatvec_kernel(QMV_HEAD_PARAMS, QMVArgs 
     XDirect xd{xa_row, xb_base, pro_owner ? a.pro.store_x : nullptr, pro_owner ? a.pro.store_mid : nullptr, K, 1.0f, false};
     Group cur;
     if (XD) {
+        const bool norm = PRO && a.pro.kind == QMV_PRO_RMSNORM_MUL;
+        SumsqRegs sq;
+        if (norm) sq = sumsq_fetch(xa_row, K, a.x_vec != 0); // before the weights (in-order vmcnt)
         cur.load(qs, sc, u, stride, u_last, xd, i);
         QMV_STAMP(1); // loads issued
-        if (PRO && a.pro.kind == QMV_PRO_RMSNORM_MUL) { // the weights are in flight while the vector is reduced
-            const float ss = block_sumsq_direct(xa_row, K, red, a.x_vec != 0);
+        if (norm) { // the weights are in flight while the vector is reduced
+            const float ss = block_sumsq_direct(sq, xa_row, K, red, a.x_vec != 0);
             xd.inv = 1.0f / sqrtf(ss / (float)K + a.pro.eps); // reference.zig:365
             xd.norm = true;
         }
@@ -1019,7 +1038,8 @@ void launch_packed(hipStream_t s, QMVArgs& a, const QWeightDev& w0, uint32_t tot
     static const bool xd_norm = !(getenv("ZGML_QMV_XDIRECT_NORM") && atoi(getenv("ZGML_QMV_XDIRECT_NORM")) == 0);
     // (measured: with the rmsnorm prologue the extra per-lane dword loads of x and gamma cost more than the
     // LDS round trip they replace once K is large: Llama-2-7B -5 %, SmolLM-135M +2.7 %)
-    const bool xd = xd_enabled && (a.pro.kind != QMV_PRO_RMSNORM_MUL || (xd_norm && a.K <= 2048));
+    static const uint32_t xd_norm_max_k = getenv("ZGML_QMV_XDNORM_MAXK") ? (uint32_t)atoi(getenv("ZGML_QMV_XDNORM_MAXK")) : 2048u;
+    const bool xd = xd_enabled && (a.pro.kind != QMV_PRO_RMSNORM_MUL || (xd_norm && a.K <= xd_norm_max_k));
     uint32_t waves = qmv_waves(w0, total_blocks);
     if (!xd && a.pro.kind != QMV_PRO_NONE) // a staged prologue keeps all of x in the register window: 16 floats per thread
         while (waves < (uint32_t)kMaxWaves && waves * 64 * 4 * kXRegs < a.K) waves++;
