@@ -334,9 +334,16 @@ enum {
     ZGML_HIP_OPT_GRAPH = 2,          /* 0/1: replay a captured hipGraph per execute (default 1) */
     ZGML_HIP_OPT_PROFILE = 3,        /* 0/1: per-op hipEvent timing into time_ns (default 0) */
     ZGML_HIP_OPT_SKIP_DEAD_UPLOADS = 4, /* 0/1: do not allocate/upload buffers no op touches (default 1) */
-    ZGML_HIP_OPT_F16_DENSE_WEIGHTS = 5  /* 0/1: f16 weight promotion for dense matmul B (default 0) */
+    ZGML_HIP_OPT_F16_DENSE_WEIGHTS = 5, /* 0/1: f16 weight promotion for dense matmul B (default 0) */
+    /* bytes (0 = off, default): zgml_hip_dense_matmul_f32 keeps device copies of its B operands, keyed by
+     * host pointer, up to this many bytes (plain ComputeGraph.compute() users whose
+     * weights never move). The caller promises B is not mutated between calls, or invalidates. */
+    ZGML_HIP_OPT_DENSE_WEIGHT_CACHE = 6
 };
 int zgml_hip_set_option(zgml_hip_ctx* ctx, int option, int64_t value);
+/* Drop the cached device copy of host operand `b` (NULL: all of them). */
+void zgml_hip_dense_cache_invalidate(zgml_hip_ctx* ctx, const float* b);
+void zgml_hip_dense_cache_stats(zgml_hip_ctx* ctx, uint64_t* hits, uint64_t* misses, uint64_t* bytes);
 
 /* Raw device access for harnesses that keep data resident (bench, multi-GPU all-gather glue):
  * device pointer of program buffer `buf_idx` (NULL if elided). */

@@ -166,6 +166,43 @@ def test_host_dense_matmul_override(hip_backend):
     assert dst.tolist() == [-1, 58, 64, -1, 139, 154, -1]
 
 
+def test_host_dense_override_weight_cache(hip_backend):
+    """opt-in device cache of the override's B operands keyed by host pointer; the
+    second call with the same B skips its upload, invalidation makes a mutated B visible."""
+    import ctypes as C
+    from zgml_amd import capi
+    rng = np.random.default_rng(11)
+    M, K, N = 3, 64, 48
+    a, b = rng.standard_normal(M * K).astype(f32), rng.standard_normal(K * N).astype(f32)
+    g = MatMulGeometry(M, N, K, K, 1, N, 1, 0, 0, 0, N)
+
+    def stats():
+        h, m, by = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        hip_backend._lib.zgml_hip_dense_cache_stats(hip_backend.ctx, C.byref(h), C.byref(m), C.byref(by))
+        return h.value, m.value, by.value
+
+    def run():
+        dst = np.zeros(M * N, f32)
+        assert tryDenseMatMul(hip_backend, DenseMatMulSpecF32(dst, a, b, g))
+        return dst
+    want = (a.reshape(M, K).astype(np.float64) @ b.reshape(K, N).astype(np.float64)).ravel()
+    hip_backend.set_option(capi.OPT_DENSE_WEIGHT_CACHE, 1 << 20)
+    try:
+        h0, m0, _ = stats()
+        y1, y2 = run(), run()
+        h1, m1, by = stats()
+        assert (h1 - h0, m1 - m0) == (1, 1) and by == b.nbytes
+        assert np.array_equal(y1, y2) and np.allclose(y1, want, rtol=1e-4, atol=1e-4)
+        b *= 2.0  # mutated in place: the cache still holds the old copy ...
+        assert np.array_equal(run(), y1)
+        hip_backend._lib.zgml_hip_dense_cache_invalidate(hip_backend.ctx, b.ctypes.data)  # ... until invalidated
+        assert np.allclose(run(), 2 * want, rtol=1e-4, atol=1e-4)
+    finally:
+        hip_backend.set_option(capi.OPT_DENSE_WEIGHT_CACHE, 0)
+    assert stats()[2] == 0
+    assert np.allclose(run(), 2 * want, rtol=1e-4, atol=1e-4)  # cache off: plain path
+
+
 def test_profile_counters_and_no_fallback(hip_backend, oracle):
     name, prog, idx, n = core_cases()[3]
     h = hip_backend.compileProgram(prog)

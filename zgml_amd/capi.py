@@ -173,11 +173,11 @@ HIP_SYMBOLS = [
     "zgml_hip_free_program", "zgml_hip_get_runtime_profile", "zgml_hip_set_option",
     "zgml_hip_program_buffer_ptr", "zgml_hip_stream", "zgml_hip_enqueue_program",
     "zgml_hip_enqueue_ops", "zgml_hip_program_set_barriers", "zgml_hip_synchronize", "zgml_hip_upload_inputs", "zgml_hip_download_outputs", "zgml_hip_argmax", "zgml_hip_qmatvec_bench",
-    "zgml_hip_qmatmul_bench", "zgml_hip_dense_f16_bench",
+    "zgml_hip_qmatmul_bench", "zgml_hip_dense_f16_bench", "zgml_hip_dense_cache_invalidate", "zgml_hip_dense_cache_stats",
     "zgml_hip_qmatvec_synth", "zgml_hip_copy_bench", "zgml_hip_resident_setup", "zgml_hip_resident_decode",
 ]
 
-OPT_FUSION, OPT_GRAPH, OPT_PROFILE, OPT_SKIP_DEAD_UPLOADS, OPT_F16_DENSE_WEIGHTS = 1, 2, 3, 4, 5
+OPT_FUSION, OPT_GRAPH, OPT_PROFILE, OPT_SKIP_DEAD_UPLOADS, OPT_F16_DENSE_WEIGHTS, OPT_DENSE_WEIGHT_CACHE = 1, 2, 3, 4, 5, 6
 
 _PKG_DIR = Path(__file__).resolve().parent
 HIP_LIB_PATH = _PKG_DIR / "lib" / "libzgml_hip.so"
@@ -222,6 +222,9 @@ def _bind_hip(lib: C.CDLL) -> None:
     lib.zgml_hip_argmax.argtypes = [vp, vp, C.c_uint16, u64, u64]
     lib.zgml_hip_qmatvec_bench.restype = C.c_double
     lib.zgml_hip_qmatvec_bench.argtypes = [vp, u32, u32, i32, u32, u32, u32, C.POINTER(u64)]
+    lib.zgml_hip_dense_cache_invalidate.restype, lib.zgml_hip_dense_cache_invalidate.argtypes = None, [vp, vp]
+    lib.zgml_hip_dense_cache_stats.restype = None
+    lib.zgml_hip_dense_cache_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     lib.zgml_hip_dense_f16_bench.restype = C.c_double
     lib.zgml_hip_dense_f16_bench.argtypes = [vp, u32, u32, u32, u32, u32, u32, C.POINTER(u64)]
     lib.zgml_hip_qmatmul_bench.restype = C.c_double

@@ -73,6 +73,18 @@ struct zgml_hip_ctx {
     // host dense override scratch
     float *mm_a = nullptr, *mm_b = nullptr, *mm_c = nullptr;
     uint64_t mm_a_cap = 0, mm_b_cap = 0, mm_c_cap = 0;
+    // host dense override: device copies of B operands keyed by host pointer; opt-in
+    struct CachedB {
+        float* dev;
+        uint64_t span; // elements
+    };
+    std::map<const float*, CachedB> b_cache;
+    uint64_t b_cache_cap = 0, b_cache_bytes = 0, b_cache_hits = 0, b_cache_misses = 0;
+    void drop_b_cache() {
+        for (auto& kv : b_cache) hipFree(kv.second.dev);
+        b_cache.clear();
+        b_cache_bytes = 0;
+    }
     // argmax scratch
     float* arg_val = nullptr;
     int64_t* arg_idx = nullptr;
@@ -1533,6 +1545,7 @@ void zgml_hip_destroy(zgml_hip_ctx* ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
+    ctx->drop_b_cache();
     hipFree(ctx->mm_a);
     hipFree(ctx->mm_b);
     hipFree(ctx->mm_c);
@@ -1564,6 +1577,10 @@ int zgml_hip_set_option(zgml_hip_ctx* ctx, int option, int64_t value) {
         case ZGML_HIP_OPT_PROFILE: ctx->opt_profile = value != 0; return 0;
         case ZGML_HIP_OPT_SKIP_DEAD_UPLOADS: ctx->opt_skip_dead = value != 0; return 0;
         case ZGML_HIP_OPT_F16_DENSE_WEIGHTS: ctx->opt_f16_dense = value != 0; return 0;
+        case ZGML_HIP_OPT_DENSE_WEIGHT_CACHE:
+            ctx->b_cache_cap = value > 0 ? (uint64_t)value : 0;
+            if (!ctx->b_cache_cap) ctx->drop_b_cache();
+            return 0;
         default: return -1;
     }
 }
@@ -1584,14 +1601,41 @@ int zgml_hip_dense_matmul_f32(zgml_hip_ctx* ctx, float* dst, uint64_t dst_len, c
         return 0;
     hipStream_t s = ctx->stream;
     if (!CTX_CHECK(ctx, hipMemcpyAsync(ctx->mm_a, a, a_span * 4, hipMemcpyHostToDevice, s))) return 0;
-    if (!CTX_CHECK(ctx, hipMemcpyAsync(ctx->mm_b, b, b_span * 4, hipMemcpyHostToDevice, s))) return 0;
+    const float* b_dev = ctx->mm_b;
+    bool b_cached = false;
+    if (ctx->b_cache_cap && b_span * 4 <= ctx->b_cache_cap) { // weight cache: B stays on the device across calls
+        auto it = ctx->b_cache.find(b);
+        if (it != ctx->b_cache.end() && it->second.span >= b_span) {
+            b_dev = it->second.dev, b_cached = true;
+            ctx->b_cache_hits++;
+        } else {
+            if (it != ctx->b_cache.end()) { // same pointer, larger span now: replace
+                ctx->b_cache_bytes -= it->second.span * 4;
+                hipFree(it->second.dev);
+                ctx->b_cache.erase(it);
+            }
+            if (ctx->b_cache_bytes + b_span * 4 > ctx->b_cache_cap) ctx->drop_b_cache(); // simplest policy: start over
+            float* d = nullptr;
+            if (hipMalloc((void**)&d, b_span * 4) == hipSuccess) {
+                if (!CTX_CHECK(ctx, hipMemcpyAsync(d, b, b_span * 4, hipMemcpyHostToDevice, s))) {
+                    hipFree(d);
+                    return 0;
+                }
+                ctx->b_cache[b] = {d, b_span};
+                ctx->b_cache_bytes += b_span * 4;
+                b_dev = d, b_cached = true;
+            }
+            ctx->b_cache_misses++;
+        }
+    }
+    if (!b_cached && !CTX_CHECK(ctx, hipMemcpyAsync(ctx->mm_b, b, b_span * 4, hipMemcpyHostToDevice, s))) return 0;
     // rows of dst may be strided: keep the untouched gaps as the caller has them
     if (g->dst_row_stride != g->N || g->dst_offset != 0)
         if (!CTX_CHECK(ctx, hipMemcpyAsync(ctx->mm_c, dst, c_span * 4, hipMemcpyHostToDevice, s))) return 0;
     DenseMatmulParams dp{};
     dp.dst = ctx->mm_c + g->dst_offset;
     dp.a = ctx->mm_a + g->a_offset;
-    dp.b = ctx->mm_b + g->b_offset;
+    dp.b = b_dev + g->b_offset;
     dp.M = (uint32_t)g->M, dp.N = (uint32_t)g->N, dp.K = (uint32_t)g->K;
     dp.a_rs = (uint32_t)g->a_row_stride, dp.a_cs = (uint32_t)g->a_col_stride;
     dp.b_rs = (uint32_t)g->b_row_stride, dp.b_cs = (uint32_t)g->b_col_stride;
@@ -1600,6 +1644,28 @@ int zgml_hip_dense_matmul_f32(zgml_hip_ctx* ctx, float* dst, uint64_t dst_len, c
     if (!CTX_CHECK(ctx, hipMemcpyAsync(dst, ctx->mm_c, c_span * 4, hipMemcpyDeviceToHost, s))) return 0;
     if (!CTX_CHECK(ctx, hipStreamSynchronize(s))) return 0;
     return 1;
+}
+
+void zgml_hip_dense_cache_invalidate(zgml_hip_ctx* ctx, const float* b) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    if (!b) {
+        ctx->drop_b_cache();
+        return;
+    }
+    auto it = ctx->b_cache.find(b);
+    if (it == ctx->b_cache.end()) return;
+    ctx->b_cache_bytes -= it->second.span * 4;
+    hipFree(it->second.dev);
+    ctx->b_cache.erase(it);
+}
+
+void zgml_hip_dense_cache_stats(zgml_hip_ctx* ctx, uint64_t* hits, uint64_t* misses, uint64_t* bytes) {
+    if (!ctx) return;
+    if (hits) *hits = ctx->b_cache_hits;
+    if (misses) *misses = ctx->b_cache_misses;
+    if (bytes) *bytes = ctx->b_cache_bytes;
 }
 
 zgml_hip_program* zgml_hip_compile_program(zgml_hip_ctx* ctx, const zgml_device_program* prog) {
