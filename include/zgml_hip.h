@@ -348,6 +348,11 @@ void zgml_hip_dense_cache_stats(zgml_hip_ctx* ctx, uint64_t* hits, uint64_t* mis
 /* Raw device access for harnesses that keep data resident (bench, multi-GPU all-gather glue):
  * device pointer of program buffer `buf_idx` (NULL if elided). */
 void* zgml_hip_program_buffer_ptr(zgml_hip_program* handle, uint16_t buf_idx);
+/* Device-to-device copy of n_elems f32 between buffers of two compiled programs of this context
+ * (stream-ordered): hands the KV caches of a prefill plan (token_len = N program) to the decode plan,
+ * which the reference does through host-visible program memory. Returns 0 on success. */
+int zgml_hip_copy_program_buffer(zgml_hip_ctx* ctx, zgml_hip_program* dst, uint16_t dst_buf, uint64_t dst_offset,
+                                 zgml_hip_program* src, uint16_t src_buf, uint64_t src_offset, uint64_t n_elems);
 /* The HIP stream (hipStream_t as void*) the context launches on. */
 void* zgml_hip_stream(zgml_hip_ctx* ctx);
 /* Execute without host I/O and without blocking: enqueue the program on the context stream. */

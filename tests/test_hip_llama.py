@@ -169,3 +169,37 @@ def test_gguf_block_model_equals_expanded_model(hip_backend, oracle):
     for s in (sa, sb, so):
         s.close()
     ma.close(), mb.close()
+
+
+def test_prefill_plan_hands_kv_to_decode_plan(hip_backend, oracle):
+    """The reference's flow (llama_inference.prefill, then step): a token_len = 8 plan fills the KV
+    caches, the decode plan continues from them. The two compiled programs own separate buffers, so
+    the caches are handed over on the device (zgml_hip_copy_program_buffer); the continuation must
+    equal decoding all tokens one by one."""
+    cfg = llama.preset("tiny")
+    T, n_dec = 8, 5
+    toks = [(5 * i + 2) % cfg.vocab_size for i in range(T)]
+    fns = llama.hip_backend_fns(hip_backend)
+    m_pre, m_dec, m_seq = llama.Model(cfg, llama.Q4_0, token_len=T), llama.Model(cfg, llama.Q4_0), llama.Model(cfg, llama.Q4_0)
+    s_pre, s_dec, s_seq = llama.Session(m_pre, fns), llama.Session(m_dec, fns), llama.Session(m_seq, fns)
+    nxt, logits_pre = s_pre.prefill(toks, 0)
+    S, dh, kv = cfg.max_seq_len, cfg.d_model // cfg.n_heads, cfg.n_kv_heads
+    for layer in range(cfg.n_layers):
+        for which in ("k_cache", "v_cache"):
+            rc = hip_backend._lib.zgml_hip_copy_program_buffer(hip_backend.ctx, s_dec.handle, m_dec.buf(which, layer), 0,
+                                                              s_pre.handle, m_pre.buf(which, layer), 0, dh * S * kv)
+            assert rc == 0, hip_backend.last_error()
+    # sequential reference: all T tokens one by one, then the same continuation
+    for p, t in enumerate(toks):
+        t_seq, l_seq = s_seq.step(t, p)
+    assert t_seq == nxt and np.abs(l_seq - logits_pre).max() / np.abs(l_seq).max() < 2e-4
+    tok_a = tok_b = nxt
+    for i in range(n_dec):
+        ta, la = s_dec.step(tok_a, T + i)
+        tb, lb = s_seq.step(tok_b, T + i)
+        assert ta == tb and np.abs(la - lb).max() / np.abs(lb).max() < 2e-4
+        tok_a, tok_b = ta, tb
+    for s in (s_pre, s_dec, s_seq):
+        s.close()
+    for m in (m_pre, m_dec, m_seq):
+        m.close()

@@ -2070,6 +2070,24 @@ void zgml_hip_enqueue_program(zgml_hip_ctx* ctx, zgml_hip_program* p) {
     enqueue(p);
 }
 
+int zgml_hip_copy_program_buffer(zgml_hip_ctx* ctx, zgml_hip_program* dst, uint16_t dst_buf, uint64_t dst_offset,
+                                 zgml_hip_program* src, uint16_t src_buf, uint64_t src_offset, uint64_t n_elems) {
+    if (!ctx || !dst || !src) return -1;
+    if (dst_buf >= dst->bufs.size() || src_buf >= src->bufs.size() || !dst->bufs[dst_buf] || !src->bufs[src_buf]) {
+        ctx->fail("copy_program_buffer: no such live buffer");
+        return -1;
+    }
+    if (dst_offset + n_elems > dst->sizes[dst_buf] || src_offset + n_elems > src->sizes[src_buf]) {
+        ctx->fail("copy_program_buffer: range exceeds a buffer");
+        return -1;
+    }
+    hipSetDevice(ctx->device);
+    return CTX_CHECK(ctx, hipMemcpyAsync(dst->bufs[dst_buf] + dst_offset, src->bufs[src_buf] + src_offset, n_elems * sizeof(float),
+                                         hipMemcpyDeviceToDevice, ctx->stream))
+               ? 0
+               : -1;
+}
+
 void zgml_hip_enqueue_ops(zgml_hip_ctx* ctx, zgml_hip_program* p, uint64_t first, uint64_t count) {
     if (!ctx || !p) return;
     hipSetDevice(ctx->device);
