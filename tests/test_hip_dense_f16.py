@@ -113,3 +113,30 @@ def test_io_on_promoted_buffer_fails_loudly(hip_backend, oracle, f16_mode):
     finally:
         hip_backend._lib.zgml_hip_clear_error(hip_backend.ctx)
         hip_backend.freeProgram(h)
+
+
+def test_f16_matmul_rows_equal_matvec_full_size(hip_backend, oracle, f16_mode):
+    """Size-independent property at the BASELINE shape (4096 x 4096, batch 32): each row of the MFMA
+    result equals the M = 1 kernel on that row up to the rounding of A to f16 (M > 1 only; the M = 1
+    kernel keeps A in f32): |delta| <= 2^-10 * sum|a*b|. A zero row gives exact zeros."""
+    K = N = 4096
+    M = 32
+    rng = np.random.default_rng(31)
+    b = (rng.standard_normal(K * N) * 0.02).astype(f32)
+    a = rng.standard_normal((M, K)).astype(f32)
+    a[9] = 0.0
+    g_m = MatMulGeometry(M=M, N=N, K=K, a_row_stride=K, a_col_stride=1, b_row_stride=N, b_col_stride=1,
+                         a_offset=0, b_offset=0, dst_offset=0, dst_row_stride=N)
+    g_1 = MatMulGeometry(M=1, N=N, K=K, a_row_stride=K, a_col_stride=1, b_row_stride=N, b_col_stride=1,
+                         a_offset=0, b_offset=0, dst_offset=0, dst_row_stride=N)
+    prog = DeviceProgram(ops=[DeviceOp.matmul(2, 0, 1, g_m), DeviceOp.matmul(4, 3, 1, g_1)],
+                         buffer_sizes=[M * K, K * N, M * N, K, N], initial_uploads=[ProgramIO(1, b)])
+    h = hip_backend.compileProgram(prog)
+    Y, y = np.zeros(M * N, f32), np.zeros(N, f32)
+    absb = np.abs(b.reshape(K, N)).astype(np.float64)
+    for m in (0, 9, 31):
+        hip_backend.executeProgram(h, [ProgramIO(0, a.ravel()), ProgramIO(3, a[m].copy())], [ProgramIO(2, Y), ProgramIO(4, y)])
+        bound = np.abs(a[m]).astype(np.float64) @ absb
+        assert np.all(np.abs(Y.reshape(M, N)[m] - y) <= 2.0 ** -10 * bound + 1e-30), m
+    assert np.all(Y.reshape(M, N)[9] == 0)
+    hip_backend.freeProgram(h)

@@ -136,3 +136,28 @@ def test_device_synth_generator_matches_host(hip_backend, oracle, q4):
     want = oracle.qmatmul_exact(data, scales, x, 1, N, K)
     b = bound(data, scales, x, 1, N, K, 32).ravel()
     assert np.all(np.abs(y - want) <= TOL * b)
+
+
+@pytest.mark.parametrize("kind", ["q4", "q8"])
+def test_tile_kernel_rows_equal_matvec_full_size(hip_backend, oracle, kind):
+    """Size-independent property at the BASELINE shape (4096 x 4096, prefill batch 32): every row of the
+    M = 32 tile-kernel result equals the M = 1 mat-vec of that row (two different kernels, same packed
+    weights) within the summation-order bound; zero rows give exact zeros."""
+    K = N = 4096
+    M = 32
+    data, scales = synth_weight(K, N, kind == "q4", 7)
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal((M, K)).astype(f32)
+    x[5] = 0.0
+    qw = QuantizedWeightUpload(data, scales, K, N, 32)
+    prog = DeviceProgram(ops=[DeviceOp.qmatmul(1, 0, 0, M, N, K), DeviceOp.qmatmul(3, 2, 0, 1, N, K)],
+                         buffer_sizes=[M * K, M * N, K, N], qweights=[qw])
+    h = hip_backend.compileProgram(prog)
+    Y, y = np.zeros(M * N, f32), np.zeros(N, f32)
+    absw = np.abs(data.astype(np.float32) * np.repeat(scales, 32)).reshape(K, N)
+    for m in (0, 5, 17, 31):
+        hip_backend.executeProgram(h, [ProgramIO(0, x.ravel()), ProgramIO(2, x[m].copy())], [ProgramIO(1, Y), ProgramIO(3, y)])
+        bound = np.abs(x[m]).astype(np.float64) @ absw.astype(np.float64)
+        assert np.all(np.abs(Y.reshape(M, N)[m] - y) <= 2 * TOL * bound + 1e-30), m
+    assert np.all(Y.reshape(M, N)[5] == 0)
+    hip_backend.freeProgram(h)
