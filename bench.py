@@ -246,19 +246,46 @@ def bench_sharded(args):
     dec = ShardedDecoder(model, ex)
     buf_logits = model.buf("logits")
 
-    def step(tok, pos):
+    def step_eager(tok, pos):
         dec.step(tok, pos, download=False)
         return be.argmax(ex.handle, buf_logits, 0, cfg.vocab_size)
 
     K = min(args.steps, 256)
     tok = 1
-    for pos in range(max(1, args.warmup)):
-        tok = step(tok, pos)
+    W = max(2, args.warmup)
+    for pos in range(W - 1):
+        tok = step_eager(tok, pos)
+    # One graph per token (ops + RCCL all-gathers + argmax recorded once, replayed per token) unless
+    # ZGML_SHARD_GRAPH=0. The first replay is checked against the eager step of the same token; any
+    # failure falls back to the eager loop, so the line is always produced.
+    mode, step = "eager", step_eager
+    if os.environ.get("ZGML_SHARD_GRAPH", "1") != "0":
+        captured = 1
+        try:
+            dec.capture(buf_logits)
+        except Exception as e:  # capture unsupported here: keep the eager loop
+            captured = 0
+            log(f"[bench] rank {rank}: graph capture failed ({type(e).__name__}: {str(e)[:160]}); eager loop")
+        flag = torch.tensor([captured], device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # every rank replays, or none does
+        t_eager = None
+        if int(flag.item()) == 1:
+            t_graph = dec.step_graph(tok, W - 1)
+            t_eager = step_eager(tok, W - 1)  # same token and position again: idempotent for the KV cache
+            flag = torch.tensor([1 if t_graph == t_eager else 0], device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                mode, step = "graph", dec.step_graph
+            else:
+                log(f"[bench] rank {rank}: graph replay disagreed with the eager step ({t_graph} vs {t_eager}); eager loop")
+        tok = t_eager if t_eager is not None else step_eager(tok, W - 1)
+    else:
+        tok = step_eager(tok, W - 1)
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(K):
-        tok = step(tok, max(1, args.warmup) + i)
+        tok = step(tok, W + i)
     torch.cuda.synchronize()
     dist.barrier()
     dt = torch.tensor([time.perf_counter() - t0], device="cuda")
@@ -274,7 +301,7 @@ def bench_sharded(args):
                                    "(BASELINE configs[3])",
                        "weights": "synthetic Q4_0", "max_seq": cfg.max_seq_len,
                        "parallelism": f"tp{ws} (N-split weights, replicated activations, head-sharded KV)",
-                       "collectives_per_token": len(model.gather_points()),
+                       "collectives_per_token": len(model.gather_points()) if ws > 1 else 0, "step_mode": mode,
                        "compare_with": "extra.llama2_7b.tok_s of the --gpus 1 line (same model, unsharded)"},
             "roofline": None, "cpu_baseline": None,
             "extra": {"q4_0_weight_bytes_per_rank": qb},

@@ -364,6 +364,16 @@ void zgml_hip_enqueue_ops(zgml_hip_ctx* ctx, zgml_hip_program* handle, uint64_t 
 int zgml_hip_program_set_barriers(zgml_hip_ctx* ctx, zgml_hip_program* handle, const uint64_t* op_indices,
                                   uint64_t n);
 void zgml_hip_synchronize(zgml_hip_ctx* ctx);
+/* Capture-friendly split of a step, for harnesses that record ops + collectives into ONE graph per
+ * token (multi-GPU): stage_inputs does the host side (validation + copy into pinned staging),
+ * enqueue_staged the device side (one H2D, scatter kernel, dynamic-parameter block) and may be recorded
+ * into a stream capture; a replay picks up what stage_inputs / refresh_program wrote last.
+ * enqueue_argmax leaves the index in pinned memory: read it with argmax_result after the stream (or
+ * the graph replay) has completed. */
+int zgml_hip_stage_inputs(zgml_hip_ctx* ctx, zgml_hip_program* handle, const zgml_program_io* inputs, uint64_t n_inputs);
+void zgml_hip_enqueue_staged(zgml_hip_ctx* ctx, zgml_hip_program* handle);
+int zgml_hip_enqueue_argmax(zgml_hip_ctx* ctx, zgml_hip_program* handle, uint16_t buf_idx, uint64_t offset, uint64_t n);
+int64_t zgml_hip_argmax_result(zgml_hip_ctx* ctx);
 /* The two halves of execute_program on their own, for harnesses that interleave collectives with
  * op ranges: enqueue the host->device transfers / run the device->host transfers (blocking). */
 void zgml_hip_upload_inputs(zgml_hip_ctx* ctx, zgml_hip_program* handle, const zgml_program_io* inputs,

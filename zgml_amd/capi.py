@@ -171,7 +171,8 @@ HIP_SYMBOLS = [
     "zgml_hip_capabilities", "zgml_hip_program_supported", "zgml_hip_dense_matmul_f32",
     "zgml_hip_compile_program", "zgml_hip_refresh_program", "zgml_hip_execute_program",
     "zgml_hip_free_program", "zgml_hip_get_runtime_profile", "zgml_hip_set_option",
-    "zgml_hip_program_buffer_ptr", "zgml_hip_copy_program_buffer", "zgml_hip_stream", "zgml_hip_enqueue_program",
+    "zgml_hip_program_buffer_ptr", "zgml_hip_copy_program_buffer", "zgml_hip_stage_inputs", "zgml_hip_enqueue_staged",
+    "zgml_hip_enqueue_argmax", "zgml_hip_argmax_result", "zgml_hip_stream", "zgml_hip_enqueue_program",
     "zgml_hip_enqueue_ops", "zgml_hip_program_set_barriers", "zgml_hip_synchronize", "zgml_hip_upload_inputs", "zgml_hip_download_outputs", "zgml_hip_argmax", "zgml_hip_qmatvec_bench",
     "zgml_hip_qmatmul_bench", "zgml_hip_dense_f16_bench", "zgml_hip_dense_cache_invalidate", "zgml_hip_dense_cache_stats",
     "zgml_hip_qmatvec_synth", "zgml_hip_copy_bench", "zgml_hip_resident_setup", "zgml_hip_resident_decode",
@@ -208,6 +209,10 @@ def _bind_hip(lib: C.CDLL) -> None:
     lib.zgml_hip_get_runtime_profile.argtypes = [vp, vp]
     lib.zgml_hip_set_option.restype, lib.zgml_hip_set_option.argtypes = i32, [vp, i32, C.c_int64]
     lib.zgml_hip_program_buffer_ptr.restype, lib.zgml_hip_program_buffer_ptr.argtypes = vp, [vp, C.c_uint16]
+    lib.zgml_hip_stage_inputs.restype, lib.zgml_hip_stage_inputs.argtypes = i32, [vp, vp, C.POINTER(ProgramIOC), u64]
+    lib.zgml_hip_enqueue_staged.restype, lib.zgml_hip_enqueue_staged.argtypes = None, [vp, vp]
+    lib.zgml_hip_enqueue_argmax.restype, lib.zgml_hip_enqueue_argmax.argtypes = i32, [vp, vp, C.c_uint16, u64, u64]
+    lib.zgml_hip_argmax_result.restype, lib.zgml_hip_argmax_result.argtypes = C.c_int64, [vp]
     lib.zgml_hip_copy_program_buffer.restype = i32
     lib.zgml_hip_copy_program_buffer.argtypes = [vp, vp, C.c_uint16, u64, vp, C.c_uint16, u64, u64]
     lib.zgml_hip_stream.restype, lib.zgml_hip_stream.argtypes = vp, [vp]

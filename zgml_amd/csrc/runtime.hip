@@ -139,6 +139,7 @@ struct zgml_hip_program {
     void* stage_dev = nullptr;
     uint64_t stage_cap = 0;
     IoPlan in_plan, out_plan;
+    uint64_t staged_bytes = 0, staged_n = 0; // zgml_hip_stage_inputs / enqueue_staged
     zgml_runtime_profile profile{};
     zgml_resident* resident = nullptr;
 };
@@ -1992,6 +1993,53 @@ void zgml_hip_execute_program(zgml_hip_ctx* ctx, zgml_hip_program* p, const zgml
     p->profile.backend_dispatch_count += p->plan.size();
     CTX_CHECK(ctx, hipGetLastError());
 }
+
+// ── capture-friendly split of a step (multi-GPU harness records ops + collectives into one graph) ──
+// stage_inputs: host side only — validate the transfer table and copy the host leaves into the
+// pinned staging buffer. enqueue_staged: device side only — one H2D of the staging buffer, the
+// scatter kernel and an unconditional copy of the dynamic-parameter block; safe to record into a
+// stream capture and replay, the replay picks up whatever stage_inputs / refresh_program wrote last.
+int zgml_hip_stage_inputs(zgml_hip_ctx* ctx, zgml_hip_program* p, const zgml_program_io* inputs, uint64_t n_inputs) {
+    if (!ctx || !p) return -1;
+    hipSetDevice(ctx->device);
+    if (!prepare_io(p, p->in_plan, inputs, n_inputs)) return -1;
+    if (n_inputs && !p->in_plan.word_aligned) {
+        ctx->fail("stage_inputs: inputs must be 4-byte aligned in offset and size");
+        return -1;
+    }
+    char* st = (char*)p->stage_host;
+    uint64_t off = 0;
+    for (uint64_t i = 0; i < n_inputs; i++) {
+        memcpy(st + off, inputs[i].host_ptr, inputs[i].size);
+        off += (inputs[i].size + 3) / 4 * 4;
+    }
+    p->staged_bytes = off;
+    p->staged_n = n_inputs;
+    return 0;
+}
+
+void zgml_hip_enqueue_staged(zgml_hip_ctx* ctx, zgml_hip_program* p) {
+    if (!ctx || !p) return;
+    hipSetDevice(ctx->device);
+    hipStream_t s = ctx->stream;
+    if (p->staged_n) {
+        hipMemcpyAsync(p->stage_dev, p->stage_host, p->staged_bytes, hipMemcpyHostToDevice, s);
+        scatter_words_kernel<<<(uint32_t)p->staged_n, 256, 0, s>>>(p->in_plan.table_dev, (const uint32_t*)p->stage_dev);
+    }
+    if (!p->ops.empty()) hipMemcpyAsync(p->dyn_dev, p->dyn_host, p->ops.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s);
+    p->dyn_dirty = false;
+}
+
+// argmax without the blocking read-back: result lands in pinned memory, read it with
+// zgml_hip_argmax_result after synchronising the stream (or after a graph replay completed)
+int zgml_hip_enqueue_argmax(zgml_hip_ctx* ctx, zgml_hip_program* p, uint16_t buf_idx, uint64_t offset, uint64_t n) {
+    if (!ctx || !p || buf_idx >= p->bufs.size() || !p->bufs[buf_idx] || offset + n > p->sizes[buf_idx]) return -1;
+    hipSetDevice(ctx->device);
+    launch_argmax(ctx->stream, p->bufs[buf_idx] + offset, n, ctx->arg_val, ctx->arg_idx, ctx->arg_out);
+    hipMemcpyAsync(ctx->arg_out_host, ctx->arg_out, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream);
+    return 0;
+}
+int64_t zgml_hip_argmax_result(zgml_hip_ctx* ctx) { return ctx ? *ctx->arg_out_host : -1; }
 
 void zgml_hip_upload_inputs(zgml_hip_ctx* ctx, zgml_hip_program* p, const zgml_program_io* inputs, uint64_t n_inputs) {
     if (!ctx || !p) return;

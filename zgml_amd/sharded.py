@@ -56,6 +56,21 @@ class HipExecutor:
     def upload(self):
         self.lib.zgml_hip_upload_inputs(self.be.ctx, self.handle, self._in[0], self._in[1])
 
+    # capture-friendly split (one graph per token): host side / device side of the upload, argmax
+    def stage(self):
+        if self.lib.zgml_hip_stage_inputs(self.be.ctx, self.handle, self._in[0], self._in[1]) != 0:
+            raise RuntimeError("stage_inputs: " + self.be.last_error())
+
+    def enqueue_staged(self):
+        self.lib.zgml_hip_enqueue_staged(self.be.ctx, self.handle)
+
+    def enqueue_argmax(self, buf: int, n: int):
+        if self.lib.zgml_hip_enqueue_argmax(self.be.ctx, self.handle, buf, 0, n) != 0:
+            raise RuntimeError("enqueue_argmax failed")
+
+    def argmax_result(self) -> int:
+        return int(self.lib.zgml_hip_argmax_result(self.be.ctx))
+
     def run_ops(self, first: int, count: int):
         if count > 0:
             self.lib.zgml_hip_enqueue_ops(self.be.ctx, self.handle, first, count)
@@ -93,6 +108,10 @@ class ShardedDecoder:
         self.rank = model.cfg.shard_rank
         self.points = model.gather_points()
         self.inplace = inplace
+        self.graph = None
+        # rehearsal switch: issue the collectives even at world size 1 (exercises RCCL under capture)
+        import os
+        self.force_gather = os.environ.get("ZGML_SHARD_FORCE_GATHER", "0") == "1"
 
     def _all_gather(self, full: torch.Tensor, n: int):
         mine = full[self.rank * n:(self.rank + 1) * n]
@@ -108,12 +127,40 @@ class ShardedDecoder:
         self.model.patch(token, pos)
         self.ex.refresh()
         self.ex.upload()
-        prev = 0
         with self.ex.collective_stream():
-            for gp in self.points:
-                self.ex.run_ops(prev, gp.op_end - prev)
-                if self.ws > 1:
-                    self._all_gather(self.ex.tensor(gp.buf, gp.offset, self.ws * gp.len_per_rank), gp.len_per_rank)
-                prev = gp.op_end
-            self.ex.run_ops(prev, self.ex.n_ops - prev)
+            self._segments()
         return self.ex.download_logits() if download else None
+
+    def _segments(self):
+        prev = 0
+        for gp in self.points:
+            self.ex.run_ops(prev, gp.op_end - prev)
+            if self.ws > 1 or self.force_gather:
+                self._all_gather(self.ex.tensor(gp.buf, gp.offset, self.ws * gp.len_per_rank), gp.len_per_rank)
+            prev = gp.op_end
+        self.ex.run_ops(prev, self.ex.n_ops - prev)
+
+    # ── one graph per token ───────────────────────────────────────────────────────────────────
+    # The eager step costs ~130 host-issued collectives plus ~650 kernel launches per token; the
+    # whole device side of a step (H2D of the staged inputs, op ranges, RCCL all-gathers, argmax)
+    # is recorded ONCE into a graph on the library's stream and replayed per token. Host work per
+    # token: patch the leaves, refresh the dynamic words, fill the pinned staging buffer, replay.
+    def capture(self, logits_buf: int) -> None:
+        import torch
+        ex = self.ex
+        ex.stage()  # builds the transfer table outside the capture
+        ex.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=ex.stream, capture_error_mode="relaxed"):
+            ex.enqueue_staged()
+            self._segments()
+            ex.enqueue_argmax(logits_buf, self.model.cfg.vocab_size)
+        self.graph = g
+
+    def step_graph(self, token: int, pos: int) -> int:
+        self.model.patch(token, pos)
+        self.ex.refresh()
+        self.ex.stage()
+        self.graph.replay()
+        self.ex.synchronize()
+        return self.ex.argmax_result()
