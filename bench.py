@@ -268,24 +268,32 @@ def bench_sharded(args):
             log(f"[bench] rank {rank}: graph capture failed ({type(e).__name__}: {str(e)[:160]}); eager loop")
         flag = torch.tensor([captured], device="cuda")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # every rank replays, or none does
-        t_eager = None
+        checked = False
         if int(flag.item()) == 1:
-            t_graph = dec.step_graph(tok, W - 1)
-            t_eager = step_eager(tok, W - 1)  # same token and position again: idempotent for the KV cache
-            flag = torch.tensor([1 if t_graph == t_eager else 0], device="cuda")
+            same = 1
+            for pos in (W - 1, W):  # two consecutive positions: inputs and dynamic words must follow the replays
+                t_graph = dec.step_graph(tok, pos)
+                t_eager = step_eager(tok, pos)  # same token and position again: idempotent for the KV cache
+                same &= int(t_graph == t_eager)
+                tok = t_eager
+            checked = True
+            flag = torch.tensor([same], device="cuda")
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 1:
                 mode, step = "graph", dec.step_graph
             else:
-                log(f"[bench] rank {rank}: graph replay disagreed with the eager step ({t_graph} vs {t_eager}); eager loop")
-        tok = t_eager if t_eager is not None else step_eager(tok, W - 1)
+                log(f"[bench] rank {rank}: graph replay disagreed with the eager step; eager loop")
+        if not checked:
+            for pos in (W - 1, W):
+                tok = step_eager(tok, pos)
     else:
-        tok = step_eager(tok, W - 1)
+        for pos in (W - 1, W):
+            tok = step_eager(tok, pos)
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(K):
-        tok = step(tok, W + i)
+        tok = step(tok, W + 1 + i)
     torch.cuda.synchronize()
     dist.barrier()
     dt = torch.tensor([time.perf_counter() - t0], device="cuda")

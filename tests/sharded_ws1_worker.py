@@ -63,6 +63,16 @@ def main():
         lg = dec.step(dec2_tok, pos)
         np.testing.assert_allclose(lg, want[pos][1], atol=1e-6 * np.abs(want[pos][1]).max(), rtol=0)
         dec2_tok = want[pos][0]
+    # one graph per token: ops + (forced) collectives + argmax recorded once, replayed per token
+    os.environ["ZGML_SHARD_FORCE_GATHER"] = "1"
+    dec3 = ShardedDecoder(m, ex)
+    dec3.step(3, 0, download=False)  # plan + transfer tables exist before the capture
+    dec3.capture(m.buf("logits"))
+    tok = 3
+    for pos in range(5):
+        tok = dec3.step_graph(tok, pos)
+        assert not be.last_error(), be.last_error()
+        assert tok == want[pos][0], (pos, tok, want[pos][0])
     ex.close()
     m.close()
     be.close()

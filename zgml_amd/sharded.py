@@ -161,6 +161,7 @@ class ShardedDecoder:
         self.model.patch(token, pos)
         self.ex.refresh()
         self.ex.stage()
-        self.graph.replay()
+        with self.ex.collective_stream():  # replay on the library's stream (torch replays on its CURRENT stream)
+            self.graph.replay()
         self.ex.synchronize()
         return self.ex.argmax_result()
