@@ -66,15 +66,19 @@ __device__ __forceinline__ uint2 pack_half4(float4 v) {
     return r;
 }
 
-// R m-tiles of 16 rows (MFMA form), or R == 0: the M == 1 mat-vec form.
-template <int R, bool XVEC>
+// R m-tiles of 16 rows (MFMA form), or R == 0: the M == 1 mat-vec form. G column groups per workgroup:
+// wave w = (column group w / KW, K slice w % KW); the G wave sets share every staged x chunk, which is
+// what the M > 1 form is bound by (x re-staged per 16 columns costs ~1/3 of the kernel at M = 32).
+template <int R, bool XVEC, int G>
 __global__ void __launch_bounds__(512) dense_f16_kernel(F16Args a) {
     constexpr bool MV = R == 0;
     constexpr int ROWS = MV ? 1 : 16 * R;
-    constexpr int NX = MV ? 1 : 8 * R; // float4 of x each thread stages per step (4 waves: 512 k per step)
+    constexpr int NX = MV ? 1 : 8 * R / G; // float4 of x each thread stages per step (KW = 4: 512 k per step)
     extern __shared__ float smem[];
-    const uint32_t g = column_group(blockIdx.x, a.NB2), m0 = blockIdx.y * ROWS;
-    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6, n_kw = (blockDim.x >> 6) / G;
+    const uint32_t w = wv % n_kw, cgi = wv / n_kw; // K slice, column group within the workgroup
+    const uint32_t g_raw = blockIdx.x * G + cgi, g = min(g_raw, a.NB2 - 1), m0 = blockIdx.y * ROWS;
+    const uint32_t n_waves = n_kw;
     const uint32_t row = lane >> 4, i = lane & 15;
     const uint32_t step_chunks = n_waves * kDepth, chf = step_chunks * 32;
     // LDS row: f16 form chf halves + 8 pad (= (chf + 8) / 2 floats); f32 form chf floats
@@ -190,14 +194,17 @@ __global__ void __launch_bounds__(512) dense_f16_kernel(F16Args a) {
 #pragma unroll
         for (int t = 0; t < RT; t++)
 #pragma unroll
-            for (int v = 0; v < 4; v++) smem[((w * RT + t) * 4 + v) * 64 + lane] = acc[t][v];
+            for (int v = 0; v < 4; v++) smem[((wv * RT + t) * 4 + v) * 64 + lane] = acc[t][v];
         __syncthreads();
-        for (uint32_t idx = threadIdx.x; idx < (uint32_t)RT * 256; idx += blockDim.x) {
-            const uint32_t t = idx >> 8, v = (idx >> 6) & 3, l = idx & 63;
-            float sum = smem[(t * 4 + v) * 64 + l];
-            for (uint32_t ww = 1; ww < n_waves; ww++) sum += smem[((ww * RT + t) * 4 + v) * 64 + l];
-            const uint32_t m = m0 + t * 16 + 4 * (l >> 4) + v, n = g * 16 + (l & 15);
-            if (m < a.M) a.out[(uint64_t)m * a.out_rs + n] = sum;
+        for (uint32_t idx = threadIdx.x; idx < (uint32_t)G * RT * 256; idx += blockDim.x) {
+            const uint32_t cg = idx / (RT * 256), rem = idx % (RT * 256);
+            const uint32_t t = rem >> 8, v = (rem >> 6) & 3, l = rem & 63;
+            const uint32_t w0 = cg * n_kw; // this column group's K-slice waves, summed in wave order
+            float sum = smem[((w0 * RT + t) * 4 + v) * 64 + l];
+            for (uint32_t ww = 1; ww < n_kw; ww++) sum += smem[(((w0 + ww) * RT + t) * 4 + v) * 64 + l];
+            const uint32_t gg = blockIdx.x * G + cg;
+            const uint32_t m = m0 + t * 16 + 4 * (l >> 4) + v, n = gg * 16 + (l & 15);
+            if (m < a.M && gg < a.NB2) a.out[(uint64_t)m * a.out_rs + n] = sum;
         }
     }
 }
@@ -243,31 +250,27 @@ void launch_dense_f16(hipStream_t s, const DenseF16Params& p) {
     if (p.M == 1) {
         const size_t lds = 2ull * chf * sizeof(float);
         if (xvec)
-            dense_f16_kernel<0, true><<<dim3(a.NB2, 1), waves * 64, lds, s>>>(a);
+            dense_f16_kernel<0, true, 1><<<dim3(a.NB2, 1), waves * 64, lds, s>>>(a);
         else
-            dense_f16_kernel<0, false><<<dim3(a.NB2, 1), waves * 64, lds, s>>>(a);
+            dense_f16_kernel<0, false, 1><<<dim3(a.NB2, 1), waves * 64, lds, s>>>(a);
         return;
     }
     const uint32_t R = p.M > 16 ? 2 : 1;
+    // two column groups per workgroup share the staged x chunk — only worth it when the grid stays several
+    // rounds deep (measured at M = 32: N = 32000 75 -> 67 us; N = 11008 neutral, N = 4096 slower)
+    static const int env_g = getenv("ZGML_F16_GROUPS") ? atoi(getenv("ZGML_F16_GROUPS")) : 0;
+    const uint32_t G = env_g ? (uint32_t)env_g : (a.NB2 >= 1536 ? 2u : 1u);
     size_t lds = 2ull * 16 * R * ((chf + 8) / 2) * sizeof(float);
-    const size_t red = (size_t)waves * R * 256 * sizeof(float);
+    const size_t red = (size_t)waves * G * R * 256 * sizeof(float);
     if (red > lds) lds = red;
-    const dim3 grid(a.NB2, cdiv(p.M, 16 * R));
-    if (lds > 64 * 1024) {
-        hipFuncSetAttribute((const void*)dense_f16_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute((const void*)dense_f16_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    }
-    if (R == 2) {
-        if (xvec)
-            dense_f16_kernel<2, true><<<grid, waves * 64, lds, s>>>(a);
-        else
-            dense_f16_kernel<2, false><<<grid, waves * 64, lds, s>>>(a);
-    } else {
-        if (xvec)
-            dense_f16_kernel<1, true><<<grid, waves * 64, lds, s>>>(a);
-        else
-            dense_f16_kernel<1, false><<<grid, waves * 64, lds, s>>>(a);
-    }
+    const dim3 grid(cdiv(a.NB2, G), cdiv(p.M, 16 * R));
+    using Fn = void (*)(F16Args);
+    const Fn fn = G == 2 ? (R == 2 ? (xvec ? (Fn)dense_f16_kernel<2, true, 2> : (Fn)dense_f16_kernel<2, false, 2>)
+                                   : (xvec ? (Fn)dense_f16_kernel<1, true, 2> : (Fn)dense_f16_kernel<1, false, 2>))
+                         : (R == 2 ? (xvec ? (Fn)dense_f16_kernel<2, true, 1> : (Fn)dense_f16_kernel<2, false, 1>)
+                                   : (xvec ? (Fn)dense_f16_kernel<1, true, 1> : (Fn)dense_f16_kernel<1, false, 1>));
+    if (lds > 64 * 1024) hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(fn, grid, dim3(waves * G * 64), lds, s, a);
 }
 
 } // namespace zgml
