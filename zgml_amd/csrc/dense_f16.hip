@@ -16,7 +16,8 @@
 //
 // Thread mapping (same shape as the quantized mat-vec): a workgroup owns one 16-column group and all
 // of K; its waves split K. Per step a wave takes DEPTH consecutive 32-k chunks (4 KiB of weights in
-// flight per wave, next step prefetched), x for the step is staged through LDS by row-contiguous
+// flight per wave, next step prefetched; DEPTH = 8: with 4 the step count doubled and every step exposed
+// the x-load latency, 4096^2 at M = 32 15.3 -> 12.2 us), x for the step is staged through LDS by row-contiguous
 // loads — as f16 [16R rows][chunk] for the MFMA form (ds_read_b128 = one A operand), as f32 for the
 // M == 1 form (v_fma_mix_f32: f32 x times the f16 weight, no rounding of x).
 #include "kernels.h"
@@ -29,7 +30,6 @@ namespace zgml {
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kDepth = 4; // 32-k chunks per wave per step
 
 typedef float mfma_f4 __attribute__((ext_vector_type(4)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -71,9 +71,13 @@ __device__ __forceinline__ uint2 pack_half4(float4 v) {
 // what the M > 1 form is bound by (x re-staged per 16 columns costs ~1/3 of the kernel at M = 32).
 template <int R, bool XVEC, int G>
 __global__ void __launch_bounds__(512) dense_f16_kernel(F16Args a) {
+    // 32-k chunks per wave per step. 8 halves the step count (every step exposes one x-load latency:
+    // 4096^2 at M = 1 9.7 -> 8.5 us); the R = 2 form cannot afford the staging registers for that and
+    // runs 8 K-slice waves of depth 4 instead (same 1024-k step).
+    constexpr int kDepth = R == 2 ? 4 : 8;
     constexpr bool MV = R == 0;
     constexpr int ROWS = MV ? 1 : 16 * R;
-    constexpr int NX = MV ? 1 : 8 * R / G; // float4 of x each thread stages per step (KW = 4: 512 k per step)
+    constexpr int NX = MV ? 1 : 2 * kDepth * R / G; // float4 of x each thread stages per step (16R rows x KW*kDepth*32 k)
     extern __shared__ float smem[];
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6, n_kw = (blockDim.x >> 6) / G;
     const uint32_t w = wv % n_kw, cgi = wv / n_kw; // K slice, column group within the workgroup
@@ -242,29 +246,31 @@ void launch_pack_f16(hipStream_t s, const float* b, uint32_t b_rs, uint32_t b_cs
 void launch_dense_f16(hipStream_t s, const DenseF16Params& p) {
     if (p.M == 0 || p.N == 0) return;
     F16Args a{(const uint4*)p.bp, p.a, p.dst, p.M, p.K, (p.K + 31) / 32, p.a_rs, p.dst_rs, p.N / 16};
-    uint32_t waves = cdiv(a.KC, kDepth);
-    static const int max_waves = getenv("ZGML_F16_WAVES") ? atoi(getenv("ZGML_F16_WAVES")) : 4;
-    if (waves > (uint32_t)max_waves) waves = max_waves;
+    const uint32_t R = p.M == 1 ? 0 : (p.M > 16 ? 2 : 1);
+    // see kDepth in the kernel; the 8-wave R = 2 form only pays while the grid is about one round (N <= 6144)
+    const uint32_t depth = R == 2 ? 4 : 8, max_kw = (R == 2 && a.NB2 <= 384) ? 8 : 4;
+    uint32_t waves = cdiv(a.KC, depth);
+    if (waves > max_kw) waves = max_kw;
     const bool xvec = ((uintptr_t)p.a % 16 == 0) && (p.K % 4 == 0) && (p.M == 1 || p.a_rs % 4 == 0);
-    const uint32_t chf = waves * kDepth * 32;
-    if (p.M == 1) {
+    const uint32_t chf = waves * depth * 32;
+    using Fn = void (*)(F16Args);
+    if (R == 0) {
         const size_t lds = 2ull * chf * sizeof(float);
-        if (xvec)
-            dense_f16_kernel<0, true, 1><<<dim3(a.NB2, 1), waves * 64, lds, s>>>(a);
-        else
-            dense_f16_kernel<0, false, 1><<<dim3(a.NB2, 1), waves * 64, lds, s>>>(a);
+        const Fn fn = xvec ? (Fn)dense_f16_kernel<0, true, 1> : (Fn)dense_f16_kernel<0, false, 1>;
+        if (lds > 64 * 1024) hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(fn, dim3(a.NB2, 1), dim3(waves * 64), lds, s, a);
         return;
     }
-    const uint32_t R = p.M > 16 ? 2 : 1;
     // two column groups per workgroup share the staged x chunk — only worth it when the grid stays several
-    // rounds deep (measured at M = 32: N = 32000 75 -> 67 us; N = 11008 neutral, N = 4096 slower)
+    // rounds deep (measured at M = 32: N = 32000 75 -> 67 us; N = 11008 neutral, N = 4096 slower); the
+    // 8-wave R = 2 form has no room for a second wave set
     static const int env_g = getenv("ZGML_F16_GROUPS") ? atoi(getenv("ZGML_F16_GROUPS")) : 0;
-    const uint32_t G = env_g ? (uint32_t)env_g : (a.NB2 >= 1536 ? 2u : 1u);
+    uint32_t G = env_g ? (uint32_t)env_g : (a.NB2 >= 1536 ? 2u : 1u);
+    if (waves * G > 8) G = 1;
     size_t lds = 2ull * 16 * R * ((chf + 8) / 2) * sizeof(float);
     const size_t red = (size_t)waves * G * R * 256 * sizeof(float);
     if (red > lds) lds = red;
     const dim3 grid(cdiv(a.NB2, G), cdiv(p.M, 16 * R));
-    using Fn = void (*)(F16Args);
     const Fn fn = G == 2 ? (R == 2 ? (xvec ? (Fn)dense_f16_kernel<2, true, 2> : (Fn)dense_f16_kernel<2, false, 2>)
                                    : (xvec ? (Fn)dense_f16_kernel<1, true, 2> : (Fn)dense_f16_kernel<1, false, 2>))
                          : (R == 2 ? (xvec ? (Fn)dense_f16_kernel<2, true, 1> : (Fn)dense_f16_kernel<2, false, 1>)
