@@ -138,6 +138,7 @@ struct QWeightDev {
     uint32_t K = 0, N = 0, bs = 0;
     uint32_t KC = 0;       // K chunks of 32 (padded)
     uint32_t scale_f16 = 0; // packed formats: scales stored as f16 (exact) or f32
+    uint32_t stream_nt = 0; // read with non-temporal loads: the program's weights exceed the Infinity Cache
     void* qs = nullptr;     // packed quants or raw int8
     void* sc = nullptr;     // packed scales or raw f32 scales
     uint64_t qs_bytes = 0, sc_bytes = 0;

@@ -321,6 +321,20 @@ __device__ __forceinline__ void reduce_store(float acc, float* red, const QMVArg
 // {load next; compute current}; compute last — the prefetch is unconditional inside the loop so
 // hipcc can keep counted vmcnt waits (a prefetch under a branch would degrade them to vmcnt(0)).
 
+// Weight loads. NT: non-temporal (`global_load … nt`) — for weight sets larger than the 256 MB
+// Infinity Cache every byte is read once per token, and not allocating it in the caches is worth
+// ~5 % on the stream (4096^2 Q4_0 4.92 -> 4.67 us); a model that fits (SmolLM-135M) keeps the default
+// policy because its weights stay cache-resident from one token to the next (nt: -1.8 % tok/s).
+template <bool NT>
+__device__ __forceinline__ uint4 wload(const uint4* p) {
+    if (NT) {
+        typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+        const u4v v = __builtin_nontemporal_load((const u4v*)p);
+        return make_uint4(v.x, v.y, v.z, v.w);
+    }
+    return *p;
+}
+
 // XD ("x direct"): x is not staged through LDS; each lane loads the x value(s) of "its" k of the
 // unit together with the unit's weights (dword loads, L2-resident vector), so the kernel has no
 // x round trip + LDS store + barrier before its first FMA. PROMUL: x = a * b (the absorbed
@@ -402,7 +416,7 @@ __device__ __forceinline__ float block_sumsq_direct(const SumsqRegs& r, const fl
     return t;
 }
 
-template <typename ST, int DEPTH, bool XD, bool PROMUL>
+template <typename ST, int DEPTH, bool XD, bool PROMUL, bool NT>
 struct Q4Group {
     uint4 wq[DEPTH];
     Pair<ST> s2[DEPTH];
@@ -417,7 +431,7 @@ struct Q4Group {
                 xa[d] = xd.a[ka], xb[d] = xd.a[kb];
                 if (PROMUL) ya[d] = xd.b[ka], yb[d] = xd.b[kb];
             }
-            wq[d] = qs[(uint64_t)ud * 16];
+            wq[d] = wload<NT>(qs + (uint64_t)ud * 16);
             s2[d] = sc[(uint64_t)ud * 16];
         }
     }
@@ -451,7 +465,7 @@ struct Q4Group {
     }
 };
 
-template <typename ST, int DEPTH, bool XD, bool PROMUL>
+template <typename ST, int DEPTH, bool XD, bool PROMUL, bool NT>
 struct Q8Group {
     uint4 wq[DEPTH];
     ST s1[DEPTH];
@@ -466,7 +480,7 @@ struct Q8Group {
                 xa[d] = xd.a[ka];
                 if (PROMUL) ya[d] = xd.b[ka];
             }
-            wq[d] = qs[(uint64_t)ud * 16];
+            wq[d] = wload<NT>(qs + (uint64_t)ud * 16);
             s1[d] = sc[(uint64_t)ud * 16];
         }
     }
@@ -504,11 +518,11 @@ struct Q8Group {
     const uint4 *__restrict__ qs0, const void *__restrict__ sc0, float *__restrict__ out0, const float *__restrict__ xa_base, \
         const float *__restrict__ xb_base, uint32_t U, uint32_t K, uint32_t NB2_0, uint32_t out_rs0, uint32_t in_rs,         \
         uint32_t n_parts
-template <typename ST, bool XVEC, int DEPTH, bool Q4, bool PRO, bool GROUPED, bool XD>
+template <typename ST, bool XVEC, int DEPTH, bool Q4, bool PRO, bool GROUPED, bool XD, bool NT>
 __global__ void __launch_bounds__(1024) qmatvec_kernel(QMV_HEAD_PARAMS, QMVArgs a) {
     constexpr uint32_t UNIT_X = Q4 ? 32 : 16;
     using ScaleT = typename std::conditional<Q4, Pair<ST>, ST>::type;
-    using Group = typename std::conditional<Q4, Q4Group<ST, DEPTH, XD, PRO>, Q8Group<ST, DEPTH, XD, PRO>>::type;
+    using Group = typename std::conditional<Q4, Q4Group<ST, DEPTH, XD, PRO, NT>, Q8Group<ST, DEPTH, XD, PRO, NT>>::type;
     extern __shared__ float smem[];
 #ifdef ZGML_TRACE // build with -DZGML_TRACE: the stamps serialise the kernel-argument loads, so never in product builds
 #define QMV_STAMP(i) do { if (a.trace && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.trace[i] = wall_clock64(); } while (0)
@@ -1011,23 +1025,23 @@ uint32_t qmv_waves(const QWeightDev& w, uint32_t total_blocks = 0) {
 using KernelFn = void (*)(QMV_HEAD_PARAMS, QMVArgs);
 
 template <typename ST, bool XV, bool Q, bool PRO, bool GRP, bool XD>
-KernelFn pick_depth(int depth_sel) {
-    switch (depth_sel) {
-        case 0: return qmatvec_kernel<ST, XV, 1, Q, PRO, GRP, XD>;
-        case 1: return qmatvec_kernel<ST, XV, 2, Q, PRO, GRP, XD>;
-        default: return qmatvec_kernel<ST, XV, 4, Q, PRO, GRP, XD>;
+KernelFn pick_depth(int depth_sel, bool nt) {
+    switch (depth_sel) { // nt only exists at full depth: a weight set beyond the Infinity Cache means K >= 4096
+        case 0: return qmatvec_kernel<ST, XV, 1, Q, PRO, GRP, XD, false>;
+        case 1: return qmatvec_kernel<ST, XV, 2, Q, PRO, GRP, XD, false>;
+        default: return nt ? qmatvec_kernel<ST, XV, 4, Q, PRO, GRP, XD, true> : qmatvec_kernel<ST, XV, 4, Q, PRO, GRP, XD, false>;
     }
 }
 template <typename ST, bool XV, bool Q, bool XD>
-KernelFn pick_mode(bool pro, bool grp, int depth_sel) {
-    if (pro) return grp ? pick_depth<ST, XV, Q, true, true, XD>(depth_sel) : pick_depth<ST, XV, Q, true, false, XD>(depth_sel);
-    return grp ? pick_depth<ST, XV, Q, false, true, XD>(depth_sel) : pick_depth<ST, XV, Q, false, false, XD>(depth_sel);
+KernelFn pick_mode(bool pro, bool grp, int depth_sel, bool nt) {
+    if (pro) return grp ? pick_depth<ST, XV, Q, true, true, XD>(depth_sel, nt) : pick_depth<ST, XV, Q, true, false, XD>(depth_sel, nt);
+    return grp ? pick_depth<ST, XV, Q, false, true, XD>(depth_sel, nt) : pick_depth<ST, XV, Q, false, false, XD>(depth_sel, nt);
 }
 template <typename ST>
-KernelFn pick_kernel(bool xvec, bool q4, bool pro, bool grp, int depth_sel, bool xd) {
-    if (xd) return q4 ? pick_mode<ST, false, true, true>(pro, grp, depth_sel) : pick_mode<ST, false, false, true>(pro, grp, depth_sel);
-    if (xvec) return q4 ? pick_mode<ST, true, true, false>(pro, grp, depth_sel) : pick_mode<ST, true, false, false>(pro, grp, depth_sel);
-    return q4 ? pick_mode<ST, false, true, false>(pro, grp, depth_sel) : pick_mode<ST, false, false, false>(pro, grp, depth_sel);
+KernelFn pick_kernel(bool xvec, bool q4, bool pro, bool grp, int depth_sel, bool xd, bool nt) {
+    if (xd) return q4 ? pick_mode<ST, false, true, true>(pro, grp, depth_sel, nt) : pick_mode<ST, false, false, true>(pro, grp, depth_sel, nt);
+    if (xvec) return q4 ? pick_mode<ST, true, true, false>(pro, grp, depth_sel, nt) : pick_mode<ST, true, false, false>(pro, grp, depth_sel, nt);
+    return q4 ? pick_mode<ST, false, true, false>(pro, grp, depth_sel, nt) : pick_mode<ST, false, false, false>(pro, grp, depth_sel, nt);
 }
 
 void launch_packed(hipStream_t s, QMVArgs& a, const QWeightDev& w0, uint32_t total_blocks, uint32_t M, bool xvec) {
@@ -1048,8 +1062,9 @@ void launch_packed(hipStream_t s, QMVArgs& a, const QWeightDev& w0, uint32_t tot
     const uint32_t n_steps = cdiv(a.U, waves * 4);
     const int depth_sel = n_steps >= 4 ? 2 : (n_steps >= 2 ? 1 : 0); // DEPTH 4 / 2 / 1
     const bool pro = a.pro.kind != QMV_PRO_NONE, grp = a.n_parts > 1;
-    const KernelFn fn = w0.scale_f16 ? pick_kernel<__half>(xvec, q4, pro, grp, depth_sel, xd)
-                                     : pick_kernel<float>(xvec, q4, pro, grp, depth_sel, xd);
+    const bool nt = w0.stream_nt != 0;
+    const KernelFn fn = w0.scale_f16 ? pick_kernel<__half>(xvec, q4, pro, grp, depth_sel, xd, nt)
+                                     : pick_kernel<float>(xvec, q4, pro, grp, depth_sel, xd, nt);
     if (lds > 64 * 1024) // > 64 KiB of dynamic LDS needs an explicit opt-in per kernel (idempotent)
         hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
     hipLaunchKernelGGL(fn, grid, dim3(waves * 64), lds, s, a.parts[0].qs, a.parts[0].sc, a.parts[0].out, a.pro.a, a.pro.b, a.U, a.K,

@@ -1870,6 +1870,13 @@ zgml_hip_program* zgml_hip_compile_program(zgml_hip_ctx* ctx, const zgml_device_
         hipFree(raw_s);
     }
     if (flags) hipFree(flags);
+    { // weight sets beyond the 256 MB Infinity Cache are streamed with non-temporal loads (see qmatvec.hip: wload)
+        static const uint64_t nt_min = getenv("ZGML_HIP_NT_MIN_BYTES") ? strtoull(getenv("ZGML_HIP_NT_MIN_BYTES"), nullptr, 0) : (192ull << 20);
+        uint64_t total = 0;
+        for (const QWeightDev& w : p->qweights) total += w.qs_bytes + w.sc_bytes;
+        if (total >= nt_min)
+            for (QWeightDev& w : p->qweights) w.stream_nt = 1;
+    }
 
     // split-K scratch shared by all qmatmul launches (they are serialised on one stream)
     for (const auto& op : p->ops)
@@ -2264,6 +2271,8 @@ double zgml_hip_qmatmul_bench(zgml_hip_ctx* ctx, uint32_t M, uint32_t K, uint32_
     std::vector<QWeightDev> ring(n_matrices);
     bool ok = true;
     for (uint32_t i = 0; ok && i < n_matrices; i++) ok = make_synth_weight(ctx, K, N, q4, i, &ring[i]);
+    if (ok && (ring[0].qs_bytes + ring[0].sc_bytes) * n_matrices >= (192ull << 20)) // the ring stands for a model beyond the cache
+        for (auto& w : ring) w.stream_nt = 1;
     float *x = nullptr, *y = nullptr, *scratch = nullptr;
     std::vector<float> xh((size_t)M * K);
     for (size_t i = 0; i < xh.size(); i++) xh[i] = ((int)(i % 17) - 8) * 0.03125f;
