@@ -69,7 +69,7 @@ __device__ __forceinline__ uint2 pack_half4(float4 v) {
 // R m-tiles of 16 rows (MFMA form), or R == 0: the M == 1 mat-vec form. G column groups per workgroup:
 // wave w = (column group w / KW, K slice w % KW); the G wave sets share every staged x chunk, which is
 // what the M > 1 form is bound by (x re-staged per 16 columns costs ~1/3 of the kernel at M = 32).
-template <int R, bool XVEC, int G>
+template <int R, bool XVEC, int G, bool NT>
 __global__ void __launch_bounds__(512) dense_f16_kernel(F16Args a) {
     // 32-k chunks per wave per step. 8 halves the step count (every step exposes one x-load latency:
     // 4096^2 at M = 1 9.7 -> 8.5 us); the R = 2 form cannot afford the staging registers for that and
@@ -125,7 +125,13 @@ __global__ void __launch_bounds__(512) dense_f16_kernel(F16Args a) {
 #pragma unroll
         for (int d = 0; d < kDepth; d++) { // clamped, unconditional; x of chunks >= KC is staged as zero
             const uint32_t c = min(step * step_chunks + w * kDepth + d, a.KC - 1);
-            b[d] = bp[(uint64_t)c * 64];
+            if (NT) { // weight set beyond the Infinity Cache: read-once stream, do not allocate (see qmatvec.hip wload)
+                typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+                const u4v v = __builtin_nontemporal_load((const u4v*)(bp + (uint64_t)c * 64));
+                b[d] = make_uint4(v.x, v.y, v.z, v.w);
+            } else {
+                b[d] = bp[(uint64_t)c * 64];
+            }
         }
     };
 
@@ -254,9 +260,11 @@ void launch_dense_f16(hipStream_t s, const DenseF16Params& p) {
     const bool xvec = ((uintptr_t)p.a % 16 == 0) && (p.K % 4 == 0) && (p.M == 1 || p.a_rs % 4 == 0);
     const uint32_t chf = waves * depth * 32;
     using Fn = void (*)(F16Args);
+    const bool nt = p.stream_nt != 0;
     if (R == 0) {
         const size_t lds = 2ull * chf * sizeof(float);
-        const Fn fn = xvec ? (Fn)dense_f16_kernel<0, true, 1> : (Fn)dense_f16_kernel<0, false, 1>;
+        const Fn fn = nt ? (xvec ? (Fn)dense_f16_kernel<0, true, 1, true> : (Fn)dense_f16_kernel<0, false, 1, true>)
+                         : (xvec ? (Fn)dense_f16_kernel<0, true, 1, false> : (Fn)dense_f16_kernel<0, false, 1, false>);
         if (lds > 64 * 1024) hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipLaunchKernelGGL(fn, dim3(a.NB2, 1), dim3(waves * 64), lds, s, a);
         return;
@@ -271,10 +279,14 @@ void launch_dense_f16(hipStream_t s, const DenseF16Params& p) {
     const size_t red = (size_t)waves * G * R * 256 * sizeof(float);
     if (red > lds) lds = red;
     const dim3 grid(cdiv(a.NB2, G), cdiv(p.M, 16 * R));
-    const Fn fn = G == 2 ? (R == 2 ? (xvec ? (Fn)dense_f16_kernel<2, true, 2> : (Fn)dense_f16_kernel<2, false, 2>)
-                                   : (xvec ? (Fn)dense_f16_kernel<1, true, 2> : (Fn)dense_f16_kernel<1, false, 2>))
-                         : (R == 2 ? (xvec ? (Fn)dense_f16_kernel<2, true, 1> : (Fn)dense_f16_kernel<2, false, 1>)
-                                   : (xvec ? (Fn)dense_f16_kernel<1, true, 1> : (Fn)dense_f16_kernel<1, false, 1>));
+    Fn fn;
+#define ZGML_F16_PICK(NTV)                                                                                                   \
+    (G == 2 ? (R == 2 ? (xvec ? (Fn)dense_f16_kernel<2, true, 2, NTV> : (Fn)dense_f16_kernel<2, false, 2, NTV>)               \
+                      : (xvec ? (Fn)dense_f16_kernel<1, true, 2, NTV> : (Fn)dense_f16_kernel<1, false, 2, NTV>))              \
+            : (R == 2 ? (xvec ? (Fn)dense_f16_kernel<2, true, 1, NTV> : (Fn)dense_f16_kernel<2, false, 1, NTV>)               \
+                      : (xvec ? (Fn)dense_f16_kernel<1, true, 1, NTV> : (Fn)dense_f16_kernel<1, false, 1, NTV>)))
+    fn = nt ? ZGML_F16_PICK(true) : ZGML_F16_PICK(false);
+#undef ZGML_F16_PICK
     if (lds > 64 * 1024) hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(fn, grid, dim3(waves * G * 64), lds, s, a);
 }

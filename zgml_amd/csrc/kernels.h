@@ -120,6 +120,7 @@ struct DenseF16Params {
     const void* bp;  // packed half[N/16][ceil(K/32)][64][8]
     uint32_t M, N, K;
     uint32_t a_rs, dst_rs;
+    uint32_t stream_nt; // non-temporal weight loads: the program's promoted weights exceed the Infinity Cache
 };
 bool f16_packable(uint64_t K, uint64_t N);
 uint64_t f16_packed_bytes(uint64_t K, uint64_t N);

@@ -663,7 +663,7 @@ __device__ __forceinline__ float cvt_i8(uint32_t w) {
 // a 4/8-bit integer and an f16 scale is exact in f32 — and feeds R MFMAs per value with the A
 // operand x[m, k] read straight from the staged LDS chunk. (Q4 values come out of the convert as
 // q/16; the kernel multiplies the finished tile by 16, exact.)
-template <typename ST, bool Q4>
+template <typename ST, bool Q4, bool NT>
 struct TileUnit {
     static constexpr int KU = Q4 ? 32 : 16;             // k per unit
     static constexpr int NS = KU * (int)sizeof(ST) / 16; // uint4 of scales per unit
@@ -672,7 +672,7 @@ struct TileUnit {
     uint4 sraw[NS];
     __device__ __forceinline__ void load(const uint4* qs, const uint4* sc, uint32_t u, uint32_t U) {
         const uint32_t uc = min(u, U - 1); // clamped, unconditional; x of units >= U is staged as zero
-        wq = qs[(uint64_t)uc * 16];
+        wq = wload<NT>(qs + (uint64_t)uc * 16);
 #pragma unroll
         for (int q = 0; q < NS; q++) sraw[q] = sc[(uint64_t)uc * NS + q];
     }
@@ -727,9 +727,9 @@ struct TileUnit {
     }
 };
 
-template <typename ST, bool Q4, int R, bool XVEC>
+template <typename ST, bool Q4, int R, bool XVEC, bool NT>
 __global__ void __launch_bounds__(512) qmatmul_tile_kernel(QMMArgs a) {
-    using Unit = TileUnit<ST, Q4>;
+    using Unit = TileUnit<ST, Q4, NT>;
     constexpr int KU = Unit::KU;
     constexpr int NX = R * KU / 4; // float4 of x each thread stages per step
     extern __shared__ float smem[];
@@ -1072,10 +1072,14 @@ void launch_packed(hipStream_t s, QMVArgs& a, const QWeightDev& w0, uint32_t tot
 }
 
 using TileFn = void (*)(QMMArgs);
+template <typename ST, bool Q4, bool NT>
+TileFn pick_tile_nt(bool two, bool xvec) {
+    if (two) return xvec ? qmatmul_tile_kernel<ST, Q4, 2, true, NT> : qmatmul_tile_kernel<ST, Q4, 2, false, NT>;
+    return xvec ? qmatmul_tile_kernel<ST, Q4, 1, true, NT> : qmatmul_tile_kernel<ST, Q4, 1, false, NT>;
+}
 template <typename ST, bool Q4>
-TileFn pick_tile(bool two, bool xvec) {
-    if (two) return xvec ? qmatmul_tile_kernel<ST, Q4, 2, true> : qmatmul_tile_kernel<ST, Q4, 2, false>;
-    return xvec ? qmatmul_tile_kernel<ST, Q4, 1, true> : qmatmul_tile_kernel<ST, Q4, 1, false>;
+TileFn pick_tile(bool two, bool xvec, bool nt) {
+    return nt ? pick_tile_nt<ST, Q4, true>(two, xvec) : pick_tile_nt<ST, Q4, false>(two, xvec);
 }
 
 void launch_tile(hipStream_t s, const QWeightDev& w, const QMatmulParams& p, bool xvec) {
@@ -1085,8 +1089,9 @@ void launch_tile(hipStream_t s, const QWeightDev& w, const QMatmulParams& p, boo
     uint32_t waves = cdiv(a.U, 4);
     static const int env_w = getenv("ZGML_QMM_WAVES") ? atoi(getenv("ZGML_QMM_WAVES")) : 8;
     if (waves > (uint32_t)env_w) waves = env_w; // x chunk per step = 16R rows x 4*waves units in LDS
-    const TileFn fn = w.scale_f16 ? (q4 ? pick_tile<__half, true>(two, xvec) : pick_tile<__half, false>(two, xvec))
-                                  : (q4 ? pick_tile<float, true>(two, xvec) : pick_tile<float, false>(two, xvec));
+    const bool nt = w.stream_nt != 0 && cdiv(p.M, 16 * R) == 1; // several m-tiles re-read the weights: keep them cached
+    const TileFn fn = w.scale_f16 ? (q4 ? pick_tile<__half, true>(two, xvec, nt) : pick_tile<__half, false>(two, xvec, nt))
+                                  : (q4 ? pick_tile<float, true>(two, xvec, nt) : pick_tile<float, false>(two, xvec, nt));
     dim3 grid(a.NB2, cdiv(p.M, 16 * R));
     const size_t x_bytes = 16ull * R * (waves * 4 * KU + 4) * sizeof(float);
     const size_t red_bytes = (size_t)waves * R * 256 * sizeof(float);

@@ -117,6 +117,7 @@ struct zgml_hip_program {
     };
     std::vector<QmvTrace> qmv_traces; // diagnostics (ZGML_HIP_QMV_TRACE)
     float* zero_word = nullptr;                   // a device 0.0f: mask operand of unmasked decode attention
+    bool f16_stream_nt = false;     // promoted weights exceed the Infinity Cache: non-temporal loads
     std::vector<void*> f16_weights; // per buffer: MFMA-packed f16 copy of a promoted matmul B operand (else nullptr)
     std::vector<void*> owned; // other device allocations
     float* scratch = nullptr;
@@ -454,7 +455,7 @@ bool make_single(zgml_hip_program* p, size_t i, Launch& L) {
             dp.dst_rs = (uint32_t)m.geom.dst_row_stride;
             dp.b_f16 = 0;
             if (m.b < p->f16_weights.size() && p->f16_weights[m.b]) { // promoted at compile time
-                DenseF16Params fp{dp.dst, dp.a, p->f16_weights[m.b], dp.M, dp.N, dp.K, dp.a_rs, dp.dst_rs};
+                DenseF16Params fp{dp.dst, dp.a, p->f16_weights[m.b], dp.M, dp.N, dp.K, dp.a_rs, dp.dst_rs, p->f16_stream_nt ? 1u : 0u};
                 L.run = [=](hipStream_t s) { launch_dense_f16(s, fp); };
                 return true;
             }
@@ -1770,6 +1771,7 @@ zgml_hip_program* zgml_hip_compile_program(zgml_hip_ctx* ctx, const zgml_device_
     }
 
     // promoted weights: stage the f32 image, pack to f16 on the device, drop the f32 image
+    uint64_t f16_total = 0;
     for (size_t b = 0; ok && b < nb; b++) {
         if (promo_state[b] != 1) continue;
         const Promo& g = promo[b];
@@ -1800,10 +1802,13 @@ zgml_hip_program* zgml_hip_compile_program(zgml_hip_ctx* ctx, const zgml_device_
         if (ok) {
             p->f16_weights[b] = packed;
             p->owned.push_back(packed);
+            f16_total += f16_packed_bytes(g.K, g.N);
         } else {
             hipFree(packed);
         }
     }
+
+    p->f16_stream_nt = f16_total >= (192ull << 20);
 
     // quantized weights: upload raw, classify and re-pack on the device
     p->qweights.resize(prog->n_qweights);
@@ -2215,7 +2220,7 @@ double zgml_hip_dense_f16_bench(zgml_hip_ctx* ctx, uint32_t M, uint32_t K, uint3
     }
     double us = -1.0;
     if (ok) {
-        DenseF16Params fp{y, x, nullptr, M, N, K, K, N};
+        DenseF16Params fp{y, x, nullptr, M, N, K, K, N, f16_packed_bytes(K, N) * n_matrices >= (192ull << 20) ? 1u : 0u};
         for (uint32_t i = 0; i < warmup; i++) {
             fp.bp = ring[i % n_matrices];
             launch_dense_f16(ctx->stream, fp);
