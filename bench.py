@@ -175,9 +175,22 @@ def prefill_leg(be, llama, kind, T=32, reps=8, max_seq=512):
             be._lib.zgml_hip_enqueue_program(be.ctx, s.handle)
         be.synchronize()
         dt = (time.perf_counter() - t0) / reps
+        dec = None
+        if dense:  # the same f16-promoted weights at token_len 1, for the "fp16 dense vs Q4_0" comparison at batch 1
+            s.close()
+            m.close()
+            m = llama.Model(llama.preset("llama2-7b", max_seq), llama.F32_DENSE, threads=16)
+            s = llama.Session(m, llama.hip_backend_fns(be))
+            s.resident_setup(be)
+            w = s.resident_decode(1, 0, 4)
+            be.synchronize()
+            t0 = time.perf_counter()
+            s.resident_decode(int(w[-1]), 4, 48)
+            be.synchronize()
+            dec = round(48 / (time.perf_counter() - t0), 1)
         s.close()
         m.close()
-        return {"prefill_tok_s": round(T / dt, 1), "ms_per_chunk": round(dt * 1e3, 3), "token_len": T, "first_token": int(nxt),
+        return {"decode_tok_s_batch1": dec, "prefill_tok_s": round(T / dt, 1), "ms_per_chunk": round(dt * 1e3, 3), "token_len": T, "first_token": int(nxt),
                 "logits_finite": finite, "build_s": round(build_s, 1)}
     finally:
         be.set_option(capi.OPT_F16_DENSE_WEIGHTS, 0)
