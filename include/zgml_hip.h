@@ -80,7 +80,11 @@ enum {
     ZGML_DOP_ROPE = 9,
     ZGML_DOP_ATTENTION = 10,
     ZGML_DOP_FUSED_ELEMENTWISE = 11,
-    ZGML_DOP_COUNT = 12
+    ZGML_DOP_COUNT = 12,
+    /* Extension kinds (no reference DeviceOp): the quantised KV cache of
+     * src/quant.zig:645-1091 as device ops. Never counted in the reference-shaped profile arrays. */
+    ZGML_DOP_KVQ_STORE = 13,     /* QuantizedKVCache.storeColumn */
+    ZGML_DOP_ATTENTION_KVQ = 14  /* attentionQuantized */
 };
 
 /* MatMulGeometry, src/backend.zig:146-158 (usize -> uint64_t). */
@@ -167,6 +171,38 @@ typedef struct zgml_op_attention {
     uint32_t q_rs, q_cs, k_rs, k_cs, v_rs, v_cs, mask_rs, mask_cs, dst_rs, dst_cs;
 } zgml_op_attention;
 
+/* A quantised KV cache lives in ONE program buffer (f32-element sized like every buffer):
+ *   int8 q_data[n_cols * d_head]            column c at byte offset c * d_head
+ *   f32  scales[n_cols * d_head/block_size] at element offset n_cols * d_head / 4, column-major
+ * so buffer_sizes[cache] >= n_cols*d_head/4 + n_cols*d_head/block_size (n_cols*d_head % 4 == 0). */
+
+/* QuantizedKVCache.storeColumn (src/quant.zig:687-699 -> quantizeInput :320-341): quantise the d_head
+ * f32 values at src[src_offset ..] (unit stride) into column `col`. `col` is the dynamic field
+ * (refresh: col_base + pos * patch_stride, like slice_assign.dst_offset). */
+typedef struct zgml_op_kvq_store {
+    uint16_t cache, src;
+    uint32_t d_head, block_size, n_cols;
+    uint32_t src_offset;
+    uint32_t col_base;
+    uint32_t col; /* dynamic */
+    uint32_t patch_stride;
+} zgml_op_kvq_store;
+
+/* attentionQuantized (src/quant.zig:925-1091): q / dst dense f32 columns (unit row stride), K and V
+ * columns [k_col_start, k_col_start + seq_kv) / [v_col_start, ...) of two quantised caches, optional
+ * additive mask, streaming softmax; a query with no valid key yields zeros. */
+typedef struct zgml_op_attention_kvq {
+    uint16_t dst, q, k, v, mask;
+    uint8_t has_mask, _pad;
+    uint32_t d_head, seq_q;
+    uint32_t seq_kv; /* dynamic */
+    float scale;
+    uint32_t block_size, n_cols;
+    uint32_t k_col_start, v_col_start;
+    uint32_t q_off, q_cs, dst_off, dst_cs;
+    uint32_t mask_off, mask_rs, mask_cs;
+} zgml_op_attention_kvq;
+
 typedef struct zgml_op_fused_elementwise {
     const zgml_fused_step* steps; /* borrowed: must outlive the compiled program's use of `ops` */
     uint32_t n_steps;
@@ -192,6 +228,8 @@ typedef struct zgml_device_op {
         zgml_op_rope rope;
         zgml_op_attention attention;
         zgml_op_fused_elementwise fused_elementwise;
+        zgml_op_kvq_store kvq_store;         /* extension */
+        zgml_op_attention_kvq attention_kvq; /* extension */
     } u;
 } zgml_device_op;
 

@@ -582,6 +582,123 @@ static void zo_attention(const zo_buffer* b, const zgml_op_attention* att) {
     }
 }
 
+/* ───────────────────── quantised KV cache (extension ops) ───────────────────── */
+/* Cache buffer layout (include/zgml_hip.h): int8 q_data[n_cols*d_head], then f32 scales[n_cols*bpc]
+ * at element offset n_cols*d_head/4. */
+void zo_quantize_input(const float* input, uint64_t K, uint64_t bs, int8_t* inp_q, float* inp_scales);
+
+static inline int8_t* zo_kvq_data(float* base) { return (int8_t*)base; }
+static inline float* zo_kvq_scales(float* base, uint64_t n_cols, uint64_t dh) { return base + n_cols * dh / 4; }
+
+/* QuantizedKVCache.storeColumn, src/quant.zig:687-699 */
+static void zo_kvq_store(const zo_buffer* b, const zgml_op_kvq_store* st) {
+    const uint64_t dh = st->d_head, bpc = dh / st->block_size;
+    int8_t* qd = zo_kvq_data(b[st->cache].ptr) + (uint64_t)st->col * dh;
+    float* sc = zo_kvq_scales(b[st->cache].ptr, st->n_cols, dh) + (uint64_t)st->col * bpc;
+    zo_quantize_input(b[st->src].ptr + st->src_offset, dh, st->block_size, qd, sc);
+}
+
+/* dotI8F32, src/quant.zig:801-828: per block 8 lanes of f*q, lane-order reduce, times the block scale */
+static float zo_kvq_dot(const float* f, const int8_t* q, const float* sc, uint64_t bs, uint64_t nb) {
+    float total = 0;
+    for (uint64_t bl = 0; bl < nb; bl++) {
+        const uint64_t base = bl * bs;
+        float lanes[ZO_V] = {0};
+        uint64_t i = 0;
+        for (; i + ZO_V <= bs; i += ZO_V)
+            for (int j = 0; j < ZO_V; j++) lanes[j] += f[base + i + j] * (float)q[base + i + j];
+        float sub = zo_reduce8(lanes);
+        for (; i < bs; i++) sub += f[base + i] * (float)q[base + i];
+        total += sub * sc[bl];
+    }
+    return total;
+}
+
+/* attentionQuantized, src/quant.zig:925-1091, the non-SDOT (x86) path: flash tiles of Bs = 8 columns
+ * (whole-tile mask skip, one rescale per tile, accumBatchI8F32 :861-908), then a one-column tail
+ * (accumI8F32 :830-857). */
+static void zo_attention_kvq(const zo_buffer* b, const zgml_op_attention_kvq* a) {
+    enum { BS_TILE = 8 };
+    const uint64_t dh = a->d_head, bs = a->block_size, nb = dh / bs, ncols = a->n_cols;
+    const int8_t* kq = zo_kvq_data(b[a->k].ptr);
+    const float* ks = zo_kvq_scales(b[a->k].ptr, ncols, dh);
+    const int8_t* vq = zo_kvq_data(b[a->v].ptr);
+    const float* vs = zo_kvq_scales(b[a->v].ptr, ncols, dh);
+    const float* mask = b[a->mask].ptr;
+    float acc[512];
+    if (dh > 512) return;
+    for (uint64_t qi = 0; qi < a->seq_q; qi++) {
+        const float* q = b[a->q].ptr + a->q_off + qi * a->q_cs;
+        const uint64_t mask_base = (uint64_t)a->mask_off + qi * a->mask_cs;
+        float m_val = -INFINITY, l = 0;
+        for (uint64_t r = 0; r < dh; r++) acc[r] = 0;
+        uint64_t s = 0;
+        for (; s + BS_TILE <= a->seq_kv; s += BS_TILE) {
+            float scores[BS_TILE], ws[BS_TILE];
+            if (a->has_mask) {
+                int any = 0;
+                for (int t = 0; t < BS_TILE; t++) any |= isfinite(mask[mask_base + (s + t) * a->mask_rs]) != 0;
+                if (!any) continue;
+            }
+            float tile_max = -INFINITY;
+            for (int t = 0; t < BS_TILE; t++) {
+                const float mask_add = a->has_mask ? mask[mask_base + (s + t) * a->mask_rs] : 0.0f;
+                if (isfinite(mask_add)) {
+                    const uint64_t c = a->k_col_start + s + t;
+                    const float score = zo_kvq_dot(q, kq + c * dh, ks + c * nb, bs, nb) * a->scale + mask_add;
+                    scores[t] = score;
+                    if (score > tile_max) tile_max = score;
+                } else {
+                    scores[t] = -INFINITY;
+                }
+            }
+            if (tile_max == -INFINITY) continue;
+            const float new_m = (m_val == -INFINITY) ? tile_max : zo_maxf(m_val, tile_max);
+            const float alpha = (m_val == -INFINITY) ? 0.0f : expf(m_val - new_m);
+            float tile_l = 0;
+            for (int t = 0; t < BS_TILE; t++) {
+                ws[t] = expf(scores[t] - new_m);
+                tile_l += ws[t];
+            }
+            if (m_val != -INFINITY && alpha != 1.0f)
+                for (uint64_t r = 0; r < dh; r++) acc[r] *= alpha;
+            for (uint64_t bl = 0; bl < nb; bl++) { /* accumBatchI8F32 */
+                float wsc[BS_TILE];
+                for (int t = 0; t < BS_TILE; t++) wsc[t] = ws[t] * vs[(a->v_col_start + s + t) * nb + bl];
+                for (uint64_t i = 0; i < bs; i++) {
+                    float sum = acc[bl * bs + i];
+                    for (int t = 0; t < BS_TILE; t++) sum = sum + wsc[t] * (float)vq[(a->v_col_start + s + t) * dh + bl * bs + i];
+                    acc[bl * bs + i] = sum;
+                }
+            }
+            l = l * alpha + tile_l;
+            m_val = new_m;
+        }
+        for (; s < a->seq_kv; s++) { /* tail, one column at a time */
+            const float mask_add = a->has_mask ? mask[mask_base + s * a->mask_rs] : 0.0f;
+            if (!isfinite(mask_add)) continue;
+            const uint64_t c = a->k_col_start + s;
+            const float score = zo_kvq_dot(q, kq + c * dh, ks + c * nb, bs, nb) * a->scale + mask_add;
+            if (!isfinite(score)) continue;
+            const float new_m = zo_maxf(m_val, score);
+            const float alpha = (m_val == -INFINITY) ? 0.0f : expf(m_val - new_m);
+            const float w = expf(score - new_m);
+            if (m_val != -INFINITY && alpha != 1.0f)
+                for (uint64_t r = 0; r < dh; r++) acc[r] *= alpha;
+            const uint64_t cv = a->v_col_start + s;
+            for (uint64_t bl = 0; bl < nb; bl++) { /* accumI8F32 */
+                const float wsc = w * vs[cv * nb + bl];
+                for (uint64_t i = 0; i < bs; i++) acc[bl * bs + i] = acc[bl * bs + i] + wsc * (float)vq[cv * dh + bl * bs + i];
+            }
+            l = l * alpha + w;
+            m_val = new_m;
+        }
+        const float inv_l = l > 0 ? 1.0f / l : 0.0f;
+        float* dst = b[a->dst].ptr + a->dst_off + qi * a->dst_cs;
+        for (uint64_t r = 0; r < dh; r++) dst[r] = acc[r] * inv_l;
+    }
+}
+
 /* ───────────────────────────── dispatch ───────────────────────────── */
 
 void zo_execute_op(const zo_buffer* buffers, const zo_qweight* qweights, const zgml_device_op* op) {
@@ -598,6 +715,8 @@ void zo_execute_op(const zo_buffer* buffers, const zo_qweight* qweights, const z
         case ZGML_DOP_ROPE: zo_rope(buffers, &op->u.rope); break;
         case ZGML_DOP_ATTENTION: zo_attention(buffers, &op->u.attention); break;
         case ZGML_DOP_FUSED_ELEMENTWISE: zo_fused_elementwise(buffers, &op->u.fused_elementwise); break;
+        case ZGML_DOP_KVQ_STORE: zo_kvq_store(buffers, &op->u.kvq_store); break;
+        case ZGML_DOP_ATTENTION_KVQ: zo_attention_kvq(buffers, &op->u.attention_kvq); break;
         default: break;
     }
 }
@@ -835,6 +954,18 @@ int zo_program_supported(const zgml_device_program* pr, int fused_elementwise, i
                 if (attn_max_seq_kv >= 0 && (int64_t)a->seq_kv > attn_max_seq_kv) return 0;
                 if (attn_max_d_head >= 0 && (int64_t)a->d_head > attn_max_d_head) return 0;
                 if (!HAS(a->dst) || !HAS(a->q) || !HAS(a->k) || !HAS(a->v) || !HAS(a->mask)) return 0;
+                break;
+            }
+            case ZGML_DOP_KVQ_STORE: { /* extension: the reference's CpuBackend has no such op; shape checks only */
+                const zgml_op_kvq_store* st = &op->u.kvq_store;
+                if (!HAS(st->cache) || !HAS(st->src) || !st->block_size || st->d_head % st->block_size) return 0;
+                if (((uint64_t)st->n_cols * st->d_head) % 4) return 0;
+                break;
+            }
+            case ZGML_DOP_ATTENTION_KVQ: {
+                const zgml_op_attention_kvq* a = &op->u.attention_kvq;
+                if (!HAS(a->dst) || !HAS(a->q) || !HAS(a->k) || !HAS(a->v) || !HAS(a->mask)) return 0;
+                if (!a->block_size || a->d_head % a->block_size || a->d_head > 512) return 0;
                 break;
             }
             case ZGML_DOP_FUSED_ELEMENTWISE: {

@@ -203,3 +203,29 @@ def test_prefill_plan_hands_kv_to_decode_plan(hip_backend, oracle):
         s.close()
     for m in (m_pre, m_dec, m_seq):
         m.close()
+
+
+@pytest.mark.parametrize("name,steps", [("tiny", 10), ("smollm-135m", 4)])
+def test_quantised_kv_cache_decode(hip_backend, oracle, name, steps):
+    """the decode program with int8 KV caches (kvq_store + attention_kvq extension ops,
+    block 32): HIP equals the oracle's restatement (identical greedy tokens, logits within 2e-4 of the
+    range), through the vtable and through the device-resident loop."""
+    cfg = llama.preset(name)
+    cfg.kv_quant_block = 32
+    oracle.set_threads(8)
+    m = llama.Model(cfg, llama.Q4_0, threads=8)
+    s_ref, s_hip = llama.Session(m, oracle.backend_fns()), llama.Session(m, llama.hip_backend_fns(hip_backend))
+    tok, toks = 3, []
+    for pos in range(steps):
+        t_ref, l_ref = s_ref.step(tok, pos)
+        t_hip, l_hip = s_hip.step(tok, pos)
+        assert not hip_backend.last_error(), hip_backend.last_error()
+        assert np.abs(l_hip - l_ref).max() / np.abs(l_ref).max() < 2e-4 and t_hip == t_ref
+        tok = t_ref
+        toks.append(tok)
+    s_hip.close()
+    s_res = llama.Session(m, llama.hip_backend_fns(hip_backend))
+    s_res.resident_setup(hip_backend)
+    got = s_res.resident_decode(3, 0, steps)
+    assert [int(t) for t in got] == toks
+    s_res.close(), s_ref.close(), m.close()

@@ -267,3 +267,48 @@ def test_oracle_accepts_packed_gguf_upload():
     a = O.run_program(program(QuantizedWeightUpload(data, scales, K, N, 32)), 1, N)
     b = O.run_program(program(QuantizedWeightUpload.from_gguf_blocks(raw, K, N, "q4_0")), 1, N)
     assert np.array_equal(a, b) and np.abs(a).max() > 0
+
+
+def test_quantised_kv_ops_meet_the_reference_tests_bounds():
+    """The reference's own acceptance tests for QuantizedKVCache / attentionQuantized
+    (src/quant.zig:1259-1606) restated on the oracle's extension ops, with inputs uniform in [-1, 1) as
+    fillRandF32 produces: store -> dequant round trip within 0.02 (:1259-1276), decode attention within
+    0.01 of the streaming softmax over the dequantised K/V (:1339-1411), a causal broadcast mask
+    (:1413-1485) and a column offset selecting the right slab (:1487-1545), tile + tail path (:1547+)."""
+    from zgml_amd import DeviceOp, DeviceProgram, ProgramIO
+    from oracle import oracle as O
+    f32 = np.float32
+    rng = np.random.default_rng(12)
+    dh, bs, n_cols, start = 64, 32, 32, 3
+    ce = n_cols * dh // 4 + n_cols * (dh // bs)
+    for seq_kv, causal_pos in ((8, None), (8, 4), (19, None)):  # 19 = two tiles of 8 + tail of 3
+        k = ((rng.random((seq_kv, dh)) - 0.5) * 2).astype(f32)
+        v = ((rng.random((seq_kv, dh)) - 0.5) * 2).astype(f32)
+        q = ((rng.random(dh) - 0.5) * 2).astype(f32)
+        mask = np.zeros(seq_kv, f32)
+        if causal_pos is not None:
+            mask[causal_pos + 1:] = -np.inf
+        ops = []
+        for c in range(seq_kv):
+            ops.append(DeviceOp.kvq_store(0, 2, dh, bs, n_cols, c * dh, start, start + c, 1))
+            ops.append(DeviceOp.kvq_store(1, 3, dh, bs, n_cols, c * dh, start, start + c, 1))
+        scale = float(1 / np.sqrt(dh))
+        ops.append(DeviceOp.attention_kvq(5, 4, 0, 1, 6, True, dh, 1, seq_kv, scale, bs, n_cols, start, start, 0, dh, 0, dh, 0, 1, 0))
+        prog = DeviceProgram(ops=ops, buffer_sizes=[ce, ce, seq_kv * dh, seq_kv * dh, dh, dh, seq_kv],
+                             initial_uploads=[ProgramIO(2, k.ravel()), ProgramIO(3, v.ravel()), ProgramIO(4, q), ProgramIO(6, mask)])
+        be = O.OracleBackend()
+        h = be.compileProgram(prog)
+        out, kc, vc = np.zeros(dh, f32), np.zeros(ce, f32), np.zeros(ce, f32)
+        be.executeProgram(h, [], [ProgramIO(5, out), ProgramIO(0, kc), ProgramIO(1, vc)])
+        be.freeProgram(h)
+
+        def dequant(c):
+            qd = c.view(np.int8)[:n_cols * dh].reshape(n_cols, dh).astype(f32)
+            return (qd * np.repeat(c[n_cols * dh // 4:].reshape(n_cols, dh // bs), bs, axis=1))[start:start + seq_kv]
+        kd, vd = dequant(kc), dequant(vc)
+        assert np.abs(kd - k).max() <= 0.02 and np.abs(vd - v).max() <= 0.02
+        s = kd.astype(np.float64) @ q.astype(np.float64) * scale + mask
+        w = np.exp(s - s.max())
+        ref = (w[:, None] * vd).sum(0) / w.sum()
+        assert np.abs(out - ref).max() <= 0.01
+        assert np.abs(out - ref).max() <= 1e-5  # in fact the same dequantised operands: only the order differs

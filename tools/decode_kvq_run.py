@@ -1,0 +1,24 @@
+"""Resident greedy decode with the quantised KV cache (int8 blocks of 32) next to the f32 cache."""
+import sys
+import time
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from zgml_amd import Backend, llama  # noqa: E402
+
+name = sys.argv[1] if len(sys.argv) > 1 else "smollm-135m"
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+be = Backend(0)
+for kvq in (0, 32):
+    cfg = llama.preset(name, 2048)
+    cfg.kv_quant_block = kvq
+    m = llama.Model(cfg, llama.Q4_0, threads=16)
+    s = llama.Session(m, llama.hip_backend_fns(be))
+    s.resident_setup(be)
+    w = s.resident_decode(1, 0, 4)
+    t0 = time.perf_counter()
+    s.resident_decode(int(w[-1]), 4, steps)
+    dt = time.perf_counter() - t0
+    print(f"{name} kv_quant_block={kvq}: {steps / dt:.1f} tok/s, {1e3 * dt / steps:.3f} ms/token")
+    s.close()
+    m.close()
+be.close()

@@ -30,6 +30,7 @@ DOP_KINDS = [
     "repeat", "slice_assign", "rope", "attention", "fused_elementwise",
 ]
 DOP = {name: i for i, name in enumerate(DOP_KINDS)}
+DOP.update({"kvq_store": 13, "attention_kvq": 14})  # extension kinds (quantised KV cache)
 
 
 class MatMulGeom(C.Structure):
@@ -110,11 +111,27 @@ class OpFusedElementwise(C.Structure):
                 ("src_offset", C.c_uint32)]
 
 
+class OpKvqStore(C.Structure):
+    _fields_ = [("cache", C.c_uint16), ("src", C.c_uint16), ("d_head", C.c_uint32), ("block_size", C.c_uint32),
+                ("n_cols", C.c_uint32), ("src_offset", C.c_uint32), ("col_base", C.c_uint32), ("col", C.c_uint32),
+                ("patch_stride", C.c_uint32)]
+
+
+class OpAttentionKvq(C.Structure):
+    _fields_ = [("dst", C.c_uint16), ("q", C.c_uint16), ("k", C.c_uint16), ("v", C.c_uint16),
+                ("mask", C.c_uint16), ("has_mask", C.c_uint8), ("_pad", C.c_uint8),
+                ("d_head", C.c_uint32), ("seq_q", C.c_uint32), ("seq_kv", C.c_uint32), ("scale", C.c_float),
+                ("block_size", C.c_uint32), ("n_cols", C.c_uint32), ("k_col_start", C.c_uint32),
+                ("v_col_start", C.c_uint32), ("q_off", C.c_uint32), ("q_cs", C.c_uint32), ("dst_off", C.c_uint32),
+                ("dst_cs", C.c_uint32), ("mask_off", C.c_uint32), ("mask_rs", C.c_uint32), ("mask_cs", C.c_uint32)]
+
+
 class _OpUnion(C.Union):
     _fields_ = [("elementwise", OpElementwise), ("matmul", OpMatmul), ("qmatmul", OpQMatmul),
                 ("softmax", OpRowwise), ("layernorm", OpRowwise), ("rmsnorm", OpRowwise),
                 ("reduce", OpReduce), ("repeat", OpRepeat), ("slice_assign", OpSliceAssign),
-                ("rope", OpRope), ("attention", OpAttention), ("fused_elementwise", OpFusedElementwise)]
+                ("rope", OpRope), ("attention", OpAttention), ("fused_elementwise", OpFusedElementwise),
+                ("kvq_store", OpKvqStore), ("attention_kvq", OpAttentionKvq)]
 
 
 class DeviceOpC(C.Structure):

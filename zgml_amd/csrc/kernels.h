@@ -104,6 +104,26 @@ struct AttnDecodeParams {
     unsigned long long* trace; // diagnostics (ZGML_HIP_ATTN_TRACE=1): 8 wall-clock stamps, else nullptr
 };
 
+// quantised KV cache (extension ops; layout in include/zgml_hip.h)
+struct KvqStoreParams {
+    float* cache;                // buffer base
+    const float* src;            // src_offset applied, d_head values, unit stride
+    const uint32_t* dyn_col;     // device word with the current column
+    uint32_t d_head, block_size, n_cols;
+};
+struct KvqAttentionParams {
+    float* dst;                  // dst_off applied
+    const float* q;              // q_off applied
+    const float* k_cache;        // buffer bases
+    const float* v_cache;
+    const float* mask;           // mask_off applied; nullptr when !has_mask
+    const uint32_t* dyn_seq_kv;
+    uint32_t d_head, seq_q, block_size, n_cols, k_col_start, v_col_start, q_cs, dst_cs, mask_rs, mask_cs;
+    float scale;
+};
+void launch_kvq_store_batch(hipStream_t s, const KvqStoreParams* dev_params, uint32_t n_ops);
+void launch_kvq_attention_batch(hipStream_t s, const KvqAttentionParams* dev_params, uint32_t n_ops, uint32_t max_seq_q, uint32_t d_head);
+
 struct DenseMatmulParams {
     float* dst;       // dst_offset applied
     const float* a;   // a_offset applied

@@ -668,6 +668,96 @@ __global__ void __launch_bounds__(kAttnBlock) attention_decode_kernel(const Attn
 #undef ATTN_STAMP
 }
 
+// ── quantised KV cache (extension ops; src/quant.zig:645-1091) ───────────────────────────────
+// storeColumn: one wave per op; lane r handles elements r, r+64, ... of each block. Same arithmetic
+// as quantizeInput (:320-341): scale = absmax/127 (1 if the block is all zero), q = trunc(clamp(v * (127/absmax))).
+__global__ void __launch_bounds__(64) kvq_store_kernel(const KvqStoreParams* __restrict__ params) {
+    const KvqStoreParams& p = params[blockIdx.x];
+    const uint32_t col = *p.dyn_col;
+    if (col >= p.n_cols) return; // never write outside the cache
+    const uint32_t dh = p.d_head, bs = p.block_size, bpc = dh / bs, lane = threadIdx.x;
+    int8_t* qd = (int8_t*)p.cache + (uint64_t)col * dh;
+    float* sc = p.cache + (uint64_t)p.n_cols * dh / 4 + (uint64_t)col * bpc;
+    for (uint32_t b = 0; b < bpc; b++) {
+        float mx = 0.f;
+        for (uint32_t i = lane; i < bs; i += 64) mx = fmaxf(mx, fabsf(p.src[b * bs + i]));
+        mx = wave_max(mx);
+        const float scale = mx > 0.f ? mx / 127.0f : 1.0f, inv = mx > 0.f ? 127.0f / mx : 0.0f;
+        if (lane == 0) sc[b] = scale;
+        for (uint32_t i = lane; i < bs; i += 64) {
+            const float v = fminf(fmaxf(p.src[b * bs + i] * inv, -127.0f), 127.0f);
+            qd[b * bs + i] = (int8_t)(int)v; // @intFromFloat truncates toward zero
+        }
+    }
+}
+
+// attentionQuantized: one workgroup of 256 threads per (query, op). A key is handled by LPK = d_head/4
+// lanes, each dequantising 4 consecutive dims of the int8 row (one 4-byte load); per-slot online softmax
+// merged at the end like attention_decode_kernel. Only the summation / rescale order differs from the
+// reference's Bs = 8 flash tiles.
+template <int LPK>
+__global__ void __launch_bounds__(256) kvq_attention_kernel(const KvqAttentionParams* __restrict__ params) {
+    constexpr int DH = 4 * LPK, KPW = 64 / LPK, NWV = 4;
+    const KvqAttentionParams& p = params[blockIdx.y];
+    if (blockIdx.x >= p.seq_q) return;
+    __shared__ float part_ml[2 * NWV];
+    __shared__ float4 part_acc[NWV * LPK];
+    const uint32_t qi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t slot = lane / LPK, li = lane % LPK, d0 = 4 * li;
+    uint32_t seq_kv = *p.dyn_seq_kv;
+    const uint32_t room_k = p.n_cols > p.k_col_start ? p.n_cols - p.k_col_start : 0, room_v = p.n_cols > p.v_col_start ? p.n_cols - p.v_col_start : 0;
+    seq_kv = min(seq_kv, min(room_k, room_v)); // never read outside the caches
+    const uint32_t bpc = DH / p.block_size, blk = d0 / p.block_size;
+    const int8_t* kq = (const int8_t*)p.k_cache;
+    const float* ks = p.k_cache + (uint64_t)p.n_cols * DH / 4;
+    const int8_t* vq = (const int8_t*)p.v_cache;
+    const float* vs = p.v_cache + (uint64_t)p.n_cols * DH / 4;
+    const float4 qv = *(const float4*)(p.q + (uint64_t)qi * p.q_cs + d0);
+    SoftState st{-INFINITY, 0.f, make_float4(0.f, 0.f, 0.f, 0.f)};
+    for (uint32_t base = 0; base < seq_kv; base += KPW * NWV) {
+        const uint32_t t = base + w * KPW + slot;
+        const uint32_t tc = min(t, seq_kv - 1);
+        const uint64_t ck = (uint64_t)p.k_col_start + tc, cv = (uint64_t)p.v_col_start + tc;
+        const uint32_t kw = *(const uint32_t*)(kq + ck * DH + d0), vw = *(const uint32_t*)(vq + cv * DH + d0);
+        const float ksc = ks[ck * bpc + blk], vsc = vs[cv * bpc + blk];
+        const float mk = p.mask ? p.mask[(uint64_t)qi * p.mask_cs + (uint64_t)tc * p.mask_rs] : 0.0f;
+        // dequantised dot: the block scale applies to this lane's 4 dims (block_size % 4 == 0)
+        float dot = (qv.x * (float)(int8_t)(kw & 255) + qv.y * (float)(int8_t)((kw >> 8) & 255) + qv.z * (float)(int8_t)((kw >> 16) & 255) +
+                     qv.w * (float)(int8_t)(kw >> 24)) * ksc;
+        dot = group_sum<LPK>(dot);
+        const float sc = t < seq_kv ? score_of(dot, mk, p.scale) : -INFINITY;
+        if (sc > -INFINITY) {
+            const float nm = fmaxf(st.m, sc);
+            const float alpha = st.m > -INFINITY ? expf(st.m - nm) : 0.0f, wgt = expf(sc - nm);
+            const float ws = wgt * vsc;
+            st.l = st.l * alpha + wgt;
+            st.acc.x = st.acc.x * alpha + ws * (float)(int8_t)(vw & 255);
+            st.acc.y = st.acc.y * alpha + ws * (float)(int8_t)((vw >> 8) & 255);
+            st.acc.z = st.acc.z * alpha + ws * (float)(int8_t)((vw >> 16) & 255);
+            st.acc.w = st.acc.w * alpha + ws * (float)(int8_t)(vw >> 24);
+            st.m = nm;
+        }
+    }
+#pragma unroll
+    for (int off = LPK; off < 64; off <<= 1) {
+        const float om = __shfl_xor(st.m, off, 64), ol = __shfl_xor(st.l, off, 64);
+        const float4 oa = make_float4(__shfl_xor(st.acc.x, off, 64), __shfl_xor(st.acc.y, off, 64), __shfl_xor(st.acc.z, off, 64),
+                                      __shfl_xor(st.acc.w, off, 64));
+        soft_merge(st, om, ol, oa);
+    }
+    if (lane < LPK) {
+        part_acc[w * LPK + lane] = st.acc;
+        if (lane == 0) part_ml[2 * w] = st.m, part_ml[2 * w + 1] = st.l;
+    }
+    __syncthreads();
+    if (tid < LPK) {
+        SoftState r{part_ml[0], part_ml[1], part_acc[tid]};
+        for (uint32_t ww = 1; ww < NWV; ww++) soft_merge(r, part_ml[2 * ww], part_ml[2 * ww + 1], part_acc[ww * LPK + tid]);
+        const float inv_l = r.l > 0.f ? 1.0f / r.l : 0.0f;
+        *(float4*)(p.dst + (uint64_t)qi * p.dst_cs + 4 * tid) = make_float4(r.acc.x * inv_l, r.acc.y * inv_l, r.acc.z * inv_l, r.acc.w * inv_l);
+    }
+}
+
 // ── dense f32 matmul (reference.zig:480-497 -> forward.blasSgemm index contract) ───────────
 // C[m*dst_rs + n] = sum_k A[m*a_rs + k*a_cs] * B[k*b_rs + n*b_cs]
 
@@ -857,6 +947,24 @@ void launch_repeat_batch(hipStream_t s, const RepeatParams* dev_params, uint32_t
 void launch_move_batch(hipStream_t s, const MoveParams* dev_params, uint32_t n_ops, uint32_t max_elems) {
     if (!n_ops || !max_elems) return;
     move_kernel<<<dim3(cdiv(max_elems, kBlock), n_ops), kBlock, 0, s>>>(dev_params);
+}
+
+void launch_kvq_store_batch(hipStream_t s, const KvqStoreParams* dev_params, uint32_t n_ops) {
+    if (n_ops) kvq_store_kernel<<<n_ops, 64, 0, s>>>(dev_params);
+}
+
+// all ops of a launch share d_head (the planner groups them); d_head in {16, 32, 64, 128, 256}
+void launch_kvq_attention_batch(hipStream_t s, const KvqAttentionParams* dev_params, uint32_t n_ops, uint32_t max_seq_q, uint32_t d_head) {
+    if (!n_ops || !max_seq_q) return;
+    const dim3 grid(max_seq_q, n_ops);
+    switch (d_head) {
+        case 16: kvq_attention_kernel<4><<<grid, 256, 0, s>>>(dev_params); break;
+        case 32: kvq_attention_kernel<8><<<grid, 256, 0, s>>>(dev_params); break;
+        case 64: kvq_attention_kernel<16><<<grid, 256, 0, s>>>(dev_params); break;
+        case 128: kvq_attention_kernel<32><<<grid, 256, 0, s>>>(dev_params); break;
+        case 256: kvq_attention_kernel<64><<<grid, 256, 0, s>>>(dev_params); break;
+        default: break;
+    }
 }
 
 void launch_attention_decode_batch(hipStream_t s, const AttnDecodeParams* dev_params, uint32_t n_heads, uint32_t d_head) {

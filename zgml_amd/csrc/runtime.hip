@@ -164,7 +164,7 @@ void fill_caps(zgml_capabilities* c) {
     c->dynamic_program_refresh = 1;
     c->prefill_attention = 1;
     c->decode_attention = 1;
-    c->quantized_kv = 0;
+    c->quantized_kv = 1; // extension ops kvq_store / attention_kvq (include/zgml_hip.h)
     c->command_buffer_execution = 1;
     c->attention_supported = 1;
     c->attention_max_seq_kv_has = 0; // online softmax over key tiles: no score-buffer cap
@@ -210,6 +210,11 @@ void op_buffers(const zgml_device_op& op, std::vector<uint16_t>& out) {
                 if (fe.steps[s].op == ZGML_OP_ADD || fe.steps[s].op == ZGML_OP_MUL) out.push_back(fe.steps[s].secondary_buf);
             break;
         }
+        case ZGML_DOP_KVQ_STORE: out.insert(out.end(), {op.u.kvq_store.cache, op.u.kvq_store.src}); break;
+        case ZGML_DOP_ATTENTION_KVQ:
+            out.insert(out.end(), {op.u.attention_kvq.dst, op.u.attention_kvq.q, op.u.attention_kvq.k, op.u.attention_kvq.v,
+                                   op.u.attention_kvq.mask});
+            break;
         default: break;
     }
 }
@@ -250,6 +255,21 @@ bool program_supported(const zgml_device_program* pr) {
             case ZGML_DOP_ATTENTION:
                 if (op.u.attention.d_head > 512) return false;
                 break;
+            case ZGML_DOP_KVQ_STORE: { // extension ops: quantised KV cache
+                const auto& st = op.u.kvq_store;
+                if (!st.block_size || st.block_size % 4 || st.d_head % st.block_size || ((uint64_t)st.n_cols * st.d_head) % 4) return false;
+                if ((uint64_t)st.n_cols * st.d_head / 4 + (uint64_t)st.n_cols * (st.d_head / st.block_size) > pr->buffer_sizes[st.cache]) return false;
+                break;
+            }
+            case ZGML_DOP_ATTENTION_KVQ: {
+                const auto& a = op.u.attention_kvq;
+                if (!a.block_size || a.block_size % 4 || a.d_head % a.block_size || ((uint64_t)a.n_cols * a.d_head) % 4) return false;
+                if (a.d_head < 16 || a.d_head > 256 || (a.d_head & (a.d_head - 1))) return false; // kernel instances: 16..256, power of two
+                if (a.q_off % 4 || a.q_cs % 4 || a.dst_off % 4 || a.dst_cs % 4) return false;    // float4 access to q / dst
+                const uint64_t need = (uint64_t)a.n_cols * a.d_head / 4 + (uint64_t)a.n_cols * (a.d_head / a.block_size);
+                if (need > pr->buffer_sizes[a.k] || need > pr->buffer_sizes[a.v]) return false;
+                break;
+            }
             case ZGML_DOP_FUSED_ELEMENTWISE: {
                 const auto& fe = op.u.fused_elementwise;
                 if (fe.n_steps > (uint32_t)kMaxFusedSteps) return false;
@@ -532,6 +552,9 @@ void emit_batches(zgml_hip_program* p, const std::vector<PlanItem>& group) {
     std::vector<RepeatParams> reps;
     std::vector<MoveParams> moves;
     std::vector<AttentionParams> atts;
+    std::vector<KvqStoreParams> kstores;
+    std::map<uint32_t, std::vector<KvqAttentionParams>> katts; // by d_head
+    uint32_t kst_lo = UINT32_MAX, kst_hi = 0, kat_lo = UINT32_MAX, kat_hi = 0, kat_max_q = 0;
     uint32_t rep_max = 0, move_max = 0, att_max = 0, n_rep = 0, n_move = 0, n_att = 0;
     uint32_t lo[3] = {UINT32_MAX, UINT32_MAX, UINT32_MAX}, hi[3] = {0, 0, 0};
     auto track = [&](int k, const PlanItem& it) {
@@ -592,11 +615,41 @@ void emit_batches(zgml_hip_program* p, const std::vector<PlanItem>& group) {
                 track(2, it);
                 break;
             }
+            case ZGML_DOP_KVQ_STORE: {
+                const auto& st = op.u.kvq_store;
+                kstores.push_back({p->bufs[st.cache], buf_at(p, st.src, st.src_offset), p->dyn_dev + i, st.d_head, st.block_size, st.n_cols});
+                kst_lo = std::min(kst_lo, i), kst_hi = std::max(kst_hi, i);
+                break;
+            }
+            case ZGML_DOP_ATTENTION_KVQ: {
+                const auto& a = op.u.attention_kvq;
+                KvqAttentionParams kp{};
+                kp.dst = buf_at(p, a.dst, a.dst_off), kp.q = buf_at(p, a.q, a.q_off);
+                kp.k_cache = p->bufs[a.k], kp.v_cache = p->bufs[a.v];
+                kp.mask = a.has_mask ? buf_at(p, a.mask, a.mask_off) : nullptr;
+                kp.dyn_seq_kv = p->dyn_dev + i;
+                kp.d_head = a.d_head, kp.seq_q = a.seq_q, kp.block_size = a.block_size, kp.n_cols = a.n_cols;
+                kp.k_col_start = a.k_col_start, kp.v_col_start = a.v_col_start, kp.q_cs = a.q_cs, kp.dst_cs = a.dst_cs;
+                kp.mask_rs = a.mask_rs, kp.mask_cs = a.mask_cs, kp.scale = a.scale;
+                katts[a.d_head].push_back(kp);
+                kat_lo = std::min(kat_lo, i), kat_hi = std::max(kat_hi, i), kat_max_q = std::max(kat_max_q, a.seq_q);
+                break;
+            }
             default: {
                 Launch L;
                 if (make_single(p, i, L)) p->plan.push_back(std::move(L));
             }
         }
+    }
+    if (!kstores.empty()) {
+        const KvqStoreParams* d = upload_params(p, kstores);
+        const uint32_t n = (uint32_t)kstores.size();
+        p->plan.push_back({ZGML_DOP_KVQ_STORE, n, kst_lo, kst_hi, [=](hipStream_t s) { launch_kvq_store_batch(s, d, n); }});
+    }
+    for (auto& kv : katts) {
+        const KvqAttentionParams* d = upload_params(p, kv.second);
+        const uint32_t n = (uint32_t)kv.second.size(), dh = kv.first, mq = kat_max_q;
+        p->plan.push_back({ZGML_DOP_ATTENTION_KVQ, n, kat_lo, kat_hi, [=](hipStream_t s) { launch_kvq_attention_batch(s, d, n, mq, dh); }});
     }
     if (!reps.empty()) {
         const RepeatParams* d = upload_params(p, reps);
@@ -1239,7 +1292,8 @@ void build_plan(zgml_hip_program* p) {
     p->plan_dirty = false;
     if (getenv("ZGML_HIP_DEBUG_PLAN")) {
         uint64_t by_kind[ZGML_DOP_COUNT] = {0}, ops_by_kind[ZGML_DOP_COUNT] = {0};
-        for (const auto& L : p->plan) by_kind[L.kind]++, ops_by_kind[L.kind] += L.n_ops;
+        for (const auto& L : p->plan)
+            if (L.kind < ZGML_DOP_COUNT) by_kind[L.kind]++, ops_by_kind[L.kind] += L.n_ops;
         fprintf(stderr, "[zgml_hip] plan: %zu launches for %zu ops (batched=%d):", p->plan.size(), p->ops.size(), (int)p->plan_batched);
         for (int k = 0; k < ZGML_DOP_COUNT; k++)
             if (by_kind[k]) fprintf(stderr, " kind%d=%llu(%llu ops)", k, (unsigned long long)by_kind[k], (unsigned long long)ops_by_kind[k]);
@@ -1252,6 +1306,8 @@ void set_dyn_from_ops(zgml_hip_program* p) {
         uint32_t v = 0;
         if (p->ops[i].kind == ZGML_DOP_SLICE_ASSIGN) v = p->ops[i].u.slice_assign.dst_offset;
         if (p->ops[i].kind == ZGML_DOP_ATTENTION) v = p->ops[i].u.attention.seq_kv;
+        if (p->ops[i].kind == ZGML_DOP_KVQ_STORE) v = p->ops[i].u.kvq_store.col;
+        if (p->ops[i].kind == ZGML_DOP_ATTENTION_KVQ) v = p->ops[i].u.attention_kvq.seq_kv;
         if (p->dyn_host[i] != v) {
             p->dyn_host[i] = v;
             p->dyn_dirty = true;
@@ -1278,6 +1334,8 @@ bool same_static(const zgml_device_op& a, const zgml_device_op& b) {
     zgml_device_op x = a, y = b;
     if (a.kind == ZGML_DOP_SLICE_ASSIGN) x.u.slice_assign.dst_offset = y.u.slice_assign.dst_offset = 0;
     if (a.kind == ZGML_DOP_ATTENTION) x.u.attention.seq_kv = y.u.attention.seq_kv = 0;
+    if (a.kind == ZGML_DOP_KVQ_STORE) x.u.kvq_store.col = y.u.kvq_store.col = 0;
+    if (a.kind == ZGML_DOP_ATTENTION_KVQ) x.u.attention_kvq.seq_kv = y.u.attention_kvq.seq_kv = 0;
     if (a.kind == ZGML_DOP_FUSED_ELEMENTWISE) {
         const auto &fa = a.u.fused_elementwise, &fb = b.u.fused_elementwise;
         if (fa.n_steps != fb.n_steps) return false;
@@ -1310,6 +1368,8 @@ bool same_static(const zgml_device_op& a, const zgml_device_op& b) {
         ARM(ZGML_DOP_ROPE, rope)
         ARM(ZGML_DOP_ATTENTION, attention)
         ARM(ZGML_DOP_FUSED_ELEMENTWISE, fused_elementwise)
+        ARM(ZGML_DOP_KVQ_STORE, kvq_store)
+        ARM(ZGML_DOP_ATTENTION_KVQ, attention_kvq)
         default: return false;
     }
 #undef ARM
@@ -1359,7 +1419,7 @@ void enqueue(zgml_hip_program* p) {
             hipEventSynchronize(e1);
             float ms = 0;
             hipEventElapsedTime(&ms, e0, e1);
-            p->profile.time_ns[L.kind] += (uint64_t)(ms * 1e6);
+            if (L.kind < ZGML_DOP_COUNT) p->profile.time_ns[L.kind] += (uint64_t)(ms * 1e6);
             L.prof_ns += (uint64_t)(ms * 1e6);
             L.prof_calls++;
         }
@@ -1918,6 +1978,8 @@ void zgml_hip_refresh_program(zgml_hip_ctx* ctx, zgml_hip_program* p, const zgml
         for (uint64_t i = 0; i < n_ops; i++) {
             if (ops[i].kind == ZGML_DOP_SLICE_ASSIGN) p->ops[i].u.slice_assign.dst_offset = ops[i].u.slice_assign.dst_offset;
             if (ops[i].kind == ZGML_DOP_ATTENTION) p->ops[i].u.attention.seq_kv = ops[i].u.attention.seq_kv;
+            if (ops[i].kind == ZGML_DOP_KVQ_STORE) p->ops[i].u.kvq_store.col = ops[i].u.kvq_store.col;
+            if (ops[i].kind == ZGML_DOP_ATTENTION_KVQ) p->ops[i].u.attention_kvq.seq_kv = ops[i].u.attention_kvq.seq_kv;
         }
         set_dyn_from_ops(p);
         if (p->plan_batched && !dynamic_fields_in_bounds(p->sched, p->ops)) {
@@ -2412,8 +2474,10 @@ int zgml_hip_resident_setup(zgml_hip_ctx* ctx, zgml_hip_program* p, const zgml_r
     for (size_t i = 0; i < n_ops; i++) {
         if (p->ops[i].kind == ZGML_DOP_SLICE_ASSIGN && p->ops[i].u.slice_assign.patch_stride) {
             kind[i] = 1, base[i] = p->ops[i].u.slice_assign.dst_base_offset, stride[i] = p->ops[i].u.slice_assign.patch_stride;
-        } else if (p->ops[i].kind == ZGML_DOP_ATTENTION) {
+        } else if (p->ops[i].kind == ZGML_DOP_ATTENTION || p->ops[i].kind == ZGML_DOP_ATTENTION_KVQ) {
             kind[i] = 2;
+        } else if (p->ops[i].kind == ZGML_DOP_KVQ_STORE && p->ops[i].u.kvq_store.patch_stride) { // col = col_base + pos * stride
+            kind[i] = 1, base[i] = p->ops[i].u.kvq_store.col_base, stride[i] = p->ops[i].u.kvq_store.patch_stride;
         }
     }
     const size_t tab = (size_t)d->max_seq * d->d_head * 4, emb = (size_t)d->vocab * d->d_model * 4;

@@ -108,6 +108,22 @@ OpAccess op_access(const zgml_device_op& op, const DynBound& b) {
             if (t.has_mask) a.reads.push_back(span(t.mask, t.mask_off, ext2(skv, t.mask_rs, t.seq_q, t.mask_cs)));
             break;
         }
+        case ZGML_DOP_KVQ_STORE: { // the column is dynamic: the whole cache buffer counts as written
+            const auto& st = op.u.kvq_store;
+            a.reads.push_back(span(st.src, st.src_offset, st.d_head));
+            a.writes.push_back(span(st.cache, 0, (uint64_t)st.n_cols * st.d_head / 4 + (uint64_t)st.n_cols * (st.d_head / st.block_size)));
+            break;
+        }
+        case ZGML_DOP_ATTENTION_KVQ: {
+            const auto& t = op.u.attention_kvq;
+            const uint64_t cache = (uint64_t)t.n_cols * t.d_head / 4 + (uint64_t)t.n_cols * (t.d_head / t.block_size);
+            a.writes.push_back(span2(t.dst, t.dst_off, t.d_head, 1, t.seq_q, t.dst_cs));
+            a.reads.push_back(span2(t.q, t.q_off, t.d_head, 1, t.seq_q, t.q_cs));
+            a.reads.push_back(span(t.k, 0, cache));
+            a.reads.push_back(span(t.v, 0, cache));
+            if (t.has_mask) a.reads.push_back(span(t.mask, t.mask_off, ext2(b.max_seq_kv, t.mask_rs, t.seq_q, t.mask_cs)));
+            break;
+        }
         default: break;
     }
     return a;
@@ -141,6 +157,9 @@ Schedule build_schedule(const std::vector<zgml_device_op>& ops, const std::vecto
         } else if (ops[i].kind == ZGML_DOP_ATTENTION) {
             s.bounds[i].kind = 2;
             s.bounds[i].max_seq_kv = ops[i].u.attention.seq_kv;
+        } else if (ops[i].kind == ZGML_DOP_ATTENTION_KVQ) {
+            s.bounds[i].kind = 3;
+            s.bounds[i].max_seq_kv = ops[i].u.attention_kvq.seq_kv;
         }
     }
     s.access.resize(n);
@@ -197,6 +216,8 @@ bool dynamic_fields_in_bounds(const Schedule& s, const std::vector<zgml_device_o
             if (lo < b.lo || hi > b.hi) return false;
         } else if (b.kind == 2) {
             if (ops[i].u.attention.seq_kv > b.max_seq_kv) return false;
+        } else if (b.kind == 3) {
+            if (ops[i].u.attention_kvq.seq_kv > b.max_seq_kv) return false;
         }
     }
     return true;

@@ -62,6 +62,11 @@ struct Capabilities {
             case ZGML_DOP_ROPE: return true;
             case ZGML_DOP_REDUCE: return op.u.reduce.op == ZGML_OP_SUM || op.u.reduce.op == ZGML_OP_MAX;
             case ZGML_DOP_ATTENTION: return attention.supports(op.u.attention.seq_kv, op.u.attention.d_head);
+            case ZGML_DOP_KVQ_STORE: // extension ops (quantised KV cache) behind the reference's capability flag
+                return quantized_kv && op.u.kvq_store.block_size && op.u.kvq_store.d_head % op.u.kvq_store.block_size == 0;
+            case ZGML_DOP_ATTENTION_KVQ:
+                return quantized_kv && op.u.attention_kvq.block_size && op.u.attention_kvq.d_head % op.u.attention_kvq.block_size == 0 &&
+                       attention.supports(op.u.attention_kvq.seq_kv, op.u.attention_kvq.d_head);
             case ZGML_DOP_FUSED_ELEMENTWISE: {
                 const auto& fe = op.u.fused_elementwise;
                 if (!fused_elementwise) return false;
@@ -181,6 +186,19 @@ struct DeviceOp : zgml_device_op {
         o.u.attention = a;
         return o;
     }
+    // extension ops: quantised KV cache (include/zgml_hip.h; src/quant.zig:645-1091)
+    static DeviceOp kvq_store(const zgml_op_kvq_store& a) {
+        DeviceOp o;
+        o.kind = ZGML_DOP_KVQ_STORE;
+        o.u.kvq_store = a;
+        return o;
+    }
+    static DeviceOp attention_kvq(const zgml_op_attention_kvq& a) {
+        DeviceOp o;
+        o.kind = ZGML_DOP_ATTENTION_KVQ;
+        o.u.attention_kvq = a;
+        return o;
+    }
     // `steps` is borrowed (as the Zig slice is): the owner must outlive uses of the op.
     static DeviceOp fused_elementwise(const FusedEwStep* steps, uint32_t n_steps, uint32_t n, uint16_t dst, uint16_t src,
                                       uint32_t dst_offset = 0, uint32_t src_offset = 0) {
@@ -235,6 +253,11 @@ struct DeviceProgram {
             case ZGML_DOP_ROPE: return hasBuffer(op.u.rope.dst) && hasBuffer(op.u.rope.src) && hasBuffer(op.u.rope.cos_sin);
             case ZGML_DOP_ATTENTION: {
                 const auto& a = op.u.attention;
+                return hasBuffer(a.dst) && hasBuffer(a.q) && hasBuffer(a.k) && hasBuffer(a.v) && hasBuffer(a.mask);
+            }
+            case ZGML_DOP_KVQ_STORE: return hasBuffer(op.u.kvq_store.cache) && hasBuffer(op.u.kvq_store.src);
+            case ZGML_DOP_ATTENTION_KVQ: {
+                const auto& a = op.u.attention_kvq;
                 return hasBuffer(a.dst) && hasBuffer(a.q) && hasBuffer(a.k) && hasBuffer(a.v) && hasBuffer(a.mask);
             }
             case ZGML_DOP_FUSED_ELEMENTWISE: {

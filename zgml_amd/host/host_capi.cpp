@@ -18,6 +18,7 @@ typedef struct zh_config {
     float rope_base, rms_norm_eps;
     uint32_t tied_lm_head;
     uint32_t shard_rank, shard_world;
+    uint32_t kv_quant_block; // 0 = f32 KV caches, 32 = int8 blocks (quantised KV cache extension ops)
 } zh_config;
 
 typedef struct zh_backend_fns { // same signatures as include/zgml_hip.h
@@ -53,7 +54,7 @@ void zh_preset(const char* name, uint32_t max_seq, zh_config* out) {
     LlamaConfig c = !strcmp(name, "smollm-135m") ? smollm_135m() : !strcmp(name, "llama2-7b") ? llama2_7b(max_seq ? max_seq : 2048) : tiny_test();
     if (max_seq) c.max_seq_len = max_seq;
     *out = {c.vocab_size, c.d_model, c.n_heads, c.n_kv_heads, c.d_ff, c.n_layers, c.max_seq_len, c.rope_base, c.rms_norm_eps,
-            c.tied_lm_head ? 1u : 0u, 0, 1};
+            c.tied_lm_head ? 1u : 0u, 0, 1, 0};
 }
 
 zh_model* zh_model_create_ex(const zh_config* cfg, int weight_kind, int fused_elementwise, int include_dead_f32, int threads,
@@ -69,6 +70,8 @@ zh_model* zh_model_create_ex(const zh_config* cfg, int weight_kind, int fused_el
     c.d_ff = cfg->d_ff, c.n_layers = cfg->n_layers, c.max_seq_len = cfg->max_seq_len, c.rope_base = cfg->rope_base;
     c.rms_norm_eps = cfg->rms_norm_eps, c.tied_lm_head = cfg->tied_lm_head != 0;
     c.shard_rank = cfg->shard_rank, c.shard_world = cfg->shard_world ? cfg->shard_world : 1;
+    c.kv_quant_block = cfg->kv_quant_block;
+    if (c.kv_quant_block && (c.d_head() % c.kv_quant_block || c.kv_quant_block % 4 || ((uint64_t)c.max_seq_len * c.d_head()) % 4)) return nullptr;
     if (c.n_heads == 0 || c.d_model % c.n_heads || c.n_heads % c.n_kv_heads) return nullptr;
     if (c.shard_world > 1 && (c.tied_lm_head || c.n_kv_heads % c.shard_world || (c.d_model / c.shard_world) % 32 ||
                               (c.d_ff / c.shard_world) % 32 || (c.vocab_size / c.shard_world) % 32 || c.d_ff % c.shard_world ||

@@ -205,14 +205,25 @@ std::unique_ptr<LlamaModel> make_synthetic_model(const LlamaConfig& cfg, WeightK
 // ── DeviceInference lowering of the decode plan ─────────────────────────────────────────────
 void DecodeProgram::patchSliceAssignOffset(uint32_t pos) {
     for (uint32_t idx : slice_assign_op_indices) {
-        auto& sa = program.ops[idx].u.slice_assign;
+        auto& op = program.ops[idx];
+        if (op.kind == ZGML_DOP_KVQ_STORE) { // quantised cache: the dynamic field is the column
+            op.u.kvq_store.col = op.u.kvq_store.col_base + pos * op.u.kvq_store.patch_stride;
+            continue;
+        }
+        auto& sa = op.u.slice_assign;
         if (sa.patch_stride == 0) continue;
         sa.dst_offset = sa.dst_base_offset + pos * sa.patch_stride;
     }
 }
 
 void DecodeProgram::patchAttentionSeqKV(uint32_t seq_kv) {
-    for (uint32_t idx : attention_op_indices) program.ops[idx].u.attention.seq_kv = seq_kv;
+    for (uint32_t idx : attention_op_indices) {
+        auto& op = program.ops[idx];
+        if (op.kind == ZGML_DOP_ATTENTION_KVQ)
+            op.u.attention_kvq.seq_kv = seq_kv;
+        else
+            op.u.attention.seq_kv = seq_kv;
+    }
 }
 
 namespace {
@@ -332,6 +343,13 @@ std::unique_ptr<DecodeProgram> build_decode_program(const LlamaModel& model, boo
         std::vector<char> kv_done(KV_loc, 0);
         bool k_proj_done = false, v_proj_done = false;
         std::vector<uint16_t> attn_out(H_loc);
+        const uint32_t kvq = c.kv_quant_block; // quantised KV: one int8 cache buffer per kv head (K and V)
+        std::vector<uint16_t> kq_cache(KV_loc), vq_cache(KV_loc);
+        if (kvq)
+            for (uint32_t j = 0; j < KV_loc; j++) {
+                const uint64_t elems = (uint64_t)S * dh / 4 + (uint64_t)S * (dh / kvq);
+                kq_cache[j] = b.buffer(elems), vq_cache[j] = b.buffer(elems);
+            }
         for (int hl = (int)H_loc - 1; hl >= 0; hl--) {
             const uint32_t h = h0 + hl, kvh = h / n_rep, kvl = kvh - kv0;
             if (!q_done) {
@@ -349,16 +367,40 @@ std::unique_ptr<DecodeProgram> build_decode_program(const LlamaModel& model, boo
                 const uint16_t k_rot = b.buffer((uint64_t)dh * T);
                 b.op(DeviceOp::rope(k_rot, k_proj, rope_cs, dh / 2, T, kvl * dh, 0, 0, 1, kvd_loc, 2 * dh));
                 const uint32_t slab = kvl * S * dh; // k_cache.sliceColumns(kv_h*max_seq, ...)
-                dp.slice_assign_op_indices.push_back((uint32_t)dp.program.ops.size());
-                b.op(DeviceOp::slice_assign(k_cache, k_rot, dh, T, slab, slab, 1, dh, 0, 1, dh, dh));
+                if (kvq) { // k_cache.storeColumn(pos + j, k_rot[:, j]) (llama_inference.zig:300-320)
+                    for (uint32_t j = 0; j < T; j++) {
+                        dp.slice_assign_op_indices.push_back((uint32_t)dp.program.ops.size());
+                        b.op(DeviceOp::kvq_store({kq_cache[kvl], k_rot, dh, kvq, S, j * dh, j, j, 1}));
+                    }
+                } else {
+                    dp.slice_assign_op_indices.push_back((uint32_t)dp.program.ops.size());
+                    b.op(DeviceOp::slice_assign(k_cache, k_rot, dh, T, slab, slab, 1, dh, 0, 1, dh, dh));
+                }
                 if (!v_proj_done) {
                     b.proj(v_proj, norm1, wv, T, kvd_loc, d, 0, d, 0, kvd_loc);
                     v_proj_done = true;
                 }
-                dp.slice_assign_op_indices.push_back((uint32_t)dp.program.ops.size());
-                b.op(DeviceOp::slice_assign(v_cache, v_proj, dh, T, slab, slab, 1, dh, kvl * dh, 1, kvd_loc, dh));
+                if (kvq) {
+                    for (uint32_t j = 0; j < T; j++) {
+                        dp.slice_assign_op_indices.push_back((uint32_t)dp.program.ops.size());
+                        b.op(DeviceOp::kvq_store({vq_cache[kvl], v_proj, dh, kvq, S, j * kvd_loc + kvl * dh, j, j, 1}));
+                    }
+                } else {
+                    dp.slice_assign_op_indices.push_back((uint32_t)dp.program.ops.size());
+                    b.op(DeviceOp::slice_assign(v_cache, v_proj, dh, T, slab, slab, 1, dh, kvl * dh, 1, kvd_loc, dh));
+                }
             }
             attn_out[hl] = b.buffer((uint64_t)dh * T);
+            if (kvq) { // attentionQuantized over the kv head's caches
+                zgml_op_attention_kvq a{};
+                a.dst = attn_out[hl], a.q = q_rot, a.k = kq_cache[kvl], a.v = vq_cache[kvl], a.mask = dp.buf_attn_mask, a.has_mask = 1;
+                a.d_head = dh, a.seq_q = T, a.seq_kv = S, a.scale = attn_scale, a.block_size = kvq, a.n_cols = S;
+                a.k_col_start = 0, a.v_col_start = 0, a.q_off = 0, a.q_cs = dh, a.dst_off = 0, a.dst_cs = dh;
+                a.mask_off = 0, a.mask_rs = 1, a.mask_cs = S;
+                dp.attention_op_indices.push_back((uint32_t)dp.program.ops.size());
+                b.op(DeviceOp::attention_kvq(a));
+                continue;
+            }
             zgml_op_attention a{};
             a.dst = attn_out[hl], a.q = q_rot, a.k = k_cache, a.v = v_cache, a.mask = dp.buf_attn_mask, a.has_mask = 1;
             a.d_head = dh, a.seq_q = T, a.seq_kv = S, a.scale = attn_scale;

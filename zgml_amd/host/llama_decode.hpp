@@ -35,6 +35,10 @@ struct LlamaConfig {
     // Row-shard (config 4): this rank owns columns [rank*N/ws, (rank+1)*N/ws) of every weight and
     // n_heads/ws query heads; 1/1 = unsharded. Only Llama-7B-like shapes shard.
     uint32_t shard_rank = 0, shard_world = 1;
+    // Quantised KV cache (src/quant.zig:645-1091, wiring src/llama_inference.zig:277-377):
+    // 0 = f32 caches (slice_assign + attention), else the int8 block size (32): one cache buffer per kv
+    // head, written by kvq_store and read by attention_kvq (extension DeviceOps, include/zgml_hip.h).
+    uint32_t kv_quant_block = 0;
 };
 
 LlamaConfig smollm_135m();               // benchmarks/llama_smollm_bench.zig:31-42

@@ -18,7 +18,7 @@ class Config(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("vocab_size", "d_model", "n_heads", "n_kv_heads", "d_ff", "n_layers",
                                            "max_seq_len")] + [
         ("rope_base", C.c_float), ("rms_norm_eps", C.c_float), ("tied_lm_head", C.c_uint32),
-        ("shard_rank", C.c_uint32), ("shard_world", C.c_uint32)]
+        ("shard_rank", C.c_uint32), ("shard_world", C.c_uint32), ("kv_quant_block", C.c_uint32)]
 
     @property
     def d_head(self):

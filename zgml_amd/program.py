@@ -145,6 +145,20 @@ class DeviceOp:
                         mask_off=mask_off, dst_off=dst_off, q_rs=q_rs, q_cs=q_cs, k_rs=k_rs, k_cs=k_cs,
                         v_rs=v_rs, v_cs=v_cs, mask_rs=mask_rs, mask_cs=mask_cs, dst_rs=dst_rs, dst_cs=dst_cs)
 
+    # extension ops: quantised KV cache (include/zgml_hip.h; src/quant.zig:645-1091)
+    @staticmethod
+    def kvq_store(cache, src, d_head, block_size, n_cols, src_offset, col_base, col, patch_stride):
+        return DeviceOp("kvq_store", cache=cache, src=src, d_head=d_head, block_size=block_size, n_cols=n_cols,
+                        src_offset=src_offset, col_base=col_base, col=col, patch_stride=patch_stride)
+
+    @staticmethod
+    def attention_kvq(dst, q, k, v, mask, has_mask, d_head, seq_q, seq_kv, scale, block_size, n_cols, k_col_start,
+                      v_col_start, q_off, q_cs, dst_off, dst_cs, mask_off=0, mask_rs=0, mask_cs=0):
+        return DeviceOp("attention_kvq", dst=dst, q=q, k=k, v=v, mask=mask, has_mask=has_mask, d_head=d_head,
+                        seq_q=seq_q, seq_kv=seq_kv, scale=scale, block_size=block_size, n_cols=n_cols,
+                        k_col_start=k_col_start, v_col_start=v_col_start, q_off=q_off, q_cs=q_cs, dst_off=dst_off,
+                        dst_cs=dst_cs, mask_off=mask_off, mask_rs=mask_rs, mask_cs=mask_cs)
+
     @staticmethod
     def fused_elementwise(steps: Sequence[FusedEwStep], n, dst, src, dst_offset=0, src_offset=0):
         return DeviceOp("fused_elementwise", steps=list(steps), n=n, dst=dst, src=src, dst_offset=dst_offset,
@@ -164,8 +178,10 @@ class DeviceOp:
             return [f["dst"], f["src"]]
         if k == "rope":
             return [f["dst"], f["src"], f["cos_sin"]]
-        if k == "attention":
+        if k in ("attention", "attention_kvq"):
             return [f["dst"], f["q"], f["k"], f["v"], f["mask"]]
+        if k == "kvq_store":
+            return [f["cache"], f["src"]]
         if k == "fused_elementwise":
             out = [f["dst"], f["src"]]
             out += [s.secondary_buf for s in f["steps"] if s.op in ("add", "mul")]
@@ -304,6 +320,10 @@ class Capabilities:
             return op.op in ("sum", "max", OP["sum"], OP["max"])
         if k == "attention":
             return self.attention.supports(op.seq_kv, op.d_head)
+        if k in ("kvq_store", "attention_kvq"):  # extension ops behind the reference's own capability flag
+            if not self.quantized_kv or op.block_size == 0 or op.d_head % op.block_size:
+                return False
+            return k == "kvq_store" or self.attention.supports(op.seq_kv, op.d_head)
         if k == "fused_elementwise":
             if not self.fused_elementwise:
                 return False
