@@ -691,51 +691,91 @@ __global__ void __launch_bounds__(64) kvq_store_kernel(const KvqStoreParams* __r
     }
 }
 
-// attentionQuantized: one workgroup of 256 threads per (query, op). A key is handled by LPK = d_head/4
-// lanes, each dequantising 4 consecutive dims of the int8 row (one 4-byte load); per-slot online softmax
-// merged at the end like attention_decode_kernel. Only the summation / rescale order differs from the
-// reference's Bs = 8 flash tiles.
+// attentionQuantized: one workgroup per (query, op), shaped like attention_decode_kernel: a key is
+// handled by LPK = d_head/4 lanes, each dequantising 4 consecutive dims of the int8 row (one 4-byte
+// load); a wave streams KPW keys x U per step with the next step's rows prefetched; waves the context
+// does not need retire at the top; per-slot online softmax merged at the end (one barrier). Only the
+// summation / rescale order differs from the reference's Bs = 8 flash tiles.
 template <int LPK>
-__global__ void __launch_bounds__(256) kvq_attention_kernel(const KvqAttentionParams* __restrict__ params) {
-    constexpr int DH = 4 * LPK, KPW = 64 / LPK, NWV = 4;
+__global__ void __launch_bounds__(kAttnBlock) kvq_attention_kernel(const KvqAttentionParams* __restrict__ params) {
+    constexpr int DH = 4 * LPK, KPW = 64 / LPK, U = kAttnUnroll, MAXW = kAttnBlock / 64;
     const KvqAttentionParams& p = params[blockIdx.y];
     if (blockIdx.x >= p.seq_q) return;
-    __shared__ float part_ml[2 * NWV];
-    __shared__ float4 part_acc[NWV * LPK];
+    __shared__ float part_ml[2 * MAXW];
+    __shared__ float4 part_acc[MAXW * LPK];
     const uint32_t qi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t slot = lane / LPK, li = lane % LPK, d0 = 4 * li;
     uint32_t seq_kv = *p.dyn_seq_kv;
     const uint32_t room_k = p.n_cols > p.k_col_start ? p.n_cols - p.k_col_start : 0, room_v = p.n_cols > p.v_col_start ? p.n_cols - p.v_col_start : 0;
     seq_kv = min(seq_kv, min(room_k, room_v)); // never read outside the caches
+    uint32_t NW = (seq_kv + KPW * U - 1) / (KPW * U);
+    NW = NW < 1 ? 1 : (NW > (uint32_t)MAXW ? (uint32_t)MAXW : NW);
+    if (w >= NW) return;
+    const uint32_t keys_per_iter = KPW * NW, step_keys = keys_per_iter * U, last = seq_kv ? seq_kv - 1 : 0;
     const uint32_t bpc = DH / p.block_size, blk = d0 / p.block_size;
-    const int8_t* kq = (const int8_t*)p.k_cache;
-    const float* ks = p.k_cache + (uint64_t)p.n_cols * DH / 4;
-    const int8_t* vq = (const int8_t*)p.v_cache;
-    const float* vs = p.v_cache + (uint64_t)p.n_cols * DH / 4;
+    const int8_t* kq = (const int8_t*)p.k_cache + (uint64_t)p.k_col_start * DH + d0;
+    const float* ks = p.k_cache + (uint64_t)p.n_cols * DH / 4 + (uint64_t)p.k_col_start * bpc + blk;
+    const int8_t* vq = (const int8_t*)p.v_cache + (uint64_t)p.v_col_start * DH + d0;
+    const float* vs = p.v_cache + (uint64_t)p.n_cols * DH / 4 + (uint64_t)p.v_col_start * bpc + blk;
+    const float* mask = p.mask ? p.mask + (uint64_t)qi * p.mask_cs : nullptr;
     const float4 qv = *(const float4*)(p.q + (uint64_t)qi * p.q_cs + d0);
+    struct Rows {
+        uint32_t kw[U], vw[U];
+        float ksc[U], vsc[U], mk[U];
+    };
+    auto load = [&](Rows& r, uint32_t base) { // clamped to live rows, unconditional
+#pragma unroll
+        for (int j = 0; j < U; j++) {
+            const uint64_t t = min(base + j * keys_per_iter + w * KPW + slot, last);
+            r.kw[j] = *(const uint32_t*)(kq + t * DH), r.vw[j] = *(const uint32_t*)(vq + t * DH);
+            r.ksc[j] = ks[t * bpc], r.vsc[j] = vs[t * bpc];
+            r.mk[j] = mask ? mask[t * p.mask_rs] : 0.0f;
+        }
+    };
     SoftState st{-INFINITY, 0.f, make_float4(0.f, 0.f, 0.f, 0.f)};
-    for (uint32_t base = 0; base < seq_kv; base += KPW * NWV) {
-        const uint32_t t = base + w * KPW + slot;
-        const uint32_t tc = min(t, seq_kv - 1);
-        const uint64_t ck = (uint64_t)p.k_col_start + tc, cv = (uint64_t)p.v_col_start + tc;
-        const uint32_t kw = *(const uint32_t*)(kq + ck * DH + d0), vw = *(const uint32_t*)(vq + cv * DH + d0);
-        const float ksc = ks[ck * bpc + blk], vsc = vs[cv * bpc + blk];
-        const float mk = p.mask ? p.mask[(uint64_t)qi * p.mask_cs + (uint64_t)tc * p.mask_rs] : 0.0f;
-        // dequantised dot: the block scale applies to this lane's 4 dims (block_size % 4 == 0)
-        float dot = (qv.x * (float)(int8_t)(kw & 255) + qv.y * (float)(int8_t)((kw >> 8) & 255) + qv.z * (float)(int8_t)((kw >> 16) & 255) +
-                     qv.w * (float)(int8_t)(kw >> 24)) * ksc;
-        dot = group_sum<LPK>(dot);
-        const float sc = t < seq_kv ? score_of(dot, mk, p.scale) : -INFINITY;
-        if (sc > -INFINITY) {
-            const float nm = fmaxf(st.m, sc);
-            const float alpha = st.m > -INFINITY ? expf(st.m - nm) : 0.0f, wgt = expf(sc - nm);
-            const float ws = wgt * vsc;
-            st.l = st.l * alpha + wgt;
-            st.acc.x = st.acc.x * alpha + ws * (float)(int8_t)(vw & 255);
-            st.acc.y = st.acc.y * alpha + ws * (float)(int8_t)((vw >> 8) & 255);
-            st.acc.z = st.acc.z * alpha + ws * (float)(int8_t)((vw >> 16) & 255);
-            st.acc.w = st.acc.w * alpha + ws * (float)(int8_t)(vw >> 24);
+    auto step = [&](const Rows& r, uint32_t base) {
+        float sc[U];
+        float bm = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < U; j++) {
+            const uint32_t t = base + j * keys_per_iter + w * KPW + slot, kw = r.kw[j];
+            // dequantised dot: the block scale applies to this lane's 4 dims (block_size % 4 == 0)
+            float dot = (qv.x * (float)(int8_t)(kw & 255) + qv.y * (float)(int8_t)((kw >> 8) & 255) +
+                         qv.z * (float)(int8_t)((kw >> 16) & 255) + qv.w * (float)(int8_t)(kw >> 24)) * r.ksc[j];
+            dot = group_sum<LPK>(dot);
+            sc[j] = t < seq_kv ? score_of(dot, r.mk[j], p.scale) : -INFINITY;
+            bm = fmaxf(bm, sc[j]);
+        }
+        const float nm = fmaxf(st.m, bm);
+        if (nm > -INFINITY) {
+            const float alpha = st.m > -INFINITY ? expf(st.m - nm) : 0.0f;
+            st.l *= alpha;
+            st.acc = make_float4(st.acc.x * alpha, st.acc.y * alpha, st.acc.z * alpha, st.acc.w * alpha);
+#pragma unroll
+            for (int j = 0; j < U; j++) {
+                if (sc[j] > -INFINITY) {
+                    const float wgt = expf(sc[j] - nm), ws = wgt * r.vsc[j];
+                    const uint32_t vw = r.vw[j];
+                    st.l += wgt;
+                    st.acc.x += ws * (float)(int8_t)(vw & 255);
+                    st.acc.y += ws * (float)(int8_t)((vw >> 8) & 255);
+                    st.acc.z += ws * (float)(int8_t)((vw >> 16) & 255);
+                    st.acc.w += ws * (float)(int8_t)(vw >> 24);
+                }
+            }
             st.m = nm;
+        }
+    };
+    Rows cur;
+    load(cur, 0);
+    if (seq_kv <= step_keys) {
+        if (seq_kv) step(cur, 0);
+    } else {
+        for (uint32_t base = 0; base < seq_kv; base += step_keys) {
+            Rows nxt;
+            load(nxt, base + step_keys);
+            step(cur, base);
+            cur = nxt;
         }
     }
 #pragma unroll
@@ -752,7 +792,7 @@ __global__ void __launch_bounds__(256) kvq_attention_kernel(const KvqAttentionPa
     __syncthreads();
     if (tid < LPK) {
         SoftState r{part_ml[0], part_ml[1], part_acc[tid]};
-        for (uint32_t ww = 1; ww < NWV; ww++) soft_merge(r, part_ml[2 * ww], part_ml[2 * ww + 1], part_acc[ww * LPK + tid]);
+        for (uint32_t ww = 1; ww < NW; ww++) soft_merge(r, part_ml[2 * ww], part_ml[2 * ww + 1], part_acc[ww * LPK + tid]);
         const float inv_l = r.l > 0.f ? 1.0f / r.l : 0.0f;
         *(float4*)(p.dst + (uint64_t)qi * p.dst_cs + 4 * tid) = make_float4(r.acc.x * inv_l, r.acc.y * inv_l, r.acc.z * inv_l, r.acc.w * inv_l);
     }
@@ -958,11 +998,11 @@ void launch_kvq_attention_batch(hipStream_t s, const KvqAttentionParams* dev_par
     if (!n_ops || !max_seq_q) return;
     const dim3 grid(max_seq_q, n_ops);
     switch (d_head) {
-        case 16: kvq_attention_kernel<4><<<grid, 256, 0, s>>>(dev_params); break;
-        case 32: kvq_attention_kernel<8><<<grid, 256, 0, s>>>(dev_params); break;
-        case 64: kvq_attention_kernel<16><<<grid, 256, 0, s>>>(dev_params); break;
-        case 128: kvq_attention_kernel<32><<<grid, 256, 0, s>>>(dev_params); break;
-        case 256: kvq_attention_kernel<64><<<grid, 256, 0, s>>>(dev_params); break;
+        case 16: kvq_attention_kernel<4><<<grid, kAttnBlock, 0, s>>>(dev_params); break;
+        case 32: kvq_attention_kernel<8><<<grid, kAttnBlock, 0, s>>>(dev_params); break;
+        case 64: kvq_attention_kernel<16><<<grid, kAttnBlock, 0, s>>>(dev_params); break;
+        case 128: kvq_attention_kernel<32><<<grid, kAttnBlock, 0, s>>>(dev_params); break;
+        case 256: kvq_attention_kernel<64><<<grid, kAttnBlock, 0, s>>>(dev_params); break;
         default: break;
     }
 }
