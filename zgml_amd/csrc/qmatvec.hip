@@ -717,6 +717,65 @@ struct TileUnit {
             one<R, DD, 3, 1>(acc, xv, h);
         }
     }
+    // ── the same contraction on the XDL (bf16) matrix cores ──
+    // The f32 MFMA shares the FP32 lanes with the VALU (tools/exp/mfma.hip), so the f32 form above is
+    // bound by instruction issue. Here B = q itself (|q| <= 127: exact in bf16; Q4 as q/16) and the
+    // per-(k, block-column) scale goes into A: t = x * scale in f32 exactly as the reference computes it,
+    // then t is split into three bf16 pieces t = h1 + h2 + h3 (each residual is exact in f32, the third
+    // piece leaves < 2^-26 |t|), and  sum_k t*q  is three v_mfma_f32_16x16x32_bf16 with exact products and
+    // f32 accumulation. One MFMA takes k_local = 8g..8g+7 of the four units of the wave's rows as its
+    // 32 k-values. All producers of MFMA operands are compiler-visible (cvt_pk), see scaled() above.
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    template <int K_LOCAL>
+    __device__ __forceinline__ float scale_of() const {
+        constexpr int E = Q4 ? 2 * (K_LOCAL % 16) + K_LOCAL / 16 : K_LOCAL;
+        return to_f32(((const ST*)sraw)[E]);
+    }
+    template <int R, int G8>
+    __device__ __forceinline__ void group8(mfma_f4 (&acc)[R], const float* xs, uint32_t tile_stride) const {
+        const uint32_t w[4] = {wq.x, wq.y, wq.z, wq.w};
+        float qf[8];
+        if (Q4) { // dword G8: byte b low nibble = k_local 8*G8 + b, high nibble = 8*G8 + 4 + b
+            const uint32_t lo = w[G8], hi = lo >> 4;
+            qf[0] = cvt_nib<0>(lo), qf[1] = cvt_nib<1>(lo), qf[2] = cvt_nib<2>(lo), qf[3] = cvt_nib<3>(lo);
+            qf[4] = cvt_nib<0>(hi), qf[5] = cvt_nib<1>(hi), qf[6] = cvt_nib<2>(hi), qf[7] = cvt_nib<3>(hi);
+        } else { // dwords 2*G8, 2*G8+1: 8 consecutive int8
+            const uint32_t w0 = w[(2 * G8) & 3], w1 = w[(2 * G8 + 1) & 3];
+            qf[0] = cvt_i8<0>(w0), qf[1] = cvt_i8<1>(w0), qf[2] = cvt_i8<2>(w0), qf[3] = cvt_i8<3>(w0);
+            qf[4] = cvt_i8<0>(w1), qf[5] = cvt_i8<1>(w1), qf[6] = cvt_i8<2>(w1), qf[7] = cvt_i8<3>(w1);
+        }
+        bf16x8 bq;
+#pragma unroll
+        for (int e = 0; e < 8; e++) bq[e] = (__bf16)qf[e];
+        const float sk[8] = {scale_of<8 * G8 + 0>(), scale_of<8 * G8 + 1>(), scale_of<8 * G8 + 2>(), scale_of<8 * G8 + 3>(),
+                             scale_of<8 * G8 + 4>(), scale_of<8 * G8 + 5>(), scale_of<8 * G8 + 6>(), scale_of<8 * G8 + 7>()};
+#pragma unroll
+        for (int t = 0; t < R; t++) {
+            const float4 xa = *(const float4*)(xs + t * tile_stride + 8 * G8), xb = *(const float4*)(xs + t * tile_stride + 8 * G8 + 4);
+            const float tv[8] = {xa.x * sk[0], xa.y * sk[1], xa.z * sk[2], xa.w * sk[3], xb.x * sk[4], xb.y * sk[5], xb.z * sk[6], xb.w * sk[7]};
+            bf16x8 h1, h2, h3;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                h1[e] = (__bf16)tv[e];
+                const float r1 = tv[e] - (float)h1[e];
+                h2[e] = (__bf16)r1;
+                const float r2 = r1 - (float)h2[e];
+                h3[e] = (__bf16)r2;
+            }
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h1, bq, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h2, bq, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h3, bq, acc[t], 0, 0, 0);
+        }
+    }
+    template <int R>
+    __device__ __forceinline__ void compute_xdl(mfma_f4 (&acc)[R], const float* xs, uint32_t tile_stride) const {
+        group8<R, 0>(acc, xs, tile_stride);
+        group8<R, 1>(acc, xs, tile_stride);
+        if (Q4) {
+            group8<R, 2>(acc, xs, tile_stride);
+            group8<R, 3>(acc, xs, tile_stride);
+        }
+    }
     // xs: this lane's row of the staged chunk at its unit; m-tiles are `tile_stride` floats apart
     template <int R>
     __device__ __forceinline__ void compute(mfma_f4 (&acc)[R], const float* xs, uint32_t tile_stride) const {
@@ -727,7 +786,7 @@ struct TileUnit {
     }
 };
 
-template <typename ST, bool Q4, int R, bool XVEC, bool NT>
+template <typename ST, bool Q4, int R, bool XVEC, bool NT, bool XDL>
 __global__ void __launch_bounds__(512) qmatmul_tile_kernel(QMMArgs a) {
     using Unit = TileUnit<ST, Q4, NT>;
     constexpr int KU = Unit::KU;
@@ -784,14 +843,20 @@ __global__ void __launch_bounds__(512) qmatmul_tile_kernel(QMMArgs a) {
         Unit nxt;
         nxt.load(qs, sc, ul + st * stride, a.U);
         __builtin_amdgcn_sched_barrier(0); // keep the prefetch ahead of the MFMA block (hipcc sinks it otherwise)
-        cur.template compute<R>(acc, xs, 16 * row_stride);
+        if (XDL)
+            cur.template compute_xdl<R>(acc, xs, 16 * row_stride);
+        else
+            cur.template compute<R>(acc, xs, 16 * row_stride);
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
         stage_store(st);
         __syncthreads();
         cur = nxt;
     }
-    cur.template compute<R>(acc, xs, 16 * row_stride);
+    if (XDL)
+        cur.template compute_xdl<R>(acc, xs, 16 * row_stride);
+    else
+        cur.template compute<R>(acc, xs, 16 * row_stride);
     __syncthreads();
 
     // D[m = 4*row + v][n = i] in acc[t][v]; fold the waves in fixed order (reuses the x buffer)
@@ -1072,14 +1137,17 @@ void launch_packed(hipStream_t s, QMVArgs& a, const QWeightDev& w0, uint32_t tot
 }
 
 using TileFn = void (*)(QMMArgs);
-template <typename ST, bool Q4, bool NT>
+template <typename ST, bool Q4, bool NT, bool XDL>
 TileFn pick_tile_nt(bool two, bool xvec) {
-    if (two) return xvec ? qmatmul_tile_kernel<ST, Q4, 2, true, NT> : qmatmul_tile_kernel<ST, Q4, 2, false, NT>;
-    return xvec ? qmatmul_tile_kernel<ST, Q4, 1, true, NT> : qmatmul_tile_kernel<ST, Q4, 1, false, NT>;
+    if (two) return xvec ? qmatmul_tile_kernel<ST, Q4, 2, true, NT, XDL> : qmatmul_tile_kernel<ST, Q4, 2, false, NT, XDL>;
+    return xvec ? qmatmul_tile_kernel<ST, Q4, 1, true, NT, XDL> : qmatmul_tile_kernel<ST, Q4, 1, false, NT, XDL>;
 }
 template <typename ST, bool Q4>
 TileFn pick_tile(bool two, bool xvec, bool nt) {
-    return nt ? pick_tile_nt<ST, Q4, true>(two, xvec) : pick_tile_nt<ST, Q4, false>(two, xvec);
+    // ZGML_QMM_XDL=0 keeps the contraction on the f32 MFMA (same results up to rounding order)
+    static const bool xdl = !(getenv("ZGML_QMM_XDL") && atoi(getenv("ZGML_QMM_XDL")) == 0);
+    if (xdl) return nt ? pick_tile_nt<ST, Q4, true, true>(two, xvec) : pick_tile_nt<ST, Q4, false, true>(two, xvec);
+    return nt ? pick_tile_nt<ST, Q4, true, false>(two, xvec) : pick_tile_nt<ST, Q4, false, false>(two, xvec);
 }
 
 void launch_tile(hipStream_t s, const QWeightDev& w, const QMatmulParams& p, bool xvec) {
