@@ -292,8 +292,7 @@ __device__ __forceinline__ void run_epilogue(const QMVPartDev& part, uint32_t n,
 // a run-time index into the argument block is a dependent scalar load that costs ~1 us at the
 // start and again in the tail of a 5 us kernel.
 template <bool GROUPED>
-__device__ __forceinline__ void reduce_store(float acc, float* red, const QMVArgs& a, uint32_t pi, float* out,
-                                             uint32_t out_rs, uint32_t g, uint32_t m) {
+__device__ __forceinline__ void reduce_store(float acc, float* red, const QMVArgs& a, uint32_t pi, float* out0, uint32_t g, uint32_t m) {
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     acc += __shfl_xor(acc, 16, 64);
     acc += __shfl_xor(acc, 32, 64);
@@ -303,7 +302,16 @@ __device__ __forceinline__ void reduce_store(float acc, float* red, const QMVArg
         float v = red[threadIdx.x];
         for (uint32_t ww = 1; ww < n_waves; ww++) v += red[ww * 16 + threadIdx.x];
         const uint32_t n = g * 16 + threadIdx.x;
-        float* const out_row = out + (uint64_t)m * out_rs;
+        // part 0's output pointer is a preloaded argument; further parts' come from the argument block
+        // (static indices), long arrived by now; the row stride only matters for M > 1
+        float* out = out0;
+        if (GROUPED) out = pi == 1 ? a.parts[1].out : pi == 2 ? a.parts[2].out : pi == 3 ? a.parts[3].out : out;
+        float* out_row = out;
+        if (m) {
+            uint32_t out_rs = a.parts[0].out_rs;
+            if (GROUPED) out_rs = pi == 1 ? a.parts[1].out_rs : pi == 2 ? a.parts[2].out_rs : pi == 3 ? a.parts[3].out_rs : out_rs;
+            out_row = out + (uint64_t)m * out_rs;
+        }
         out_row[n] = v;
         if (!GROUPED || pi == 0)
             run_epilogue(a.parts[0], n, v, out_row);
@@ -510,14 +518,17 @@ struct Q8Group {
 
 // Q4: unit = 32 k, UNIT_X = 32 floats of x per unit; Q8: unit = 16 k.
 // PRO: the launch has a prologue (second vector b, optional rmsnorm); GROUPED: more than one matrix.
-// The first 16 argument dwords are what the kernel needs before it can issue its first loads; the
+// The leading 14 argument dwords are what the kernel needs before it can issue its first loads; the
 // build preloads them into SGPRs (-amdgpu-kernarg-preload-count=16), so the x and weight streams
-// start without waiting for an s_load round trip to the argument block. Part 0's fields are
-// repeated there; `a` carries the rest (further parts, prologue, epilogues).
-#define QMV_HEAD_PARAMS                                                                                                  \
+// start without waiting for an s_load round trip to the argument block. A grouped launch (q/k/v,
+// gate/up) whose weights sit back to back in the weight arenas (compile_program packs them in index
+// order) finds its part from NB2_0..2 alone: part t starts at block sum(NB2_u, u < t) and at the
+// same offset, in column groups, inside the arenas. `a` carries the rest (outputs, prologue,
+// epilogues, non-contiguous parts), needed late or rarely.
+#define QMV_HEAD_PARAMS                                                                                                 \
     const uint4 *__restrict__ qs0, const void *__restrict__ sc0, float *__restrict__ out0, const float *__restrict__ xa_base, \
-        const float *__restrict__ xb_base, uint32_t U, uint32_t K, uint32_t NB2_0, uint32_t out_rs0, uint32_t in_rs,         \
-        uint32_t n_parts
+        const float *__restrict__ xb_base, uint32_t in_rs, uint32_t K, uint32_t nb2_0_flags /* NB2_0 | n_parts << 24 | contiguous << 28 */, \
+        uint32_t nb2_12 /* NB2_1 | NB2_2 << 16 */
 template <typename ST, bool XVEC, int DEPTH, bool Q4, bool PRO, bool GROUPED, bool XD, bool NT>
 __global__ void __launch_bounds__(1024) qmatvec_kernel(QMV_HEAD_PARAMS, QMVArgs a) {
     constexpr uint32_t UNIT_X = Q4 ? 32 : 16;
@@ -530,6 +541,7 @@ __global__ void __launch_bounds__(1024) qmatvec_kernel(QMV_HEAD_PARAMS, QMVArgs 
 #define QMV_STAMP(i) do { } while (0)
 #endif
     QMV_STAMP(0);
+    const uint32_t U = Q4 ? (K + 31) >> 5 : ((K + 31) >> 5) * 2; // units per column group (KC or 2 KC)
     float* xs = smem;                     // U * UNIT_X floats (+4 spare)
     float* red = XD ? smem : smem + U * UNIT_X + 4; // waves * 16 floats
     // which matrix of the group this workgroup belongs to (wave-uniform); fields are selected from
@@ -537,19 +549,26 @@ __global__ void __launch_bounds__(1024) qmatvec_kernel(QMV_HEAD_PARAMS, QMVArgs 
     uint32_t pi = 0;
     const uint4* qs_base = qs0;
     const void* sc_base = sc0;
-    float* out = out0;
-    uint32_t NB2 = NB2_0, block_begin = 0, out_rs = out_rs0;
+    const uint32_t NB2_0 = nb2_0_flags & 0xFFFFFFu, n_parts = (nb2_0_flags >> 24) & 0xF, NB2_1 = nb2_12 & 0xFFFFu, NB2_2 = nb2_12 >> 16;
+    uint32_t NB2 = NB2_0, block_begin = 0;
     if (GROUPED) {
+        if (nb2_0_flags >> 28) { // contiguous parts: everything from preloaded scalars
+            const uint32_t b1 = NB2_0, b2 = b1 + NB2_1, b3 = b2 + NB2_2;
+            if (n_parts > 1 && blockIdx.x >= b1) pi = 1, block_begin = b1, NB2 = NB2_1;
+            if (n_parts > 2 && blockIdx.x >= b2) pi = 2, block_begin = b2, NB2 = NB2_2;
+            if (n_parts > 3 && blockIdx.x >= b3) pi = 3, block_begin = b3, NB2 = a.parts[3].NB2;
+            qs_base = qs0 + (uint64_t)block_begin * U * 16;
+            sc_base = (const ScaleT*)sc0 + (uint64_t)(block_begin >> 1) * U * 16;
+        } else {
 #pragma unroll
-        for (uint32_t t = 1; t < (uint32_t)kMaxQmvParts; t++) {
-            const bool take = t < n_parts && blockIdx.x >= a.parts[t].block_begin;
-            pi = take ? t : pi;
-            qs_base = take ? a.parts[t].qs : qs_base;
-            sc_base = take ? a.parts[t].sc : sc_base;
-            out = take ? a.parts[t].out : out;
-            NB2 = take ? a.parts[t].NB2 : NB2;
-            block_begin = take ? a.parts[t].block_begin : block_begin;
-            out_rs = take ? a.parts[t].out_rs : out_rs;
+            for (uint32_t t = 1; t < (uint32_t)kMaxQmvParts; t++) {
+                const bool take = t < n_parts && blockIdx.x >= a.parts[t].block_begin;
+                pi = take ? t : pi;
+                qs_base = take ? a.parts[t].qs : qs_base;
+                sc_base = take ? a.parts[t].sc : sc_base;
+                NB2 = take ? a.parts[t].NB2 : NB2;
+                block_begin = take ? a.parts[t].block_begin : block_begin;
+            }
         }
     }
     const uint32_t g = column_group(blockIdx.x - block_begin, NB2), m = blockIdx.y;
@@ -572,6 +591,7 @@ __global__ void __launch_bounds__(1024) qmatvec_kernel(QMV_HEAD_PARAMS, QMVArgs 
         if (norm) sq = sumsq_fetch(xa_row, K, a.x_vec != 0); // before the weights (in-order vmcnt)
         cur.load(qs, sc, u, stride, u_last, xd, i);
         QMV_STAMP(1); // loads issued
+        __builtin_amdgcn_sched_barrier(0); // argument-block reads below wait while the loads above fly
         if (norm) { // the weights are in flight while the vector is reduced
             const float ss = block_sumsq_direct(sq, xa_row, K, red, a.x_vec != 0);
             xd.inv = 1.0f / sqrtf(ss / (float)K + a.pro.eps); // reference.zig:365
@@ -605,7 +625,7 @@ __global__ void __launch_bounds__(1024) qmatvec_kernel(QMV_HEAD_PARAMS, QMVArgs 
     }
     cur.compute(xs, u, stride, U, i, acc0, acc1, acc2, acc3, xd);
     QMV_STAMP(4); // weights streamed
-    reduce_store<GROUPED>((acc0 + acc1) + (acc2 + acc3), red, a, pi, out, out_rs, g, m);
+    reduce_store<GROUPED>((acc0 + acc1) + (acc2 + acc3), red, a, pi, out0, g, m);
     QMV_STAMP(5);
 #undef QMV_STAMP
 }
@@ -1132,8 +1152,20 @@ void launch_packed(hipStream_t s, QMVArgs& a, const QWeightDev& w0, uint32_t tot
                                      : pick_kernel<float>(xvec, q4, pro, grp, depth_sel, xd, nt);
     if (lds > 64 * 1024) // > 64 KiB of dynamic LDS needs an explicit opt-in per kernel (idempotent)
         hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
-    hipLaunchKernelGGL(fn, grid, dim3(waves * 64), lds, s, a.parts[0].qs, a.parts[0].sc, a.parts[0].out, a.pro.a, a.pro.b, a.U, a.K,
-                       a.parts[0].NB2, a.parts[0].out_rs, a.in_rs, a.n_parts, a);
+    // parts back to back in the weight arenas (and <= 4 of them): the kernel needs no argument-block fetch to find them
+    static const bool contig_ok = !(getenv("ZGML_QMV_CONTIG") && atoi(getenv("ZGML_QMV_CONTIG")) == 0);
+    bool contig = a.n_parts > 1 && contig_ok;
+    const size_t sc_elem = (q4 ? 2 : 1) * (w0.scale_f16 ? 2 : 4);
+    for (uint32_t t = 1; t < a.n_parts && contig; t++) {
+        const QMVPartDev &pv = a.parts[t - 1], &pt = a.parts[t];
+        contig = (const char*)pt.qs == (const char*)pv.qs + (size_t)pv.NB2 * a.U * 256 &&
+                 (const char*)pt.sc == (const char*)pv.sc + (size_t)(pv.NB2 / 2) * a.U * 16 * sc_elem &&
+                 pt.block_begin == pv.block_begin + pv.NB2;
+    }
+    if (a.n_parts > 1 && (a.parts[1].NB2 > 0xFFFFu || (a.n_parts > 2 && a.parts[2].NB2 > 0xFFFFu))) contig = false; // 16-bit fields
+    const uint32_t nb2_12 = contig ? (a.parts[1].NB2 | (a.n_parts > 2 ? a.parts[2].NB2 << 16 : 0u)) : 0u;
+    hipLaunchKernelGGL(fn, grid, dim3(waves * 64), lds, s, a.parts[0].qs, a.parts[0].sc, a.parts[0].out, a.pro.a, a.pro.b, a.in_rs, a.K,
+                       a.parts[0].NB2 | (a.n_parts << 24) | (contig ? 1u << 28 : 0u), nb2_12, a);
 }
 
 using TileFn = void (*)(QMMArgs);

@@ -1870,10 +1870,20 @@ zgml_hip_program* zgml_hip_compile_program(zgml_hip_ctx* ctx, const zgml_device_
 
     p->f16_stream_nt = f16_total >= (192ull << 20);
 
-    // quantized weights: upload raw, classify and re-pack on the device
+    // quantized weights: upload raw, classify, then re-pack on the device into TWO arenas (quants, scales)
+    // in weight-index order with nothing between consecutive weights: the weights a grouped mat-vec launch
+    // reads (q/k/v, gate/up) are then contiguous and the kernel derives every part's pointers from part 0's
+    // (preloaded) ones instead of waiting for an argument-block fetch (qmatvec.hip, QMV_HEAD_PARAMS).
     p->qweights.resize(prog->n_qweights);
     uint32_t* flags = nullptr;
     if (ok && prog->n_qweights) ok = CTX_CHECK(ctx, hipMalloc((void**)&flags, 2 * sizeof(uint32_t)));
+    struct PendingPack {
+        void* raw_a = nullptr; // int8 values, or the GGUF blocks
+        float* raw_s = nullptr;
+        bool gguf = false;
+    };
+    std::vector<PendingPack> pending(prog->n_qweights);
+    uint64_t qs_total = 0, sc_total = 0;
     for (uint64_t i = 0; ok && i < prog->n_qweights; i++) {
         if (!qw_live[i]) continue;
         const zgml_qweight_upload& qw = prog->qweights[i];
@@ -1882,57 +1892,65 @@ zgml_hip_program* zgml_hip_compile_program(zgml_hip_ctx* ctx, const zgml_device_
         const uint64_t n_elems = qw.rows * qw.cols;
         const uint64_t n_blocks = (n_elems + qw.block_size - 1) / qw.block_size;
         if (const int form = gguf_form(qw)) { // file blocks straight to the device, unpacked + re-packed there
-            uint8_t* raw = nullptr;
             w.format = form == 1 ? QW_Q4 : QW_Q8;
             w.scale_f16 = 1;
-            w.KC = (uint32_t)((qw.rows + 31) / 32);
-            packed_bytes(w.format, 1, w.K, w.N, &w.qs_bytes, &w.sc_bytes);
-            ok = CTX_CHECK(ctx, hipMalloc((void**)&raw, qw.data_len)) &&
-                 CTX_CHECK(ctx, hipMemcpyAsync(raw, qw.data, qw.data_len, hipMemcpyHostToDevice, ctx->stream)) &&
-                 CTX_CHECK(ctx, hipMalloc(&w.qs, w.qs_bytes)) && CTX_CHECK(ctx, hipMalloc(&w.sc, w.sc_bytes));
-            if (ok) {
+            pending[i].gguf = true;
+            ok = CTX_CHECK(ctx, hipMalloc(&pending[i].raw_a, qw.data_len)) &&
+                 CTX_CHECK(ctx, hipMemcpyAsync(pending[i].raw_a, qw.data, qw.data_len, hipMemcpyHostToDevice, ctx->stream));
+        } else {
+            ok = CTX_CHECK(ctx, hipMalloc(&pending[i].raw_a, n_elems ? n_elems : 1)) &&
+                 CTX_CHECK(ctx, hipMalloc((void**)&pending[i].raw_s, (n_blocks ? n_blocks : 1) * sizeof(float))) &&
+                 CTX_CHECK(ctx, hipMemcpyAsync(pending[i].raw_a, qw.data, n_elems, hipMemcpyHostToDevice, ctx->stream)) &&
+                 CTX_CHECK(ctx, hipMemcpyAsync(pending[i].raw_s, qw.scales, n_blocks * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+            if (!ok) break;
+            if (!qweight_packable(qw.rows, qw.cols, qw.block_size)) { // odd shapes keep the raw form
+                w.format = QW_RAW;
+                w.qs = pending[i].raw_a, w.sc = pending[i].raw_s;
+                w.qs_bytes = n_elems, w.sc_bytes = n_blocks * 4;
                 p->owned.push_back(w.qs);
                 p->owned.push_back(w.sc);
-                launch_pack_gguf(ctx->stream, raw, w);
-                ok = CTX_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+                pending[i] = PendingPack{};
+                continue;
             }
-            hipFree(raw);
-            continue;
+            const uint32_t cls = classify_qweight(ctx->stream, (const int8_t*)pending[i].raw_a, n_elems, pending[i].raw_s, n_blocks, flags);
+            w.format = (cls & 1) ? QW_Q4 : QW_Q8;
+            w.scale_f16 = (cls & 2) ? 1 : 0;
         }
-        int8_t* raw_d = nullptr;
-        float* raw_s = nullptr;
-        ok = CTX_CHECK(ctx, hipMalloc((void**)&raw_d, n_elems ? n_elems : 1)) &&
-             CTX_CHECK(ctx, hipMalloc((void**)&raw_s, (n_blocks ? n_blocks : 1) * sizeof(float))) &&
-             CTX_CHECK(ctx, hipMemcpyAsync(raw_d, qw.data, n_elems, hipMemcpyHostToDevice, ctx->stream)) &&
-             CTX_CHECK(ctx, hipMemcpyAsync(raw_s, qw.scales, n_blocks * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-        if (!ok) {
-            hipFree(raw_d);
-            hipFree(raw_s);
-            break;
-        }
-        const bool packable = qweight_packable(qw.rows, qw.cols, qw.block_size);
-        if (!packable) {
-            w.format = QW_RAW;
-            w.qs = raw_d, w.sc = raw_s;
-            w.qs_bytes = n_elems, w.sc_bytes = n_blocks * 4;
-            p->owned.push_back(raw_d);
-            p->owned.push_back(raw_s);
-            continue;
-        }
-        const uint32_t cls = classify_qweight(ctx->stream, raw_d, n_elems, raw_s, n_blocks, flags);
-        w.format = (cls & 1) ? QW_Q4 : QW_Q8;
-        w.scale_f16 = (cls & 2) ? 1 : 0;
+        if (!ok) break;
         w.KC = (uint32_t)((qw.rows + 31) / 32);
         packed_bytes(w.format, w.scale_f16, w.K, w.N, &w.qs_bytes, &w.sc_bytes);
-        ok = CTX_CHECK(ctx, hipMalloc(&w.qs, w.qs_bytes)) && CTX_CHECK(ctx, hipMalloc(&w.sc, w.sc_bytes));
-        if (ok) {
-            p->owned.push_back(w.qs);
-            p->owned.push_back(w.sc);
-            launch_pack_qweight(ctx->stream, raw_d, raw_s, w);
-            ok = CTX_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        qs_total += w.qs_bytes, sc_total += w.sc_bytes;
+    }
+    char *qs_arena = nullptr, *sc_arena = nullptr;
+    static const bool use_arena = !(getenv("ZGML_HIP_WEIGHT_ARENA") && atoi(getenv("ZGML_HIP_WEIGHT_ARENA")) == 0);
+    if (ok && qs_total && use_arena) {
+        ok = CTX_CHECK(ctx, hipMalloc((void**)&qs_arena, qs_total)) && CTX_CHECK(ctx, hipMalloc((void**)&sc_arena, sc_total ? sc_total : 16));
+        if (qs_arena) p->owned.push_back(qs_arena);
+        if (sc_arena) p->owned.push_back(sc_arena);
+    }
+    uint64_t qs_off = 0, sc_off = 0;
+    for (uint64_t i = 0; i < prog->n_qweights; i++) {
+        QWeightDev& w = p->qweights[i];
+        if (ok && pending[i].raw_a) {
+            if (use_arena) {
+                w.qs = qs_arena + qs_off, w.sc = sc_arena + sc_off;
+                qs_off += w.qs_bytes, sc_off += w.sc_bytes;
+            } else { // experiment: one allocation per weight
+                ok = CTX_CHECK(ctx, hipMalloc(&w.qs, w.qs_bytes)) && CTX_CHECK(ctx, hipMalloc(&w.sc, w.sc_bytes));
+                if (!ok) break;
+                p->owned.push_back(w.qs);
+                p->owned.push_back(w.sc);
+            }
+            if (pending[i].gguf)
+                launch_pack_gguf(ctx->stream, (const uint8_t*)pending[i].raw_a, w);
+            else
+                launch_pack_qweight(ctx->stream, (const int8_t*)pending[i].raw_a, pending[i].raw_s, w);
         }
-        hipFree(raw_d);
-        hipFree(raw_s);
+    }
+    if (ok && prog->n_qweights) ok = CTX_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto& pd : pending) { // raw images are only needed until the pack kernels have run
+        if (pd.raw_a) hipFree(pd.raw_a);
+        if (pd.raw_s) hipFree(pd.raw_s);
     }
     if (flags) hipFree(flags);
     { // weight sets beyond the 256 MB Infinity Cache are streamed with non-temporal loads (see qmatvec.hip: wload)
