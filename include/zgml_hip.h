@@ -376,7 +376,11 @@ enum {
     /* bytes (0 = off, default): zgml_hip_dense_matmul_f32 keeps device copies of its B operands, keyed by
      * host pointer, up to this many bytes (plain ComputeGraph.compute() users whose
      * weights never move). The caller promises B is not mutated between calls, or invalidates. */
-    ZGML_HIP_OPT_DENSE_WEIGHT_CACHE = 6
+    ZGML_HIP_OPT_DENSE_WEIGHT_CACHE = 6,
+    /* keys per workgroup at which a fused decode attention starts to split one head's context over
+     * several workgroups (flash-decoding split; default 128, minimum 32, 0 = never split). A head splits
+     * once seq_kv >= 2 * value; below that the launch behaves exactly as without the option. */
+    ZGML_HIP_OPT_ATTN_SPLIT_MIN_KEYS = 7
 };
 int zgml_hip_set_option(zgml_hip_ctx* ctx, int option, int64_t value);
 /* Drop the cached device copy of host operand `b` (NULL: all of them). */

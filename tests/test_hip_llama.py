@@ -229,3 +229,47 @@ def test_quantised_kv_cache_decode(hip_backend, oracle, name, steps):
     got = s_res.resident_decode(3, 0, steps)
     assert [int(t) for t in got] == toks
     s_res.close(), s_ref.close(), m.close()
+
+
+def test_long_context_attention_split(hip_backend, oracle):
+    """Flash-decoding split of the fused decode attention (ZGML_HIP_OPT_ATTN_SPLIT_MIN_KEYS): with the
+    threshold lowered to 32 keys a 256-position tiny model splits every head over up to 8 workgroups
+    from position 63 on. Logits stay within 2e-4 of the oracle's over 140 positions (the merge order is
+    fixed, only the summation order differs), the unsplit build of the same program agrees, and the
+    graph-replayed resident loop (arrival counters re-armed in-kernel) gives the same tokens twice."""
+    cfg = llama.preset("tiny", 256)
+    m = llama.Model(cfg, llama.Q4_0, threads=8)
+    n = 140
+    s_ref = llama.Session(m, oracle.backend_fns())
+    hip_backend.set_option(capi.OPT_ATTN_SPLIT_MIN_KEYS, 32)
+    try:
+        s_split = llama.Session(m, llama.hip_backend_fns(hip_backend))
+        hip_backend.set_option(capi.OPT_ATTN_SPLIT_MIN_KEYS, 0)
+        s_plain = llama.Session(m, llama.hip_backend_fns(hip_backend))
+        hip_backend.set_option(capi.OPT_ATTN_SPLIT_MIN_KEYS, 32)
+        tok, toks = 3, []
+        for pos in range(n):
+            t_ref, l_ref = s_ref.step(tok, pos)
+            t_a, l_a = s_split.step(tok, pos)
+            t_b, l_b = s_plain.step(tok, pos)
+            assert not hip_backend.last_error(), hip_backend.last_error()
+            scale = np.abs(l_ref).max()
+            assert np.abs(l_a - l_ref).max() / scale < 2e-4, pos
+            assert np.abs(l_a - l_b).max() / scale < 2e-5, pos
+            if pos < 63:
+                assert np.array_equal(l_a, l_b), pos  # below the threshold the split launch is the plain one
+            top2 = np.sort(l_ref)[-2:]
+            if top2[1] - top2[0] > 1e-3 * scale:
+                assert t_a == t_ref, pos
+            tok = t_ref
+            toks.append(tok)
+        s_split.close(), s_plain.close()
+        s_res = llama.Session(m, llama.hip_backend_fns(hip_backend))
+        s_res.resident_setup(hip_backend)
+        first = s_res.resident_decode(3, 0, n)
+        second = s_res.resident_decode(3, 0, n)
+        assert first.tolist() == second.tolist()
+        s_res.close()
+    finally:
+        hip_backend.set_option(capi.OPT_ATTN_SPLIT_MIN_KEYS, -1)
+    s_ref.close(), m.close()

@@ -229,7 +229,16 @@ void launch_reduce(hipStream_t s, uint32_t op, float* dst, const float* src, uin
 void launch_repeat_batch(hipStream_t s, const RepeatParams* dev_params, uint32_t n_ops, uint32_t max_elems);
 void launch_move_batch(hipStream_t s, const MoveParams* dev_params, uint32_t n_ops, uint32_t max_elems);
 // all_dense: every op has unit row strides, 16-byte aligned q/k/v rows, d_head a power of two in [4, 256]
-void launch_attention_decode_batch(hipStream_t s, const AttnDecodeParams* dev_params, uint32_t n_heads, uint32_t d_head);
+// Long-context split of the decode attention (flash decoding): `splits` workgroups per head; partials
+// go through `buf` (n_heads * splits * (d_head + 4) floats), `cnt` holds one zeroed arrival counter per
+// head. A head splits once seq_kv >= 2 * min_keys. splits <= 1: no split, buf / cnt unused.
+struct AttnSplit {
+    uint32_t splits = 1, min_keys = 128;
+    float* buf = nullptr;
+    uint32_t* cnt = nullptr;
+};
+void launch_attention_decode_batch(hipStream_t s, const AttnDecodeParams* dev_params, uint32_t n_heads, uint32_t d_head,
+                                   const AttnSplit& sp);
 void launch_attention_batch(hipStream_t s, const AttentionParams* dev_params, uint32_t n_ops, uint32_t max_seq_q,
                             bool all_dense);
 void launch_dense_matmul(hipStream_t s, const DenseMatmulParams& p);

@@ -530,10 +530,54 @@ __device__ __forceinline__ void soft_merge(SoftState& s, float om, float ol, flo
     s.m = nm;
 }
 
+//
+// Long contexts (flash-decoding split): the launch has gridDim.y = S workgroups per head. While
+// seq_kv < 2 * split_min_keys only workgroup 0 works (the others retire after reading seq_kv) and
+// nothing below changes. Above that, n_active = min(S, seq_kv / split_min_keys) workgroups each
+// stream a contiguous chunk of the keys, publish their (m, l, acc) with write-through (sc1) stores,
+// drain, and add to the head's counter; the last arriver reads all partials with sc1 loads, merges
+// them in chunk order (so the result does not depend on arrival order), writes the output and
+// re-arms the counter. The guide's fan-in form: sc1 payload + vmcnt(0) drain + agent atomic, every
+// consumer load sc1, no fence.
+using gu64 = __attribute__((address_space(1))) unsigned long long;
+using gu32 = __attribute__((address_space(1))) unsigned int;
+__device__ __forceinline__ void split_put(float* p, float a, float b) {
+    const unsigned long long v = (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32);
+    __hip_atomic_store((gu64*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void split_get(const float* p, float& a, float& b) {
+    const unsigned long long v = __hip_atomic_load((gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    a = __uint_as_float((uint32_t)v), b = __uint_as_float((uint32_t)(v >> 32));
+}
+
+// sum l and acc over the 64 / LPK key slots of a wave (streams already on a common max)
 template <int LPK>
-__global__ void __launch_bounds__(kAttnBlock) attention_decode_kernel(const AttnDecodeParams* __restrict__ params) {
+__device__ __forceinline__ void slots_sum(SoftState& s) {
+#pragma unroll
+    for (int off = LPK; off < 64; off <<= 1) {
+        s.l += __shfl_xor(s.l, off, 64);
+        s.acc.x += __shfl_xor(s.acc.x, off, 64), s.acc.y += __shfl_xor(s.acc.y, off, 64);
+        s.acc.z += __shfl_xor(s.acc.z, off, 64), s.acc.w += __shfl_xor(s.acc.w, off, 64);
+    }
+}
+// merge the slots' online-softmax states: common max, one rescale each, sums
+template <int LPK>
+__device__ __forceinline__ void slots_merge(SoftState& s) {
+    float M = s.m;
+#pragma unroll
+    for (int off = LPK; off < 64; off <<= 1) M = fmaxf(M, __shfl_xor(M, off, 64));
+    const float f = s.m > -INFINITY ? expf(s.m - M) : 0.0f;
+    s.l *= f;
+    s.acc = make_float4(s.acc.x * f, s.acc.y * f, s.acc.z * f, s.acc.w * f);
+    s.m = M;
+    slots_sum<LPK>(s);
+}
+
+template <int LPK>
+__global__ void __launch_bounds__(kAttnBlock) attention_decode_kernel(const AttnDecodeParams* __restrict__ params, float* split_buf,
+                                                                      uint32_t* split_cnt, uint32_t split_min_keys) {
     constexpr int DH = 4 * LPK, KPW = 64 / LPK, U = kAttnUnroll, HALF = DH / 2;
-    const AttnDecodeParams& P = params[blockIdx.y];
+    const AttnDecodeParams& P = params[blockIdx.x];
     const AttentionParams& p = P.att;
 #ifdef ZGML_TRACE // build with -DZGML_TRACE (ZGML_HIP_ATTN_TRACE=1 then prints the stamps)
     unsigned long long* const trace = P.trace;
@@ -542,7 +586,7 @@ __global__ void __launch_bounds__(kAttnBlock) attention_decode_kernel(const Attn
 #define ATTN_STAMP(i) do { } while (0)
 #endif
     ATTN_STAMP(0);
-    __shared__ float part_ml[2 * (kAttnBlock / 64)];
+    __shared__ __attribute__((aligned(8))) float part_ml[2 * (kAttnBlock / 64)];
     __shared__ float4 part_acc[(kAttnBlock / 64) * LPK];
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t slot = lane / LPK, li = lane % LPK, d0 = 4 * li, pair = d0 & (HALF - 1);
@@ -556,17 +600,28 @@ __global__ void __launch_bounds__(kAttnBlock) attention_decode_kernel(const Attn
     const float4 k_c = *(const float4*)(P.k_cs + pair), k_s = *(const float4*)(P.k_cs + HALF + pair);
     const float4 v_new = *(const float4*)(P.v_src + d0);
     ATTN_STAMP(1);
-    // waves the context needs: one step of a wave covers KPW * U keys
-    uint32_t NW = (seq_kv + KPW * U - 1) / (KPW * U);
+    // this workgroup's keys [k_begin, k_end)
+    const uint32_t sp = blockIdx.y;
+    uint32_t n_active = 1, k_begin = 0, k_end = seq_kv;
+    if (gridDim.y > 1) {
+        n_active = seq_kv / split_min_keys;
+        n_active = n_active < 1 ? 1 : (n_active > gridDim.y ? gridDim.y : n_active);
+        if (sp >= n_active) return;
+        const uint32_t chunk = (seq_kv + n_active - 1) / n_active;
+        k_begin = min(sp * chunk, seq_kv), k_end = min(k_begin + chunk, seq_kv);
+    }
+    const uint32_t n_keys = k_end - k_begin;
+    // waves the chunk needs: one step of a wave covers KPW * U keys
+    uint32_t NW = (n_keys + KPW * U - 1) / (KPW * U);
     NW = NW < 1 ? 1 : (NW > (uint32_t)(kAttnBlock / 64) ? (uint32_t)(kAttnBlock / 64) : NW);
     if (w >= NW) return;
-    const uint32_t keys_per_iter = KPW * NW, step_keys = keys_per_iter * U, last = seq_kv ? seq_kv - 1 : 0;
+    const uint32_t keys_per_iter = KPW * NW, step_keys = keys_per_iter * U, last = k_end ? k_end - 1 : 0;
     // ---- phase B: first step's K / V / mask rows (clamped to live rows, unconditional)
     float4 kv[U], vv[U];
     float mk[U];
 #pragma unroll
     for (int j = 0; j < U; j++) {
-        const uint32_t s = min(j * keys_per_iter + w * KPW + slot, last);
+        const uint32_t s = min(k_begin + j * keys_per_iter + w * KPW + slot, last);
         kv[j] = *(const float4*)(p.k + (uint64_t)s * p.k_cs + d0);
         vv[j] = *(const float4*)(p.v + (uint64_t)s * p.v_cs + d0);
         mk[j] = p.mask[(uint64_t)s * p.mask_rs]; // host passes a zero word with stride 0 when there is no mask
@@ -576,7 +631,7 @@ __global__ void __launch_bounds__(kAttnBlock) attention_decode_kernel(const Attn
     const float4 qv = rope4(q_own, q_par, q_c, q_s, is_hi);
     const float4 k_new = rope4(k_own, k_par, k_c, k_s, is_hi);
     const uint32_t col_k = (dk - P.k_off) / p.k_cs, col_v = (dv - P.v_off) / p.v_cs;
-    if (w == 0 && slot == 0) {
+    if (w == 0 && slot == 0 && sp == 0) {
         *(float4*)(P.q_rot + d0) = qv;
         if (P.owner) {
             *(float4*)(P.k_rot + d0) = k_new;
@@ -595,7 +650,7 @@ __global__ void __launch_bounds__(kAttnBlock) attention_decode_kernel(const Attn
             const uint32_t t = base + j * keys_per_iter + w * KPW + slot;
             const float4 kk = t == col_k ? k_new : kv[j];
             const float dot = group_sum<LPK>(qv.x * kk.x + qv.y * kk.y + qv.z * kk.z + qv.w * kk.w);
-            sc[j] = t < seq_kv ? score_of(dot, mk[j], p.scale) : -INFINITY;
+            sc[j] = t < k_end ? score_of(dot, mk[j], p.scale) : -INFINITY;
             bm = fmaxf(bm, sc[j]);
         }
         const float nm = fmaxf(st.m, bm);
@@ -619,10 +674,10 @@ __global__ void __launch_bounds__(kAttnBlock) attention_decode_kernel(const Attn
             st.m = nm;
         }
     };
-    if (seq_kv <= step_keys) { // the usual decode case: everything is already in registers
-        if (seq_kv) step(0);
+    if (n_keys <= step_keys) { // the usual decode case: everything is already in registers
+        if (n_keys) step(k_begin);
     } else {
-        for (uint32_t base = 0; base < seq_kv; base += step_keys) {
+        for (uint32_t base = k_begin; base < k_end; base += step_keys) {
             // prefetch the next step (clamped: the last step re-reads live rows, L2 hits)
             float4 kn[U], vn[U];
             float mn[U];
@@ -639,30 +694,88 @@ __global__ void __launch_bounds__(kAttnBlock) attention_decode_kernel(const Attn
         }
     }
     ATTN_STAMP(4);
-    // ---- merge the key slots of the wave, then the waves
+    // ---- merge the key slots of the wave, then the waves. Every merge is two-pass (common max first,
+    // then ONE rescale per stream and plain sums): no chain of dependent exponentials.
+    slots_merge<LPK>(st);
+    SoftState r = st;
+    if (NW > 1) { // (uniform) a single wave has the workgroup's result already
+        if (lane < LPK) {
+            part_acc[w * LPK + lane] = st.acc;
+            if (lane == 0) part_ml[2 * w] = st.m, part_ml[2 * w + 1] = st.l;
+        }
+        ATTN_STAMP(5);
+        __syncthreads();
+        ATTN_STAMP(6);
+        if (w != 0) return;
+        // wave 0, all 64 lanes: lane ww < 16 fetches wave ww's max for the common max (DPP row reduction);
+        // slot g folds waves g, g + KPW, ... — every LDS read is issued up front, the exponentials are independent
+        constexpr int MAXW = kAttnBlock / 64, NPS = MAXW / KPW > 0 ? MAXW / KPW : 1;
+        static_assert(MAXW == 16, "lanes 0..15 (one DPP row) hold the waves' maxima");
+        float M = lane < NW ? part_ml[2 * lane] : -INFINITY;
+        float2 ml[NPS];
+        float4 pa[NPS];
 #pragma unroll
-    for (int off = LPK; off < 64; off <<= 1) {
-        const float om = __shfl_xor(st.m, off, 64), ol = __shfl_xor(st.l, off, 64);
-        const float4 oa = make_float4(__shfl_xor(st.acc.x, off, 64), __shfl_xor(st.acc.y, off, 64), __shfl_xor(st.acc.z, off, 64),
-                                      __shfl_xor(st.acc.w, off, 64));
-        soft_merge(st, om, ol, oa);
-    }
-    if (lane < LPK) {
-        part_acc[w * LPK + lane] = st.acc;
-        if (lane == 0) part_ml[2 * w] = st.m, part_ml[2 * w + 1] = st.l;
-    }
-    ATTN_STAMP(5);
-    __syncthreads();
-    ATTN_STAMP(6);
-    if (tid < LPK) {
-        SoftState r{part_ml[0], part_ml[1], part_acc[tid]};
-        for (uint32_t ww = 1; ww < NW; ww++) soft_merge(r, part_ml[2 * ww], part_ml[2 * ww + 1], part_acc[ww * LPK + tid]);
-        const float inv_l = r.l > 0.f ? 1.0f / r.l : 0.0f;
-        const float o[4] = {r.acc.x * inv_l, r.acc.y * inv_l, r.acc.z * inv_l, r.acc.w * inv_l};
-        *(float4*)(p.dst + 4 * tid) = make_float4(o[0], o[1], o[2], o[3]); // dst_rs == 1, 16-byte aligned (planner)
-        if (p.dst2)
+        for (int i = 0; i < NPS; i++) {
+            const uint32_t ww = slot + i * KPW, wc = ww < NW ? ww : 0;
+            ml[i] = *(const float2*)&part_ml[2 * wc];
+            pa[i] = part_acc[wc * LPK + li];
+        }
+        M = fmaxf(M, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(M), 0xB1, 0xF, 0xF, true)));
+        M = fmaxf(M, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(M), 0x4E, 0xF, 0xF, true)));
+        M = fmaxf(M, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(M), 0x141, 0xF, 0xF, true)));
+        M = fmaxf(M, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(M), 0x140, 0xF, 0xF, true)));
+        M = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(M)));
+        r = SoftState{M, 0.f, make_float4(0.f, 0.f, 0.f, 0.f)};
 #pragma unroll
-            for (int e = 0; e < 4; e++) p.dst2[(uint64_t)d2_off + (uint64_t)(4 * tid + e) * p.d2_rs] = o[e];
+        for (int i = 0; i < NPS; i++) {
+            const bool live = slot + i * KPW < NW && ml[i].x > -INFINITY;
+            const float f = live ? expf(ml[i].x - M) : 0.0f;
+            r.l += ml[i].y * f;
+            r.acc.x += pa[i].x * f, r.acc.y += pa[i].y * f, r.acc.z += pa[i].z * f, r.acc.w += pa[i].w * f;
+        }
+        slots_sum<LPK>(r);
+    } else {
+        ATTN_STAMP(5);
+        ATTN_STAMP(6);
+    }
+    { // wave 0 from here on
+        if (n_active > 1) { // publish this chunk; the last arriver merges all of them
+            constexpr uint32_t REC = DH + 4; // m, l, pad, pad, acc[DH]
+            float* const head_buf = split_buf + (uint64_t)blockIdx.x * gridDim.y * REC;
+            float* const mine = head_buf + (uint64_t)sp * REC;
+            if (lane < LPK) {
+                if (lane == 0) split_put(mine, r.m, r.l);
+                split_put(mine + 4 + 4 * lane, r.acc.x, r.acc.y);
+                split_put(mine + 4 + 4 * lane + 2, r.acc.z, r.acc.w);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the write-through stores have left before the count
+            uint32_t old = 0;
+            if (lane == 0) old = __hip_atomic_fetch_add((gu32*)(split_cnt + blockIdx.x), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            old = __shfl(old, 0, 64);
+            if (old != n_active - 1) return;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // compiler only: the loads below stay below the count
+            // slot g folds chunks g, g + KPW, ... in chunk order (not arrival order), then the slots merge
+            r = SoftState{-INFINITY, 0.f, make_float4(0.f, 0.f, 0.f, 0.f)};
+            for (uint32_t c = slot; c < n_active; c += KPW) {
+                const float* rec = head_buf + (uint64_t)c * REC;
+                float om, ol;
+                float4 oa;
+                split_get(rec, om, ol);
+                split_get(rec + 4 + 4 * li, oa.x, oa.y);
+                split_get(rec + 4 + 4 * li + 2, oa.z, oa.w);
+                soft_merge(r, om, ol, oa);
+            }
+            slots_merge<LPK>(r);
+            if (lane == 0) __hip_atomic_store((gu32*)(split_cnt + blockIdx.x), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // re-arm
+        }
+        if (lane < LPK) {
+            const float inv_l = r.l > 0.f ? 1.0f / r.l : 0.0f;
+            const float o[4] = {r.acc.x * inv_l, r.acc.y * inv_l, r.acc.z * inv_l, r.acc.w * inv_l};
+            *(float4*)(p.dst + 4 * lane) = make_float4(o[0], o[1], o[2], o[3]); // dst_rs == 1, 16-byte aligned (planner)
+            if (p.dst2)
+#pragma unroll
+                for (int e = 0; e < 4; e++) p.dst2[(uint64_t)d2_off + (uint64_t)(4 * lane + e) * p.d2_rs] = o[e];
+        }
     }
     ATTN_STAMP(7);
 #undef ATTN_STAMP
@@ -1007,18 +1120,21 @@ void launch_kvq_attention_batch(hipStream_t s, const KvqAttentionParams* dev_par
     }
 }
 
-void launch_attention_decode_batch(hipStream_t s, const AttnDecodeParams* dev_params, uint32_t n_heads, uint32_t d_head) {
+void launch_attention_decode_batch(hipStream_t s, const AttnDecodeParams* dev_params, uint32_t n_heads, uint32_t d_head,
+                                   const AttnSplit& sp) {
     if (!n_heads) return;
-    const dim3 grid(1, n_heads);
+    const dim3 grid(n_heads, sp.splits ? sp.splits : 1); // x = head: the always-active split 0 of every head is dispatched first
+#define ADEC(L) attention_decode_kernel<L><<<grid, kAttnBlock, 0, s>>>(dev_params, sp.buf, sp.cnt, sp.min_keys)
     switch (d_head) { // all heads of a launch share d_head (checked by the planner)
-        case 8: attention_decode_kernel<2><<<grid, kAttnBlock, 0, s>>>(dev_params); break;
-        case 16: attention_decode_kernel<4><<<grid, kAttnBlock, 0, s>>>(dev_params); break;
-        case 32: attention_decode_kernel<8><<<grid, kAttnBlock, 0, s>>>(dev_params); break;
-        case 64: attention_decode_kernel<16><<<grid, kAttnBlock, 0, s>>>(dev_params); break;
-        case 128: attention_decode_kernel<32><<<grid, kAttnBlock, 0, s>>>(dev_params); break;
-        case 256: attention_decode_kernel<64><<<grid, kAttnBlock, 0, s>>>(dev_params); break;
+        case 8: ADEC(2); break;
+        case 16: ADEC(4); break;
+        case 32: ADEC(8); break;
+        case 64: ADEC(16); break;
+        case 128: ADEC(32); break;
+        case 256: ADEC(64); break;
         default: break;
     }
+#undef ADEC
 }
 
 void launch_attention_batch(hipStream_t s, const AttentionParams* dev_params, uint32_t n_ops, uint32_t max_seq_q,

@@ -70,6 +70,7 @@ struct zgml_hip_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     bool opt_fusion = true, opt_graph = true, opt_profile = false, opt_skip_dead = true, opt_f16_dense = false;
+    int64_t opt_attn_split_min_keys = -1; // -1: environment / default (attn_split_for)
     // host dense override scratch
     float *mm_a = nullptr, *mm_b = nullptr, *mm_c = nullptr;
     uint64_t mm_a_cap = 0, mm_b_cap = 0, mm_c_cap = 0;
@@ -117,6 +118,9 @@ struct zgml_hip_program {
     };
     std::vector<QmvTrace> qmv_traces; // diagnostics (ZGML_HIP_QMV_TRACE)
     float* zero_word = nullptr;                   // a device 0.0f: mask operand of unmasked decode attention
+    float* split_buf = nullptr;                   // long-context attention split: partials + arrival counters,
+    uint32_t* split_cnt = nullptr;                // shared by the (stream-ordered) decode-attention launches
+    uint64_t split_buf_floats = 0, split_cnt_words = 0;
     bool f16_stream_nt = false;     // promoted weights exceed the Infinity Cache: non-temporal loads
     std::vector<void*> f16_weights; // per buffer: MFMA-packed f16 copy of a promoted matmul B operand (else nullptr)
     std::vector<void*> owned; // other device allocations
@@ -384,6 +388,38 @@ const T* upload_params(zgml_hip_program* p, const std::vector<T>& v) {
     hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
     p->param_blobs.push_back(d);
     return (const T*)d;
+}
+
+// Split policy of one decode-attention launch (kernels.h AttnSplit): up to 16 workgroups per head, one
+// per `min_keys` keys of the longest context the plan allows, the whole launch within ~256 workgroups.
+// ZGML_HIP_OPT_ATTN_SPLIT_MIN_KEYS (or the ZGML_HIP_ATTN_SPLIT_MIN_KEYS environment variable) moves the
+// threshold (>= 32, 0 = off); ZGML_HIP_ATTN_SPLIT caps the workgroups per head (<= 1 = off).
+AttnSplit attn_split_for(zgml_hip_program* p, uint32_t n_heads, uint32_t d_head, uint32_t max_kv) {
+    static const int want = getenv("ZGML_HIP_ATTN_SPLIT") ? atoi(getenv("ZGML_HIP_ATTN_SPLIT")) : 16;
+    static const int min_keys_env = getenv("ZGML_HIP_ATTN_SPLIT_MIN_KEYS") ? atoi(getenv("ZGML_HIP_ATTN_SPLIT_MIN_KEYS")) : 128;
+    AttnSplit sp;
+    const int64_t min_keys = p->ctx->opt_attn_split_min_keys >= 0 ? p->ctx->opt_attn_split_min_keys : min_keys_env;
+    if (min_keys == 0 || want <= 1) return sp;
+    sp.min_keys = (uint32_t)std::min<int64_t>(std::max<int64_t>(32, min_keys), 1 << 30);
+    uint32_t S = std::min<uint32_t>((uint32_t)std::max(want, 1), max_kv / sp.min_keys);
+    S = std::min(S, std::max(1u, 256u / std::max(n_heads, 1u))); // about one (1024-thread) workgroup per CU: idle ones still cost dispatch
+    if (S <= 1) return sp;
+    const uint64_t need = (uint64_t)n_heads * S * (d_head + 4);
+    if (need > p->split_buf_floats) { // earlier launches keep their (smaller) block: it stays in param_blobs
+        void* d = nullptr;
+        if (hipMalloc(&d, need * sizeof(float)) != hipSuccess) return sp;
+        p->param_blobs.push_back(d);
+        p->split_buf = (float*)d, p->split_buf_floats = need;
+    }
+    if (n_heads > p->split_cnt_words) {
+        void* d = nullptr;
+        const size_t bytes = ((size_t)n_heads * 4 + 255) / 256 * 256;
+        if (hipMalloc(&d, bytes) != hipSuccess || hipMemset(d, 0, bytes) != hipSuccess) return sp;
+        p->param_blobs.push_back(d);
+        p->split_cnt = (uint32_t*)d, p->split_cnt_words = n_heads;
+    }
+    sp.splits = S, sp.buf = p->split_buf, sp.cnt = p->split_cnt;
+    return sp;
 }
 
 RepeatParams make_repeat(zgml_hip_program* p, const zgml_op_repeat& r) {
@@ -1224,7 +1260,10 @@ void build_fused_plan(zgml_hip_program* p) {
         for (auto& kv : adec_by_dh) {
             const AttnDecodeParams* d = upload_params(p, kv.second);
             const uint32_t nh = (uint32_t)kv.second.size(), dh = kv.first;
-            p->plan.push_back({ZGML_DOP_ATTENTION, adec_ops, adec_lo, adec_hi, [=](hipStream_t s) { launch_attention_decode_batch(s, d, nh, dh); }});
+            uint32_t max_kv = 0;
+            for (const auto& a : kv.second) max_kv = std::max(max_kv, a.max_kv);
+            const AttnSplit sp = attn_split_for(p, nh, dh, max_kv);
+            p->plan.push_back({ZGML_DOP_ATTENTION, adec_ops, adec_lo, adec_hi, [=](hipStream_t s) { launch_attention_decode_batch(s, d, nh, dh, sp); }});
             adec_ops = 0; // profile accounting: ops counted once
         }
         // group mat-vecs that stage the same vector
@@ -1639,6 +1678,7 @@ int zgml_hip_set_option(zgml_hip_ctx* ctx, int option, int64_t value) {
         case ZGML_HIP_OPT_PROFILE: ctx->opt_profile = value != 0; return 0;
         case ZGML_HIP_OPT_SKIP_DEAD_UPLOADS: ctx->opt_skip_dead = value != 0; return 0;
         case ZGML_HIP_OPT_F16_DENSE_WEIGHTS: ctx->opt_f16_dense = value != 0; return 0;
+        case ZGML_HIP_OPT_ATTN_SPLIT_MIN_KEYS: ctx->opt_attn_split_min_keys = value < 0 ? -1 : value; return 0;
         case ZGML_HIP_OPT_DENSE_WEIGHT_CACHE:
             ctx->b_cache_cap = value > 0 ? (uint64_t)value : 0;
             if (!ctx->b_cache_cap) ctx->drop_b_cache();
