@@ -1095,12 +1095,17 @@ namespace {
 // everywhere up to K ~ 4096 — narrower workgroups keep more of them co-resident per CU, so one
 // workgroup's x staging / reduction tail overlaps another's streaming — and 8 waves win for the long
 // K of the down projection (11008). 16-wave workgroups (the first design) lose up to 35 % on
-// multi-round grids.
+// multi-round grids. Inside the fused decode stream the short-K launches (K <= 2048: SmolLM's 576 and
+// 1536) behave differently from the isolated sweep: the launch is a single latency chain, and one
+// wave per 4 units (one load step each, up to 16 waves) shortens it: SmolLM-135M decode +3.8 %
+// (ZGML_QMV_WAVES_SMALLK sweep: 4 -> 1414, 5 -> 1400, 6 -> 1450, 8 -> 1445, 12+ -> 1470 tok/s);
+// for K = 4096 more waves lose in the stream (Llama-2-7B: 8 waves -18 %).
 uint32_t qmv_waves(const QWeightDev& w, uint32_t total_blocks = 0) {
     (void)total_blocks;
     const uint32_t U = w.format == QW_Q4 ? w.KC : 2 * w.KC;
     uint32_t waves = cdiv(U, 4);
-    uint32_t cap = w.K > 6144 ? 8 : 4;
+    static const int small_cap = getenv("ZGML_QMV_WAVES_SMALLK") ? atoi(getenv("ZGML_QMV_WAVES_SMALLK")) : 16;
+    uint32_t cap = w.K > 6144 ? 8 : (w.K <= 2048 ? (uint32_t)small_cap : 4); // short K: the launch is one latency chain, more waves shorten it
     static const int env_cap = getenv("ZGML_QMV_WAVES") ? atoi(getenv("ZGML_QMV_WAVES")) : 0;
     if (env_cap > 0) cap = (uint32_t)env_cap;
     if (waves > cap) waves = cap;
