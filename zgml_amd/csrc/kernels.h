@@ -216,6 +216,7 @@ struct QMatmulParams {
     const float* input; // input_offset applied
     uint32_t M, N, K;
     uint32_t in_rs, dst_rs;
+    uint32_t reuse_split = 0; // M > 1: the scratch already holds this input's A pieces (previous launch, same rows)
 };
 
 // generic kernels (kernels_generic.hip)

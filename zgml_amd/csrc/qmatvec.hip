@@ -894,6 +894,181 @@ __global__ void __launch_bounds__(512) qmatmul_tile_kernel(QMMArgs a) {
     }
 }
 
+// ── XDL tile kernel, second form (Q4_0 with f16 block scales): the scale goes into B ──────────
+// The form above pays ~6.5 VALU instructions per (row, k, 32-column block) to scale and split the A
+// operand, in every workgroup, and stages x through LDS with two barriers per step: measured 21 us
+// for 32 x 4096 x 4096 against an HBM time of 1.2 us. Here
+//   * A = x itself, split ONCE per matmul (split_a_kernel) into three bf16 pieces by truncation
+//     (x = h1 + h2 + h3 exactly: 8 + 8 + 8 significant bits) and laid out as the MFMA A operand, so a
+//     lane's load is 16 contiguous bytes of a 1 KB wave-contiguous block (L2-resident, no LDS, no
+//     barrier in the K loop);
+//   * B = w = (q - 8)/16 * scale, exact in f32 (4-bit integer x 11-bit f16 scale = 15 significant
+//     bits), split into two bf16 pieces w = b1 + b2 exactly (8 + 7 bits): 5 VALU instructions per
+//     weight, independent of M;
+//   * x*w = sum of the 3 x 2 piece products, each exact in the MFMA's f32 accumulator: six
+//     v_mfma_f32_16x16x32_bf16 per 8-k group and m-tile, f32-level accuracy as before.
+// Waves of a workgroup split the K steps (128 k each) and fold their tiles through LDS in wave order;
+// a workgroup owns G column groups of one 32-column scale block and R m-tiles.
+struct QMM2Args {
+    const uint4* qs;
+    const uint4* sc;
+    const uint4* ap; // split_a_kernel output
+    float* out;
+    uint32_t M, U, S, out_rs, NB2; // S = K steps = ceil(U / 4)
+};
+
+// A pieces: ap[(((t * S + s) * 4 + j) * 3 + p) * 64 + lane] = the 8 bf16 of piece p that lane (i = lane % 16:
+// row 16 t + i, r = lane / 16: unit 4 s + r) feeds to the MFMA of k_local 8 j .. 8 j + 7. Rows >= M and k >= K are zero.
+__global__ void __launch_bounds__(256) split_a_kernel(const float* __restrict__ x, uint32_t M, uint32_t K, uint32_t in_rs, uint4* __restrict__ ap,
+                                                      uint32_t S) {
+    const uint32_t s = blockIdx.x, t = blockIdx.y, j = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, r = lane >> 4;
+    const uint32_t m = 16 * t + i, k0 = (4 * s + r) * 32 + 8 * j;
+    uint32_t h[3][8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const float v = (m < M && k0 + e < K) ? x[(uint64_t)m * in_rs + k0 + e] : 0.0f;
+        const uint32_t h1 = __float_as_uint(v) & 0xFFFF0000u;
+        const float r1 = v - __uint_as_float(h1);
+        const uint32_t h2 = __float_as_uint(r1) & 0xFFFF0000u;
+        const float r2 = r1 - __uint_as_float(h2); // <= 8 significant bits: a bf16
+        h[0][e] = h1, h[1][e] = h2, h[2][e] = __float_as_uint(r2);
+    }
+    uint4* dst = ap + ((((uint64_t)t * S + s) * 4 + j) * 3) * 64 + lane;
+#pragma unroll
+    for (int p = 0; p < 3; p++)
+        dst[p * 64] = make_uint4((h[p][0] >> 16) | (h[p][1] & 0xFFFF0000u), (h[p][2] >> 16) | (h[p][3] & 0xFFFF0000u),
+                                 (h[p][4] >> 16) | (h[p][5] & 0xFFFF0000u), (h[p][6] >> 16) | (h[p][7] & 0xFFFF0000u));
+}
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8_t as_bf16x8(uint4 v) { return __builtin_bit_cast(bf16x8_t, v); }
+// (hi16(a), hi16(b)) -> one dword of two bf16 (a in the low half)
+__device__ __forceinline__ uint32_t pack_hi16(float a, float b) { return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u); }
+
+template <int R, int G, bool NT>
+__global__ void __launch_bounds__(512) qmatmul_xdl2_kernel(QMM2Args a) {
+    extern __shared__ float smem[];
+    const uint32_t g0 = (G == 1 ? column_group(blockIdx.x, a.NB2) : blockIdx.x * G), t0 = blockIdx.y * R;
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    const uint32_t row = lane >> 4, i = lane & 15;
+    const uint4* qs = a.qs + (uint64_t)g0 * a.U * 16 + i;
+    const uint4* sc = a.sc + (uint64_t)(g0 >> 1) * a.U * 4; // 32 f16 scales per unit, element 2 * (k_local % 16) + k_local / 16
+    const uint4* ap = a.ap + (uint64_t)t0 * a.S * 12 * 64 + lane;
+    const uint64_t tile_stride = (uint64_t)a.S * 12 * 64; // uint4 between m-tiles
+
+    // one accumulator per (column group, m-tile, A piece): consecutive MFMAs never chain through the same
+    // registers (a dependent v_mfma waits out its predecessor: half the wave cycles were issue stalls with one
+    // accumulator per tile); the pieces are summed once, at the end
+    mfma_f4 acc[G][R][3];
+#pragma unroll
+    for (int g = 0; g < G; g++)
+#pragma unroll
+        for (int t = 0; t < R; t++)
+#pragma unroll
+            for (int p = 0; p < 3; p++) acc[g][t][p] = mfma_f4{0.f, 0.f, 0.f, 0.f};
+
+    struct BStep { // one K step of this lane: its unit's nibbles per column group, the unit's scales
+        uint4 wq[G];
+        uint4 s4[4];
+    };
+    struct AGrp { // the A pieces of one 8-k group
+        uint4 v[R][3];
+    };
+    auto load_b = [&](BStep& b, uint32_t s) {
+        const uint32_t u = min(4 * s + row, a.U - 1); // units past the end: A is zero there
+#pragma unroll
+        for (int g = 0; g < G; g++) b.wq[g] = wload<NT>(qs + ((uint64_t)g * a.U + u) * 16);
+#pragma unroll
+        for (int q = 0; q < 4; q++) b.s4[q] = sc[(uint64_t)u * 4 + q];
+    };
+    auto load_a = [&](AGrp& x, uint32_t s, uint32_t j) {
+#pragma unroll
+        for (int t = 0; t < R; t++)
+#pragma unroll
+            for (int p = 0; p < 3; p++) x.v[t][p] = ap[t * tile_stride + (((uint64_t)s * 4 + j) * 3 + p) * 64];
+    };
+    auto group = [&](const BStep& b, const AGrp& x, auto jc) {
+        constexpr int J = decltype(jc)::value;
+        // scales of k_local 8 J + e: element 2 * ((8 J + e) % 16) + (8 J + e) / 16 -> dword 8 * (J & 1) + e, half J >> 1
+        const uint32_t sd[8] = {J & 1 ? b.s4[2].x : b.s4[0].x, J & 1 ? b.s4[2].y : b.s4[0].y, J & 1 ? b.s4[2].z : b.s4[0].z,
+                                J & 1 ? b.s4[2].w : b.s4[0].w, J & 1 ? b.s4[3].x : b.s4[1].x, J & 1 ? b.s4[3].y : b.s4[1].y,
+                                J & 1 ? b.s4[3].z : b.s4[1].z, J & 1 ? b.s4[3].w : b.s4[1].w};
+        float sk[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const __half2 hh = __builtin_bit_cast(__half2, sd[e]);
+            sk[e] = __half2float(J >> 1 ? hh.y : hh.x);
+        }
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const uint32_t lo = J == 0 ? b.wq[g].x : J == 1 ? b.wq[g].y : J == 2 ? b.wq[g].z : b.wq[g].w, hi = lo >> 4;
+            float wv[8];
+            wv[0] = cvt_nib<0>(lo) * sk[0], wv[1] = cvt_nib<1>(lo) * sk[1], wv[2] = cvt_nib<2>(lo) * sk[2], wv[3] = cvt_nib<3>(lo) * sk[3];
+            wv[4] = cvt_nib<0>(hi) * sk[4], wv[5] = cvt_nib<1>(hi) * sk[5], wv[6] = cvt_nib<2>(hi) * sk[6], wv[7] = cvt_nib<3>(hi) * sk[7];
+            float lo2[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) lo2[e] = wv[e] - __uint_as_float(__float_as_uint(wv[e]) & 0xFFFF0000u);
+            const bf16x8_t b1 = as_bf16x8(make_uint4(pack_hi16(wv[0], wv[1]), pack_hi16(wv[2], wv[3]), pack_hi16(wv[4], wv[5]), pack_hi16(wv[6], wv[7])));
+            const bf16x8_t b2 = as_bf16x8(make_uint4(pack_hi16(lo2[0], lo2[1]), pack_hi16(lo2[2], lo2[3]), pack_hi16(lo2[4], lo2[5]), pack_hi16(lo2[6], lo2[7])));
+#pragma unroll
+            for (int p = 0; p < 3; p++)
+#pragma unroll
+                for (int t = 0; t < R; t++) acc[g][t][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(x.v[t][p]), b1, acc[g][t][p], 0, 0, 0);
+#pragma unroll
+            for (int p = 0; p < 3; p++)
+#pragma unroll
+                for (int t = 0; t < R; t++) acc[g][t][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(x.v[t][p]), b2, acc[g][t][p], 0, 0, 0);
+        }
+    };
+
+    if (w < a.S) {
+        BStep cur, nxt;
+        AGrp a0, a1;
+        uint32_t s = w;
+        load_b(cur, s);
+        load_a(a0, s, 0);
+        for (; s < a.S; s += n_waves) {
+            const uint32_t sn = min(s + n_waves, a.S - 1); // clamped, unconditional: the last prefetch re-reads live lines
+            // sched_barrier: hipcc otherwise sinks each prefetch down to its first use
+            load_b(nxt, sn);
+            load_a(a1, s, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            group(cur, a0, std::integral_constant<int, 0>{});
+            __builtin_amdgcn_sched_barrier(0);
+            load_a(a0, s, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            group(cur, a1, std::integral_constant<int, 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            load_a(a1, s, 3);
+            __builtin_amdgcn_sched_barrier(0);
+            group(cur, a0, std::integral_constant<int, 2>{});
+            __builtin_amdgcn_sched_barrier(0);
+            load_a(a0, sn, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            group(cur, a1, std::integral_constant<int, 3>{});
+            __builtin_amdgcn_sched_barrier(0);
+            cur = nxt;
+        }
+    }
+
+    // D[m = 4 * row + v][n = i] in acc[g][t][v]; fold the waves in fixed order; the tile carries q/16: x 16 (exact)
+#pragma unroll
+    for (int g = 0; g < G; g++)
+#pragma unroll
+        for (int t = 0; t < R; t++)
+#pragma unroll
+            for (int v = 0; v < 4; v++) smem[((w * (G * R) + g * R + t) * 4 + v) * 64 + lane] = (acc[g][t][0][v] + acc[g][t][1][v]) + acc[g][t][2][v];
+    __syncthreads();
+    for (uint32_t idx = threadIdx.x; idx < (uint32_t)(G * R) * 256; idx += blockDim.x) {
+        const uint32_t gt = idx >> 8, v = (idx >> 6) & 3, l = idx & 63;
+        float sum = smem[(gt * 4 + v) * 64 + l];
+        for (uint32_t ww = 1; ww < n_waves; ww++) sum += smem[((ww * (G * R) + gt) * 4 + v) * 64 + l];
+        const uint32_t g = gt / R, t = gt % R;
+        const uint32_t m = (t0 + t) * 16 + 4 * (l >> 4) + v, n = (g0 + g) * 16 + (l & 15);
+        if (m < a.M) a.out[(uint64_t)m * a.out_rs + n] = sum * 16.0f;
+    }
+}
+
 // Raw layout (any block size, any N): one thread per (m, n), k sequential — exactly the
 // reference's loop order, coalesced along n. Used for odd shapes (e.g. the bs=4 conformance case).
 __global__ void __launch_bounds__(kBlock) qmatmul_raw_kernel(const int8_t* __restrict__ data,
@@ -1075,7 +1250,19 @@ void launch_pack_gguf(hipStream_t s, const uint8_t* raw_blocks, const QWeightDev
     pack_gguf_kernel<<<2048, kBlock, 0, s>>>(raw_blocks, out);
 }
 
-uint64_t qmatmul_scratch_bytes(const QWeightDev&, uint32_t) { return 0; } // single launch: no split-K slabs
+// Scratch of one M > 1 launch: the pre-split A operand of the second XDL form (split_a_kernel): per
+// 16-row tile and 128-k step 12 KB (4 groups x 3 pieces x 64 lanes x 16 B). Launches are serialised on one
+// stream, so one block serves all of a program's quantized matmuls.
+static bool xdl2_enabled() {
+    static const bool on = !(getenv("ZGML_QMM_XDL2") && atoi(getenv("ZGML_QMM_XDL2")) == 0);
+    return on;
+}
+static bool xdl2_applies(const QWeightDev& w, uint32_t M) { return M > 1 && w.format == QW_Q4 && w.scale_f16 && xdl2_enabled(); }
+uint64_t qmatmul_scratch_bytes(const QWeightDev& w, uint32_t M) {
+    if (!xdl2_applies(w, M)) return 0;
+    const uint64_t S = (w.KC + 3) / 4, tiles = (M + 15) / 16, R = M > 16 ? 2 : 1;
+    return (tiles + R - 1) / R * R * S * 12 * 1024;
+}
 
 bool qweight_packable(uint64_t K, uint64_t N, uint64_t bs) {
     if (bs != 32 || N == 0 || K == 0 || N % 32 != 0) return false;
@@ -1187,7 +1374,37 @@ TileFn pick_tile(bool two, bool xvec, bool nt) {
     return nt ? pick_tile_nt<ST, Q4, true, false>(two, xvec) : pick_tile_nt<ST, Q4, false, false>(two, xvec);
 }
 
-void launch_tile(hipStream_t s, const QWeightDev& w, const QMatmulParams& p, bool xvec) {
+template <int R, bool NT>
+void launch_xdl2_rg(hipStream_t s, const QMM2Args& a, uint32_t G, dim3 grid, uint32_t waves, size_t lds) {
+    if (G == 2)
+        hipLaunchKernelGGL((qmatmul_xdl2_kernel<R, 2, NT>), grid, dim3(waves * 64), lds, s, a);
+    else
+        hipLaunchKernelGGL((qmatmul_xdl2_kernel<R, 1, NT>), grid, dim3(waves * 64), lds, s, a);
+}
+
+// second XDL form: split x once, then the B-scaled tile kernel (Q4_0, f16 scales)
+void launch_xdl2(hipStream_t s, const QWeightDev& w, const QMatmulParams& p, float* scratch) {
+    const uint32_t U = w.KC, S = cdiv(U, 4), R = p.M > 16 ? 2 : 1, tiles = cdiv(cdiv(p.M, 16), R) * R, NB2 = p.N / 16;
+    if (!p.reuse_split) hipLaunchKernelGGL(split_a_kernel, dim3(S, tiles), dim3(256), 0, s, p.input, p.M, p.K, p.in_rs, (uint4*)scratch, S);
+    static const int env_g = getenv("ZGML_QMM_XDL2_G") ? atoi(getenv("ZGML_QMM_XDL2_G")) : 0;
+    const uint32_t G = env_g ? (uint32_t)env_g : (NB2 >= 512 ? 2 : 1);
+    static const int env_w = getenv("ZGML_QMM_WAVES") ? atoi(getenv("ZGML_QMM_WAVES")) : 8;
+    const uint32_t waves = std::min<uint32_t>(S, (uint32_t)env_w);
+    const QMM2Args a{(const uint4*)w.qs, (const uint4*)w.sc, (const uint4*)scratch, p.dst, p.M, U, S, p.dst_rs, NB2};
+    const dim3 grid(NB2 / G, tiles / R);
+    const size_t lds = (size_t)waves * G * R * 256 * sizeof(float);
+    const bool nt = w.stream_nt != 0 && tiles / R == 1;
+    if (R == 2)
+        nt ? launch_xdl2_rg<2, true>(s, a, G, grid, waves, lds) : launch_xdl2_rg<2, false>(s, a, G, grid, waves, lds);
+    else
+        nt ? launch_xdl2_rg<1, true>(s, a, G, grid, waves, lds) : launch_xdl2_rg<1, false>(s, a, G, grid, waves, lds);
+}
+
+void launch_tile(hipStream_t s, const QWeightDev& w, const QMatmulParams& p, bool xvec, float* scratch) {
+    if (scratch && xdl2_applies(w, p.M)) {
+        launch_xdl2(s, w, p, scratch);
+        return;
+    }
     const bool q4 = w.format == QW_Q4, two = p.M > 16;
     const uint32_t R = two ? 2 : 1, KU = q4 ? 32 : 16;
     QMMArgs a{(const uint4*)w.qs, w.sc, p.input, p.dst, p.M, p.K, q4 ? w.KC : 2 * w.KC, p.in_rs, p.dst_rs, p.N / 16};
@@ -1209,7 +1426,7 @@ void launch_tile(hipStream_t s, const QWeightDev& w, const QMatmulParams& p, boo
 
 uint32_t qmv_max_prologue_k(const QWeightDev&) { return kMaxWaves * 64 * 4 * kXRegs; } // widest workgroup; launch_packed widens to fit
 
-void launch_qmatmul(hipStream_t s, const QWeightDev& w, const QMatmulParams& p, float*) {
+void launch_qmatmul(hipStream_t s, const QWeightDev& w, const QMatmulParams& p, float* scratch) {
     if (p.M == 0 || p.N == 0) return;
     if (w.format == QW_RAW) {
         dim3 grid(cdiv(p.N, kBlock), p.M);
@@ -1219,7 +1436,7 @@ void launch_qmatmul(hipStream_t s, const QWeightDev& w, const QMatmulParams& p, 
     const bool xvec = ((uintptr_t)p.input % 16 == 0) && (p.K % 4 == 0) && (p.M == 1 || p.in_rs % 4 == 0);
     static const int tile_min_m = getenv("ZGML_QMM_TILE_MIN_M") ? atoi(getenv("ZGML_QMM_TILE_MIN_M")) : 2;
     if (p.M >= (uint32_t)tile_min_m && p.M > 1) {
-        launch_tile(s, w, p, xvec);
+        launch_tile(s, w, p, xvec, scratch);
         return;
     }
     QMVArgs a{};

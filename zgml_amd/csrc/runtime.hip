@@ -126,6 +126,10 @@ struct zgml_hip_program {
     std::vector<void*> owned; // other device allocations
     float* scratch = nullptr;
     uint64_t scratch_bytes = 0;
+    // plan building: the last quantized matmul launch that split its input into the scratch (make_single)
+    uint64_t split_pos = UINT64_MAX - 1;
+    const float* split_input = nullptr;
+    uint32_t split_M = 0, split_K = 0, split_in_rs = 0;
     // dynamic parameter block: one word per op
     uint32_t* dyn_dev = nullptr;
     uint32_t* dyn_host = nullptr; // pinned
@@ -528,6 +532,14 @@ bool make_single(zgml_hip_program* p, size_t i, Launch& L) {
             qp.dst_rs = q.dst_row_stride ? q.dst_row_stride : q.N;
             const QWeightDev w = p->qweights[q.weight_idx];
             float* scratch = p->scratch;
+            // q/k/v and gate/up read the same rows: the launch right after one that split the same input
+            // (adjacent in the plan, so nothing rewrote the rows or the scratch in between) reuses its A pieces
+            const uint64_t pos = p->plan.size();
+            const bool splits = scratch && qmatmul_scratch_bytes(w, qp.M) != 0;
+            qp.reuse_split = splits && p->split_pos + 1 == pos && p->split_input == qp.input && p->split_M == qp.M && p->split_K == qp.K &&
+                             p->split_in_rs == qp.in_rs;
+            if (splits)
+                p->split_pos = pos, p->split_input = qp.input, p->split_M = qp.M, p->split_K = qp.K, p->split_in_rs = qp.in_rs;
             L.run = [=](hipStream_t s) { launch_qmatmul(s, w, qp, scratch); };
             return true;
         }
@@ -1318,6 +1330,8 @@ void build_plan(zgml_hip_program* p) {
     hipStreamSynchronize(p->ctx->stream); // the previous plan's parameter arrays may still be in use
     p->plan.clear();
     free_param_blobs(p);
+    p->split_buf = nullptr, p->split_cnt = nullptr, p->split_buf_floats = 0, p->split_cnt_words = 0; // lived in the blobs
+    p->split_pos = UINT64_MAX - 1, p->split_input = nullptr;
     p->plan_batched = p->ctx->opt_fusion && p->batching_safe;
     if (p->plan_batched) {
         p->sched = build_schedule(p->ops, p->sizes, p->barriers);
@@ -2401,7 +2415,7 @@ double zgml_hip_qmatmul_bench(zgml_hip_ctx* ctx, uint32_t M, uint32_t K, uint32_
     float *x = nullptr, *y = nullptr, *scratch = nullptr;
     std::vector<float> xh((size_t)M * K);
     for (size_t i = 0; i < xh.size(); i++) xh[i] = ((int)(i % 17) - 8) * 0.03125f;
-    uint64_t sb = ok ? qmatmul_scratch_bytes(ring[0], 1) : 0;
+    uint64_t sb = ok ? qmatmul_scratch_bytes(ring[0], M) : 0;
     ok = ok && CTX_CHECK(ctx, hipMalloc((void**)&x, xh.size() * 4)) && CTX_CHECK(ctx, hipMalloc((void**)&y, (size_t)M * N * 4)) &&
          (!sb || CTX_CHECK(ctx, hipMalloc((void**)&scratch, sb))) &&
          CTX_CHECK(ctx, hipMemcpy(x, xh.data(), xh.size() * 4, hipMemcpyHostToDevice));
