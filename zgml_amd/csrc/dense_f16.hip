@@ -25,6 +25,8 @@
 #include <hip/hip_fp16.h>
 #include <stdlib.h>
 
+#include <algorithm>
+
 namespace zgml {
 
 namespace {
@@ -219,6 +221,97 @@ __global__ void __launch_bounds__(512) dense_f16_kernel(F16Args a) {
     }
 }
 
+// ── M > 1, second form: A pre-rounded and pre-laid-out, no LDS in the K loop ─────────────────
+// The staged form above re-reads f32 x through LDS in every workgroup (rounding it to f16 each time) with a
+// barrier per step: 13.3 us for 32 x 4096 x 4096 against 4.2 us of weight streaming. Here pack_a_f16_kernel
+// rounds x to f16 ONCE per matmul (same round-to-nearest-even, so the products are the same numbers) into
+// the MFMA A-operand layout  Ap: half[tiles][KC][64][8], item (t, c, lane = 16 r + i) = A[16 t + i][32 c + 8 r + e],
+// and a lane's A operand is one 16-byte load of a wave-contiguous 1 KB block (L2-resident), exactly like
+// its B operand. Waves split the 32-k chunks round-robin and keep DEPTH chunks (B and A) in flight.
+struct F16Args2 {
+    const uint4* bp;
+    const uint4* ap;
+    float* out;
+    uint32_t M, KC, out_rs, NB2;
+};
+
+__global__ void __launch_bounds__(kBlock) pack_a_f16_kernel(const float* __restrict__ x, uint32_t M, uint32_t K, uint32_t a_rs, uint32_t KC,
+                                                            uint32_t tiles, uint4* __restrict__ ap) {
+    const uint64_t n_items = (uint64_t)tiles * KC * 64;
+    for (uint64_t it = (uint64_t)blockIdx.x * kBlock + threadIdx.x; it < n_items; it += (uint64_t)gridDim.x * kBlock) {
+        const uint32_t lane = it & 63, i = lane & 15, r = lane >> 4;
+        const uint64_t tc = it >> 6;
+        const uint32_t c = tc % KC, t = tc / KC, m = 16 * t + i, k0 = 32 * c + 8 * r;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] = (m < M && k0 + e < K) ? x[(uint64_t)m * a_rs + k0 + e] : 0.f;
+        const uint2 lo = pack_half4(make_float4(v[0], v[1], v[2], v[3])), hi = pack_half4(make_float4(v[4], v[5], v[6], v[7]));
+        ap[it] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    }
+}
+
+template <int R, bool NT>
+__global__ void __launch_bounds__(512) dense_f16_tile2_kernel(F16Args2 a) {
+    constexpr int DEPTH = 4; // chunks in flight per wave: (1 + R) x 16 B per lane each
+    extern __shared__ float smem[];
+    // w in an SGPR: the chunk guard below must be a scalar branch — a v_mfma ignores EXEC, so a predicated
+    // (if-converted) guard would still accumulate the clamped duplicate chunks
+    const uint32_t lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n_waves = blockDim.x >> 6;
+    const uint32_t g = blockIdx.x, t0 = blockIdx.y * R;
+    const uint4* bp = a.bp + (uint64_t)g * a.KC * 64 + lane;
+    const uint4* ap = a.ap + (uint64_t)t0 * a.KC * 64 + lane;
+    const uint64_t tile_stride = (uint64_t)a.KC * 64;
+    struct Chunk {
+        uint4 b;
+        uint4 av[R];
+    };
+    auto load = [&](Chunk& x, uint32_t c) { // clamped, unconditional: a repeated chunk is never used twice (the loop bounds decide)
+        const uint32_t cc = min(c, a.KC - 1);
+        if (NT) {
+            typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+            const u4v v = __builtin_nontemporal_load((const u4v*)(bp + (uint64_t)cc * 64));
+            x.b = make_uint4(v.x, v.y, v.z, v.w);
+        } else {
+            x.b = bp[(uint64_t)cc * 64];
+        }
+#pragma unroll
+        for (int t = 0; t < R; t++) x.av[t] = ap[t * tile_stride + (uint64_t)cc * 64];
+    };
+    mfma_f4 acc[R];
+#pragma unroll
+    for (int t = 0; t < R; t++) acc[t] = mfma_f4{0.f, 0.f, 0.f, 0.f};
+    // wave w takes chunks w, w + n_waves, ...; ring of DEPTH chunks
+    Chunk ring[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++) load(ring[d], w + d * n_waves);
+    for (uint32_t c = w; c < a.KC; c += DEPTH * n_waves) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; d++) {
+            const Chunk cur = ring[d];
+            load(ring[d], c + (d + DEPTH) * n_waves);
+            __builtin_amdgcn_sched_barrier(0); // the refill is issued before the MFMAs of this chunk
+            if (c + d * n_waves < a.KC) { // (wave-uniform)
+                const half8 bv = __builtin_bit_cast(half8, cur.b);
+#pragma unroll
+                for (int t = 0; t < R; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, cur.av[t]), bv, acc[t], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < R; t++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) smem[((w * R + t) * 4 + v) * 64 + lane] = acc[t][v];
+    __syncthreads();
+    for (uint32_t idx = threadIdx.x; idx < (uint32_t)R * 256; idx += blockDim.x) {
+        const uint32_t t = idx >> 8, v = (idx >> 6) & 3, l = idx & 63;
+        float sum = smem[(t * 4 + v) * 64 + l];
+        for (uint32_t ww = 1; ww < n_waves; ww++) sum += smem[((ww * R + t) * 4 + v) * 64 + l];
+        const uint32_t m = (t0 + t) * 16 + 4 * (l >> 4) + v, n = g * 16 + (l & 15);
+        if (m < a.M) a.out[(uint64_t)m * a.out_rs + n] = sum;
+    }
+}
+
 // f32 B (any strides, device memory) -> MFMA-packed f16. One thread per 16-byte item.
 __global__ void __launch_bounds__(kBlock) pack_f16_kernel(const float* __restrict__ b, uint32_t b_rs, uint32_t b_cs,
                                                           uint32_t K, uint32_t N, uint32_t KC, uint4* __restrict__ out) {
@@ -249,8 +342,38 @@ void launch_pack_f16(hipStream_t s, const float* b, uint32_t b_rs, uint32_t b_cs
     pack_f16_kernel<<<2048, kBlock, 0, s>>>(b, b_rs, b_cs, K, N, (K + 31) / 32, (uint4*)out);
 }
 
+uint64_t dense_f16_scratch_bytes(uint32_t M, uint32_t K) {
+    static const bool on = !(getenv("ZGML_F16_TILE2") && atoi(getenv("ZGML_F16_TILE2")) == 0);
+    if (!on || M <= 1) return 0;
+    const uint64_t tiles = (M + 15) / 16, R = M > 16 ? 2 : 1;
+    return (tiles + R - 1) / R * R * ((K + 31) / 32) * 1024;
+}
+
+static void launch_dense_f16_tile2(hipStream_t s, const DenseF16Params& p) {
+    const uint32_t KC = (p.K + 31) / 32, R = p.M > 16 ? 2 : 1, tiles = cdiv(cdiv(p.M, 16), R) * R, NB2 = p.N / 16;
+    if (!p.reuse_a) {
+        const uint64_t items = (uint64_t)tiles * KC * 64;
+        pack_a_f16_kernel<<<(uint32_t)std::min<uint64_t>(2048, (items + kBlock - 1) / kBlock), kBlock, 0, s>>>(p.a, p.M, p.K, p.a_rs, KC, tiles,
+                                                                                                             (uint4*)p.scratch);
+    }
+    static const int env_w = getenv("ZGML_F16_TILE2_WAVES") ? atoi(getenv("ZGML_F16_TILE2_WAVES")) : 8;
+    const uint32_t waves = std::max(1u, std::min<uint32_t>(KC, (uint32_t)env_w));
+    const F16Args2 a{(const uint4*)p.bp, (const uint4*)p.scratch, p.dst, p.M, KC, p.dst_rs, NB2};
+    const dim3 grid(NB2, tiles / R);
+    const size_t lds = (size_t)waves * R * 256 * sizeof(float);
+    const bool nt = p.stream_nt != 0 && tiles / R == 1;
+    using Fn2 = void (*)(F16Args2);
+    const Fn2 fn = R == 2 ? (nt ? (Fn2)dense_f16_tile2_kernel<2, true> : (Fn2)dense_f16_tile2_kernel<2, false>)
+                          : (nt ? (Fn2)dense_f16_tile2_kernel<1, true> : (Fn2)dense_f16_tile2_kernel<1, false>);
+    hipLaunchKernelGGL(fn, grid, dim3(waves * 64), lds, s, a);
+}
+
 void launch_dense_f16(hipStream_t s, const DenseF16Params& p) {
     if (p.M == 0 || p.N == 0) return;
+    if (p.M > 1 && p.scratch && dense_f16_scratch_bytes(p.M, p.K)) {
+        launch_dense_f16_tile2(s, p);
+        return;
+    }
     F16Args a{(const uint4*)p.bp, p.a, p.dst, p.M, p.K, (p.K + 31) / 32, p.a_rs, p.dst_rs, p.N / 16};
     const uint32_t R = p.M == 1 ? 0 : (p.M > 16 ? 2 : 1);
     // see kDepth in the kernel; the 8-wave R = 2 form only pays while the grid is about one round (N <= 6144)

@@ -141,7 +141,12 @@ struct DenseF16Params {
     uint32_t M, N, K;
     uint32_t a_rs, dst_rs;
     uint32_t stream_nt; // non-temporal weight loads: the program's promoted weights exceed the Infinity Cache
+    // M > 1: device block of dense_f16_scratch_bytes(M, K) for the pre-rounded A operand (nullptr: staged form);
+    // reuse_a: the block already holds this input (previous launch, same rows)
+    void* scratch = nullptr;
+    uint32_t reuse_a = 0;
 };
+uint64_t dense_f16_scratch_bytes(uint32_t M, uint32_t K);
 bool f16_packable(uint64_t K, uint64_t N);
 uint64_t f16_packed_bytes(uint64_t K, uint64_t N);
 void launch_pack_f16(hipStream_t s, const float* b, uint32_t b_rs, uint32_t b_cs, uint32_t K, uint32_t N, void* out);

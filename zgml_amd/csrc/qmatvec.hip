@@ -949,7 +949,8 @@ template <int R, int G, bool NT>
 __global__ void __launch_bounds__(512) qmatmul_xdl2_kernel(QMM2Args a) {
     extern __shared__ float smem[];
     const uint32_t g0 = (G == 1 ? column_group(blockIdx.x, a.NB2) : blockIdx.x * G), t0 = blockIdx.y * R;
-    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    // w in an SGPR: loop bounds that guard MFMAs must be scalar (a v_mfma ignores EXEC)
+    const uint32_t lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n_waves = blockDim.x >> 6;
     const uint32_t row = lane >> 4, i = lane & 15;
     const uint4* qs = a.qs + (uint64_t)g0 * a.U * 16 + i;
     const uint4* sc = a.sc + (uint64_t)(g0 >> 1) * a.U * 4; // 32 f16 scales per unit, element 2 * (k_local % 16) + k_local / 16

@@ -129,7 +129,7 @@ struct zgml_hip_program {
     // plan building: the last quantized matmul launch that split its input into the scratch (make_single)
     uint64_t split_pos = UINT64_MAX - 1;
     const float* split_input = nullptr;
-    uint32_t split_M = 0, split_K = 0, split_in_rs = 0;
+    uint32_t split_M = 0, split_K = 0, split_in_rs = 0, split_kind = 0; // kind: 1 = bf16 pieces (quantized), 2 = f16 A (dense)
     // dynamic parameter block: one word per op
     uint32_t* dyn_dev = nullptr;
     uint32_t* dyn_host = nullptr; // pinned
@@ -516,6 +516,13 @@ bool make_single(zgml_hip_program* p, size_t i, Launch& L) {
             dp.b_f16 = 0;
             if (m.b < p->f16_weights.size() && p->f16_weights[m.b]) { // promoted at compile time
                 DenseF16Params fp{dp.dst, dp.a, p->f16_weights[m.b], dp.M, dp.N, dp.K, dp.a_rs, dp.dst_rs, p->f16_stream_nt ? 1u : 0u};
+                if (p->scratch && dense_f16_scratch_bytes(dp.M, dp.K)) { // same adjacency rule as the quantized split below
+                    const uint64_t pos = p->plan.size();
+                    fp.scratch = p->scratch;
+                    fp.reuse_a = p->split_pos + 1 == pos && p->split_input == dp.a && p->split_M == dp.M && p->split_K == dp.K &&
+                                 p->split_in_rs == dp.a_rs && p->split_kind == 2;
+                    p->split_pos = pos, p->split_input = dp.a, p->split_M = dp.M, p->split_K = dp.K, p->split_in_rs = dp.a_rs, p->split_kind = 2;
+                }
                 L.run = [=](hipStream_t s) { launch_dense_f16(s, fp); };
                 return true;
             }
@@ -537,9 +544,9 @@ bool make_single(zgml_hip_program* p, size_t i, Launch& L) {
             const uint64_t pos = p->plan.size();
             const bool splits = scratch && qmatmul_scratch_bytes(w, qp.M) != 0;
             qp.reuse_split = splits && p->split_pos + 1 == pos && p->split_input == qp.input && p->split_M == qp.M && p->split_K == qp.K &&
-                             p->split_in_rs == qp.in_rs;
+                             p->split_in_rs == qp.in_rs && p->split_kind == 1;
             if (splits)
-                p->split_pos = pos, p->split_input = qp.input, p->split_M = qp.M, p->split_K = qp.K, p->split_in_rs = qp.in_rs;
+                p->split_pos = pos, p->split_input = qp.input, p->split_M = qp.M, p->split_K = qp.K, p->split_in_rs = qp.in_rs, p->split_kind = 1;
             L.run = [=](hipStream_t s) { launch_qmatmul(s, w, qp, scratch); };
             return true;
         }
@@ -2020,6 +2027,9 @@ zgml_hip_program* zgml_hip_compile_program(zgml_hip_ctx* ctx, const zgml_device_
         if (op.kind == ZGML_DOP_QMATMUL) {
             uint64_t b = qmatmul_scratch_bytes(p->qweights[op.u.qmatmul.weight_idx], op.u.qmatmul.M);
             if (b > p->scratch_bytes) p->scratch_bytes = b;
+        } else if (op.kind == ZGML_DOP_MATMUL && op.u.matmul.b < p->f16_weights.size() && p->f16_weights[op.u.matmul.b]) {
+            uint64_t b = dense_f16_scratch_bytes((uint32_t)op.u.matmul.geom.M, (uint32_t)op.u.matmul.geom.K); // pre-rounded A operand
+            if (b > p->scratch_bytes) p->scratch_bytes = b;
         }
     if (ok && p->scratch_bytes) ok = CTX_CHECK(ctx, hipMalloc((void**)&p->scratch, p->scratch_bytes));
 
@@ -2341,6 +2351,7 @@ double zgml_hip_dense_f16_bench(zgml_hip_ctx* ctx, uint32_t M, uint32_t K, uint3
     hipSetDevice(ctx->device);
     std::vector<void*> ring(n_matrices, nullptr);
     float *b32 = nullptr, *x = nullptr, *y = nullptr;
+    void* a_scratch = nullptr;
     std::vector<float> bh((size_t)K * N), xh((size_t)M * K);
     for (size_t i = 0; i < bh.size(); i++) bh[i] = ((int)((i * 7 + (i >> 5) * 3) % 31) - 15) * 0.00390625f;
     for (size_t i = 0; i < xh.size(); i++) xh[i] = ((int)(i % 17) - 8) * 0.03125f;
@@ -2355,7 +2366,9 @@ double zgml_hip_dense_f16_bench(zgml_hip_ctx* ctx, uint32_t M, uint32_t K, uint3
     double us = -1.0;
     if (ok) {
         DenseF16Params fp{y, x, nullptr, M, N, K, K, N, f16_packed_bytes(K, N) * n_matrices >= (192ull << 20) ? 1u : 0u};
-        for (uint32_t i = 0; i < warmup; i++) {
+        if (const uint64_t sb = dense_f16_scratch_bytes(M, K)) ok = CTX_CHECK(ctx, hipMalloc(&a_scratch, sb));
+        fp.scratch = a_scratch;
+        for (uint32_t i = 0; ok && i < warmup; i++) {
             fp.bp = ring[i % n_matrices];
             launch_dense_f16(ctx->stream, fp);
         }
@@ -2392,6 +2405,7 @@ double zgml_hip_dense_f16_bench(zgml_hip_ctx* ctx, uint32_t M, uint32_t K, uint3
     }
     if (bytes_per_launch) *bytes_per_launch = 2ull * K * N + 4ull * M * K + 4ull * M * N;
     for (void* r : ring) hipFree(r);
+    hipFree(a_scratch);
     hipFree(b32);
     hipFree(x);
     hipFree(y);
