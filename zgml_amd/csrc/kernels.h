@@ -270,6 +270,10 @@ void launch_pack_qweight(hipStream_t s, const int8_t* raw_data, const float* raw
 // Bytes of split-K scratch a qmatmul launch may need (f32 partial slabs).
 uint64_t qmatmul_scratch_bytes(const QWeightDev& w, uint32_t M);
 void launch_qmatmul(hipStream_t s, const QWeightDev& w, const QMatmulParams& p, float* scratch);
+// M > 1: up to qmatmul_max_group() quantized matmuls over the same rows in one launch (qmatmul_can_group pairwise)
+bool qmatmul_can_group(const QWeightDev& a, const QMatmulParams& pa, const QWeightDev& b, const QMatmulParams& pb);
+uint32_t qmatmul_max_group();
+void launch_qmatmul_group(hipStream_t s, const QWeightDev* w, const QMatmulParams* p, uint32_t n, float* scratch);
 // Fused M == 1 launch; all parts must be packed, share K, format and scale type (qmv_can_group).
 bool qmv_can_group(const QWeightDev& a, const QWeightDev& b);
 // Prologue kinds other than NONE keep the whole input in registers: K <= qmv_max_prologue_k(w).

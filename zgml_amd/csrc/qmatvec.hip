@@ -39,6 +39,7 @@
 #include <string.h>
 
 #include <type_traits>
+#include <utility>
 
 namespace zgml {
 
@@ -909,12 +910,17 @@ __global__ void __launch_bounds__(512) qmatmul_tile_kernel(QMMArgs a) {
 //     v_mfma_f32_16x16x32_bf16 per 8-k group and m-tile, f32-level accuracy as before.
 // Waves of a workgroup split the K steps (128 k each) and fold their tiles through LDS in wave order;
 // a workgroup owns G column groups of one 32-column scale block and R m-tiles.
-struct QMM2Args {
+struct QMM2Part { // one weight of a grouped launch (q/k/v, gate/up: same rows, same K)
     const uint4* qs;
     const uint4* sc;
-    const uint4* ap; // split_a_kernel output
     float* out;
-    uint32_t M, U, S, out_rs, NB2; // S = K steps = ceil(U / 4)
+    uint32_t out_rs, NB2, block_begin; // first workgroup of the part
+};
+constexpr int kMaxQmmParts = 3;
+struct QMM2Args {
+    QMM2Part parts[kMaxQmmParts];
+    const uint4* ap; // split_a_kernel output
+    uint32_t n_parts, M, U, S; // S = K steps = ceil(U / 4)
 };
 
 // A pieces: ap[(((t * S + s) * 4 + j) * 3 + p) * 64 + lane] = the 8 bf16 of piece p that lane (i = lane % 16:
@@ -948,12 +954,18 @@ __device__ __forceinline__ uint32_t pack_hi16(float a, float b) { return __built
 template <int R, int G, bool NT>
 __global__ void __launch_bounds__(512) qmatmul_xdl2_kernel(QMM2Args a) {
     extern __shared__ float smem[];
-    const uint32_t g0 = (G == 1 ? column_group(blockIdx.x, a.NB2) : blockIdx.x * G), t0 = blockIdx.y * R;
+    uint32_t pi = 0;
+#pragma unroll
+    for (uint32_t t = 1; t < (uint32_t)kMaxQmmParts; t++)
+        if (t < a.n_parts && blockIdx.x >= a.parts[t].block_begin) pi = t;
+    const QMM2Part& P = a.parts[pi];
+    const uint32_t pb = blockIdx.x - P.block_begin;
+    const uint32_t g0 = (G == 1 ? column_group(pb, P.NB2) : pb * G), t0 = blockIdx.y * R;
     // w in an SGPR: loop bounds that guard MFMAs must be scalar (a v_mfma ignores EXEC)
     const uint32_t lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n_waves = blockDim.x >> 6;
     const uint32_t row = lane >> 4, i = lane & 15;
-    const uint4* qs = a.qs + (uint64_t)g0 * a.U * 16 + i;
-    const uint4* sc = a.sc + (uint64_t)(g0 >> 1) * a.U * 4; // 32 f16 scales per unit, element 2 * (k_local % 16) + k_local / 16
+    const uint4* qs = P.qs + (uint64_t)g0 * a.U * 16 + i;
+    const uint4* sc = P.sc + (uint64_t)(g0 >> 1) * a.U * 4; // 32 f16 scales per unit, element 2 * (k_local % 16) + k_local / 16
     const uint4* ap = a.ap + (uint64_t)t0 * a.S * 12 * 64 + lane;
     const uint64_t tile_stride = (uint64_t)a.S * 12 * 64; // uint4 between m-tiles
 
@@ -1066,7 +1078,7 @@ __global__ void __launch_bounds__(512) qmatmul_xdl2_kernel(QMM2Args a) {
         for (uint32_t ww = 1; ww < n_waves; ww++) sum += smem[((ww * (G * R) + gt) * 4 + v) * 64 + l];
         const uint32_t g = gt / R, t = gt % R;
         const uint32_t m = (t0 + t) * 16 + 4 * (l >> 4) + v, n = (g0 + g) * 16 + (l & 15);
-        if (m < a.M) a.out[(uint64_t)m * a.out_rs + n] = sum * 16.0f;
+        if (m < a.M) P.out[(uint64_t)m * P.out_rs + n] = sum * 16.0f;
     }
 }
 
@@ -1383,18 +1395,27 @@ void launch_xdl2_rg(hipStream_t s, const QMM2Args& a, uint32_t G, dim3 grid, uin
         hipLaunchKernelGGL((qmatmul_xdl2_kernel<R, 1, NT>), grid, dim3(waves * 64), lds, s, a);
 }
 
-// second XDL form: split x once, then the B-scaled tile kernel (Q4_0, f16 scales)
-void launch_xdl2(hipStream_t s, const QWeightDev& w, const QMatmulParams& p, float* scratch) {
-    const uint32_t U = w.KC, S = cdiv(U, 4), R = p.M > 16 ? 2 : 1, tiles = cdiv(cdiv(p.M, 16), R) * R, NB2 = p.N / 16;
-    if (!p.reuse_split) hipLaunchKernelGGL(split_a_kernel, dim3(S, tiles), dim3(256), 0, s, p.input, p.M, p.K, p.in_rs, (uint4*)scratch, S);
+// second XDL form: split x once, then the B-scaled tile kernel (Q4_0, f16 scales); n >= 1 weights that
+// read the same rows share one launch (blockIdx.x ranges)
+void launch_xdl2(hipStream_t s, const QWeightDev* w, const QMatmulParams* p, uint32_t n, float* scratch) {
+    const uint32_t U = w[0].KC, S = cdiv(U, 4), R = p[0].M > 16 ? 2 : 1, tiles = cdiv(cdiv(p[0].M, 16), R) * R;
+    if (!p[0].reuse_split) hipLaunchKernelGGL(split_a_kernel, dim3(S, tiles), dim3(256), 0, s, p[0].input, p[0].M, p[0].K, p[0].in_rs, (uint4*)scratch, S);
     static const int env_g = getenv("ZGML_QMM_XDL2_G") ? atoi(getenv("ZGML_QMM_XDL2_G")) : 0;
-    const uint32_t G = env_g ? (uint32_t)env_g : (NB2 >= 512 ? 2 : 1);
+    uint32_t total_nb2 = 0;
+    for (uint32_t t = 0; t < n; t++) total_nb2 += p[t].N / 16;
+    const uint32_t G = env_g ? (uint32_t)env_g : (total_nb2 >= 512 ? 2 : 1);
     static const int env_w = getenv("ZGML_QMM_WAVES") ? atoi(getenv("ZGML_QMM_WAVES")) : 8;
     const uint32_t waves = std::min<uint32_t>(S, (uint32_t)env_w);
-    const QMM2Args a{(const uint4*)w.qs, (const uint4*)w.sc, (const uint4*)scratch, p.dst, p.M, U, S, p.dst_rs, NB2};
-    const dim3 grid(NB2 / G, tiles / R);
+    QMM2Args a{};
+    uint32_t blocks = 0;
+    for (uint32_t t = 0; t < n; t++) {
+        a.parts[t] = {(const uint4*)w[t].qs, (const uint4*)w[t].sc, p[t].dst, p[t].dst_rs, p[t].N / 16, blocks};
+        blocks += p[t].N / 16 / G;
+    }
+    a.ap = (const uint4*)scratch, a.n_parts = n, a.M = p[0].M, a.U = U, a.S = S;
+    const dim3 grid(blocks, tiles / R);
     const size_t lds = (size_t)waves * G * R * 256 * sizeof(float);
-    const bool nt = w.stream_nt != 0 && tiles / R == 1;
+    const bool nt = w[0].stream_nt != 0 && tiles / R == 1;
     if (R == 2)
         nt ? launch_xdl2_rg<2, true>(s, a, G, grid, waves, lds) : launch_xdl2_rg<2, false>(s, a, G, grid, waves, lds);
     else
@@ -1403,7 +1424,7 @@ void launch_xdl2(hipStream_t s, const QWeightDev& w, const QMatmulParams& p, flo
 
 void launch_tile(hipStream_t s, const QWeightDev& w, const QMatmulParams& p, bool xvec, float* scratch) {
     if (scratch && xdl2_applies(w, p.M)) {
-        launch_xdl2(s, w, p, scratch);
+        launch_xdl2(s, &w, &p, 1, scratch);
         return;
     }
     const bool q4 = w.format == QW_Q4, two = p.M > 16;
@@ -1426,6 +1447,25 @@ void launch_tile(hipStream_t s, const QWeightDev& w, const QMatmulParams& p, boo
 } // namespace
 
 uint32_t qmv_max_prologue_k(const QWeightDev&) { return kMaxWaves * 64 * 4 * kXRegs; } // widest workgroup; launch_packed widens to fit
+
+bool qmatmul_can_group(const QWeightDev& a, const QMatmulParams& pa, const QWeightDev& b, const QMatmulParams& pb) {
+    // one launch computes both: neither output may overlap the other output or the shared input rows
+    auto span = [](const float* base, uint32_t M, uint32_t rs, uint32_t n) { return std::make_pair(base, base + (uint64_t)(M - 1) * rs + n); };
+    auto apart = [](std::pair<const float*, const float*> x, std::pair<const float*, const float*> y) { return x.second <= y.first || y.second <= x.first; };
+    const auto da = span(pa.dst, pa.M, pa.dst_rs, pa.N), db = span(pb.dst, pb.M, pb.dst_rs, pb.N), in = span(pa.input, pa.M, pa.in_rs, pa.K);
+    return xdl2_applies(a, pa.M) && xdl2_applies(b, pb.M) && a.KC == b.KC && a.K == b.K && pa.input == pb.input && pa.M == pb.M &&
+           pa.K == pb.K && pa.in_rs == pb.in_rs && a.stream_nt == b.stream_nt && (pa.N / 16) % 2 == 0 && (pb.N / 16) % 2 == 0 &&
+           apart(da, db) && apart(da, in) && apart(db, in);
+}
+uint32_t qmatmul_max_group() { return (uint32_t)kMaxQmmParts; }
+
+void launch_qmatmul_group(hipStream_t s, const QWeightDev* w, const QMatmulParams* p, uint32_t n, float* scratch) {
+    if (n == 1 || !scratch) {
+        for (uint32_t t = 0; t < n; t++) launch_qmatmul(s, w[t], p[t], scratch);
+        return;
+    }
+    launch_xdl2(s, w, p, n, scratch);
+}
 
 void launch_qmatmul(hipStream_t s, const QWeightDev& w, const QMatmulParams& p, float* scratch) {
     if (p.M == 0 || p.N == 0) return;

@@ -23,6 +23,7 @@
 #include <cstring>
 #include <functional>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -129,6 +130,7 @@ struct zgml_hip_program {
     // plan building: the last quantized matmul launch that split its input into the scratch (make_single)
     uint64_t split_pos = UINT64_MAX - 1;
     const float* split_input = nullptr;
+    std::shared_ptr<std::vector<std::pair<QWeightDev, QMatmulParams>>> qmm_group; // parts of the launch at split_pos
     uint32_t split_M = 0, split_K = 0, split_in_rs = 0, split_kind = 0; // kind: 1 = bf16 pieces (quantized), 2 = f16 A (dense)
     // dynamic parameter block: one word per op
     uint32_t* dyn_dev = nullptr;
@@ -547,7 +549,26 @@ bool make_single(zgml_hip_program* p, size_t i, Launch& L) {
                              p->split_in_rs == qp.in_rs && p->split_kind == 1;
             if (splits)
                 p->split_pos = pos, p->split_input = qp.input, p->split_M = qp.M, p->split_K = qp.K, p->split_in_rs = qp.in_rs, p->split_kind = 1;
-            L.run = [=](hipStream_t s) { launch_qmatmul(s, w, qp, scratch); };
+            // ... and joins its launch when the kernel can take another part (same rows, same K: q/k/v, gate/up)
+            bool joins = qp.reuse_split && p->qmm_group && p->qmm_group->size() < qmatmul_max_group();
+            for (size_t t = 0; joins && t < p->qmm_group->size(); t++) joins = qmatmul_can_group((*p->qmm_group)[t].first, (*p->qmm_group)[t].second, w, qp);
+            if (joins) {
+                p->qmm_group->push_back({w, qp});
+                Launch& prev = p->plan.back();
+                prev.n_ops++, prev.op_hi = (uint32_t)i;
+                p->split_pos = pos - 1; // the merged launch still sits at the previous plan position
+                return false;
+            }
+            auto group = std::make_shared<std::vector<std::pair<QWeightDev, QMatmulParams>>>();
+            group->push_back({w, qp});
+            p->qmm_group = splits ? group : nullptr;
+            L.run = [=](hipStream_t s) {
+                QWeightDev ws[4];
+                QMatmulParams ps[4];
+                const uint32_t n = (uint32_t)group->size();
+                for (uint32_t t = 0; t < n; t++) ws[t] = (*group)[t].first, ps[t] = (*group)[t].second;
+                launch_qmatmul_group(s, ws, ps, n, scratch);
+            };
             return true;
         }
         case ZGML_DOP_SOFTMAX:
@@ -1338,7 +1359,7 @@ void build_plan(zgml_hip_program* p) {
     p->plan.clear();
     free_param_blobs(p);
     p->split_buf = nullptr, p->split_cnt = nullptr, p->split_buf_floats = 0, p->split_cnt_words = 0; // lived in the blobs
-    p->split_pos = UINT64_MAX - 1, p->split_input = nullptr;
+    p->split_pos = UINT64_MAX - 1, p->split_input = nullptr, p->qmm_group = nullptr;
     p->plan_batched = p->ctx->opt_fusion && p->batching_safe;
     if (p->plan_batched) {
         p->sched = build_schedule(p->ops, p->sizes, p->barriers);
