@@ -26,6 +26,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <utility>
 
 namespace zgml {
 
@@ -228,11 +229,16 @@ __global__ void __launch_bounds__(512) dense_f16_kernel(F16Args a) {
 // the MFMA A-operand layout  Ap: half[tiles][KC][64][8], item (t, c, lane = 16 r + i) = A[16 t + i][32 c + 8 r + e],
 // and a lane's A operand is one 16-byte load of a wave-contiguous 1 KB block (L2-resident), exactly like
 // its B operand. Waves split the 32-k chunks round-robin and keep DEPTH chunks (B and A) in flight.
-struct F16Args2 {
+struct F16Part2 { // one weight of a grouped launch (q/k/v, gate/up: same rows, same K)
     const uint4* bp;
-    const uint4* ap;
     float* out;
-    uint32_t M, KC, out_rs, NB2;
+    uint32_t out_rs, block_begin; // first workgroup (column group) of the part
+};
+constexpr int kMaxF16Parts = 3;
+struct F16Args2 {
+    F16Part2 parts[kMaxF16Parts];
+    const uint4* ap;
+    uint32_t n_parts, M, KC;
 };
 
 __global__ void __launch_bounds__(kBlock) pack_a_f16_kernel(const float* __restrict__ x, uint32_t M, uint32_t K, uint32_t a_rs, uint32_t KC,
@@ -257,8 +263,13 @@ __global__ void __launch_bounds__(512) dense_f16_tile2_kernel(F16Args2 a) {
     // w in an SGPR: the chunk guard below must be a scalar branch — a v_mfma ignores EXEC, so a predicated
     // (if-converted) guard would still accumulate the clamped duplicate chunks
     const uint32_t lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n_waves = blockDim.x >> 6;
-    const uint32_t g = blockIdx.x, t0 = blockIdx.y * R;
-    const uint4* bp = a.bp + (uint64_t)g * a.KC * 64 + lane;
+    uint32_t pi = 0;
+#pragma unroll
+    for (uint32_t t = 1; t < (uint32_t)kMaxF16Parts; t++)
+        if (t < a.n_parts && blockIdx.x >= a.parts[t].block_begin) pi = t;
+    const F16Part2& P = a.parts[pi];
+    const uint32_t g = blockIdx.x - P.block_begin, t0 = blockIdx.y * R;
+    const uint4* bp = P.bp + (uint64_t)g * a.KC * 64 + lane;
     const uint4* ap = a.ap + (uint64_t)t0 * a.KC * 64 + lane;
     const uint64_t tile_stride = (uint64_t)a.KC * 64;
     struct Chunk {
@@ -308,7 +319,7 @@ __global__ void __launch_bounds__(512) dense_f16_tile2_kernel(F16Args2 a) {
         float sum = smem[(t * 4 + v) * 64 + l];
         for (uint32_t ww = 1; ww < n_waves; ww++) sum += smem[((ww * R + t) * 4 + v) * 64 + l];
         const uint32_t m = (t0 + t) * 16 + 4 * (l >> 4) + v, n = g * 16 + (l & 15);
-        if (m < a.M) a.out[(uint64_t)m * a.out_rs + n] = sum;
+        if (m < a.M) P.out[(uint64_t)m * P.out_rs + n] = sum;
     }
 }
 
@@ -349,29 +360,52 @@ uint64_t dense_f16_scratch_bytes(uint32_t M, uint32_t K) {
     return (tiles + R - 1) / R * R * ((K + 31) / 32) * 1024;
 }
 
-static void launch_dense_f16_tile2(hipStream_t s, const DenseF16Params& p) {
-    const uint32_t KC = (p.K + 31) / 32, R = p.M > 16 ? 2 : 1, tiles = cdiv(cdiv(p.M, 16), R) * R, NB2 = p.N / 16;
-    if (!p.reuse_a) {
+static void launch_dense_f16_tile2(hipStream_t s, const DenseF16Params* p, uint32_t n) {
+    const uint32_t KC = (p[0].K + 31) / 32, R = p[0].M > 16 ? 2 : 1, tiles = cdiv(cdiv(p[0].M, 16), R) * R;
+    if (!p[0].reuse_a) {
         const uint64_t items = (uint64_t)tiles * KC * 64;
-        pack_a_f16_kernel<<<(uint32_t)std::min<uint64_t>(2048, (items + kBlock - 1) / kBlock), kBlock, 0, s>>>(p.a, p.M, p.K, p.a_rs, KC, tiles,
-                                                                                                             (uint4*)p.scratch);
+        pack_a_f16_kernel<<<(uint32_t)std::min<uint64_t>(2048, (items + kBlock - 1) / kBlock), kBlock, 0, s>>>(p[0].a, p[0].M, p[0].K, p[0].a_rs, KC,
+                                                                                                             tiles, (uint4*)p[0].scratch);
     }
     static const int env_w = getenv("ZGML_F16_TILE2_WAVES") ? atoi(getenv("ZGML_F16_TILE2_WAVES")) : 8;
     const uint32_t waves = std::max(1u, std::min<uint32_t>(KC, (uint32_t)env_w));
-    const F16Args2 a{(const uint4*)p.bp, (const uint4*)p.scratch, p.dst, p.M, KC, p.dst_rs, NB2};
-    const dim3 grid(NB2, tiles / R);
+    F16Args2 a{};
+    uint32_t blocks = 0;
+    for (uint32_t t = 0; t < n; t++) {
+        a.parts[t] = {(const uint4*)p[t].bp, p[t].dst, p[t].dst_rs, blocks};
+        blocks += p[t].N / 16;
+    }
+    a.ap = (const uint4*)p[0].scratch, a.n_parts = n, a.M = p[0].M, a.KC = KC;
+    const dim3 grid(blocks, tiles / R);
     const size_t lds = (size_t)waves * R * 256 * sizeof(float);
-    const bool nt = p.stream_nt != 0 && tiles / R == 1;
+    const bool nt = p[0].stream_nt != 0 && tiles / R == 1;
     using Fn2 = void (*)(F16Args2);
     const Fn2 fn = R == 2 ? (nt ? (Fn2)dense_f16_tile2_kernel<2, true> : (Fn2)dense_f16_tile2_kernel<2, false>)
                           : (nt ? (Fn2)dense_f16_tile2_kernel<1, true> : (Fn2)dense_f16_tile2_kernel<1, false>);
     hipLaunchKernelGGL(fn, grid, dim3(waves * 64), lds, s, a);
 }
 
+bool dense_f16_can_group(const DenseF16Params& a, const DenseF16Params& b) {
+    auto span = [](const float* base, uint32_t M, uint32_t rs, uint32_t n) { return std::make_pair(base, base + (uint64_t)(M - 1) * rs + n); };
+    auto apart = [](std::pair<const float*, const float*> x, std::pair<const float*, const float*> y) { return x.second <= y.first || y.second <= x.first; };
+    const auto da = span(a.dst, a.M, a.dst_rs, a.N), db = span(b.dst, b.M, b.dst_rs, b.N), in = span(a.a, a.M, a.a_rs, a.K);
+    return a.M > 1 && a.scratch && a.scratch == b.scratch && dense_f16_scratch_bytes(a.M, a.K) && a.a == b.a && a.M == b.M && a.K == b.K &&
+           a.a_rs == b.a_rs && a.stream_nt == b.stream_nt && apart(da, db) && apart(da, in) && apart(db, in);
+}
+uint32_t dense_f16_max_group() { return (uint32_t)kMaxF16Parts; }
+
+void launch_dense_f16_group(hipStream_t s, const DenseF16Params* p, uint32_t n) {
+    if (n == 1) {
+        launch_dense_f16(s, p[0]);
+        return;
+    }
+    launch_dense_f16_tile2(s, p, n);
+}
+
 void launch_dense_f16(hipStream_t s, const DenseF16Params& p) {
     if (p.M == 0 || p.N == 0) return;
     if (p.M > 1 && p.scratch && dense_f16_scratch_bytes(p.M, p.K)) {
-        launch_dense_f16_tile2(s, p);
+        launch_dense_f16_tile2(s, &p, 1);
         return;
     }
     F16Args a{(const uint4*)p.bp, p.a, p.dst, p.M, p.K, (p.K + 31) / 32, p.a_rs, p.dst_rs, p.N / 16};

@@ -147,6 +147,10 @@ struct DenseF16Params {
     uint32_t reuse_a = 0;
 };
 uint64_t dense_f16_scratch_bytes(uint32_t M, uint32_t K);
+// M > 1: up to dense_f16_max_group() promoted matmuls over the same rows in one launch
+bool dense_f16_can_group(const DenseF16Params& a, const DenseF16Params& b);
+uint32_t dense_f16_max_group();
+void launch_dense_f16_group(hipStream_t s, const DenseF16Params* p, uint32_t n);
 bool f16_packable(uint64_t K, uint64_t N);
 uint64_t f16_packed_bytes(uint64_t K, uint64_t N);
 void launch_pack_f16(hipStream_t s, const float* b, uint32_t b_rs, uint32_t b_cs, uint32_t K, uint32_t N, void* out);

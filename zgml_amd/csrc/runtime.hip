@@ -131,6 +131,7 @@ struct zgml_hip_program {
     uint64_t split_pos = UINT64_MAX - 1;
     const float* split_input = nullptr;
     std::shared_ptr<std::vector<std::pair<QWeightDev, QMatmulParams>>> qmm_group; // parts of the launch at split_pos
+    std::shared_ptr<std::vector<DenseF16Params>> f16_group;
     uint32_t split_M = 0, split_K = 0, split_in_rs = 0, split_kind = 0; // kind: 1 = bf16 pieces (quantized), 2 = f16 A (dense)
     // dynamic parameter block: one word per op
     uint32_t* dyn_dev = nullptr;
@@ -524,6 +525,20 @@ bool make_single(zgml_hip_program* p, size_t i, Launch& L) {
                     fp.reuse_a = p->split_pos + 1 == pos && p->split_input == dp.a && p->split_M == dp.M && p->split_K == dp.K &&
                                  p->split_in_rs == dp.a_rs && p->split_kind == 2;
                     p->split_pos = pos, p->split_input = dp.a, p->split_M = dp.M, p->split_K = dp.K, p->split_in_rs = dp.a_rs, p->split_kind = 2;
+                    bool joins = fp.reuse_a && p->f16_group && p->f16_group->size() < dense_f16_max_group();
+                    for (size_t t = 0; joins && t < p->f16_group->size(); t++) joins = dense_f16_can_group((*p->f16_group)[t], fp);
+                    if (joins) { // same rows, same K (q/k/v, gate/up): one launch
+                        p->f16_group->push_back(fp);
+                        Launch& prev = p->plan.back();
+                        prev.n_ops++, prev.op_hi = (uint32_t)i;
+                        p->split_pos = pos - 1;
+                        return false;
+                    }
+                    auto group = std::make_shared<std::vector<DenseF16Params>>();
+                    group->push_back(fp);
+                    p->f16_group = group;
+                    L.run = [=](hipStream_t s) { launch_dense_f16_group(s, group->data(), (uint32_t)group->size()); };
+                    return true;
                 }
                 L.run = [=](hipStream_t s) { launch_dense_f16(s, fp); };
                 return true;
@@ -1359,7 +1374,7 @@ void build_plan(zgml_hip_program* p) {
     p->plan.clear();
     free_param_blobs(p);
     p->split_buf = nullptr, p->split_cnt = nullptr, p->split_buf_floats = 0, p->split_cnt_words = 0; // lived in the blobs
-    p->split_pos = UINT64_MAX - 1, p->split_input = nullptr, p->qmm_group = nullptr;
+    p->split_pos = UINT64_MAX - 1, p->split_input = nullptr, p->qmm_group = nullptr, p->f16_group = nullptr;
     p->plan_batched = p->ctx->opt_fusion && p->batching_safe;
     if (p->plan_batched) {
         p->sched = build_schedule(p->ops, p->sizes, p->barriers);
