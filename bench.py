@@ -104,6 +104,15 @@ def bench_single(args):
     value = K / dt
 
     extra = {}
+    # long context: the same stream continued at position ~1900 of 2048 (attention reads 1900 KV rows per head;
+    # the fused decode attention splits each head over several workgroups there)
+    if cfg.max_seq_len >= 2048:
+        n_lc = min(64, K)
+        be.synchronize()
+        t0 = time.perf_counter()
+        sess.resident_decode(int(toks[-1]), 1900, n_lc)
+        be.synchronize()
+        extra["long_context_pos1900_tok_s"] = round(n_lc / (time.perf_counter() - t0), 1)
     # vtable-faithful path: host patches + 32 uploads + logits download + host argmax per token
     n_vt = min(K, 128)
     _, secs = sess.decode(1, 0, n_vt)
@@ -153,8 +162,9 @@ def bench_single(args):
 
 
 def prefill_leg(be, llama, kind, T=32, reps=8, max_seq=512):
-    """BASELINE configs[4]: Llama-2-7B prefill of one token_len = 32 chunk, Q4_0 (f32-MFMA tile kernel over the
-    packed 4-bit weights) or dense f16 (weights promoted to f16, v_mfma_f32_16x16x32_f16). Timed region:
+    """BASELINE configs[4]: Llama-2-7B prefill of one token_len = 32 chunk, Q4_0 (bf16-XDL tile kernel over the
+    packed 4-bit weights: exact bf16 splits of x and of scale * q, f32 accumulation) or dense f16 (weights
+    promoted to f16, v_mfma_f32_16x16x32_f16). Timed region:
     resident replays of the chunk's program (inputs already in HBM), HIP work only."""
     import numpy as np
     from zgml_amd import capi
@@ -211,6 +221,11 @@ def bench_llama7b_single(be, llama, args):
     be.synchronize()
     dt = time.perf_counter() - t0
     qb, nw = model.quant_bytes()
+    be.synchronize()
+    t0 = time.perf_counter()
+    sess.resident_decode(1, 1900, 32)  # long context (see bench_single)
+    be.synchronize()
+    long_ctx = round(32 / (time.perf_counter() - t0), 1)
     sess.close()
     model.close()
     tok_s = K / dt
@@ -222,7 +237,7 @@ def bench_llama7b_single(be, llama, args):
             except Exception as e:
                 prefill[kind] = {"error": str(e)[:200]}
         prefill["workload"] = "Llama-2-7B prefill, one chunk of 32 tokens, Q4_0 vs dense f16 (BASELINE configs[4])"
-    return {"prefill_batch32": prefill, "tok_s": round(tok_s, 1), "ms_per_token": round(1e3 * dt / K, 3), "steps": K, "build_s": round(build_s, 1),
+    return {"prefill_batch32": prefill, "tok_s": round(tok_s, 1), "long_context_pos1900_tok_s": long_ctx, "ms_per_token": round(1e3 * dt / K, 3), "steps": K, "build_s": round(build_s, 1),
             "q4_0_weight_bytes": qb, "weight_stream_GBps": round(qb * tok_s / 1e9, 1),
             "frac_of_hbm_peak": round(qb * tok_s / 1e9 / HBM_PEAK_GBPS, 4),
             "workload": "Llama-2-7B Q4_0 greedy decode, batch 1, 1xMI355X (BASELINE configs[2])"}
