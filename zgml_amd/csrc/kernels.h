@@ -234,6 +234,20 @@ void launch_fused_elementwise(hipStream_t s, const FusedParams& p);
 void launch_softmax(hipStream_t s, float* dst, const float* src, uint32_t rows, uint32_t cols);
 void launch_layernorm(hipStream_t s, float* dst, const float* src, uint32_t rows, uint32_t cols, float eps);
 void launch_rmsnorm(hipStream_t s, float* dst, const float* src, uint32_t rows, uint32_t cols, float eps);
+// [elementwise add ->] rmsnorm [-> elementwise mul] over dense rows in one launch; every intermediate is
+// still stored and the arithmetic (order included) is that of the separate kernels.
+struct RowChainParams {
+    const float* a0 = nullptr; // pre-add: src row = a0 + a1, stored to add_dst (all nullptr: no add)
+    const float* a1 = nullptr;
+    float* add_dst = nullptr;
+    const float* src = nullptr; // rmsnorm input (== add_dst with a pre-add)
+    float* norm_dst = nullptr;
+    const float* mul_other = nullptr; // post-mul: mul_dst = norm * mul_other (nullptr: none)
+    float* mul_dst = nullptr;
+    uint32_t cols = 0;
+    float eps = 0.f;
+};
+void launch_row_chain(hipStream_t s, const RowChainParams& p, uint32_t rows);
 void launch_reduce(hipStream_t s, uint32_t op, float* dst, const float* src, uint32_t n_out, uint32_t reduce_size);
 // batched: dev_params = device array of n_ops records; one launch covers all of them
 void launch_repeat_batch(hipStream_t s, const RepeatParams* dev_params, uint32_t n_ops, uint32_t max_elems);

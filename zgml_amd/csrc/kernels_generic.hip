@@ -158,6 +158,87 @@ __global__ void __launch_bounds__(kBlock) rmsnorm_kernel(float* __restrict__ dst
     for (uint32_t j = threadIdx.x; j < cols; j += kBlock) d[j] = s[j] * inv;
 }
 
+// [add ->] rmsnorm [-> mul] of one row per workgroup: the same element-to-thread mapping and the same block
+// reduction as elementwise_kernel / rmsnorm_kernel, so every stored value is bit-identical to the three-launch
+// form. NPT > 0: the row fits NPT elements per thread — everything is loaded up front with independent loads
+// (a row is one dependent chain otherwise: 32 rows x 4096 columns took ~25 us) and kept in registers between
+// the two passes. NPT == 0: any width, looping.
+template <int NPT>
+__global__ void __launch_bounds__(kBlock) row_chain_kernel(RowChainParams p) {
+    __shared__ float red[8];
+    const uint64_t base = (uint64_t)blockIdx.x * p.cols;
+    const float* s = p.src + base;
+    float* nd = p.norm_dst + base;
+    float ss = 0;
+    if (NPT > 0) {
+        constexpr int N = NPT > 0 ? NPT : 1;
+        float v[N], mo[N];
+        const uint32_t last = p.cols - 1;
+        if (p.add_dst) {
+            const float *a0 = p.a0 + base, *a1 = p.a1 + base;
+            float w[N];
+#pragma unroll
+            for (int k = 0; k < N; k++) v[k] = a0[min(threadIdx.x + k * kBlock, last)];
+#pragma unroll
+            for (int k = 0; k < N; k++) w[k] = a1[min(threadIdx.x + k * kBlock, last)];
+#pragma unroll
+            for (int k = 0; k < N; k++) v[k] = v[k] + w[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < N; k++) v[k] = s[min(threadIdx.x + k * kBlock, last)];
+        }
+        if (p.mul_dst) {
+#pragma unroll
+            for (int k = 0; k < N; k++) mo[k] = p.mul_other[base + min(threadIdx.x + k * kBlock, last)];
+        }
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            const uint32_t j = threadIdx.x + k * kBlock;
+            if (j < p.cols) {
+                if (p.add_dst) p.add_dst[base + j] = v[k];
+                ss += v[k] * v[k];
+            }
+        }
+        ss = block_sum(ss, red);
+        const float inv = 1.0f / sqrtf(ss / (float)p.cols + p.eps);
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            const uint32_t j = threadIdx.x + k * kBlock;
+            if (j < p.cols) {
+                const float nv = v[k] * inv;
+                nd[j] = nv;
+                if (p.mul_dst) p.mul_dst[base + j] = nv * mo[k];
+            }
+        }
+        return;
+    }
+    if (p.add_dst) {
+        const float *a0 = p.a0 + base, *a1 = p.a1 + base;
+        float* ad = p.add_dst + base;
+        for (uint32_t j = threadIdx.x; j < p.cols; j += kBlock) {
+            const float v = a0[j] + a1[j];
+            ad[j] = v;
+            ss += v * v;
+        }
+    } else {
+        for (uint32_t j = threadIdx.x; j < p.cols; j += kBlock) ss += s[j] * s[j];
+    }
+    ss = block_sum(ss, red);
+    const float inv = 1.0f / sqrtf(ss / (float)p.cols + p.eps);
+    // a thread re-reads only the elements it wrote itself above (same j): no barrier needed
+    if (p.mul_dst) {
+        const float* mo = p.mul_other + base;
+        float* md = p.mul_dst + base;
+        for (uint32_t j = threadIdx.x; j < p.cols; j += kBlock) {
+            const float nv = s[j] * inv;
+            nd[j] = nv;
+            md[j] = nv * mo[j];
+        }
+    } else {
+        for (uint32_t j = threadIdx.x; j < p.cols; j += kBlock) nd[j] = s[j] * inv;
+    }
+}
+
 // reference.zig:376-389: one wave per output
 __global__ void __launch_bounds__(kBlock) reduce_kernel(uint32_t op, float* __restrict__ dst,
                                                         const float* __restrict__ src, uint32_t n_out,
@@ -1083,6 +1164,18 @@ void launch_layernorm(hipStream_t s, float* dst, const float* src, uint32_t rows
 void launch_rmsnorm(hipStream_t s, float* dst, const float* src, uint32_t rows, uint32_t cols, float eps) {
     if (rows == 0) return;
     rmsnorm_kernel<<<rows, kBlock, 0, s>>>(dst, src, cols, eps);
+}
+
+void launch_row_chain(hipStream_t s, const RowChainParams& p, uint32_t rows) {
+    if (rows == 0) return;
+    if (p.cols <= 4 * kBlock)
+        row_chain_kernel<4><<<rows, kBlock, 0, s>>>(p);
+    else if (p.cols <= 16 * kBlock)
+        row_chain_kernel<16><<<rows, kBlock, 0, s>>>(p);
+    else if (p.cols <= 32 * kBlock)
+        row_chain_kernel<32><<<rows, kBlock, 0, s>>>(p);
+    else
+        row_chain_kernel<0><<<rows, kBlock, 0, s>>>(p);
 }
 
 void launch_reduce(hipStream_t s, uint32_t op, float* dst, const float* src, uint32_t n_out, uint32_t reduce_size) {

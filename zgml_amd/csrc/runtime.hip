@@ -801,6 +801,9 @@ struct Macro {
     };
     std::vector<Head> heads;
     uint32_t rk = 0, sk = 0, sv = 0;
+    // [add ->] rmsnorm [-> mul] over dense rows (any row count): one launch (RowChainParams)
+    bool chain = false;
+    int chain_add = -1, chain_mul = -1;
 };
 
 bool ops_conflict(const OpAccess& x, const OpAccess& c) {
@@ -1234,6 +1237,56 @@ void build_fused_plan(zgml_hip_program* p) {
             break;
         }
     }
+    // [elementwise add ->] rmsnorm [-> elementwise mul] on the same dense rows: one launch instead of three
+    // (the M > 1 / prefill form of what the mat-vec prologue does at M = 1; every intermediate is still stored)
+    {
+        static const bool enabled = !(getenv("ZGML_HIP_ROW_CHAIN") && atoi(getenv("ZGML_HIP_ROW_CHAIN")) == 0);
+        auto free_op = [&](int j) { return j >= 0 && !in_macro[j] && owner[j] == -1; };
+        for (uint32_t i = 0; enabled && i < n; i++) {
+            if (!free_op((int)i) || ops[i].kind != ZGML_DOP_RMSNORM) continue;
+            const auto& rn = ops[i].u.rmsnorm;
+            const uint64_t cnt = (uint64_t)rn.rows * rn.cols;
+            if (!cnt) continue;
+            const ExactSpan S{rn.src, rn.src_offset, cnt}, D{rn.dst, rn.dst_offset, cnt};
+            int A = last_writer(S, i), P = -1;
+            if (free_op(A) && ops[A].kind == ZGML_DOP_ELEMENTWISE && ops[A].u.elementwise.op == ZGML_OP_ADD) {
+                const auto& e = ops[A].u.elementwise;
+                if (!(ExactSpan{e.dst, e.dst_offset, e.n} == S)) A = -1;
+            } else {
+                A = -1;
+            }
+            std::vector<uint32_t> readers;
+            readers_until_overwrite(D, i, readers);
+            if (readers.size() == 1 && free_op((int)readers[0]) && ops[readers[0]].kind == ZGML_DOP_ELEMENTWISE &&
+                ops[readers[0]].u.elementwise.op == ZGML_OP_MUL) {
+                const auto& e = ops[readers[0]].u.elementwise;
+                const bool s0 = ExactSpan{e.src0, e.src0_offset, e.n} == D, s1 = ExactSpan{e.src1, e.src1_offset, e.n} == D;
+                if (e.n == cnt && (s0 != s1)) P = (int)readers[0];
+            }
+            // widest legal chain first
+            const std::vector<std::vector<int>> tries = {{A, (int)i, P}, {(int)i, P}, {A, (int)i}};
+            for (const auto& t : tries) {
+                std::vector<uint32_t> mem;
+                for (int x : t)
+                    if (x >= 0) mem.push_back((uint32_t)x);
+                if (mem.size() < 2 || std::find(t.begin(), t.end(), -1) != t.end()) continue;
+                if (!delay_legal(mem, mem.back())) continue;
+                Macro m;
+                m.chain = true;
+                m.members = mem;
+                m.position = mem.back();
+                m.anchor = i;
+                m.chain_add = t.front() == (int)i ? -1 : t.front();
+                m.chain_mul = t.back() == (int)i ? -1 : t.back();
+                for (uint32_t x : mem) {
+                    add_access(m.access, s0.access[x]);
+                    in_macro[x] = 1;
+                }
+                macros.push_back(std::move(m));
+                break;
+            }
+        }
+    }
     // everything else is a singleton
     for (uint32_t i = 0; i < n; i++) {
         if (in_macro[i]) continue;
@@ -1254,6 +1307,7 @@ void build_fused_plan(zgml_hip_program* p) {
 
     for (const auto& lv : levels) {
         std::vector<PlanItem> plain_ops;
+        std::vector<Launch> chains; // the items of a level are mutually independent: their order is free
         std::vector<const Macro*> qmvs;
         std::map<uint32_t, std::vector<AttnDecodeParams>> adec_by_dh; // one launch per head size
         uint32_t adec_lo = UINT32_MAX, adec_hi = 0, adec_ops = 0;
@@ -1304,6 +1358,26 @@ void build_fused_plan(zgml_hip_program* p) {
                 adec_ops += (uint32_t)m.members.size();
                 continue;
             }
+            if (macros[mi].chain) {
+                const Macro& m = macros[mi];
+                const auto& rn = ops[m.anchor].u.rmsnorm;
+                RowChainParams rc;
+                rc.src = buf_at(p, rn.src, rn.src_offset), rc.norm_dst = buf_at(p, rn.dst, rn.dst_offset), rc.cols = rn.cols, rc.eps = rn.eps;
+                if (m.chain_add >= 0) {
+                    const auto& e = ops[m.chain_add].u.elementwise;
+                    rc.a0 = buf_at(p, e.src0, e.src0_offset), rc.a1 = buf_at(p, e.src1, e.src1_offset), rc.add_dst = buf_at(p, e.dst, e.dst_offset);
+                }
+                if (m.chain_mul >= 0) {
+                    const auto& e = ops[m.chain_mul].u.elementwise;
+                    const bool norm_is_s0 = e.src0 == rn.dst && e.src0_offset == rn.dst_offset;
+                    rc.mul_other = norm_is_s0 ? buf_at(p, e.src1, e.src1_offset) : buf_at(p, e.src0, e.src0_offset);
+                    rc.mul_dst = buf_at(p, e.dst, e.dst_offset);
+                }
+                const uint32_t rows = rn.rows;
+                chains.push_back({ZGML_DOP_RMSNORM, (uint32_t)m.members.size(), m.members.front(), m.members.back(),
+                                  [=](hipStream_t s) { launch_row_chain(s, rc, rows); }});
+                continue;
+            }
             if (macros[mi].qmv)
                 qmvs.push_back(&macros[mi]);
             else if (macros[mi].store >= 0)
@@ -1312,6 +1386,7 @@ void build_fused_plan(zgml_hip_program* p) {
                 plain_ops.push_back({macros[mi].members[0], -1});
         }
         emit_batches(p, plain_ops);
+        for (Launch& c : chains) p->plan.push_back(std::move(c));
         for (auto& kv : adec_by_dh) {
             const AttnDecodeParams* d = upload_params(p, kv.second);
             const uint32_t nh = (uint32_t)kv.second.size(), dh = kv.first;
