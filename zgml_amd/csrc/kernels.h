@@ -25,6 +25,22 @@ struct FusedParams {
     FusedStepDev steps[kMaxFusedSteps];
 };
 
+// a chain of elementwise / fused_elementwise ops over the same n elements (each consumes its predecessor's
+// output at the same index) as one launch; every op's output is still stored (step.store)
+constexpr int kMaxChainSteps = 12;
+struct ChainStepDev {
+    uint32_t op;
+    uint32_t swapped;
+    const float* secondary; // already offset; nullptr for unary ops
+    float* store;           // output of the op this step completes (nullptr inside an op's own step list)
+};
+struct EltChainParams {
+    const float* src;
+    uint32_t n, n_steps;
+    ChainStepDev steps[kMaxChainSteps];
+};
+void launch_eltwise_chain(hipStream_t s, const EltChainParams& p);
+
 struct RepeatParams {
     float* dst;       // base (dst_offset applied in kernel, as the reference indexes)
     const float* src; // base

@@ -105,6 +105,27 @@ __global__ void __launch_bounds__(kBlock) fused_elementwise_kernel(FusedParams p
     p.dst[i] = v;
 }
 
+// several elementwise / fused_elementwise ops in a row (same arithmetic, same order, per element)
+__global__ void __launch_bounds__(kBlock) eltwise_chain_kernel(EltChainParams p) {
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= p.n) return;
+    float v = p.src[i];
+#pragma unroll 1
+    for (uint32_t s = 0; s < p.n_steps; s++) {
+        const uint32_t op = p.steps[s].op;
+        if (op == ZGML_OP_ADD) {
+            float o = p.steps[s].secondary[i];
+            v = p.steps[s].swapped ? o + v : v + o;
+        } else if (op == ZGML_OP_MUL) {
+            float o = p.steps[s].secondary[i];
+            v = p.steps[s].swapped ? o * v : v * o;
+        } else {
+            v = apply_unary(op, v);
+        }
+        if (p.steps[s].store) p.steps[s].store[i] = v;
+    }
+}
+
 // reference.zig:309-327 with the finite-shift guard of forward.zig:1306-1322 (all -inf -> zeros)
 __global__ void __launch_bounds__(kBlock) softmax_kernel(float* __restrict__ dst, const float* __restrict__ src,
                                                          uint32_t cols) {
@@ -1149,6 +1170,11 @@ void launch_elementwise(hipStream_t s, uint32_t op, float* dst, const float* s0,
 void launch_fused_elementwise(hipStream_t s, const FusedParams& p) {
     if (p.n == 0) return;
     fused_elementwise_kernel<<<cdiv(p.n, kBlock), kBlock, 0, s>>>(p);
+}
+
+void launch_eltwise_chain(hipStream_t s, const EltChainParams& p) {
+    if (p.n == 0) return;
+    eltwise_chain_kernel<<<cdiv(p.n, kBlock), kBlock, 0, s>>>(p);
 }
 
 void launch_softmax(hipStream_t s, float* dst, const float* src, uint32_t rows, uint32_t cols) {

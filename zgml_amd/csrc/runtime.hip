@@ -804,6 +804,9 @@ struct Macro {
     // [add ->] rmsnorm [-> mul] over dense rows (any row count): one launch (RowChainParams)
     bool chain = false;
     int chain_add = -1, chain_mul = -1;
+    // elementwise / fused_elementwise ops feeding each other index by index: one launch (EltChainParams)
+    bool elt_chain = false;
+    EltChainParams elt{};
 };
 
 bool ops_conflict(const OpAccess& x, const OpAccess& c) {
@@ -1287,6 +1290,84 @@ void build_fused_plan(zgml_hip_program* p) {
             }
         }
     }
+    // elementwise chains (the SiLU chain and its product with the up projection at M > 1, ...): ops over the
+    // same n elements where each consumes its predecessor's output at the same index become one launch
+    {
+        static const bool enabled = !(getenv("ZGML_HIP_ELT_CHAIN") && atoi(getenv("ZGML_HIP_ELT_CHAIN")) == 0);
+        auto free_op = [&](int j) { return j >= 0 && !in_macro[j] && owner[j] == -1; };
+        auto is_elt = [&](uint32_t j) { return ops[j].kind == ZGML_DOP_ELEMENTWISE || ops[j].kind == ZGML_DOP_FUSED_ELEMENTWISE; };
+        // append op j's steps; `cur` = the chain value's span (nullptr for the first op, which sets src)
+        auto append = [&](EltChainParams& c, uint32_t j, const ExactSpan* cur, ExactSpan& out) -> bool {
+            const zgml_device_op& o = ops[j];
+            if (o.kind == ZGML_DOP_ELEMENTWISE) {
+                const auto& e = o.u.elementwise;
+                const bool binary = e.op == ZGML_OP_ADD || e.op == ZGML_OP_MUL;
+                const ExactSpan a{e.src0, e.src0_offset, e.n}, b{e.src1, e.src1_offset, e.n};
+                if (c.n_steps + 1 > (uint32_t)kMaxChainSteps) return false;
+                ChainStepDev st{e.op, 0, nullptr, buf_at(p, e.dst, e.dst_offset)};
+                if (!cur) {
+                    c.src = buf_at(p, e.src0, e.src0_offset), c.n = e.n;
+                    st.secondary = binary ? buf_at(p, e.src1, e.src1_offset) : nullptr;
+                } else if (a == *cur && !(binary && b == *cur)) {
+                    st.secondary = binary ? buf_at(p, e.src1, e.src1_offset) : nullptr;
+                } else if (binary && b == *cur && !(a == *cur)) {
+                    st.swapped = 1, st.secondary = buf_at(p, e.src0, e.src0_offset);
+                } else {
+                    return false;
+                }
+                c.steps[c.n_steps++] = st;
+                out = {e.dst, e.dst_offset, e.n};
+                return true;
+            }
+            const auto& f = o.u.fused_elementwise;
+            if (f.n_steps == 0 || c.n_steps + f.n_steps > (uint32_t)kMaxChainSteps) return false;
+            if (!cur)
+                c.src = buf_at(p, f.src, f.src_offset), c.n = f.n;
+            else if (!(ExactSpan{f.src, f.src_offset, f.n} == *cur))
+                return false;
+            for (uint32_t t = 0; t < f.n_steps; t++) {
+                const bool binary = f.steps[t].op == ZGML_OP_ADD || f.steps[t].op == ZGML_OP_MUL;
+                c.steps[c.n_steps++] = {f.steps[t].op, f.steps[t].is_swapped,
+                                        binary ? buf_at(p, f.steps[t].secondary_buf, f.steps[t].secondary_offset) : nullptr, nullptr};
+            }
+            c.steps[c.n_steps - 1].store = buf_at(p, f.dst, f.dst_offset);
+            out = {f.dst, f.dst_offset, f.n};
+            return true;
+        };
+        for (uint32_t i = 0; enabled && i < n; i++) {
+            if (!free_op((int)i) || !is_elt(i)) continue;
+            Macro m;
+            ExactSpan cur{};
+            if (!append(m.elt, i, nullptr, cur)) continue;
+            m.members = {i};
+            for (;;) {
+                std::vector<uint32_t> readers;
+                readers_until_overwrite(cur, m.members.back(), readers);
+                bool grown = false;
+                for (uint32_t r : readers) {
+                    if (!free_op((int)r) || !is_elt(r) || std::find(m.members.begin(), m.members.end(), r) != m.members.end()) continue;
+                    EltChainParams trial_p = m.elt;
+                    ExactSpan nxt{};
+                    if (!append(trial_p, r, &cur, nxt) || nxt.n != cur.n) continue;
+                    std::vector<uint32_t> trial = m.members;
+                    trial.push_back(r);
+                    if (!delay_legal(trial, r)) continue;
+                    m.elt = trial_p, m.members = trial, cur = nxt, grown = true;
+                    break;
+                }
+                if (!grown) break;
+            }
+            if (m.members.size() < 2) continue;
+            m.elt_chain = true;
+            m.position = m.members.back();
+            m.anchor = i;
+            for (uint32_t x : m.members) {
+                add_access(m.access, s0.access[x]);
+                in_macro[x] = 1;
+            }
+            macros.push_back(std::move(m));
+        }
+    }
     // everything else is a singleton
     for (uint32_t i = 0; i < n; i++) {
         if (in_macro[i]) continue;
@@ -1376,6 +1457,13 @@ void build_fused_plan(zgml_hip_program* p) {
                 const uint32_t rows = rn.rows;
                 chains.push_back({ZGML_DOP_RMSNORM, (uint32_t)m.members.size(), m.members.front(), m.members.back(),
                                   [=](hipStream_t s) { launch_row_chain(s, rc, rows); }});
+                continue;
+            }
+            if (macros[mi].elt_chain) {
+                const Macro& m = macros[mi];
+                const EltChainParams ec = m.elt;
+                chains.push_back({ZGML_DOP_FUSED_ELEMENTWISE, (uint32_t)m.members.size(), m.members.front(), m.members.back(),
+                                  [=](hipStream_t s) { launch_eltwise_chain(s, ec); }});
                 continue;
             }
             if (macros[mi].qmv)
