@@ -279,8 +279,8 @@ struct AttnSplit {
 };
 void launch_attention_decode_batch(hipStream_t s, const AttnDecodeParams* dev_params, uint32_t n_heads, uint32_t d_head,
                                    const AttnSplit& sp);
-void launch_attention_batch(hipStream_t s, const AttentionParams* dev_params, uint32_t n_ops, uint32_t max_seq_q,
-                            bool all_dense);
+void launch_attention_batch(hipStream_t s, const AttentionParams* dev_params, uint32_t n_ops, uint32_t max_seq_q, bool all_dense,
+                            uint32_t rows_d_head = 0, const float* zero_word = nullptr); // rows_d_head: the common d_head when every op is dense (else 0)
 void launch_dense_matmul(hipStream_t s, const DenseMatmulParams& p);
 void launch_argmax(hipStream_t s, const float* v, uint64_t n, float* scratch_val, int64_t* scratch_idx, int64_t* out);
 void launch_copy_f4(hipStream_t s, void* dst, const void* src, uint64_t bytes);

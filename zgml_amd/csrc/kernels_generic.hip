@@ -883,6 +883,134 @@ __global__ void __launch_bounds__(kAttnBlock) attention_decode_kernel(const Attn
 #undef ATTN_STAMP
 }
 
+// ── attention of seq_q > 1 query columns (prefill), dense layouts ─────────────────────────────
+// attention_dense_kernel spends a 1024-thread workgroup with a score buffer and four block reductions per key
+// tile on every (query, head): 23 us per layer for a 32-token chunk whose queries see 32 keys. This is the
+// decode kernel's streaming scheme without its fused ropes / cache stores: a key is LPK lanes holding one
+// float4 of the head dimension each, every key slot runs its own online softmax, waves the context does not
+// need retire at the top, one barrier, two-pass merges. One workgroup per (query column, op).
+template <int LPK>
+__global__ void __launch_bounds__(kAttnBlock) attention_rows_kernel(const AttentionParams* __restrict__ params, const float* __restrict__ zero_word) {
+    constexpr int KPW = 64 / LPK, U = kAttnUnroll;
+    const AttentionParams& p = params[blockIdx.y];
+    const uint32_t qi = blockIdx.x;
+    if (qi >= p.seq_q) return; // batched ops may have fewer queries than the grid
+    __shared__ __attribute__((aligned(8))) float part_ml[2 * (kAttnBlock / 64)];
+    __shared__ float4 part_acc[(kAttnBlock / 64) * LPK];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t slot = lane / LPK, li = lane % LPK, d0 = 4 * li;
+    const uint32_t seq_kv = *p.dyn_seq_kv;
+    const uint32_t d2_off = p.dst2 ? *p.dyn_dst2_off : 0;
+    const float4 qv = *(const float4*)(p.q + (uint64_t)qi * p.q_cs + d0);
+    const float* mask = p.mask ? p.mask + (uint64_t)qi * p.mask_cs : zero_word; // no mask: a zero word with stride 0
+    const uint32_t mask_rs = p.mask ? p.mask_rs : 0;
+    uint32_t NW = (seq_kv + KPW * U - 1) / (KPW * U);
+    const uint32_t max_w = blockDim.x >> 6; // 4 when the grid alone fills the chip (many queries), else 16
+    NW = NW < 1 ? 1 : (NW > max_w ? max_w : NW);
+    if (w >= NW) return;
+    const uint32_t keys_per_iter = KPW * NW, step_keys = keys_per_iter * U, last = seq_kv ? seq_kv - 1 : 0;
+    float4 kv[U], vv[U];
+    float mk[U];
+#pragma unroll
+    for (int j = 0; j < U; j++) { // clamped to live rows, unconditional
+        const uint32_t s = min(j * keys_per_iter + w * KPW + slot, last);
+        kv[j] = *(const float4*)(p.k + (uint64_t)s * p.k_cs + d0);
+        vv[j] = *(const float4*)(p.v + (uint64_t)s * p.v_cs + d0);
+        mk[j] = mask[(uint64_t)s * mask_rs];
+    }
+    SoftState st{-INFINITY, 0.f, make_float4(0.f, 0.f, 0.f, 0.f)};
+    auto step = [&](uint32_t base) {
+        float sc[U];
+        float bm = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < U; j++) {
+            const uint32_t t = base + j * keys_per_iter + w * KPW + slot;
+            const float dot = group_sum<LPK>(qv.x * kv[j].x + qv.y * kv[j].y + qv.z * kv[j].z + qv.w * kv[j].w);
+            sc[j] = t < seq_kv ? score_of(dot, mk[j], p.scale) : -INFINITY;
+            bm = fmaxf(bm, sc[j]);
+        }
+        const float nm = fmaxf(st.m, bm);
+        if (nm > -INFINITY) {
+            const float alpha = st.m > -INFINITY ? expf(st.m - nm) : 0.0f;
+            st.l *= alpha;
+            st.acc = make_float4(st.acc.x * alpha, st.acc.y * alpha, st.acc.z * alpha, st.acc.w * alpha);
+#pragma unroll
+            for (int j = 0; j < U; j++) {
+                const float wgt = sc[j] > -INFINITY ? expf(sc[j] - nm) : 0.0f;
+                st.l += wgt;
+                if (sc[j] > -INFINITY) { // rows of dead slots are never touched
+                    st.acc.x += wgt * vv[j].x;
+                    st.acc.y += wgt * vv[j].y;
+                    st.acc.z += wgt * vv[j].z;
+                    st.acc.w += wgt * vv[j].w;
+                }
+            }
+            st.m = nm;
+        }
+    };
+    if (seq_kv <= step_keys) {
+        if (seq_kv) step(0);
+    } else {
+        for (uint32_t base = 0; base < seq_kv; base += step_keys) {
+            float4 kn[U], vn[U];
+            float mn[U];
+#pragma unroll
+            for (int j = 0; j < U; j++) {
+                const uint32_t s = min(base + step_keys + j * keys_per_iter + w * KPW + slot, last);
+                kn[j] = *(const float4*)(p.k + (uint64_t)s * p.k_cs + d0);
+                vn[j] = *(const float4*)(p.v + (uint64_t)s * p.v_cs + d0);
+                mn[j] = mask[(uint64_t)s * mask_rs];
+            }
+            step(base);
+#pragma unroll
+            for (int j = 0; j < U; j++) kv[j] = kn[j], vv[j] = vn[j], mk[j] = mn[j];
+        }
+    }
+    slots_merge<LPK>(st);
+    SoftState r = st;
+    if (NW > 1) {
+        if (lane < LPK) {
+            part_acc[w * LPK + lane] = st.acc;
+            if (lane == 0) part_ml[2 * w] = st.m, part_ml[2 * w + 1] = st.l;
+        }
+        __syncthreads();
+        if (w != 0) return;
+        constexpr int MAXW = kAttnBlock / 64, NPS = MAXW / KPW > 0 ? MAXW / KPW : 1;
+        float M = lane < NW ? part_ml[2 * lane] : -INFINITY;
+        float2 ml[NPS];
+        float4 pa[NPS];
+#pragma unroll
+        for (int i = 0; i < NPS; i++) {
+            const uint32_t ww = slot + i * KPW, wc = ww < NW ? ww : 0;
+            ml[i] = *(const float2*)&part_ml[2 * wc];
+            pa[i] = part_acc[wc * LPK + li];
+        }
+        M = fmaxf(M, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(M), 0xB1, 0xF, 0xF, true)));
+        M = fmaxf(M, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(M), 0x4E, 0xF, 0xF, true)));
+        M = fmaxf(M, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(M), 0x141, 0xF, 0xF, true)));
+        M = fmaxf(M, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(M), 0x140, 0xF, 0xF, true)));
+        M = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(M)));
+        r = SoftState{M, 0.f, make_float4(0.f, 0.f, 0.f, 0.f)};
+#pragma unroll
+        for (int i = 0; i < NPS; i++) {
+            const bool live = slot + i * KPW < NW && ml[i].x > -INFINITY;
+            const float f = live ? expf(ml[i].x - M) : 0.0f;
+            r.l += ml[i].y * f;
+            r.acc.x += pa[i].x * f, r.acc.y += pa[i].y * f, r.acc.z += pa[i].z * f, r.acc.w += pa[i].w * f;
+        }
+        slots_sum<LPK>(r);
+    }
+    if (lane < LPK) {
+        const float inv_l = r.l > 0.f ? 1.0f / r.l : 0.0f;
+        const float o[4] = {r.acc.x * inv_l, r.acc.y * inv_l, r.acc.z * inv_l, r.acc.w * inv_l};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            p.dst[(uint64_t)qi * p.dst_cs + (uint64_t)(4 * lane + e) * p.dst_rs] = o[e];
+            if (p.dst2) p.dst2[(uint64_t)d2_off + (uint64_t)(4 * lane + e) * p.d2_rs + (uint64_t)qi * p.d2_cs] = o[e];
+        }
+    }
+}
+
 // ── quantised KV cache (extension ops; src/quant.zig:645-1091) ───────────────────────────────
 // storeColumn: one wave per op; lane r handles elements r, r+64, ... of each block. Same arithmetic
 // as quantizeInput (:320-341): scale = absmax/127 (1 if the block is all zero), q = trunc(clamp(v * (127/absmax))).
@@ -1257,8 +1385,26 @@ void launch_attention_decode_batch(hipStream_t s, const AttnDecodeParams* dev_pa
 }
 
 void launch_attention_batch(hipStream_t s, const AttentionParams* dev_params, uint32_t n_ops, uint32_t max_seq_q,
-                            bool all_dense) {
+                            bool all_dense, uint32_t rows_d_head, const float* zero_word) {
     if (!n_ops || !max_seq_q) return;
+    static const bool rows_on = !(getenv("ZGML_HIP_ATTN_ROWS") && atoi(getenv("ZGML_HIP_ATTN_ROWS")) == 0);
+    if (all_dense && rows_d_head && zero_word && rows_on) { // every op dense with this d_head: the streaming kernel
+        const dim3 grid(max_seq_q, n_ops);
+        // enough (query, head) workgroups to fill the chip: 4 waves each (a 16-wave workgroup whose context needs 2
+        // still pays for launching 16); few workgroups: all 16 so a long context is spread over more waves
+        const uint32_t block = (uint64_t)max_seq_q * n_ops >= 256 ? 256 : kAttnBlock;
+#define AROWS(L) attention_rows_kernel<L><<<grid, block, 0, s>>>(dev_params, zero_word)
+        switch (rows_d_head) {
+            case 8: AROWS(2); return;
+            case 16: AROWS(4); return;
+            case 32: AROWS(8); return;
+            case 64: AROWS(16); return;
+            case 128: AROWS(32); return;
+            case 256: AROWS(64); return;
+            default: break;
+        }
+#undef AROWS
+    }
     if (all_dense)
         attention_dense_kernel<<<dim3(max_seq_q, n_ops), kAttnBlock, 0, s>>>(dev_params);
     else

@@ -760,9 +760,13 @@ void emit_batches(zgml_hip_program* p, const std::vector<PlanItem>& group) {
                     (a.q_cs % 4) == 0 && (a.k_cs % 4) == 0 && (a.v_cs % 4) == 0 && ((uintptr_t)a.q % 16) == 0 &&
                     ((uintptr_t)a.k % 16) == 0 && ((uintptr_t)a.v % 16) == 0;
         }
+        uint32_t rows_dh = dense ? atts[0].d_head : 0; // the streaming kernel: one d_head >= 8 per launch
+        for (const AttentionParams& a : atts)
+            if (a.d_head != rows_dh || a.d_head < 8) rows_dh = 0;
+        const float* zero = p->zero_word;
         const AttentionParams* d = upload_params(p, atts);
         const uint32_t n = (uint32_t)atts.size(), mx = att_max;
-        p->plan.push_back({ZGML_DOP_ATTENTION, n_att, lo[2], hi[2], [=](hipStream_t s) { launch_attention_batch(s, d, n, mx, dense); }});
+        p->plan.push_back({ZGML_DOP_ATTENTION, n_att, lo[2], hi[2], [=](hipStream_t s) { launch_attention_batch(s, d, n, mx, dense, rows_dh, zero); }});
     }
 }
 
