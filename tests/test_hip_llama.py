@@ -231,13 +231,15 @@ def test_quantised_kv_cache_decode(hip_backend, oracle, name, steps):
     s_res.close(), s_ref.close(), m.close()
 
 
-def test_long_context_attention_split(hip_backend, oracle):
+@pytest.mark.parametrize("kvq", [0, 32])
+def test_long_context_attention_split(hip_backend, oracle, kvq):
     """Flash-decoding split of the fused decode attention (ZGML_HIP_OPT_ATTN_SPLIT_MIN_KEYS): with the
     threshold lowered to 32 keys a 256-position tiny model splits every head over up to 8 workgroups
     from position 63 on. Logits stay within 2e-4 of the oracle's over 140 positions (the merge order is
     fixed, only the summation order differs), the unsplit build of the same program agrees, and the
     graph-replayed resident loop (arrival counters re-armed in-kernel) gives the same tokens twice."""
     cfg = llama.preset("tiny", 256)
+    cfg.kv_quant_block = kvq  # 32: the int8 KV cache ops (kvq_store / attention_kvq) take the same split
     m = llama.Model(cfg, llama.Q4_0, threads=8)
     n = 140
     s_ref = llama.Session(m, oracle.backend_fns())

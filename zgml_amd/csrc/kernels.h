@@ -138,7 +138,7 @@ struct KvqAttentionParams {
     float scale;
 };
 void launch_kvq_store_batch(hipStream_t s, const KvqStoreParams* dev_params, uint32_t n_ops);
-void launch_kvq_attention_batch(hipStream_t s, const KvqAttentionParams* dev_params, uint32_t n_ops, uint32_t max_seq_q, uint32_t d_head);
+
 
 struct DenseMatmulParams {
     float* dst;       // dst_offset applied
@@ -279,6 +279,8 @@ struct AttnSplit {
 };
 void launch_attention_decode_batch(hipStream_t s, const AttnDecodeParams* dev_params, uint32_t n_heads, uint32_t d_head,
                                    const AttnSplit& sp);
+void launch_kvq_attention_batch(hipStream_t s, const KvqAttentionParams* dev_params, uint32_t n_ops, uint32_t max_seq_q, uint32_t d_head,
+                                const AttnSplit& sp = AttnSplit{}); // split applies to seq_q == 1 launches only
 void launch_attention_batch(hipStream_t s, const AttentionParams* dev_params, uint32_t n_ops, uint32_t max_seq_q, bool all_dense,
                             uint32_t rows_d_head = 0, const float* zero_word = nullptr); // rows_d_head: the common d_head when every op is dense (else 0)
 void launch_dense_matmul(hipStream_t s, const DenseMatmulParams& p);

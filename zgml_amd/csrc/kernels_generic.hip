@@ -1040,21 +1040,33 @@ __global__ void __launch_bounds__(64) kvq_store_kernel(const KvqStoreParams* __r
 // does not need retire at the top; per-slot online softmax merged at the end (one barrier). Only the
 // summation / rescale order differs from the reference's Bs = 8 flash tiles.
 template <int LPK>
-__global__ void __launch_bounds__(kAttnBlock) kvq_attention_kernel(const KvqAttentionParams* __restrict__ params) {
+__global__ void __launch_bounds__(kAttnBlock) kvq_attention_kernel(const KvqAttentionParams* __restrict__ params, float* split_buf, uint32_t* split_cnt,
+                                                                   uint32_t split_min_keys) {
     constexpr int DH = 4 * LPK, KPW = 64 / LPK, U = kAttnUnroll, MAXW = kAttnBlock / 64;
     const KvqAttentionParams& p = params[blockIdx.y];
     if (blockIdx.x >= p.seq_q) return;
-    __shared__ float part_ml[2 * MAXW];
+    __shared__ __attribute__((aligned(8))) float part_ml[2 * MAXW];
     __shared__ float4 part_acc[MAXW * LPK];
-    const uint32_t qi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t qi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t slot = lane / LPK, li = lane % LPK, d0 = 4 * li;
     uint32_t seq_kv = *p.dyn_seq_kv;
     const uint32_t room_k = p.n_cols > p.k_col_start ? p.n_cols - p.k_col_start : 0, room_v = p.n_cols > p.v_col_start ? p.n_cols - p.v_col_start : 0;
     seq_kv = min(seq_kv, min(room_k, room_v)); // never read outside the caches
-    uint32_t NW = (seq_kv + KPW * U - 1) / (KPW * U);
+    // long contexts: gridDim.z workgroups per (query, op) split the keys exactly as attention_decode_kernel does
+    const uint32_t sp = blockIdx.z;
+    uint32_t n_active = 1, k_begin = 0, k_end = seq_kv;
+    if (gridDim.z > 1) {
+        n_active = seq_kv / split_min_keys;
+        n_active = n_active < 1 ? 1 : (n_active > gridDim.z ? gridDim.z : n_active);
+        if (sp >= n_active) return;
+        const uint32_t chunk = (seq_kv + n_active - 1) / n_active;
+        k_begin = min(sp * chunk, seq_kv), k_end = min(k_begin + chunk, seq_kv);
+    }
+    const uint32_t n_keys = k_end - k_begin;
+    uint32_t NW = (n_keys + KPW * U - 1) / (KPW * U);
     NW = NW < 1 ? 1 : (NW > (uint32_t)MAXW ? (uint32_t)MAXW : NW);
     if (w >= NW) return;
-    const uint32_t keys_per_iter = KPW * NW, step_keys = keys_per_iter * U, last = seq_kv ? seq_kv - 1 : 0;
+    const uint32_t keys_per_iter = KPW * NW, step_keys = keys_per_iter * U, last = k_end ? k_end - 1 : 0;
     const uint32_t bpc = DH / p.block_size, blk = d0 / p.block_size;
     const int8_t* kq = (const int8_t*)p.k_cache + (uint64_t)p.k_col_start * DH + d0;
     const float* ks = p.k_cache + (uint64_t)p.n_cols * DH / 4 + (uint64_t)p.k_col_start * bpc + blk;
@@ -1086,7 +1098,7 @@ __global__ void __launch_bounds__(kAttnBlock) kvq_attention_kernel(const KvqAtte
             float dot = (qv.x * (float)(int8_t)(kw & 255) + qv.y * (float)(int8_t)((kw >> 8) & 255) +
                          qv.z * (float)(int8_t)((kw >> 16) & 255) + qv.w * (float)(int8_t)(kw >> 24)) * r.ksc[j];
             dot = group_sum<LPK>(dot);
-            sc[j] = t < seq_kv ? score_of(dot, r.mk[j], p.scale) : -INFINITY;
+            sc[j] = t < k_end ? score_of(dot, r.mk[j], p.scale) : -INFINITY;
             bm = fmaxf(bm, sc[j]);
         }
         const float nm = fmaxf(st.m, bm);
@@ -1110,34 +1122,84 @@ __global__ void __launch_bounds__(kAttnBlock) kvq_attention_kernel(const KvqAtte
         }
     };
     Rows cur;
-    load(cur, 0);
-    if (seq_kv <= step_keys) {
-        if (seq_kv) step(cur, 0);
+    load(cur, k_begin);
+    if (n_keys <= step_keys) {
+        if (n_keys) step(cur, k_begin);
     } else {
-        for (uint32_t base = 0; base < seq_kv; base += step_keys) {
+        for (uint32_t base = k_begin; base < k_end; base += step_keys) {
             Rows nxt;
             load(nxt, base + step_keys);
             step(cur, base);
             cur = nxt;
         }
     }
+    slots_merge<LPK>(st);
+    SoftState r = st;
+    if (NW > 1) {
+        if (lane < LPK) {
+            part_acc[w * LPK + lane] = st.acc;
+            if (lane == 0) part_ml[2 * w] = st.m, part_ml[2 * w + 1] = st.l;
+        }
+        __syncthreads();
+        if (w != 0) return;
+        constexpr int NPS = MAXW / KPW > 0 ? MAXW / KPW : 1;
+        static_assert(MAXW == 16, "lanes 0..15 (one DPP row) hold the waves' maxima");
+        float M = lane < NW ? part_ml[2 * lane] : -INFINITY;
+        float2 ml[NPS];
+        float4 pa[NPS];
 #pragma unroll
-    for (int off = LPK; off < 64; off <<= 1) {
-        const float om = __shfl_xor(st.m, off, 64), ol = __shfl_xor(st.l, off, 64);
-        const float4 oa = make_float4(__shfl_xor(st.acc.x, off, 64), __shfl_xor(st.acc.y, off, 64), __shfl_xor(st.acc.z, off, 64),
-                                      __shfl_xor(st.acc.w, off, 64));
-        soft_merge(st, om, ol, oa);
+        for (int i = 0; i < NPS; i++) {
+            const uint32_t ww = slot + i * KPW, wc = ww < NW ? ww : 0;
+            ml[i] = *(const float2*)&part_ml[2 * wc];
+            pa[i] = part_acc[wc * LPK + li];
+        }
+        M = fmaxf(M, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(M), 0xB1, 0xF, 0xF, true)));
+        M = fmaxf(M, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(M), 0x4E, 0xF, 0xF, true)));
+        M = fmaxf(M, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(M), 0x141, 0xF, 0xF, true)));
+        M = fmaxf(M, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(M), 0x140, 0xF, 0xF, true)));
+        M = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(M)));
+        r = SoftState{M, 0.f, make_float4(0.f, 0.f, 0.f, 0.f)};
+#pragma unroll
+        for (int i = 0; i < NPS; i++) {
+            const bool live = slot + i * KPW < NW && ml[i].x > -INFINITY;
+            const float f = live ? expf(ml[i].x - M) : 0.0f;
+            r.l += ml[i].y * f;
+            r.acc.x += pa[i].x * f, r.acc.y += pa[i].y * f, r.acc.z += pa[i].z * f, r.acc.w += pa[i].w * f;
+        }
+        slots_sum<LPK>(r);
+    }
+    if (n_active > 1) { // (wave 0) publish this chunk; the last arriver merges all of them in chunk order
+        constexpr uint32_t REC = DH + 4;
+        float* const head_buf = split_buf + ((uint64_t)blockIdx.y * gridDim.x + qi) * gridDim.z * REC;
+        float* const mine = head_buf + (uint64_t)sp * REC;
+        uint32_t* const cnt = split_cnt + (uint64_t)blockIdx.y * gridDim.x + qi;
+        if (lane < LPK) {
+            if (lane == 0) split_put(mine, r.m, r.l);
+            split_put(mine + 4 + 4 * lane, r.acc.x, r.acc.y);
+            split_put(mine + 4 + 4 * lane + 2, r.acc.z, r.acc.w);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint32_t old = 0;
+        if (lane == 0) old = __hip_atomic_fetch_add((gu32*)cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        old = __shfl(old, 0, 64);
+        if (old != n_active - 1) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        r = SoftState{-INFINITY, 0.f, make_float4(0.f, 0.f, 0.f, 0.f)};
+        for (uint32_t c = slot; c < n_active; c += KPW) {
+            const float* rec = head_buf + (uint64_t)c * REC;
+            float om, ol;
+            float4 oa;
+            split_get(rec, om, ol);
+            split_get(rec + 4 + 4 * li, oa.x, oa.y);
+            split_get(rec + 4 + 4 * li + 2, oa.z, oa.w);
+            soft_merge(r, om, ol, oa);
+        }
+        slots_merge<LPK>(r);
+        if (lane == 0) __hip_atomic_store((gu32*)cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (lane < LPK) {
-        part_acc[w * LPK + lane] = st.acc;
-        if (lane == 0) part_ml[2 * w] = st.m, part_ml[2 * w + 1] = st.l;
-    }
-    __syncthreads();
-    if (tid < LPK) {
-        SoftState r{part_ml[0], part_ml[1], part_acc[tid]};
-        for (uint32_t ww = 1; ww < NW; ww++) soft_merge(r, part_ml[2 * ww], part_ml[2 * ww + 1], part_acc[ww * LPK + tid]);
         const float inv_l = r.l > 0.f ? 1.0f / r.l : 0.0f;
-        *(float4*)(p.dst + (uint64_t)qi * p.dst_cs + 4 * tid) = make_float4(r.acc.x * inv_l, r.acc.y * inv_l, r.acc.z * inv_l, r.acc.w * inv_l);
+        *(float4*)(p.dst + (uint64_t)qi * p.dst_cs + 4 * lane) = make_float4(r.acc.x * inv_l, r.acc.y * inv_l, r.acc.z * inv_l, r.acc.w * inv_l);
     }
 }
 
@@ -1354,17 +1416,20 @@ void launch_kvq_store_batch(hipStream_t s, const KvqStoreParams* dev_params, uin
 }
 
 // all ops of a launch share d_head (the planner groups them); d_head in {16, 32, 64, 128, 256}
-void launch_kvq_attention_batch(hipStream_t s, const KvqAttentionParams* dev_params, uint32_t n_ops, uint32_t max_seq_q, uint32_t d_head) {
+void launch_kvq_attention_batch(hipStream_t s, const KvqAttentionParams* dev_params, uint32_t n_ops, uint32_t max_seq_q, uint32_t d_head,
+                                const AttnSplit& sp) {
     if (!n_ops || !max_seq_q) return;
-    const dim3 grid(max_seq_q, n_ops);
+    const dim3 grid(max_seq_q, n_ops, max_seq_q == 1 && sp.splits > 1 ? sp.splits : 1);
+#define AKVQ(L) kvq_attention_kernel<L><<<grid, kAttnBlock, 0, s>>>(dev_params, sp.buf, sp.cnt, sp.min_keys)
     switch (d_head) {
-        case 16: kvq_attention_kernel<4><<<grid, kAttnBlock, 0, s>>>(dev_params); break;
-        case 32: kvq_attention_kernel<8><<<grid, kAttnBlock, 0, s>>>(dev_params); break;
-        case 64: kvq_attention_kernel<16><<<grid, kAttnBlock, 0, s>>>(dev_params); break;
-        case 128: kvq_attention_kernel<32><<<grid, kAttnBlock, 0, s>>>(dev_params); break;
-        case 256: kvq_attention_kernel<64><<<grid, kAttnBlock, 0, s>>>(dev_params); break;
+        case 16: AKVQ(4); break;
+        case 32: AKVQ(8); break;
+        case 64: AKVQ(16); break;
+        case 128: AKVQ(32); break;
+        case 256: AKVQ(64); break;
         default: break;
     }
+#undef AKVQ
 }
 
 void launch_attention_decode_batch(hipStream_t s, const AttnDecodeParams* dev_params, uint32_t n_heads, uint32_t d_head,

@@ -740,7 +740,13 @@ void emit_batches(zgml_hip_program* p, const std::vector<PlanItem>& group) {
     for (auto& kv : katts) {
         const KvqAttentionParams* d = upload_params(p, kv.second);
         const uint32_t n = (uint32_t)kv.second.size(), dh = kv.first, mq = kat_max_q;
-        p->plan.push_back({ZGML_DOP_ATTENTION_KVQ, n, kat_lo, kat_hi, [=](hipStream_t s) { launch_kvq_attention_batch(s, d, n, mq, dh); }});
+        AttnSplit sp; // decode launches: long contexts split a head's keys over several workgroups
+        if (mq == 1) {
+            uint32_t max_kv = 0;
+            for (const auto& a : kv.second) max_kv = std::max(max_kv, a.n_cols - std::min(a.n_cols, std::max(a.k_col_start, a.v_col_start)));
+            sp = attn_split_for(p, n, dh, max_kv);
+        }
+        p->plan.push_back({ZGML_DOP_ATTENTION_KVQ, n, kat_lo, kat_hi, [=](hipStream_t s) { launch_kvq_attention_batch(s, d, n, mq, dh, sp); }});
     }
     if (!reps.empty()) {
         const RepeatParams* d = upload_params(p, reps);
