@@ -946,11 +946,20 @@ __global__ void __launch_bounds__(256) split_a_kernel(const float* __restrict__ 
                                  (h[p][4] >> 16) | (h[p][5] & 0xFFFF0000u), (h[p][6] >> 16) | (h[p][7] & 0xFFFF0000u));
 }
 
+template <int CTRL>
+__device__ __forceinline__ float row_bcast(int v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false)); }
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ bf16x8_t as_bf16x8(uint4 v) { return __builtin_bit_cast(bf16x8_t, v); }
 // (hi16(a), hi16(b)) -> one dword of two bf16 (a in the low half)
 __device__ __forceinline__ uint32_t pack_hi16(float a, float b) { return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u); }
 
+// The K loop is software-pipelined by hand: while the MFMAs of 8-k group J run on the matrix pipe, the VALU
+// prepares the B pieces of group J + 1 (a wave issues in order, so MFMAs and their own operand preparation
+// only overlap if they are interleaved in program order; sched_group_barrier asks hipcc for 1 MFMA : 3 VALU).
+// A is fetched one group ahead, the weights two steps ahead. Everything is compiler-visible (builtins, no
+// inline asm) so the scheduler can move it and inserts the VALU -> MFMA / DPP wait states itself. The block
+// scales: lane i of a row loads ONE dword (k_local i | 16 + i) and the multiply reads it from lane
+// 8 (J & 1) + e of the row through DPP row_newbcast — 16 identical 64-byte loads and 32 converts per row before.
 template <int R, int G, bool NT>
 __global__ void __launch_bounds__(512) qmatmul_xdl2_kernel(QMM2Args a) {
     extern __shared__ float smem[];
@@ -965,13 +974,12 @@ __global__ void __launch_bounds__(512) qmatmul_xdl2_kernel(QMM2Args a) {
     const uint32_t lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n_waves = blockDim.x >> 6;
     const uint32_t row = lane >> 4, i = lane & 15;
     const uint4* qs = P.qs + (uint64_t)g0 * a.U * 16 + i;
-    const uint4* sc = P.sc + (uint64_t)(g0 >> 1) * a.U * 4; // 32 f16 scales per unit, element 2 * (k_local % 16) + k_local / 16
+    // 32 f16 scales per unit = 16 dwords; dword d = {k_local d, k_local 16 + d}
+    const uint32_t* scd = (const uint32_t*)P.sc + (uint64_t)(g0 >> 1) * a.U * 16 + i;
     const uint4* ap = a.ap + (uint64_t)t0 * a.S * 12 * 64 + lane;
     const uint64_t tile_stride = (uint64_t)a.S * 12 * 64; // uint4 between m-tiles
 
-    // one accumulator per (column group, m-tile, A piece): consecutive MFMAs never chain through the same
-    // registers (a dependent v_mfma waits out its predecessor: half the wave cycles were issue stalls with one
-    // accumulator per tile); the pieces are summed once, at the end
+    // one accumulator per (column group, m-tile, A piece): consecutive MFMAs never chain through the same registers
     mfma_f4 acc[G][R][3];
 #pragma unroll
     for (int g = 0; g < G; g++)
@@ -980,19 +988,21 @@ __global__ void __launch_bounds__(512) qmatmul_xdl2_kernel(QMM2Args a) {
 #pragma unroll
             for (int p = 0; p < 3; p++) acc[g][t][p] = mfma_f4{0.f, 0.f, 0.f, 0.f};
 
-    struct BStep { // one K step of this lane: its unit's nibbles per column group, the unit's scales
+    struct BStep { // one K step of this lane: its unit's nibbles per column group, its dword of the unit's scales
         uint4 wq[G];
-        uint4 s4[4];
+        uint32_t sd;
     };
     struct AGrp { // the A pieces of one 8-k group
         uint4 v[R][3];
+    };
+    struct BPieces { // w = (q - 8)/16 * scale of one 8-k group, as two bf16x8 operands per column group
+        uint4 b1[G], b2[G];
     };
     auto load_b = [&](BStep& b, uint32_t s) {
         const uint32_t u = min(4 * s + row, a.U - 1); // units past the end: A is zero there
 #pragma unroll
         for (int g = 0; g < G; g++) b.wq[g] = wload<NT>(qs + ((uint64_t)g * a.U + u) * 16);
-#pragma unroll
-        for (int q = 0; q < 4; q++) b.s4[q] = sc[(uint64_t)u * 4 + q];
+        b.sd = scd[(uint64_t)u * 16];
     };
     auto load_a = [&](AGrp& x, uint32_t s, uint32_t j) {
 #pragma unroll
@@ -1000,29 +1010,30 @@ __global__ void __launch_bounds__(512) qmatmul_xdl2_kernel(QMM2Args a) {
 #pragma unroll
             for (int p = 0; p < 3; p++) x.v[t][p] = ap[t * tile_stride + (((uint64_t)s * 4 + j) * 3 + p) * 64];
     };
-    auto group = [&](const BStep& b, const AGrp& x, auto jc) {
+    auto prep = [&](BPieces& o, const BStep& b, auto jc) {
         constexpr int J = decltype(jc)::value;
-        // scales of k_local 8 J + e: element 2 * ((8 J + e) % 16) + (8 J + e) / 16 -> dword 8 * (J & 1) + e, half J >> 1
-        const uint32_t sd[8] = {J & 1 ? b.s4[2].x : b.s4[0].x, J & 1 ? b.s4[2].y : b.s4[0].y, J & 1 ? b.s4[2].z : b.s4[0].z,
-                                J & 1 ? b.s4[2].w : b.s4[0].w, J & 1 ? b.s4[3].x : b.s4[1].x, J & 1 ? b.s4[3].y : b.s4[1].y,
-                                J & 1 ? b.s4[3].z : b.s4[1].z, J & 1 ? b.s4[3].w : b.s4[1].w};
-        float sk[8];
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-            const __half2 hh = __builtin_bit_cast(__half2, sd[e]);
-            sk[e] = __half2float(J >> 1 ? hh.y : hh.x);
-        }
+        const __half2 hh = __builtin_bit_cast(__half2, b.sd);
+        const int sbits = __float_as_int(__half2float(J >> 1 ? hh.y : hh.x)); // this lane's scale of k_local (J >> 1) * 16 + i
 #pragma unroll
         for (int g = 0; g < G; g++) {
             const uint32_t lo = J == 0 ? b.wq[g].x : J == 1 ? b.wq[g].y : J == 2 ? b.wq[g].z : b.wq[g].w, hi = lo >> 4;
             float wv[8];
-            wv[0] = cvt_nib<0>(lo) * sk[0], wv[1] = cvt_nib<1>(lo) * sk[1], wv[2] = cvt_nib<2>(lo) * sk[2], wv[3] = cvt_nib<3>(lo) * sk[3];
-            wv[4] = cvt_nib<0>(hi) * sk[4], wv[5] = cvt_nib<1>(hi) * sk[5], wv[6] = cvt_nib<2>(hi) * sk[6], wv[7] = cvt_nib<3>(hi) * sk[7];
+            constexpr int C0 = 0x150 + 8 * (J & 1); // DPP row_newbcast:lane — the scale of k_local 8 J + e sits in lane 8 (J & 1) + e of this row
+#define XDL2_W(E, SRC, BYTE) wv[E] = row_bcast<C0 + E>(sbits) * __builtin_amdgcn_cvt_off_f32_i4((int)((SRC) >> (8 * BYTE))) /* (q - 8)/16 * scale */
+            XDL2_W(0, lo, 0), XDL2_W(1, lo, 1), XDL2_W(2, lo, 2), XDL2_W(3, lo, 3);
+            XDL2_W(4, hi, 0), XDL2_W(5, hi, 1), XDL2_W(6, hi, 2), XDL2_W(7, hi, 3);
+#undef XDL2_W
             float lo2[8];
 #pragma unroll
             for (int e = 0; e < 8; e++) lo2[e] = wv[e] - __uint_as_float(__float_as_uint(wv[e]) & 0xFFFF0000u);
-            const bf16x8_t b1 = as_bf16x8(make_uint4(pack_hi16(wv[0], wv[1]), pack_hi16(wv[2], wv[3]), pack_hi16(wv[4], wv[5]), pack_hi16(wv[6], wv[7])));
-            const bf16x8_t b2 = as_bf16x8(make_uint4(pack_hi16(lo2[0], lo2[1]), pack_hi16(lo2[2], lo2[3]), pack_hi16(lo2[4], lo2[5]), pack_hi16(lo2[6], lo2[7])));
+            o.b1[g] = make_uint4(pack_hi16(wv[0], wv[1]), pack_hi16(wv[2], wv[3]), pack_hi16(wv[4], wv[5]), pack_hi16(wv[6], wv[7]));
+            o.b2[g] = make_uint4(pack_hi16(lo2[0], lo2[1]), pack_hi16(lo2[2], lo2[3]), pack_hi16(lo2[4], lo2[5]), pack_hi16(lo2[6], lo2[7]));
+        }
+    };
+    auto mfmas = [&](const BPieces& o, const AGrp& x) {
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const bf16x8_t b1 = as_bf16x8(o.b1[g]), b2 = as_bf16x8(o.b2[g]);
 #pragma unroll
             for (int p = 0; p < 3; p++)
 #pragma unroll
@@ -1033,36 +1044,43 @@ __global__ void __launch_bounds__(512) qmatmul_xdl2_kernel(QMM2Args a) {
                 for (int t = 0; t < R; t++) acc[g][t][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(x.v[t][p]), b2, acc[g][t][p], 0, 0, 0);
         }
     };
+    // one pipeline stage: fetch A of the group after next's predecessor, prepare B of the next group, multiply the current one
+#define XDL2_STAGE(LOAD_A, PREP, MFMA)                                                  \
+    do {                                                                               \
+        LOAD_A;                                                                        \
+        PREP;                                                                          \
+        MFMA;                                                                          \
+        __builtin_amdgcn_sched_group_barrier(0x020, 3 * R, 0); /* the A loads first */ \
+        _Pragma("unroll") for (int k_ = 0; k_ < 6 * R * G; k_++) {                     \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); /* 1 MFMA */            \
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0); /* 4 VALU */            \
+        }                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+    } while (0)
 
     if (w < a.S) {
-        BStep cur, nxt;
+        BStep cur, nx1, nx2;
         AGrp a0, a1;
+        BPieces p0, p1;
         uint32_t s = w;
+        const uint32_t s_last = a.S - 1;
         load_b(cur, s);
+        load_b(nx1, min(s + n_waves, s_last));
         load_a(a0, s, 0);
+        prep(p0, cur, std::integral_constant<int, 0>{});
+        __builtin_amdgcn_sched_barrier(0);
         for (; s < a.S; s += n_waves) {
-            const uint32_t sn = min(s + n_waves, a.S - 1); // clamped, unconditional: the last prefetch re-reads live lines
-            // sched_barrier: hipcc otherwise sinks each prefetch down to its first use
-            load_b(nxt, sn);
-            load_a(a1, s, 1);
+            const uint32_t sn = min(s + n_waves, s_last); // clamped, unconditional: the last prefetches re-read live lines
+            load_b(nx2, min(s + 2 * n_waves, s_last));
             __builtin_amdgcn_sched_barrier(0);
-            group(cur, a0, std::integral_constant<int, 0>{});
-            __builtin_amdgcn_sched_barrier(0);
-            load_a(a0, s, 2);
-            __builtin_amdgcn_sched_barrier(0);
-            group(cur, a1, std::integral_constant<int, 1>{});
-            __builtin_amdgcn_sched_barrier(0);
-            load_a(a1, s, 3);
-            __builtin_amdgcn_sched_barrier(0);
-            group(cur, a0, std::integral_constant<int, 2>{});
-            __builtin_amdgcn_sched_barrier(0);
-            load_a(a0, sn, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            group(cur, a1, std::integral_constant<int, 3>{});
-            __builtin_amdgcn_sched_barrier(0);
-            cur = nxt;
+            XDL2_STAGE(load_a(a1, s, 1), prep(p1, cur, std::integral_constant<int, 1>{}), mfmas(p0, a0));
+            XDL2_STAGE(load_a(a0, s, 2), prep(p0, cur, std::integral_constant<int, 2>{}), mfmas(p1, a1));
+            XDL2_STAGE(load_a(a1, s, 3), prep(p1, cur, std::integral_constant<int, 3>{}), mfmas(p0, a0));
+            XDL2_STAGE(load_a(a0, sn, 0), prep(p0, nx1, std::integral_constant<int, 0>{}), mfmas(p1, a1));
+            cur = nx1, nx1 = nx2;
         }
     }
+#undef XDL2_STAGE
 
     // D[m = 4 * row + v][n = i] in acc[g][t][v]; fold the waves in fixed order; the tile carries q/16: x 16 (exact)
 #pragma unroll
