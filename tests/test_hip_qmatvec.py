@@ -69,8 +69,9 @@ def test_matmul_rows_offsets_strides(hip_backend, oracle):
 @pytest.mark.parametrize("K,N,kind", [(576, 192, "q4"), (1536, 576, "q4"), (100, 64, "q4"), (4096, 512, "q4"),
                                       (11008, 64, "q4"), (576, 192, "q8"), (100, 64, "q8"), (2048, 96, "q8f16")])
 def test_matmul_tile_kernel_matches_oracle(hip_backend, oracle, M, K, N, kind):
-    """M > 1 goes to the f32-MFMA tile kernel (prefill plans): same tolerance as the mat-vec,
-    with ragged M (partial 16-row tiles), K tails and row strides."""
+    """M > 1 goes to the tile kernels (prefill plans) — Q4_0 with f16-exact scales: split_a + qmatmul_xdl2
+    (exact bf16 splits of x and of scale * q); Q8_0 / f32 scales: the A-side-scale form. Same tolerance as the
+    mat-vec, with ragged M (partial 16-row tiles, three tiles at M = 45), K tails and row strides."""
     rng = np.random.default_rng(0xA11 + M * 7 + K + N)
     x = rng.standard_normal(M * K).astype(f32)
     if kind == "q4":
