@@ -1379,6 +1379,12 @@ void launch_layernorm(hipStream_t s, float* dst, const float* src, uint32_t rows
 
 void launch_rmsnorm(hipStream_t s, float* dst, const float* src, uint32_t rows, uint32_t cols, float eps) {
     if (rows == 0) return;
+    if (cols <= 32 * kBlock) { // the register-resident row kernel (same mapping and reduction: bit-identical), all loads up front
+        RowChainParams rc;
+        rc.src = src, rc.norm_dst = dst, rc.cols = cols, rc.eps = eps;
+        launch_row_chain(s, rc, rows);
+        return;
+    }
     rmsnorm_kernel<<<rows, kBlock, 0, s>>>(dst, src, cols, eps);
 }
 
