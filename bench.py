@@ -135,6 +135,17 @@ def bench_single(args):
     r8 = matvec_roofline(be, 4096, 4096, 0, 64, 1024)
     shapes["4096x4096_q8_0"] = {"us": r8["us_per_launch"], "GBps": r8["achieved"], "frac": r8["frac"]}
     extra["matvec_q4_0_other_shapes"] = shapes
+    # the same Q4_0 rings as INDEPENDENT launches (graph forked over 4 branches): what the kernel streams when
+    # launches may overlap — not the decode path, where every mat-vec waits for its predecessor (`roofline`)
+    indep = {}
+    for (k, n) in ((4096, 4096), (4096, 11008)):
+        nb = C.c_uint64()
+        us_ov = be._lib.zgml_hip_qmatvec_overlap_bench(be.ctx, k, n, 1, 64, 4, 1024, C.byref(nb))
+        if us_ov > 0:
+            indep[f"{k}x{n}"] = {"us_per_launch": round(us_ov, 3), "GBps": round(nb.value / us_ov / 1e3, 1),
+                                 "frac": round(nb.value / us_ov / 1e3 / HBM_PEAK_GBPS, 4)}
+    indep["note"] = "64 mat-vecs forked over 4 graph branches; throughput of overlapping launches, not the dependent-launch figure of `roofline`"
+    extra["matvec_q4_0_independent_launches"] = indep
     cp = be._lib.zgml_hip_copy_bench(be.ctx, 1 << 30, 3, 20)
     extra["copy_kernel_GBps_read_plus_write"] = round(2 * (1 << 30) / cp / 1e3, 1)
 

@@ -461,6 +461,12 @@ double zgml_hip_qmatvec_bench(zgml_hip_ctx* ctx, uint32_t K, uint32_t N, int q4,
  * bytes = weights + 4*M*K + 4*M*N, flops = 2*M*K*N. */
 double zgml_hip_qmatmul_bench(zgml_hip_ctx* ctx, uint32_t M, uint32_t K, uint32_t N, int q4, uint32_t n_matrices,
                               uint32_t warmup, uint32_t iters, uint64_t* bytes_per_launch);
+/* The same ring of M = 1 mat-vecs as independent launches: the captured graph forks the ring over n_streams
+ * branches (distinct outputs), so launches may overlap on the device. Not the decode path (every mat-vec there
+ * waits for its predecessor); it separates what the kernel can stream from what a dependent launch of this size
+ * costs. Returns microseconds per launch (< 0 on error). */
+double zgml_hip_qmatvec_overlap_bench(zgml_hip_ctx* ctx, uint32_t K, uint32_t N, int q4, uint32_t n_matrices, uint32_t n_streams,
+                                      uint32_t iters, uint64_t* bytes_per_launch);
 /* Ring benchmark of the f16-promoted dense matmul (M == 1: f32 x times f16 weights; M > 1: f16
  * MFMA); bytes = 2*K*N + 4*M*K + 4*M*N. N % 16 == 0. */
 double zgml_hip_dense_f16_bench(zgml_hip_ctx* ctx, uint32_t M, uint32_t K, uint32_t N, uint32_t n_matrices,

@@ -2687,6 +2687,89 @@ double zgml_hip_qmatmul_bench(zgml_hip_ctx* ctx, uint32_t M, uint32_t K, uint32_
     return us;
 }
 
+// The same ring of M = 1 mat-vecs, but as INDEPENDENT launches: the captured graph forks the ring over
+// `n_streams` branches (distinct outputs per branch), so consecutive launches may overlap on the device.
+// Not the decode path (there every mat-vec waits for its predecessor) — it separates what the kernel can
+// stream from what a dependent launch of this size costs. Returns microseconds per launch.
+double zgml_hip_qmatvec_overlap_bench(zgml_hip_ctx* ctx, uint32_t K, uint32_t N, int q4, uint32_t n_matrices, uint32_t n_streams,
+                                      uint32_t iters, uint64_t* bytes_per_launch) {
+    if (!ctx || N % 32 || !n_matrices || !iters || !n_streams || n_streams > 16) return -1.0;
+    hipSetDevice(ctx->device);
+    std::vector<QWeightDev> ring(n_matrices);
+    bool ok = true;
+    for (uint32_t i = 0; ok && i < n_matrices; i++) ok = make_synth_weight(ctx, K, N, q4, i, &ring[i]);
+    if (ok && (ring[0].qs_bytes + ring[0].sc_bytes) * n_matrices >= (192ull << 20))
+        for (auto& w : ring) w.stream_nt = 1;
+    float *x = nullptr, *y = nullptr;
+    std::vector<float> xh(K);
+    for (size_t i = 0; i < xh.size(); i++) xh[i] = ((int)(i % 17) - 8) * 0.03125f;
+    ok = ok && CTX_CHECK(ctx, hipMalloc((void**)&x, xh.size() * 4)) && CTX_CHECK(ctx, hipMalloc((void**)&y, (size_t)n_streams * N * 4)) &&
+         CTX_CHECK(ctx, hipMemcpy(x, xh.data(), xh.size() * 4, hipMemcpyHostToDevice));
+    std::vector<hipStream_t> side(n_streams, nullptr);
+    std::vector<hipEvent_t> joined(n_streams, nullptr);
+    hipEvent_t fork = nullptr;
+    for (uint32_t t = 1; ok && t < n_streams; t++)
+        ok = CTX_CHECK(ctx, hipStreamCreateWithFlags(&side[t], hipStreamNonBlocking)) && CTX_CHECK(ctx, hipEventCreateWithFlags(&joined[t], hipEventDisableTiming));
+    ok = ok && CTX_CHECK(ctx, hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+    side[0] = ctx->stream;
+    double us = -1.0;
+    if (ok) {
+        for (uint32_t i = 0; i < n_matrices; i++) { // warm (and resolve the kernels) outside the capture
+            QMatmulParams qp{y + (size_t)(i % n_streams) * N, x, 1, N, K, K, N};
+            launch_qmatmul(ctx->stream, ring[i], qp, nullptr);
+        }
+        hipStreamSynchronize(ctx->stream);
+        hipGraph_t g = nullptr;
+        hipGraphExec_t ge = nullptr;
+        ok = CTX_CHECK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+        if (ok) {
+            hipEventRecord(fork, ctx->stream);
+            for (uint32_t t = 1; t < n_streams; t++) hipStreamWaitEvent(side[t], fork, 0);
+            for (uint32_t i = 0; i < n_matrices; i++) {
+                QMatmulParams qp{y + (size_t)(i % n_streams) * N, x, 1, N, K, K, N};
+                launch_qmatmul(side[i % n_streams], ring[i], qp, nullptr);
+            }
+            for (uint32_t t = 1; t < n_streams; t++) {
+                hipEventRecord(joined[t], side[t]);
+                hipStreamWaitEvent(ctx->stream, joined[t], 0);
+            }
+            ok = CTX_CHECK(ctx, hipStreamEndCapture(ctx->stream, &g)) && CTX_CHECK(ctx, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        }
+        if (ok) {
+            const uint32_t reps = (iters + n_matrices - 1) / n_matrices;
+            hipGraphLaunch(ge, ctx->stream);
+            hipEvent_t e0, e1;
+            hipEventCreate(&e0);
+            hipEventCreate(&e1);
+            hipEventRecord(e0, ctx->stream);
+            for (uint32_t r = 0; r < reps; r++) hipGraphLaunch(ge, ctx->stream);
+            hipEventRecord(e1, ctx->stream);
+            if (CTX_CHECK(ctx, hipEventSynchronize(e1))) {
+                float ms = 0;
+                hipEventElapsedTime(&ms, e0, e1);
+                us = (double)ms * 1000.0 / ((double)reps * n_matrices);
+            }
+            hipEventDestroy(e0);
+            hipEventDestroy(e1);
+        }
+        if (ge) hipGraphExecDestroy(ge);
+        if (g) hipGraphDestroy(g);
+    }
+    if (bytes_per_launch) *bytes_per_launch = (uint64_t)K * N / 32 * (q4 ? 18 : 34) + 4ull * K + 4ull * N;
+    for (uint32_t t = 1; t < n_streams; t++) {
+        if (side[t]) hipStreamDestroy(side[t]);
+        if (joined[t]) hipEventDestroy(joined[t]);
+    }
+    if (fork) hipEventDestroy(fork);
+    for (auto& w : ring) {
+        hipFree(w.qs);
+        hipFree(w.sc);
+    }
+    hipFree(x);
+    hipFree(y);
+    return us;
+}
+
 int zgml_hip_qmatvec_synth(zgml_hip_ctx* ctx, uint32_t K, uint32_t N, int q4, uint32_t matrix_id, const float* x_host,
                            float* y_host) {
     if (!ctx || N % 32 || !x_host || !y_host) return -1;
