@@ -117,6 +117,9 @@ struct AttnDecodeParams {
     uint32_t k_off, v_off;    // att.k - k_cache, att.v - v_cache (elements)
     uint32_t owner;
     uint32_t max_kv;          // compile-time seq_kv bound: rows [0, max_kv) of the slabs are readable
+    // quantised KV caches (kvq_store + attention_kvq folded in): block size (32; 0 = f32 caches) and columns per cache;
+    // k_cache / v_cache are then the cache buffers (int8 rows, f32 block scales behind them), the dynamic words columns
+    uint32_t kvq_block = 0, kvq_cols = 0;
     unsigned long long* trace; // diagnostics (ZGML_HIP_ATTN_TRACE=1): 8 wall-clock stamps, else nullptr
 };
 
@@ -278,7 +281,7 @@ struct AttnSplit {
     uint32_t* cnt = nullptr;
 };
 void launch_attention_decode_batch(hipStream_t s, const AttnDecodeParams* dev_params, uint32_t n_heads, uint32_t d_head,
-                                   const AttnSplit& sp);
+                                   const AttnSplit& sp, bool kvq = false); // kvq: every head reads quantised caches (block 32)
 void launch_kvq_attention_batch(hipStream_t s, const KvqAttentionParams* dev_params, uint32_t n_ops, uint32_t max_seq_q, uint32_t d_head,
                                 const AttnSplit& sp = AttnSplit{}); // split applies to seq_q == 1 launches only
 void launch_attention_batch(hipStream_t s, const AttentionParams* dev_params, uint32_t n_ops, uint32_t max_seq_q, bool all_dense,

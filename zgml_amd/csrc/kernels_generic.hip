@@ -675,10 +675,50 @@ __device__ __forceinline__ void slots_merge(SoftState& s) {
     slots_sum<LPK>(s);
 }
 
-template <int LPK>
+// One key's (value's) 4 dims as this lane holds them: f32 cache rows, or the quantised-KV form (4 int8 + the
+// block scale; QuantizedKVCache, src/quant.zig:645-700). The dot / accumulate expressions of the quantised form
+// are those of kvq_attention_kernel, the quantisation is kvq_store_kernel's (= storeColumn), so the fused launch
+// writes the same cache bytes and computes the same numbers as the op-by-op plan.
+template <bool KVQ>
+struct AttnRow {
+    float4 v;
+};
+template <>
+struct AttnRow<true> {
+    uint32_t w;
+    float sc;
+};
+__device__ __forceinline__ float row_dot(const float4& q, const AttnRow<false>& r) { return q.x * r.v.x + q.y * r.v.y + q.z * r.v.z + q.w * r.v.w; }
+__device__ __forceinline__ float row_dot(const float4& q, const AttnRow<true>& r) {
+    const uint32_t kw = r.w;
+    return (q.x * (float)(int8_t)(kw & 255) + q.y * (float)(int8_t)((kw >> 8) & 255) + q.z * (float)(int8_t)((kw >> 16) & 255) +
+            q.w * (float)(int8_t)(kw >> 24)) * r.sc;
+}
+__device__ __forceinline__ void row_axpy(float4& acc, float wgt, const AttnRow<false>& r) {
+    acc.x += wgt * r.v.x, acc.y += wgt * r.v.y, acc.z += wgt * r.v.z, acc.w += wgt * r.v.w;
+}
+__device__ __forceinline__ void row_axpy(float4& acc, float wgt, const AttnRow<true>& r) {
+    const float ws = wgt * r.sc;
+    const uint32_t vw = r.w;
+    acc.x += ws * (float)(int8_t)(vw & 255), acc.y += ws * (float)(int8_t)((vw >> 8) & 255);
+    acc.z += ws * (float)(int8_t)((vw >> 16) & 255), acc.w += ws * (float)(int8_t)(vw >> 24);
+}
+// storeColumn's arithmetic on the 4 dims of a lane; a block of 32 dims = 8 adjacent lanes
+__device__ __forceinline__ AttnRow<true> quantise_block32(float4 v) {
+    float mx = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mx), 0xB1, 0xF, 0xF, true)));  // quad_perm [1,0,3,2]
+    mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mx), 0x4E, 0xF, 0xF, true)));  // quad_perm [2,3,0,1]
+    mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mx), 0x141, 0xF, 0xF, true))); // row_half_mirror
+    const float scale = mx > 0.f ? mx / 127.0f : 1.0f, inv = mx > 0.f ? 127.0f / mx : 0.0f;
+    auto q8 = [&](float x) { return (uint32_t)(uint8_t)(int8_t)(int)fminf(fmaxf(x * inv, -127.0f), 127.0f); }; // truncates toward zero
+    return AttnRow<true>{q8(v.x) | (q8(v.y) << 8) | (q8(v.z) << 16) | (q8(v.w) << 24), scale};
+}
+
+template <int LPK, bool KVQ>
 __global__ void __launch_bounds__(kAttnBlock) attention_decode_kernel(const AttnDecodeParams* __restrict__ params, float* split_buf,
                                                                       uint32_t* split_cnt, uint32_t split_min_keys) {
     constexpr int DH = 4 * LPK, KPW = 64 / LPK, U = kAttnUnroll, HALF = DH / 2;
+    using Row = AttnRow<KVQ>;
     const AttnDecodeParams& P = params[blockIdx.x];
     const AttentionParams& p = P.att;
 #ifdef ZGML_TRACE // build with -DZGML_TRACE (ZGML_HIP_ATTN_TRACE=1 then prints the stamps)
@@ -694,7 +734,8 @@ __global__ void __launch_bounds__(kAttnBlock) attention_decode_kernel(const Attn
     const uint32_t slot = lane / LPK, li = lane % LPK, d0 = 4 * li, pair = d0 & (HALF - 1);
     const bool is_hi = d0 >= (uint32_t)HALF;
     // ---- phase A: dynamic words (scalar) and everything the ropes need (vector), one round
-    const uint32_t seq_kv = *p.dyn_seq_kv, dk = *P.dyn_k_off, dv = *P.dyn_v_off;
+    // quantised KV: the stores' dynamic words are column indices, the caches are int8 rows + f32 block scales
+    const uint32_t seq_kv = KVQ ? min(*p.dyn_seq_kv, P.kvq_cols) : *p.dyn_seq_kv, dk = *P.dyn_k_off, dv = *P.dyn_v_off;
     const uint32_t d2_off = p.dst2 ? *p.dyn_dst2_off : 0; // scalar, with the other dynamic words
     const float4 q_own = *(const float4*)(P.q_src + d0), q_par = *(const float4*)(P.q_src + (d0 ^ HALF));
     const float4 q_c = *(const float4*)(P.q_cs + pair), q_s = *(const float4*)(P.q_cs + HALF + pair);
@@ -719,26 +760,62 @@ __global__ void __launch_bounds__(kAttnBlock) attention_decode_kernel(const Attn
     if (w >= NW) return;
     const uint32_t keys_per_iter = KPW * NW, step_keys = keys_per_iter * U, last = k_end ? k_end - 1 : 0;
     // ---- phase B: first step's K / V / mask rows (clamped to live rows, unconditional)
-    float4 kv[U], vv[U];
+    constexpr uint32_t BPC = DH / 32; // quantised form: 32-dim blocks per column (the planner admits block size 32 only)
+    const int8_t* const kq = (const int8_t*)P.k_cache + d0;
+    const int8_t* const vq = (const int8_t*)P.v_cache + d0;
+    const float* const ksc = P.k_cache + (uint64_t)P.kvq_cols * DH / 4 + d0 / 32;
+    const float* const vsc = P.v_cache + (uint64_t)P.kvq_cols * DH / 4 + d0 / 32;
+    auto load_k = [&](uint32_t s) -> Row {
+        if constexpr (KVQ)
+            return Row{*(const uint32_t*)(kq + (uint64_t)s * DH), ksc[(uint64_t)s * BPC]};
+        else
+            return Row{*(const float4*)(p.k + (uint64_t)s * p.k_cs + d0)};
+    };
+    auto load_v = [&](uint32_t s) -> Row {
+        if constexpr (KVQ)
+            return Row{*(const uint32_t*)(vq + (uint64_t)s * DH), vsc[(uint64_t)s * BPC]};
+        else
+            return Row{*(const float4*)(p.v + (uint64_t)s * p.v_cs + d0)};
+    };
+    Row kv[U], vv[U];
     float mk[U];
 #pragma unroll
     for (int j = 0; j < U; j++) {
         const uint32_t s = min(k_begin + j * keys_per_iter + w * KPW + slot, last);
-        kv[j] = *(const float4*)(p.k + (uint64_t)s * p.k_cs + d0);
-        vv[j] = *(const float4*)(p.v + (uint64_t)s * p.v_cs + d0);
+        kv[j] = load_k(s);
+        vv[j] = load_v(s);
         mk[j] = p.mask[(uint64_t)s * p.mask_rs]; // host passes a zero word with stride 0 when there is no mask
     }
     ATTN_STAMP(2);
     // ---- ropes; side outputs and the cache stores (one lane group writes each value)
     const float4 qv = rope4(q_own, q_par, q_c, q_s, is_hi);
     const float4 k_new = rope4(k_own, k_par, k_c, k_s, is_hi);
-    const uint32_t col_k = (dk - P.k_off) / p.k_cs, col_v = (dv - P.v_off) / p.v_cs;
+    uint32_t col_k, col_v;
+    Row k_col, v_col; // the new column as the attention sees it (quantised KV: what storeColumn writes, dequantised on use)
+    if constexpr (KVQ) {
+        col_k = dk, col_v = dv;
+        k_col = quantise_block32(k_new), v_col = quantise_block32(v_new);
+    } else {
+        col_k = (dk - P.k_off) / p.k_cs, col_v = (dv - P.v_off) / p.v_cs;
+        k_col = Row{k_new}, v_col = Row{v_new};
+    }
     if (w == 0 && slot == 0 && sp == 0) {
         *(float4*)(P.q_rot + d0) = qv;
         if (P.owner) {
             *(float4*)(P.k_rot + d0) = k_new;
-            *(float4*)(P.k_cache + dk + d0) = k_new;
-            *(float4*)(P.v_cache + dv + d0) = v_new;
+            if constexpr (KVQ) { // never outside the cache (kvq_store_kernel's guard)
+                if (col_k < P.kvq_cols) {
+                    *(uint32_t*)((int8_t*)P.k_cache + (uint64_t)col_k * DH + d0) = k_col.w;
+                    if ((li & 7) == 0) P.k_cache[(uint64_t)P.kvq_cols * DH / 4 + (uint64_t)col_k * BPC + d0 / 32] = k_col.sc;
+                }
+                if (col_v < P.kvq_cols) {
+                    *(uint32_t*)((int8_t*)P.v_cache + (uint64_t)col_v * DH + d0) = v_col.w;
+                    if ((li & 7) == 0) P.v_cache[(uint64_t)P.kvq_cols * DH / 4 + (uint64_t)col_v * BPC + d0 / 32] = v_col.sc;
+                }
+            } else {
+                *(float4*)(P.k_cache + dk + d0) = k_new;
+                *(float4*)(P.v_cache + dv + d0) = v_new;
+            }
         }
     }
     ATTN_STAMP(3);
@@ -750,8 +827,8 @@ __global__ void __launch_bounds__(kAttnBlock) attention_decode_kernel(const Attn
 #pragma unroll
         for (int j = 0; j < U; j++) {
             const uint32_t t = base + j * keys_per_iter + w * KPW + slot;
-            const float4 kk = t == col_k ? k_new : kv[j];
-            const float dot = group_sum<LPK>(qv.x * kk.x + qv.y * kk.y + qv.z * kk.z + qv.w * kk.w);
+            const Row kk = t == col_k ? k_col : kv[j];
+            const float dot = group_sum<LPK>(row_dot(qv, kk));
             sc[j] = t < k_end ? score_of(dot, mk[j], p.scale) : -INFINITY;
             bm = fmaxf(bm, sc[j]);
         }
@@ -764,14 +841,9 @@ __global__ void __launch_bounds__(kAttnBlock) attention_decode_kernel(const Attn
             for (int j = 0; j < U; j++) {
                 const uint32_t t = base + j * keys_per_iter + w * KPW + slot;
                 const float wgt = sc[j] > -INFINITY ? expf(sc[j] - nm) : 0.0f;
-                const float4 x = t == col_v ? v_new : vv[j];
+                const Row x = t == col_v ? v_col : vv[j];
                 st.l += wgt;
-                if (sc[j] > -INFINITY) { // rows of dead slots are never touched
-                    st.acc.x += wgt * x.x;
-                    st.acc.y += wgt * x.y;
-                    st.acc.z += wgt * x.z;
-                    st.acc.w += wgt * x.w;
-                }
+                if (sc[j] > -INFINITY) row_axpy(st.acc, wgt, x); // rows of dead slots are never touched
             }
             st.m = nm;
         }
@@ -781,13 +853,13 @@ __global__ void __launch_bounds__(kAttnBlock) attention_decode_kernel(const Attn
     } else {
         for (uint32_t base = k_begin; base < k_end; base += step_keys) {
             // prefetch the next step (clamped: the last step re-reads live rows, L2 hits)
-            float4 kn[U], vn[U];
+            Row kn[U], vn[U];
             float mn[U];
 #pragma unroll
             for (int j = 0; j < U; j++) {
                 const uint32_t s = min(base + step_keys + j * keys_per_iter + w * KPW + slot, last);
-                kn[j] = *(const float4*)(p.k + (uint64_t)s * p.k_cs + d0);
-                vn[j] = *(const float4*)(p.v + (uint64_t)s * p.v_cs + d0);
+                kn[j] = load_k(s);
+                vn[j] = load_v(s);
                 mn[j] = p.mask[(uint64_t)s * p.mask_rs];
             }
             step(base);
@@ -1439,17 +1511,27 @@ void launch_kvq_attention_batch(hipStream_t s, const KvqAttentionParams* dev_par
 }
 
 void launch_attention_decode_batch(hipStream_t s, const AttnDecodeParams* dev_params, uint32_t n_heads, uint32_t d_head,
-                                   const AttnSplit& sp) {
+                                   const AttnSplit& sp, bool kvq) {
     if (!n_heads) return;
     const dim3 grid(n_heads, sp.splits ? sp.splits : 1); // x = head: the always-active split 0 of every head is dispatched first
-#define ADEC(L) attention_decode_kernel<L><<<grid, kAttnBlock, 0, s>>>(dev_params, sp.buf, sp.cnt, sp.min_keys)
+#define ADEC(L, Q) attention_decode_kernel<L, Q><<<grid, kAttnBlock, 0, s>>>(dev_params, sp.buf, sp.cnt, sp.min_keys)
+    if (kvq) { // quantised KV caches (block 32): d_head a multiple of 32
+        switch (d_head) {
+            case 32: ADEC(8, true); break;
+            case 64: ADEC(16, true); break;
+            case 128: ADEC(32, true); break;
+            case 256: ADEC(64, true); break;
+            default: break;
+        }
+        return;
+    }
     switch (d_head) { // all heads of a launch share d_head (checked by the planner)
-        case 8: ADEC(2); break;
-        case 16: ADEC(4); break;
-        case 32: ADEC(8); break;
-        case 64: ADEC(16); break;
-        case 128: ADEC(32); break;
-        case 256: ADEC(64); break;
+        case 8: ADEC(2, false); break;
+        case 16: ADEC(4, false); break;
+        case 32: ADEC(8, false); break;
+        case 64: ADEC(16, false); break;
+        case 128: ADEC(32, false); break;
+        case 256: ADEC(64, false); break;
         default: break;
     }
 #undef ADEC

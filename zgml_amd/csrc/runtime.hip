@@ -811,6 +811,7 @@ struct Macro {
     };
     std::vector<Head> heads;
     uint32_t rk = 0, sk = 0, sv = 0;
+    bool kvq = false; // the same block over quantised caches: sk / sv are kvq_store ops, the heads' `att` attention_kvq ops
     // [add ->] rmsnorm [-> mul] over dense rows (any row count): one launch (RowChainParams)
     bool chain = false;
     int chain_add = -1, chain_mul = -1;
@@ -1213,6 +1214,94 @@ void build_fused_plan(zgml_hip_program* p) {
         }
     }
 
+    // ---- the same fold over quantised KV caches (extension ops): per kv head {rope k, kvq_store K, kvq_store V}
+    // + per head {rope q, attention_kvq, row store}. The fused kernel quantises the new column exactly as
+    // storeColumn does and uses the quantised values, so cache bytes and outputs equal the op-by-op plan's.
+    {
+        auto whole_writer = [&](uint16_t buf, uint32_t before) -> int { // latest op < before writing anywhere into buf
+            const Span q{buf, 0, p->sizes[buf]};
+            for (int j = (int)before - 1; j >= 0; j--)
+                for (const Span& w : s0.access[j].writes)
+                    if (spans_overlap(w, q)) return j;
+            return -1;
+        };
+        auto aligned4 = [&](uint16_t buf, uint64_t off) { return ((uintptr_t)buf_at(p, buf, off) % 16) == 0; };
+        struct Cand {
+            uint32_t rq, att, rk, sk, sv;
+            int row_store;
+        };
+        std::map<uint32_t, std::vector<Cand>> groups; // by K store op
+        static const bool enabled = !(getenv("ZGML_HIP_ATTN_DECODE") && atoi(getenv("ZGML_HIP_ATTN_DECODE")) == 0) &&
+                                    !(getenv("ZGML_HIP_ATTN_DECODE_KVQ") && atoi(getenv("ZGML_HIP_ATTN_DECODE_KVQ")) == 0);
+        for (uint32_t i = 0; enabled && i < n; i++) {
+            if (in_macro[i] || ops[i].kind != ZGML_DOP_ATTENTION_KVQ) continue;
+            const auto& t = ops[i].u.attention_kvq;
+            const uint32_t dh = t.d_head;
+            if (t.seq_q != 1 || t.block_size != 32 || (dh != 32 && dh != 64 && dh != 128 && dh != 256) || t.k_col_start || t.v_col_start ||
+                t.seq_kv == 0 || t.n_cols == 0 || !aligned4(t.q, t.q_off) || !aligned4(t.dst, t.dst_off) || t.k == t.v)
+                continue;
+            const uint64_t cache_elems = (uint64_t)t.n_cols * dh / 4 + (uint64_t)t.n_cols * (dh / 32);
+            if (cache_elems > p->sizes[t.k] || cache_elems > p->sizes[t.v]) continue;
+            const int rq = last_writer(ExactSpan{t.q, t.q_off, dh}, i);
+            if (rq < 0 || in_macro[rq] || ops[rq].kind != ZGML_DOP_ROPE) continue;
+            const auto& q = ops[rq].u.rope;
+            if (q.dst != t.q || q.dst_off != t.q_off || 2 * q.half_d != dh || q.seq_len != 1 || q.src_rs != 1 ||
+                !aligned4(q.src, q.src_off) || !aligned4(q.cos_sin, q.cs_off))
+                continue;
+            const int sk = whole_writer(t.k, i), sv = whole_writer(t.v, i);
+            if (sk < 0 || sv < 0 || in_macro[sk] || in_macro[sv] || ops[sk].kind != ZGML_DOP_KVQ_STORE || ops[sv].kind != ZGML_DOP_KVQ_STORE) continue;
+            const auto &ks = ops[sk].u.kvq_store, &vs = ops[sv].u.kvq_store;
+            if (ks.cache != t.k || vs.cache != t.v || ks.d_head != dh || vs.d_head != dh || ks.block_size != 32 || vs.block_size != 32 ||
+                ks.n_cols != t.n_cols || vs.n_cols != t.n_cols || !aligned4(vs.src, vs.src_offset))
+                continue;
+            const int rk = last_writer(ExactSpan{ks.src, ks.src_offset, dh}, sk);
+            if (rk < 0 || in_macro[rk] || ops[rk].kind != ZGML_DOP_ROPE) continue;
+            const auto& kr = ops[rk].u.rope;
+            if (kr.dst != ks.src || kr.dst_off != ks.src_offset || 2 * kr.half_d != dh || kr.seq_len != 1 || kr.src_rs != 1 ||
+                !aligned4(kr.src, kr.src_off) || !aligned4(kr.cos_sin, kr.cs_off) || !aligned4(kr.dst, kr.dst_off))
+                continue;
+            int row_store = -1;
+            if (t.dst_cs == dh) {
+                std::vector<uint32_t> readers;
+                readers_until_overwrite(ExactSpan{t.dst, t.dst_off, dh}, i, readers);
+                for (uint32_t r : readers) {
+                    if (in_macro[r] || ops[r].kind != ZGML_DOP_SLICE_ASSIGN) continue;
+                    const auto& sa = ops[r].u.slice_assign;
+                    if (sa.src != t.dst || sa.src_offset != t.dst_off || sa.rows != dh || sa.cols != 1 || sa.src_row_stride != 1) continue;
+                    row_store = (int)r;
+                    break;
+                }
+            }
+            groups[(uint32_t)sk].push_back({(uint32_t)rq, i, (uint32_t)rk, (uint32_t)sk, (uint32_t)sv, row_store});
+        }
+        for (auto& kv : groups) {
+            const std::vector<Cand>& hs = kv.second;
+            bool same = true;
+            for (const Cand& c : hs) same = same && c.rk == hs[0].rk && c.sv == hs[0].sv;
+            if (!same) continue;
+            Macro m;
+            m.kvq = true;
+            m.rk = hs[0].rk, m.sk = hs[0].sk, m.sv = hs[0].sv;
+            m.members = {m.rk, m.sk, m.sv};
+            for (const Cand& c : hs) {
+                m.members.push_back(c.rq);
+                m.members.push_back(c.att);
+                if (c.row_store >= 0) m.members.push_back((uint32_t)c.row_store);
+                m.heads.push_back({c.rq, c.att, c.row_store});
+            }
+            std::sort(m.members.begin(), m.members.end());
+            if (std::adjacent_find(m.members.begin(), m.members.end()) != m.members.end()) continue;
+            m.position = m.members.back();
+            if (!delay_legal(m.members, m.position)) continue;
+            for (uint32_t x : m.members) {
+                add_access(m.access, s0.access[x]);
+                in_macro[x] = 1;
+            }
+            m.anchor = hs[0].att;
+            macros.push_back(std::move(m));
+        }
+    }
+
     // rope -> slice_assign (K into the cache) and attention -> slice_assign (head output into the
     // concatenated buffer): the copy of the anchor's dense output is done by the anchor itself
     for (uint32_t i = 0; i < n; i++) {
@@ -1403,6 +1492,44 @@ void build_fused_plan(zgml_hip_program* p) {
         std::map<uint32_t, std::vector<AttnDecodeParams>> adec_by_dh; // one launch per head size
         uint32_t adec_lo = UINT32_MAX, adec_hi = 0, adec_ops = 0;
         for (uint32_t mi : lv) {
+            if (!macros[mi].heads.empty() && macros[mi].kvq) {
+                const Macro& m = macros[mi];
+                const auto& kr = ops[m.rk].u.rope;
+                const auto& ks = ops[m.sk].u.kvq_store;
+                const auto& vs = ops[m.sv].u.kvq_store;
+                bool first_head = true;
+                for (const Macro::Head& h : m.heads) {
+                    const auto& t = ops[h.att].u.attention_kvq;
+                    const auto& qr = ops[h.rq].u.rope;
+                    AttnDecodeParams a{};
+                    a.att.dst = buf_at(p, t.dst, t.dst_off), a.att.q = buf_at(p, t.q, t.q_off);
+                    a.att.mask = t.has_mask ? buf_at(p, t.mask, t.mask_off) : p->zero_word;
+                    a.att.mask_rs = t.has_mask ? t.mask_rs : 0, a.att.mask_cs = t.has_mask ? t.mask_cs : 0;
+                    a.att.d_head = t.d_head, a.att.seq_q = 1, a.att.dyn_seq_kv = p->dyn_dev + h.att, a.att.scale = t.scale;
+                    a.att.q_rs = 1, a.att.q_cs = t.q_cs, a.att.dst_rs = 1, a.att.dst_cs = t.dst_cs;
+                    if (h.row_store >= 0) {
+                        const auto& sa = ops[h.row_store].u.slice_assign;
+                        a.att.dst2 = p->bufs[sa.dst];
+                        a.att.dyn_dst2_off = p->dyn_dev + h.row_store;
+                        a.att.d2_rs = sa.dst_row_stride, a.att.d2_cs = sa.dst_col_stride;
+                    }
+                    a.q_rot = buf_at(p, t.q, t.q_off);
+                    a.q_src = buf_at(p, qr.src, qr.src_off), a.q_cs = buf_at(p, qr.cos_sin, qr.cs_off);
+                    a.k_src = buf_at(p, kr.src, kr.src_off), a.k_cs = buf_at(p, kr.cos_sin, kr.cs_off);
+                    a.v_src = buf_at(p, vs.src, vs.src_offset);
+                    a.k_rot = buf_at(p, kr.dst, kr.dst_off);
+                    a.k_cache = p->bufs[ks.cache], a.v_cache = p->bufs[vs.cache];
+                    a.dyn_k_off = p->dyn_dev + m.sk, a.dyn_v_off = p->dyn_dev + m.sv; // column indices
+                    a.owner = first_head ? 1 : 0;
+                    a.max_kv = t.n_cols;
+                    a.kvq_block = 32, a.kvq_cols = t.n_cols;
+                    first_head = false;
+                    adec_by_dh[t.d_head | 0x10000u].push_back(a);
+                }
+                adec_lo = std::min(adec_lo, m.members.front()), adec_hi = std::max(adec_hi, m.members.back());
+                adec_ops += (uint32_t)m.members.size();
+                continue;
+            }
             if (!macros[mi].heads.empty()) {
                 const Macro& m = macros[mi];
                 const auto& kr = ops[m.rk].u.rope;
@@ -1487,11 +1614,12 @@ void build_fused_plan(zgml_hip_program* p) {
         for (Launch& c : chains) p->plan.push_back(std::move(c));
         for (auto& kv : adec_by_dh) {
             const AttnDecodeParams* d = upload_params(p, kv.second);
-            const uint32_t nh = (uint32_t)kv.second.size(), dh = kv.first;
+            const uint32_t nh = (uint32_t)kv.second.size(), dh = kv.first & 0xFFFFu;
+            const bool kvq = (kv.first & 0x10000u) != 0; // quantised-KV heads launch on their own
             uint32_t max_kv = 0;
             for (const auto& a : kv.second) max_kv = std::max(max_kv, a.max_kv);
             const AttnSplit sp = attn_split_for(p, nh, dh, max_kv);
-            p->plan.push_back({ZGML_DOP_ATTENTION, adec_ops, adec_lo, adec_hi, [=](hipStream_t s) { launch_attention_decode_batch(s, d, nh, dh, sp); }});
+            p->plan.push_back({ZGML_DOP_ATTENTION, adec_ops, adec_lo, adec_hi, [=](hipStream_t s) { launch_attention_decode_batch(s, d, nh, dh, sp, kvq); }});
             adec_ops = 0; // profile accounting: ops counted once
         }
         // group mat-vecs that stage the same vector
