@@ -149,6 +149,29 @@ def bench_single(args):
     cp = be._lib.zgml_hip_copy_bench(be.ctx, 1 << 30, 3, 20)
     extra["copy_kernel_GBps_read_plus_write"] = round(2 * (1 << 30) / cp / 1e3, 1)
 
+    # the int8 KV cache variant of the same program (extension ops kvq_store / attention_kvq)
+    try:
+        cq = llama.preset("smollm-135m")
+        cq.kv_quant_block = 32
+        mq = llama.Model(cq, llama.Q4_0, include_dead_f32=False, threads=16)
+        sq = llama.Session(mq, llama.hip_backend_fns(be))
+        sq.resident_setup(be)
+        wq = sq.resident_decode(1, 0, 8)
+        be.synchronize()
+        t0 = time.perf_counter()
+        wq = sq.resident_decode(int(wq[-1]), 8, 128)
+        be.synchronize()
+        short = 128 / (time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        sq.resident_decode(int(wq[-1]), 1900, 64)
+        be.synchronize()
+        extra["quantised_kv_int8"] = {"tok_s": round(short, 1), "long_context_pos1900_tok_s": round(64 / (time.perf_counter() - t0), 1),
+                                      "workload": "SmolLM-135M Q4_0 decode with int8 KV caches (block 32)"}
+        sq.close()
+        mq.close()
+    except Exception as e:
+        extra["quantised_kv_int8"] = {"error": str(e)[:200]}
+
     if not args.skip_llama7b:
         try:
             extra["llama2_7b"] = bench_llama7b_single(be, llama, args)
@@ -239,6 +262,23 @@ def bench_llama7b_single(be, llama, args):
     long_ctx = round(32 / (time.perf_counter() - t0), 1)
     sess.close()
     model.close()
+    kvq_long = None
+    try:  # int8 KV caches at the same long context (3.6x fewer KV bytes per token)
+        cq = llama.preset("llama2-7b", 2048)
+        cq.kv_quant_block = 32
+        mq = llama.Model(cq, llama.Q4_0, threads=16)
+        sq = llama.Session(mq, llama.hip_backend_fns(be))
+        sq.resident_setup(be)
+        sq.resident_decode(1, 0, 4)
+        be.synchronize()
+        t0 = time.perf_counter()
+        sq.resident_decode(1, 1900, 32)
+        be.synchronize()
+        kvq_long = round(32 / (time.perf_counter() - t0), 1)
+        sq.close()
+        mq.close()
+    except Exception as e:
+        kvq_long = str(e)[:120]
     tok_s = K / dt
     prefill = {}
     if not args.skip_prefill:
@@ -248,7 +288,7 @@ def bench_llama7b_single(be, llama, args):
             except Exception as e:
                 prefill[kind] = {"error": str(e)[:200]}
         prefill["workload"] = "Llama-2-7B prefill, one chunk of 32 tokens, Q4_0 vs dense f16 (BASELINE configs[4])"
-    return {"prefill_batch32": prefill, "tok_s": round(tok_s, 1), "long_context_pos1900_tok_s": long_ctx, "ms_per_token": round(1e3 * dt / K, 3), "steps": K, "build_s": round(build_s, 1),
+    return {"prefill_batch32": prefill, "tok_s": round(tok_s, 1), "long_context_pos1900_tok_s": long_ctx, "long_context_pos1900_int8_kv_tok_s": kvq_long, "ms_per_token": round(1e3 * dt / K, 3), "steps": K, "build_s": round(build_s, 1),
             "q4_0_weight_bytes": qb, "weight_stream_GBps": round(qb * tok_s / 1e9, 1),
             "frac_of_hbm_peak": round(qb * tok_s / 1e9 / HBM_PEAK_GBPS, 4),
             "workload": "Llama-2-7B Q4_0 greedy decode, batch 1, 1xMI355X (BASELINE configs[2])"}
