@@ -275,3 +275,47 @@ def test_long_context_attention_split(hip_backend, oracle, kvq):
     finally:
         hip_backend.set_option(capi.OPT_ATTN_SPLIT_MIN_KEYS, -1)
     s_ref.close(), m.close()
+
+
+@pytest.mark.parametrize("kvq", [0, 32])
+@pytest.mark.parametrize("token_len", [1, 5])
+def test_fused_plan_equals_serial_plan(hip_backend, kvq, token_len):
+    """Every launch fusion of the runtime (mat-vec prologue / epilogue / grouping, fused decode attention incl. the
+    quantised-KV form, row chains, elementwise chains, grouped tile launches, streaming prefill attention) against the
+    one-launch-per-DeviceOp plan of the same program (ZGML_HIP_OPT_FUSION = 0): logits within 1e-5 of the logit range
+    (the fused kernels keep each op's arithmetic; only summation orders inside mat-vec / attention kernels differ) and the
+    same greedy token wherever the top-2 margin exceeds that. With int8 KV caches a last-bit difference in a projection can
+    flip one quantised value, so the bound there is the oracle-parity one (3e-4)."""
+    cfg = llama.preset("tiny", 128)
+    cfg.kv_quant_block = kvq
+    m = llama.Model(cfg, llama.Q4_0, threads=8, token_len=token_len)
+    s_f = llama.Session(m, llama.hip_backend_fns(hip_backend))
+    hip_backend.set_option(capi.OPT_FUSION, 0)
+    try:
+        s_s = llama.Session(m, llama.hip_backend_fns(hip_backend))
+    finally:
+        hip_backend.set_option(capi.OPT_FUSION, 1)
+    tol = 3e-4 if kvq else 1e-5
+
+    def check(t_f, l_f, t_s, l_s, where):
+        assert not hip_backend.last_error(), hip_backend.last_error()
+        scale = np.abs(l_s).max()
+        assert np.abs(l_f - l_s).max() <= tol * scale, where
+        top2 = np.sort(l_s)[-2:]
+        if top2[1] - top2[0] > 4 * tol * scale:
+            assert t_f == t_s, where
+
+    if token_len == 1:
+        tok = 3
+        for pos in range(40):
+            t_f, l_f = s_f.step(tok, pos)
+            t_s, l_s = s_s.step(tok, pos)
+            check(t_f, l_f, t_s, l_s, pos)
+            tok = t_s
+    else:
+        for chunk in range(4):
+            toks = [(11 * (chunk * token_len + i) + 5) % cfg.vocab_size for i in range(token_len)]
+            t_f, l_f = s_f.prefill(toks, chunk * token_len)
+            t_s, l_s = s_s.prefill(toks, chunk * token_len)
+            check(t_f, l_f, t_s, l_s, chunk)
+    s_f.close(), s_s.close(), m.close()
