@@ -269,3 +269,27 @@ def test_refresh_beyond_assumed_bounds_falls_back_correctly(hip_backend, oracle)
         res[name] = outs
     for r, g in zip(res["ref"], res["hip"]):
         np.testing.assert_allclose(g, r, atol=2e-5, rtol=0)
+
+
+@pytest.mark.parametrize("dh,sq,n_heads,skv,has_mask", [(128, 64, 8, 300, False), (64, 33, 3, 90, True), (32, 40, 8, 1030, True)])
+def test_attention_many_queries_batched_heads(hip_backend, oracle, dh, sq, n_heads, skv, has_mask):
+    """seq_q > 1 over several heads in one dependency level (the prefill shape): the streaming kernel with 4-wave
+    workgroups when (queries x heads) fills the chip, 16-wave ones otherwise; causal-style masks, multi-step contexts."""
+    rng = np.random.default_rng(dh * 1000 + sq + skv)
+    bufs, ups, ops = [], [], []
+    mask = np.zeros(skv * sq, f32)
+    for qi in range(sq):  # query qi sees keys [0, skv - sq + qi]
+        mask[qi * skv + max(0, skv - sq + qi + 1):(qi + 1) * skv] = -np.inf
+    for h in range(n_heads):
+        q, k, v = (rng.standard_normal(n).astype(f32) for n in (dh * sq, dh * skv, dh * skv))
+        base = len(bufs)
+        bufs += [dh * sq, dh * skv, dh * skv, skv * sq, dh * sq]
+        ups += [ProgramIO(base + 0, q), ProgramIO(base + 1, k), ProgramIO(base + 2, v), ProgramIO(base + 3, mask)]
+        ops.append(DeviceOp.attention(base + 4, base + 0, base + 1, base + 2, base + 3, has_mask, dh, sq, skv, dh ** -0.5, 0, 0, 0, 0, 0,
+                                      1, dh, 1, dh, 1, dh, 1, skv, 1, dh))
+    prog = DeviceProgram(ops=ops, buffer_sizes=bufs, initial_uploads=ups)
+    for h in (0, n_heads - 1):
+        want = oracle.run_program(prog, 5 * h + 4, dh * sq)
+        got = oracle.run_program(prog, 5 * h + 4, dh * sq, backend=hip_backend)
+        assert not hip_backend.last_error(), hip_backend.last_error()
+        np.testing.assert_allclose(got, want, atol=2e-5, rtol=0)
