@@ -409,7 +409,8 @@ AttnSplit attn_split_for(zgml_hip_program* p, uint32_t n_heads, uint32_t d_head,
     if (min_keys == 0 || want <= 1) return sp;
     sp.min_keys = (uint32_t)std::min<int64_t>(std::max<int64_t>(32, min_keys), 1 << 30);
     uint32_t S = std::min<uint32_t>((uint32_t)std::max(want, 1), max_kv / sp.min_keys);
-    S = std::min(S, std::max(1u, 256u / std::max(n_heads, 1u))); // about one (1024-thread) workgroup per CU: idle ones still cost dispatch
+    static const uint32_t wg_cap = getenv("ZGML_HIP_ATTN_SPLIT_WGS") ? (uint32_t)atoi(getenv("ZGML_HIP_ATTN_SPLIT_WGS")) : 256u;
+    S = std::min(S, std::max(1u, wg_cap / std::max(n_heads, 1u))); // about one (1024-thread) workgroup per CU: idle ones still cost dispatch
     if (S <= 1) return sp;
     const uint64_t need = (uint64_t)n_heads * S * (d_head + 4);
     if (need > p->split_buf_floats) { // earlier launches keep their (smaller) block: it stays in param_blobs
