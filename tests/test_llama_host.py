@@ -185,3 +185,28 @@ def test_dense_model_is_the_dequantised_q4_model():
     for s in (sq, sd, sh):
         s.close()
     mq.close(), md.close()
+
+
+def test_quantised_kv_program_tracks_the_f32_cache_program():
+    """kv_quant_block = 32 swaps slice_assign / attention for kvq_store / attention_kvq (same op count per layer, one
+    int8 cache buffer per kv head) and, on the oracle, decodes within the int8 cache's accuracy of the f32-cache program
+    (the reference bounds attentionQuantized vs float attention at 0.05-0.1, src/quant.zig:1133-1210)."""
+    from oracle import oracle as O
+    cfg = llama.preset("tiny")
+    m_f = llama.Model(cfg, llama.Q4_0)
+    cq = llama.preset("tiny")
+    cq.kv_quant_block = 32
+    m_q = llama.Model(cq, llama.Q4_0)
+    kinds_f, kinds_q = op_kinds(m_f), op_kinds(m_q)
+    assert len(kinds_f) == len(kinds_q)
+    assert kinds_q.count(KIND["kvq_store"]) == 2 * cfg.n_kv_heads * cfg.n_layers
+    assert kinds_q.count(KIND["attention_kvq"]) == cfg.n_heads * cfg.n_layers
+    assert KIND["attention"] not in kinds_q
+    s_f, s_q = llama.Session(m_f, O.backend_fns()), llama.Session(m_q, O.backend_fns())
+    tok = 3
+    for pos in range(8):
+        t_f, l_f = s_f.step(tok, pos)
+        t_q, l_q = s_q.step(tok, pos)
+        assert np.abs(l_q - l_f).max() <= 0.05 * np.abs(l_f).max(), pos
+        tok = t_f
+    s_f.close(), s_q.close(), m_f.close(), m_q.close()
