@@ -917,10 +917,12 @@ struct QMM2Part { // one weight of a grouped launch (q/k/v, gate/up: same rows, 
     uint32_t out_rs, NB2, block_begin; // first workgroup of the part
 };
 constexpr int kMaxQmmParts = 3;
+constexpr int kMaxSpw = 12; // K steps per wave the weight preload is unrolled for (8 waves: K <= 12288)
 struct QMM2Args {
     QMM2Part parts[kMaxQmmParts];
     const uint4* ap; // split_a_kernel output
     uint32_t n_parts, M, U, S; // S = K steps = ceil(U / 4)
+    uint32_t spw_max;          // ceil(S / waves) <= kMaxSpw: sizes the weights' LDS region
 };
 
 // A pieces: ap[(((t * S + s) * 4 + j) * 3 + p) * 64 + lane] = the 8 bf16 of piece p that lane (i = lane % 16:
@@ -1058,29 +1060,55 @@ __global__ void __launch_bounds__(512) qmatmul_xdl2_kernel(QMM2Args a) {
         __builtin_amdgcn_sched_barrier(0);                                             \
     } while (0)
 
-    if (w < a.S) {
-        BStep cur, nx1, nx2;
+    // The weights first, all of them: loads return in order, so a weight prefetch (HBM, ~2 us under load) issued
+    // inside the K loop sits in front of every A load issued after it and each step then costs one HBM round trip
+    // (measured: ~7000 cycles per wave-step against ~1900 of work). A wave's weights for ALL its steps are small
+    // (<= kMaxSpw x (16 G + 4) B per lane): they are fetched up front in one straight-line block, parked in a
+    // wave-private LDS region, and read back per step with ds_read (its own counter) — the vector-memory queue of
+    // the loop then holds A loads only.
+    const uint32_t spw = a.S > w ? (a.S - w + n_waves - 1) / n_waves : 0; // this wave's steps: w, w + n_waves, ...
+    uint4* const lds_wq = (uint4*)smem + (size_t)w * a.spw_max * G * 64;  // [k][g][lane]
+    uint32_t* const lds_sd = (uint32_t*)((uint4*)smem + (size_t)n_waves * a.spw_max * G * 64) + (size_t)w * a.spw_max * 64; // [k][lane]
+    {
+        BStep all[kMaxSpw];
+#pragma unroll
+        for (int k = 0; k < kMaxSpw; k++)
+            if ((uint32_t)k < spw) load_b(all[k], w + k * n_waves); // (scalar guard) everything is waited for right below anyway
+#pragma unroll
+        for (int k = 0; k < kMaxSpw; k++)
+            if ((uint32_t)k < spw) {
+#pragma unroll
+                for (int g = 0; g < G; g++) lds_wq[(k * G + g) * 64 + lane] = all[k].wq[g];
+                lds_sd[k * 64 + lane] = all[k].sd;
+            }
+    }
+    auto read_b = [&](BStep& b, uint32_t k) { // wave-private: no barrier, the wave's own ds ops are ordered
+#pragma unroll
+        for (int g = 0; g < G; g++) b.wq[g] = lds_wq[(k * G + g) * 64 + lane];
+        b.sd = lds_sd[k * 64 + lane];
+    };
+    if (spw) {
+        BStep cur, nx1;
         AGrp a0, a1;
         BPieces p0, p1;
-        uint32_t s = w;
-        const uint32_t s_last = a.S - 1;
-        load_b(cur, s);
-        load_b(nx1, min(s + n_waves, s_last));
-        load_a(a0, s, 0);
+        const uint32_t k_last = spw - 1;
+        read_b(cur, 0);
+        load_a(a0, w, 0);
         prep(p0, cur, std::integral_constant<int, 0>{});
         __builtin_amdgcn_sched_barrier(0);
-        for (; s < a.S; s += n_waves) {
-            const uint32_t sn = min(s + n_waves, s_last); // clamped, unconditional: the last prefetches re-read live lines
-            load_b(nx2, min(s + 2 * n_waves, s_last));
+        for (uint32_t k = 0; k < spw; k++) {
+            const uint32_t s = w + k * n_waves, kn = min(k + 1, k_last), sn = w + kn * n_waves; // clamped: the last prefetch re-reads live lines
+            read_b(nx1, kn);
             __builtin_amdgcn_sched_barrier(0);
             XDL2_STAGE(load_a(a1, s, 1), prep(p1, cur, std::integral_constant<int, 1>{}), mfmas(p0, a0));
             XDL2_STAGE(load_a(a0, s, 2), prep(p0, cur, std::integral_constant<int, 2>{}), mfmas(p1, a1));
             XDL2_STAGE(load_a(a1, s, 3), prep(p1, cur, std::integral_constant<int, 3>{}), mfmas(p0, a0));
             XDL2_STAGE(load_a(a0, sn, 0), prep(p0, nx1, std::integral_constant<int, 0>{}), mfmas(p1, a1));
-            cur = nx1, nx1 = nx2;
+            cur = nx1;
         }
     }
 #undef XDL2_STAGE
+    __syncthreads(); // the reduction below reuses the weights' LDS region
 
     // D[m = 4 * row + v][n = i] in acc[g][t][v]; fold the waves in fixed order; the tile carries q/16: x 16 (exact)
 #pragma unroll
@@ -1288,7 +1316,9 @@ static bool xdl2_enabled() {
     static const bool on = !(getenv("ZGML_QMM_XDL2") && atoi(getenv("ZGML_QMM_XDL2")) == 0);
     return on;
 }
-static bool xdl2_applies(const QWeightDev& w, uint32_t M) { return M > 1 && w.format == QW_Q4 && w.scale_f16 && xdl2_enabled(); }
+static bool xdl2_applies(const QWeightDev& w, uint32_t M) { // K <= 12288: a wave's weights (<= 12 steps) are preloaded into LDS
+    return M > 1 && w.format == QW_Q4 && w.scale_f16 && xdl2_enabled() && (w.KC + 3) / 4 <= 8 * 12;
+}
 uint64_t qmatmul_scratch_bytes(const QWeightDev& w, uint32_t M) {
     if (!xdl2_applies(w, M)) return 0;
     const uint64_t S = (w.KC + 3) / 4, tiles = (M + 15) / 16, R = M > 16 ? 2 : 1;
@@ -1407,10 +1437,10 @@ TileFn pick_tile(bool two, bool xvec, bool nt) {
 
 template <int R, bool NT>
 void launch_xdl2_rg(hipStream_t s, const QMM2Args& a, uint32_t G, dim3 grid, uint32_t waves, size_t lds) {
-    if (G == 2)
-        hipLaunchKernelGGL((qmatmul_xdl2_kernel<R, 2, NT>), grid, dim3(waves * 64), lds, s, a);
-    else
-        hipLaunchKernelGGL((qmatmul_xdl2_kernel<R, 1, NT>), grid, dim3(waves * 64), lds, s, a);
+    using Fn2 = void (*)(QMM2Args);
+    const Fn2 fn = G == 2 ? (Fn2)qmatmul_xdl2_kernel<R, 2, NT> : (Fn2)qmatmul_xdl2_kernel<R, 1, NT>;
+    if (lds > 64 * 1024) hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(fn, grid, dim3(waves * 64), lds, s, a);
 }
 
 // second XDL form: split x once, then the B-scaled tile kernel (Q4_0, f16 scales); n >= 1 weights that
@@ -1423,21 +1453,25 @@ void launch_xdl2(hipStream_t s, const QWeightDev* w, const QMatmulParams* p, uin
     for (uint32_t t = 0; t < n; t++) total_nb2 += p[t].N / 16;
     const uint32_t G = env_g ? (uint32_t)env_g : (total_nb2 >= 512 ? 2 : 1);
     static const int env_w = getenv("ZGML_QMM_WAVES") ? atoi(getenv("ZGML_QMM_WAVES")) : 8;
-    const uint32_t waves = std::min<uint32_t>(S, (uint32_t)env_w);
+    const uint32_t waves = std::max(std::min<uint32_t>(S, (uint32_t)env_w), cdiv(S, kMaxSpw)), spw_max = cdiv(S, waves); // <= kMaxSpw (xdl2_applies: S <= 96)
+    // LDS: the waves' weights (spw_max steps x (G KB of nibbles + 256 B of scales) each), reused by the final reduction
+    auto b_bytes = [&](uint32_t g) { return (size_t)waves * spw_max * (g * 1024 + 256); };
+    uint32_t Gs = G;
+    if (b_bytes(Gs) > 150 * 1024) Gs = 1; // long K: one column group per workgroup keeps the weights in LDS
     QMM2Args a{};
     uint32_t blocks = 0;
     for (uint32_t t = 0; t < n; t++) {
         a.parts[t] = {(const uint4*)w[t].qs, (const uint4*)w[t].sc, p[t].dst, p[t].dst_rs, p[t].N / 16, blocks};
-        blocks += p[t].N / 16 / G;
+        blocks += p[t].N / 16 / Gs;
     }
-    a.ap = (const uint4*)scratch, a.n_parts = n, a.M = p[0].M, a.U = U, a.S = S;
+    a.ap = (const uint4*)scratch, a.n_parts = n, a.M = p[0].M, a.U = U, a.S = S, a.spw_max = spw_max;
     const dim3 grid(blocks, tiles / R);
-    const size_t lds = (size_t)waves * G * R * 256 * sizeof(float);
+    const size_t lds = std::max((size_t)waves * Gs * R * 256 * sizeof(float), b_bytes(Gs));
     const bool nt = w[0].stream_nt != 0 && tiles / R == 1;
     if (R == 2)
-        nt ? launch_xdl2_rg<2, true>(s, a, G, grid, waves, lds) : launch_xdl2_rg<2, false>(s, a, G, grid, waves, lds);
+        nt ? launch_xdl2_rg<2, true>(s, a, Gs, grid, waves, lds) : launch_xdl2_rg<2, false>(s, a, Gs, grid, waves, lds);
     else
-        nt ? launch_xdl2_rg<1, true>(s, a, G, grid, waves, lds) : launch_xdl2_rg<1, false>(s, a, G, grid, waves, lds);
+        nt ? launch_xdl2_rg<1, true>(s, a, Gs, grid, waves, lds) : launch_xdl2_rg<1, false>(s, a, Gs, grid, waves, lds);
 }
 
 void launch_tile(hipStream_t s, const QWeightDev& w, const QMatmulParams& p, bool xvec, float* scratch) {
