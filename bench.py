@@ -61,26 +61,91 @@ def matvec_roofline(be, K=4096, N=4096, q4=1, ring=64, iters=2048):
             "launches": iters, "timing": "HIP events on the launch stream; ring captured in a hipGraph"}
 
 
-def cpu_baseline(llama, cfg, kind, budget_s=15.0, max_tokens=64):
-    """The oracle decoding the same model on the host cores (bounded sample)."""
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(llama, cfg, kind, budget_s=7.0, max_tokens=64):
+    """The oracle decoding the same model on the host cores, bounded sample, three variants:
+    B1 exact-dequant f32 path on ONE thread (what the reference runs for GGUF weights), B2 the same
+    arithmetic with the output columns split over all host cores, B3 the W8A8 path (quantizeInput + gemvRange over
+    GemvPool's <= 16 workers). `value` is the FASTEST of the three; all three are reported."""
     from oracle import oracle as O
     cores = os.cpu_count() or 1
-    threads = min(cores, 64)
-    O.set_threads(threads)
-    m = llama.Model(cfg, kind, threads=min(threads, 16))
-    s = llama.Session(m, O.backend_fns())
-    s.step(1, 0, want_logits=False)  # warm-up step (llama_smollm_bench.zig:147-170)
-    t0 = time.perf_counter()
-    n, tok = 0, 1
-    while n < max_tokens and (time.perf_counter() - t0) < budget_s:
-        tok, _ = s.step(tok, 1 + n, want_logits=False)
-        n += 1
-    dt = time.perf_counter() - t0
-    s.close()
+    m = llama.Model(cfg, kind, threads=min(cores, 16))
+    variants = {}
+
+    def run(label, threads, w8a8, what):
+        O.set_threads(threads)
+        O.set_w8a8(w8a8)
+        try:
+            s = llama.Session(m, O.backend_fns())
+        finally:
+            O.set_w8a8(False)
+        s.step(1, 0, want_logits=False)  # warm-up step (llama_smollm_bench.zig:147-170)
+        t0 = time.perf_counter()
+        n, tok = 0, 1
+        while n < max_tokens and (time.perf_counter() - t0) < budget_s:
+            tok, _ = s.step(tok, 1 + n, want_logits=False)
+            n += 1
+        dt = time.perf_counter() - t0
+        s.close()
+        variants[label] = {"value": round(n / dt, 2), "threads": threads, "tokens": n, "what": what}
+
+    run("B1_exact_1thread", 1, False, "exact-dequant f32 path (quant.zig:475-578), sequential")
+    run("B2_exact_all_cores", min(cores, 64), False, "same arithmetic, output columns split over the host cores")
+    run("B3_w8a8_gemvpool", min(cores, 16), True, "quantizeInput + gemvRange over GemvPool (<= 16 workers, quant.zig:24-198,320-440)")
+    O.set_threads(1)
     m.close()
-    return {"value": round(n / dt, 2), "unit": "tokens/s", "cores": threads, "kind": "port",
-            "sample": f"{n} greedy tokens of the same SmolLM-135M Q4_0 program through the C oracle "
-                      f"(exact-dequant f32 path of quant.zig:475-578, output columns split over {threads} threads)"}
+    best = max(variants, key=lambda k: variants[k]["value"])
+    return {"value": variants[best]["value"], "unit": "tokens/s", "cores": variants[best]["threads"], "kind": "port",
+            "fastest": best, "variants": variants, "host_cores": cores, "cpu_model": _cpu_model(),
+            "sample": f"greedy tokens of the same SmolLM-135M Q4_0 program through the C oracle, <= {max_tokens} tokens or "
+                      f"{budget_s:.0f} s per variant; `value` = the fastest variant ({best})"}
+
+
+def cpu_config1_q8_matvec(iters=200):
+    """BASELINE configs[0]: one 4096 x 4096 Q8_0 mat-vec through the W8A8 CPU path (prepareTransposed once,
+    then quantizeInput + GemvPool.dispatch per call) on min(cores, 16) workers. Plumbing, no GPU."""
+    import numpy as np
+    from oracle import oracle as O
+    K = N = 4096
+    cores = os.cpu_count() or 1
+    workers = min(cores, 16)
+    i = np.arange(K * N, dtype=np.int64)
+    data = (((i * 13) % 255) - 127).astype(np.int8)  # SURVEY §8d generators
+    b = np.arange(K * N // 32, dtype=np.int64)
+    scales = (2.0 ** -6 * (1.0 + (b % 7) / 8.0)).astype(np.float16).astype(np.float32)
+    x = (((np.arange(K) % 17) - 8) * 0.03125).astype(np.float32)
+    t_data, t_scales = O.prepare_transposed(data, scales, K, N, 32)
+    lib = O.load()
+    O.set_threads(workers)
+    q = np.zeros(K, np.int8)
+    s = np.zeros(K // 32, np.float32)
+    dst = np.zeros(N, np.float32)
+    args_q = (x.ctypes.data, K, 32, q.ctypes.data, s.ctypes.data)
+    args_g = (t_data.ctypes.data, t_scales.ctypes.data, q.ctypes.data, s.ctypes.data, dst.ctypes.data, N, K, 32, workers)
+    for _ in range(8):
+        lib.zo_quantize_input(*args_q)
+        lib.zo_gemv_pool_dispatch(*args_g)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        lib.zo_quantize_input(*args_q)
+        lib.zo_gemv_pool_dispatch(*args_g)
+    us = (time.perf_counter() - t0) / iters * 1e6
+    O.set_threads(1)
+    exact = O.qmatmul_exact(data, scales, x, 1, N, K, 32)
+    nbytes = K * N // 32 * 36 + 4 * K + 4 * N  # int8 [N, K] + one f32 scale per 32 along K, as the transposed copy sits in memory
+    return {"workload": "4096x4096 Q8_0 mat-vec, W8A8 (quantizeInput + gemvRange) on the CPU thread pool (BASELINE configs[0])",
+            "us_per_matvec": round(us, 1), "GBps": round(nbytes / us / 1e3, 2), "bytes_per_matvec": nbytes, "workers": workers,
+            "iters": iters, "host_cores": cores, "cpu_model": _cpu_model(),
+            "max_abs_diff_vs_exact_dequant": float(np.abs(dst - exact).max()), "out_abs_max": float(np.abs(exact).max())}
 
 
 def bench_single(args):
@@ -172,16 +237,27 @@ def bench_single(args):
     except Exception as e:
         extra["quantised_kv_int8"] = {"error": str(e)[:200]}
 
+    parity_failed = False
     if not args.skip_llama7b:
         try:
             extra["llama2_7b"] = bench_llama7b_single(be, llama, args)
+            parity_failed = any("PARITY" in str(v.get("error", "")) for v in extra["llama2_7b"].get("prefill_batch32", {}).values() if isinstance(v, dict))
+        except ParityError as e:  # no Llama-2-7B number without parity: the leg fails loudly (exit code 3 below)
+            extra["llama2_7b"] = {"error": "PARITY FAILURE: " + str(e)[:300]}
+            parity_failed = True
+            log("[bench] " + extra["llama2_7b"]["error"])
         except Exception as e:  # never lose the headline line to the optional leg
             extra["llama2_7b"] = {"error": str(e)[:200]}
 
     cpu = None
     if not args.skip_cpu:
         cpu = cpu_baseline(llama, cfg, llama.Q4_0)
-        log(f"[bench] cpu baseline: {cpu['value']} tok/s on {cpu['cores']} threads")
+        log(f"[bench] cpu baseline: {cpu['value']} tok/s ({cpu['fastest']}); " +
+            ", ".join(f"{k}={v['value']}" for k, v in cpu["variants"].items()))
+        try:
+            extra["cpu_config1_q8_0_matvec"] = cpu_config1_q8_matvec()
+        except Exception as e:
+            extra["cpu_config1_q8_0_matvec"] = {"error": str(e)[:200]}
     be.close()
     out = {
         "metric": "decode_tokens_per_sec", "value": round(value, 1), "unit": "tokens/s", "n_gpus": 1,
@@ -193,6 +269,29 @@ def bench_single(args):
         "roofline": roof, "cpu_baseline": cpu, "extra": extra,
     }
     print(json.dumps(out), flush=True)
+    if parity_failed:
+        sys.exit(3)
+
+
+def verify_l7_prefill(be, llama, kind, T=32):
+    """The tile kernels at 7B shapes (2 layers, one token_len = 32 chunk at position 0 and one at 32) against the
+    oracle's fixture; f16 promotion is compared at 2e-3 (a 1-ulp f32 difference in A can flip its f16 rounding)."""
+    gold = json.loads((ROOT / "tests" / "golden" / "l7dims.json").read_text())["prefill32_" + kind]
+    dense = kind == "f16"
+    cfg = llama.preset("llama2-7b", 512)
+    cfg.n_layers = gold["n_layers"]
+    m = llama.Model(cfg, llama.F32_DENSE if dense else llama.Q4_0, threads=16, token_len=T)
+    s = llama.Session(m, llama.hip_backend_fns(be))
+    try:
+        for ci, ch in enumerate(gold["chunks"]):
+            toks = [(7 * (i + ci * T) + 3) % cfg.vocab_size for i in range(T)]
+            t, logits = s.prefill(toks, ch["pos"])
+            _check_probe(logits, ch["probe"], 2e-3 if dense else 2e-4, f"2-layer 7B-shape prefill ({kind}), chunk at {ch['pos']}")
+            if t != ch["token"]:
+                raise ParityError(f"2-layer 7B-shape prefill ({kind}): token {t} != oracle {ch['token']}")
+    finally:
+        s.close()
+        m.close()
 
 
 def prefill_leg(be, llama, kind, T=32, reps=8, max_seq=512):
@@ -205,6 +304,7 @@ def prefill_leg(be, llama, kind, T=32, reps=8, max_seq=512):
     dense = kind == "f16"
     be.set_option(capi.OPT_F16_DENSE_WEIGHTS, int(dense))
     try:
+        verify_l7_prefill(be, llama, kind, T)  # ParityError: no number is reported for this leg
         t0 = time.perf_counter()
         m = llama.Model(llama.preset("llama2-7b", max_seq), llama.F32_DENSE if dense else llama.Q4_0, threads=16, token_len=T)
         s = llama.Session(m, llama.hip_backend_fns(be))
@@ -234,21 +334,80 @@ def prefill_leg(be, llama, kind, T=32, reps=8, max_seq=512):
             dec = round(48 / (time.perf_counter() - t0), 1)
         s.close()
         m.close()
-        return {"decode_tok_s_batch1": dec, "prefill_tok_s": round(T / dt, 1), "ms_per_chunk": round(dt * 1e3, 3), "token_len": T, "first_token": int(nxt),
+        return {"verified_against_oracle": "tests/golden/l7dims.json prefill32_" + kind + " (2 layers at 7B shapes, both chunks)",
+                "decode_tok_s_batch1": dec, "prefill_tok_s": round(T / dt, 1), "ms_per_chunk": round(dt * 1e3, 3), "token_len": T, "first_token": int(nxt),
                 "logits_finite": finite, "build_s": round(build_s, 1)}
     finally:
         be.set_option(capi.OPT_F16_DENSE_WEIGHTS, 0)
 
 
+class ParityError(RuntimeError):
+    pass
+
+
+def _check_probe(logits, want, tol, what):
+    """Logits against a fixture probe of the oracle (tests/golden/*.json, tools/gen_golden_l7.py): its top-8 values at
+    its indices, the extrema and the absolute sum within `tol` of the logit range, and the same greedy token."""
+    import numpy as np
+    rng = want["max"] - want["min"]
+    err = float(np.abs(logits[np.array(want["top8"])] - np.array(want["top8_vals"], np.float32)).max())
+    ok = (err <= tol * rng and abs(float(logits.max()) - want["max"]) <= tol * rng and abs(float(logits.min()) - want["min"]) <= tol * rng
+          and abs(float(np.sum(np.abs(logits), dtype=np.float64)) - want["abs_sum"]) <= tol * want["abs_sum"]
+          and int(np.argmax(logits)) == want["top8"][0])
+    if not ok:
+        raise ParityError(f"{what}: logits differ from the oracle fixture (top-8 error {err:.3e} of range {rng:.3e}, "
+                          f"argmax {int(np.argmax(logits))} vs {want['top8'][0]})")
+
+
+def verify_l7_shapes(be, llama):
+    """Before any Llama-2-7B number is reported: the HIP path at 7B shapes against the oracle's committed fixture
+    (tests/golden/l7dims.json: 2 layers, d 4096 / 32 x 128 heads / d_ff 11008 / vocab 32000) — vtable steps with
+    logits, then the resident loop's tokens. Raises ParityError on any difference."""
+    gold = json.loads((ROOT / "tests" / "golden" / "l7dims.json").read_text())["decode_f32kv"]
+    cfg = llama.preset("llama2-7b", 512)
+    cfg.n_layers = gold["n_layers"]
+    m = llama.Model(cfg, llama.Q4_0, threads=16)
+    s = llama.Session(m, llama.hip_backend_fns(be))
+    try:
+        tok = gold["first_token"]
+        for pos in range(6):
+            tok, logits = s.step(tok, pos)
+            _check_probe(logits, gold["probes"][pos], 2e-4, f"2-layer 7B-shape decode, position {pos}")
+            if tok != gold["tokens"][pos]:
+                raise ParityError(f"2-layer 7B-shape decode: token {tok} != oracle {gold['tokens'][pos]} at position {pos}")
+        s.resident_setup(be)
+        got = s.resident_decode(gold["first_token"], 0, len(gold["tokens"])).tolist()
+        if got != gold["tokens"]:
+            raise ParityError(f"2-layer 7B-shape resident decode: tokens {got} != oracle {gold['tokens']}")
+    finally:
+        s.close()
+        m.close()
+    return {"fixture": "tests/golden/l7dims.json (oracle, 2 layers at Llama-2-7B dimensions)", "positions_with_logits": 6,
+            "resident_tokens": len(gold["tokens"])}
+
+
 def bench_llama7b_single(be, llama, args):
+    verified = {"reduced_layers": verify_l7_shapes(be, llama)}
     cfg = llama.preset("llama2-7b", 2048)
     t0 = time.perf_counter()
     model = llama.Model(cfg, llama.Q4_0, threads=16)
     sess = llama.Session(model, llama.hip_backend_fns(be))
+    # the timed 32-layer model itself against the oracle's fixture of the SAME program (tests/golden/l7full.json,
+    # `tools/gen_golden_l7.py --full`): 4 greedy positions with logits through the vtable
+    full = json.loads((ROOT / "tests" / "golden" / "l7full.json").read_text())
+    tok = full["first_token"]
+    for pos, (want_tok, probe) in enumerate(zip(full["tokens"], full["probes"])):
+        tok, logits = sess.step(tok, pos)
+        _check_probe(logits, probe, 2e-4, f"32-layer Llama-2-7B decode, position {pos}")
+        if tok != want_tok:
+            raise ParityError(f"32-layer Llama-2-7B decode: token {tok} != oracle {want_tok} at position {pos}")
+    verified["full_model"] = {"fixture": "tests/golden/l7full.json (oracle, all 32 layers)", "positions_with_logits": len(full["tokens"])}
     sess.resident_setup(be)
     build_s = time.perf_counter() - t0
     W, K = 4, min(args.steps, 128)
     warm = sess.resident_decode(1, 0, W)
+    if warm.tolist() != full["tokens"][:W]:
+        raise ParityError(f"32-layer resident decode: tokens {warm.tolist()} != oracle {full['tokens'][:W]}")
     be.synchronize()
     t0 = time.perf_counter()
     sess.resident_decode(int(warm[-1]), W, K)
@@ -285,10 +444,13 @@ def bench_llama7b_single(be, llama, args):
         for kind in ("q4_0", "f16"):
             try:
                 prefill[kind] = prefill_leg(be, llama, kind)
+            except ParityError as e:
+                prefill[kind] = {"error": "PARITY FAILURE: " + str(e)[:300]}
+                log("[bench] " + prefill[kind]["error"])
             except Exception as e:
                 prefill[kind] = {"error": str(e)[:200]}
         prefill["workload"] = "Llama-2-7B prefill, one chunk of 32 tokens, Q4_0 vs dense f16 (BASELINE configs[4])"
-    return {"prefill_batch32": prefill, "tok_s": round(tok_s, 1), "long_context_pos1900_tok_s": long_ctx, "long_context_pos1900_int8_kv_tok_s": kvq_long, "ms_per_token": round(1e3 * dt / K, 3), "steps": K, "build_s": round(build_s, 1),
+    return {"verified_against_oracle": verified, "prefill_batch32": prefill, "tok_s": round(tok_s, 1), "long_context_pos1900_tok_s": long_ctx, "long_context_pos1900_int8_kv_tok_s": kvq_long, "ms_per_token": round(1e3 * dt / K, 3), "steps": K, "build_s": round(build_s, 1),
             "q4_0_weight_bytes": qb, "weight_stream_GBps": round(qb * tok_s / 1e9, 1),
             "frac_of_hbm_peak": round(qb * tok_s / 1e9 / HBM_PEAK_GBPS, 4),
             "workload": "Llama-2-7B Q4_0 greedy decode, batch 1, 1xMI355X (BASELINE configs[2])"}
@@ -309,7 +471,7 @@ def bench_sharded(args):
     rank, ws = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", rank))
     if ws != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={ws}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={ws}")
     torch.cuda.set_device(local)
     torch.cuda.init()  # torch's HIP runtime must be up before libzgml_hip.so is loaded (it then binds to it)
     if "MASTER_ADDR" not in os.environ:  # single-process rehearsal (ZGML_BENCH_FORCE_SHARDED)
@@ -403,6 +565,35 @@ def bench_sharded(args):
     dist.destroy_process_group()
 
 
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks as FRESH child processes
+    (torch.distributed.run, one per GPU, rendezvous on 127.0.0.1) before this process has made any GPU call, relay
+    rank 0's JSON line, return the launcher's exit code. Nothing here touches HIP (no exec of a GPU process)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve()), "--gpus", str(args.gpus), "--steps", str(args.steps),
+           "--warmup", str(args.warmup)]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    log("[bench] launching", " ".join(cmd))
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+    if line:
+        print(line, flush=True)
+    elif r.returncode == 0:
+        log("[bench] ranks exited cleanly but printed no JSON line")
+        return 1
+    return r.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -417,6 +608,8 @@ def main():
         g.build()
     if args.gpus <= 1 and not os.environ.get("ZGML_BENCH_FORCE_SHARDED"):
         bench_single(args)
+    elif args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args))  # no launcher around us: become one (before any GPU call in this process)
     else:
         bench_sharded(args)
 

@@ -35,6 +35,7 @@ def load() -> C.CDLL:
     lib.zo_set_threads.argtypes, lib.zo_set_threads.restype = [i32], None
     lib.zo_set_f16_dense.argtypes, lib.zo_set_f16_dense.restype = [i32], None
     lib.zo_get_threads.argtypes, lib.zo_get_threads.restype = [], i32
+    lib.zo_set_w8a8.argtypes, lib.zo_set_w8a8.restype = [i32], None
     lib.zo_compile_program.argtypes, lib.zo_compile_program.restype = [C.POINTER(capi.DeviceProgramC)], vp
     lib.zo_refresh_program.argtypes, lib.zo_refresh_program.restype = [vp, C.POINTER(capi.DeviceOpC), u64], None
     lib.zo_execute_program.argtypes = [vp, C.POINTER(capi.ProgramIOC), u64, C.POINTER(capi.ProgramIOC), u64]
@@ -71,6 +72,11 @@ def set_threads(n: int) -> None:
 def set_f16_dense(on: bool) -> None:
     """Programs compiled afterwards promote uploaded matmul B operands to f16 (wgpu.zig:1071-1104)."""
     load().zo_set_f16_dense(int(on))
+
+
+def set_w8a8(on: bool) -> None:
+    """Programs compiled afterwards take the W8A8 arm for M = 1 qmatmuls (CPU-baseline variant B3)."""
+    load().zo_set_w8a8(int(on))
 
 
 class OracleBackend:

@@ -525,8 +525,25 @@ void zo_qmatmul_exact(const int8_t* data, const float* scales, uint64_t bs, cons
 
 /* reference.Context.qmatmul, src/backend/reference.zig:499-566. On x86_64 the aarch64-only W8A8
  * arm (:512-528) is compiled out, so the generic exact-dequant loop is the behaviour. */
+void zo_quantize_input(const float* input, uint64_t K, uint64_t bs, int8_t* inp_q, float* inp_scales);
+void zo_gemv_pool_dispatch(const int8_t* t_d, const float* t_s, const int8_t* inp_q, const float* inp_scales,
+                           float* dst, uint64_t N, uint64_t K, uint64_t bs, int n_workers);
+
 static void zo_qmatmul(const zo_buffer* b, const zo_qweight* qws, const zgml_op_qmatmul* q) {
     const zo_qweight* w = &qws[q->weight_idx];
+    /* the W8A8 arm (reference.zig:512-528, taken on aarch64 when the weight carries its transposed copy;
+     * inference_utils.zig:157-176 runs the same arithmetic through GemvPool): only when zo_set_w8a8(1) made
+     * zo_compile_program prepare t_data / t_scales */
+    const uint64_t K = q->K, N = q->N, bs = w->block_size, bpr = bs ? (K + bs - 1) / bs : 0;
+    const uint64_t in_rs = q->input_row_stride ? q->input_row_stride : K, dst_rs = q->dst_row_stride ? q->dst_row_stride : N;
+    if (w->t_data && w->t_scales && q->M == 1 && in_rs == K && dst_rs == N && K <= 16384 && bpr <= 512) {
+        int8_t inp_q[16384];
+        float inp_scales[512];
+        zo_quantize_input(b[q->input].ptr + q->input_offset, K, bs, inp_q, inp_scales);
+        zo_gemv_pool_dispatch(w->t_data, w->t_scales, inp_q, inp_scales, b[q->dst].ptr + q->dst_offset, N, K, bs,
+                              zo_get_threads());
+        return;
+    }
     zo_qmatmul_exact(w->data, w->scales, w->block_size, b[q->input].ptr + q->input_offset,
                      b[q->dst].ptr + q->dst_offset, q->M, q->N, q->K, q->input_row_stride, q->dst_row_stride);
 }
@@ -751,10 +768,18 @@ struct zo_program {
     zgml_device_op* ops;
     zgml_fused_step** steps; /* owned copies, one per op (NULL unless fused) */
     float** f16_shadow;      /* per buffer: packed f16 [K,N] image of a promoted matmul B (else NULL) */
+    int8_t** t_data;         /* per qweight: prepareTransposed copy (zo_set_w8a8), else NULL */
+    float** t_scales;
 };
 
 static int g_f16_dense = 0;
 void zo_set_f16_dense(int on) { g_f16_dense = on; } /* consulted by zo_compile_program */
+static int g_w8a8 = 0;
+/* programs compiled afterwards carry prepareTransposed copies of their quantized weights, so M = 1 qmatmuls take
+ * the W8A8 arm (quantizeInput + gemvRange over GemvPool) — CPU-baseline variant B3, BASELINE.md §3 */
+void zo_set_w8a8(int on) { g_w8a8 = on; }
+void zo_prepare_transposed(const int8_t* data, const float* scales, uint64_t K, uint64_t N, uint64_t bs, int8_t* t_data,
+                           float* t_scales);
 
 static void zo_program_run(zo_program* p, const zgml_device_op* ops, uint64_t n_ops) {
     for (uint64_t i = 0; i < n_ops; i++) {
@@ -833,6 +858,17 @@ zo_program* zo_compile_program(const zgml_device_program* prog) {
         p->qweights[i].scales = p->q_scales[i];
         p->qweights[i].block_size = qw->block_size;
     }
+    p->t_data = (int8_t**)calloc(p->n_qweights ? p->n_qweights : 1, sizeof(int8_t*));
+    p->t_scales = (float**)calloc(p->n_qweights ? p->n_qweights : 1, sizeof(float*));
+    for (uint64_t i = 0; g_w8a8 && i < p->n_qweights; i++) {
+        const uint64_t K = prog->qweights[i].rows, N = prog->qweights[i].cols, bs = p->qweights[i].block_size;
+        if (!K || !N || !bs) continue;
+        p->t_data[i] = (int8_t*)malloc(N * K);
+        p->t_scales[i] = (float*)malloc(sizeof(float) * N * ((K + bs - 1) / bs));
+        zo_prepare_transposed(p->q_data[i], p->q_scales[i], K, N, bs, p->t_data[i], p->t_scales[i]);
+        p->qweights[i].t_data = p->t_data[i];
+        p->qweights[i].t_scales = p->t_scales[i];
+    }
     zo_copy_ops(p, prog->ops, prog->n_ops);
     zo_upload(p, prog->initial_uploads, prog->n_initial_uploads);
     p->f16_shadow = (float**)calloc(p->n_buffers ? p->n_buffers : 1, sizeof(float*));
@@ -884,7 +920,11 @@ void zo_free_program(zo_program* p) {
     for (uint64_t i = 0; i < p->n_qweights; i++) {
         free(p->q_data[i]);
         free(p->q_scales[i]);
+        if (p->t_data) free(p->t_data[i]);
+        if (p->t_scales) free(p->t_scales[i]);
     }
+    free(p->t_data);
+    free(p->t_scales);
     free(p->q_data);
     free(p->q_scales);
     free(p->qweights);

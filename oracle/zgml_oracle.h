@@ -56,6 +56,9 @@ typedef struct zo_program zo_program;
 /* 1: programs compiled from now on promote matmul B operands that have an initial upload to f16
  * (src/backend/wgpu.zig:1071-1104, kernels src/backend/metal.zig:680-760). Default 0. */
 void zo_set_f16_dense(int on);
+/* 1: programs compiled afterwards keep prepareTransposed copies and run M = 1 qmatmuls through the W8A8 arm
+ * (reference.zig:512-528 / inference_utils.zig:157-176): quantizeInput + gemvRange over GemvPool (<= 16 workers) */
+void zo_set_w8a8(int on);
 zo_program* zo_compile_program(const zgml_device_program* program);
 void zo_refresh_program(zo_program* p, const zgml_device_op* ops, uint64_t n_ops);
 void zo_execute_program(zo_program* p, const zgml_program_io* inputs, uint64_t n_inputs,

@@ -90,6 +90,32 @@ def test_resident_decode_equals_vtable_stepping(hip_backend, name, kind):
     m.close()
 
 
+def test_resident_decode_survives_a_plan_rebuild(hip_backend):
+    """The resident graph bakes the plan's kernel nodes and parameter arrays: a plan rebuild (here forced by
+    set_barriers, and by a small-seq_kv refresh in between) must re-capture it, and the rebuilt plan must keep the
+    compile-time attention bound (KV store and its attention never on one level). Checked against vtable stepping."""
+    import ctypes as C
+    hip = capi.load_hip()
+    m = llama.Model(llama.preset("tiny"), llama.Q4_0, threads=8)
+    s = llama.Session(m, llama.hip_backend_fns(hip_backend))
+    n = 16
+    s.resident_setup(hip_backend)
+    first = s.resident_decode(5, 0, n)
+    want, _ = s.decode(5, 0, n)  # the vtable path refreshes seq_kv down to 1, 2, ... (small-seq_kv refreshes)
+    assert first.tolist() == want.tolist()
+    bars = (C.c_uint64 * 1)(m.program.n_ops // 2)
+    assert hip.zgml_hip_program_set_barriers(hip_backend.ctx, s.handle, bars, 1) == 0  # plan_dirty: parameter arrays are freed
+    again = s.resident_decode(5, 0, n)
+    assert not hip_backend.last_error(), hip_backend.last_error()
+    assert again.tolist() == want.tolist()
+    assert hip.zgml_hip_program_set_barriers(hip_backend.ctx, s.handle, None, 0) == 0  # and back
+    s.step(5, 0)  # a refresh with seq_kv = 1 right before the rebuild
+    third = s.resident_decode(5, 0, n)
+    assert third.tolist() == want.tolist()
+    s.close()
+    m.close()
+
+
 @pytest.mark.parametrize("kind", [llama.Q4_0, llama.Q8_0])
 @pytest.mark.parametrize("T", [5, 32])
 def test_prefill_plan_matches_oracle_and_sequential(hip_backend, oracle, kind, T):

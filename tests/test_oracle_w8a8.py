@@ -1,0 +1,134 @@
+"""Rows a4 / a5 / a6 / a7 of SURVEY §8 — the reference's W8A8 CPU plumbing (BASELINE configs[0]):
+`prepareTransposed` (src/quant.zig:274-317), `quantizeInput` (:320-341), `gemvRange` (:358-440) and
+`GemvPool.dispatch` (:24-198), restated in oracle/zgml_oracle.c. The reference pins these by tolerance
+only (src/quant.zig:1133-1210: quantised matmul vs float 0.1, gemv vs matmul 0.15, gemv vs float 0.15 on the
+data below); the structural properties (truncation rounding, zero block -> scale 1, blocks ascending,
+int32-exact dot, N-split invariance) are pinned here as exact statements about the restatement.
+CPU only (no GPU marker): this path never touches the device."""
+import numpy as np
+import pytest
+
+# the reference's own fixtures (src/quant.zig:1165-1210, "gemv matches matmul for M=1")
+W_4x8 = np.array([
+    1.0, 0.5, -0.3, 0.8, -1.0, 0.2, 0.7, -0.4,
+    -0.5, 1.0, 0.6, -0.9, 0.3, -0.7, 0.1, 0.5,
+    0.25, -0.25, 1.0, 0.4, -0.6, 0.9, -0.2, 0.3,
+    0.7, -0.8, 0.15, 1.0, 0.5, -0.3, 0.6, -0.1], dtype=np.float32)
+X_4 = np.array([1.0, 2.0, -0.5, 0.3], dtype=np.float32)
+
+
+def test_gemv_matches_matmul_reference_fixture(oracle):
+    """src/quant.zig:1165-1210 verbatim: K=4, N=8, block 4; gemv ~ matmul (0.15) ~ float (0.15)."""
+    K, N, bs = 4, 8, 4
+    data, scales = oracle.quantize_from_slice(W_4x8, K, N, bs)
+    t_data, t_scales = oracle.prepare_transposed(data, scales, K, N, bs)
+    mm = oracle.qmatmul_exact(data, scales, X_4, 1, N, K, bs)
+    gv = oracle.gemv(t_data, t_scales, X_4, N, K, bs)
+    ref = X_4 @ W_4x8.reshape(K, N)
+    assert np.abs(mm - gv).max() < 0.15
+    assert np.abs(ref - gv).max() < 0.15
+    # the restatement is in fact far inside the reference's bound on this data
+    assert np.abs(mm - gv).max() < 0.03
+
+
+def test_quantised_matmul_reference_fixture(oracle):
+    """src/quant.zig:1133-1163: K=3, N=2, M=2, block 32 vs the float matmul, 0.1."""
+    W = np.array([1.0, 0.5, -0.5, 1.0, 0.25, -0.25], dtype=np.float32)
+    X = np.array([1, 2, 3, 4, 5, 6], dtype=np.float32)
+    data, scales = oracle.quantize_from_slice(W, 3, 2, 32)
+    out = oracle.qmatmul_exact(data, scales, X, 2, 2, 3, 32)
+    ref = (X.reshape(2, 3) @ W.reshape(3, 2)).ravel()
+    assert np.abs(out - ref).max() < 0.1
+
+
+def test_quantize_input_truncates_toward_zero_and_zero_block_scale(oracle):
+    """quant.zig:333-339 (@intFromFloat after the clamp) and :239-246: scale = max_abs/127, a zero block gets
+    scale 1 / inv_scale 0, values are truncated (not rounded) toward zero."""
+    x = np.zeros(64, np.float32)
+    x[:32] = np.linspace(-1.0, 1.0, 32, dtype=np.float32)  # max_abs = 1 -> inv_scale = 127
+    q, s = oracle.quantize_input(x, 32)
+    assert s[0] == np.float32(1.0) / np.float32(127.0) and s[1] == 1.0
+    assert (q[32:] == 0).all()
+    want = np.trunc(np.clip(x[:32] * np.float32(127.0), -127, 127)).astype(np.int8)
+    assert np.array_equal(q[:32], want)
+    # truncation, not rounding: 0.996 * 127 = 126.49 -> 126, -0.999 * 127 = -126.87 -> -126
+    y = np.array([1.0, 0.996, -0.999] + [0.0] * 29, np.float32)
+    q2, _ = oracle.quantize_input(y, 32)
+    assert q2[:3].tolist() == [127, 126, -126]
+
+
+def test_prepare_transposed_layout_and_requantisation(oracle):
+    """quant.zig:274-317: t_data is [N, K] row-major, blocks run along K per output column n, each block is
+    re-quantised from the dequantised values (scale = max_abs/127, truncation), ragged last block included."""
+    rng = np.random.default_rng(0xd3fa)
+    K, N, bs = 37, 11, 32  # the shape of the reference's dequant test (quant.zig:1111-1131): ragged K
+    W = ((rng.random(K * N, dtype=np.float32) - 0.5) * 2.0).astype(np.float32)
+    data, scales = oracle.quantize_from_slice(W, K, N, bs)
+    t_data, t_scales = oracle.prepare_transposed(data, scales, K, N, bs)
+    deq = oracle.dequantize(data, scales, bs).reshape(K, N)
+    bpr = (K + bs - 1) // bs
+    assert t_data.size == N * K and t_scales.size == N * bpr
+    for n in range(N):
+        for b in range(bpr):
+            blk = deq[b * bs:min(K, (b + 1) * bs), n]
+            mx = np.abs(blk).max()
+            sc = np.float32(mx) / np.float32(127.0) if mx > 0 else np.float32(1.0)
+            inv = np.float32(127.0) / np.float32(mx) if mx > 0 else np.float32(0.0)
+            assert t_scales[n * bpr + b] == sc
+            want = np.trunc(np.clip(blk * inv, -127, 127)).astype(np.int8)
+            assert np.array_equal(t_data[n * K + b * bs:n * K + b * bs + blk.size], want)
+
+
+def _gemv_model(t_data, t_scales, q, s, N, K, bs):
+    """gemvRange's arithmetic in numpy: int32-exact block dots, acc += f32(dot) * (s_x[b] * s_w[n,b]), blocks ascending."""
+    bpr = (K + bs - 1) // bs
+    out = np.zeros(N, np.float32)
+    for n in range(N):
+        acc = np.float32(0)
+        for b in range(bpr):
+            k0, k1 = b * bs, min(K, (b + 1) * bs)
+            dot = int(np.dot(q[k0:k1].astype(np.int32), t_data[n * K + k0:n * K + k1].astype(np.int32)))
+            acc = np.float32(acc + np.float32(dot) * np.float32(s[b] * t_scales[n * bpr + b]))
+        out[n] = acc
+    return out
+
+
+@pytest.mark.parametrize("K,N", [(64, 32), (100, 24), (256, 96)])
+def test_gemv_range_is_bit_exact_with_its_definition(oracle, K, N):
+    rng = np.random.default_rng(K * 131 + N)
+    W = rng.standard_normal(K * N).astype(np.float32)
+    x = rng.standard_normal(K).astype(np.float32)
+    data, scales = oracle.quantize_from_slice(W, K, N, 32)
+    t_data, t_scales = oracle.prepare_transposed(data, scales, K, N, 32)
+    q, s = oracle.quantize_input(x, 32)
+    got = oracle.gemv(t_data, t_scales, x, N, K, 32)
+    assert np.array_equal(got, _gemv_model(t_data, t_scales, q, s, N, K, 32))
+    # and W8A8 stays within the reference's 0.15-style bound of the exact-dequant path, scaled to this data
+    exact = oracle.qmatmul_exact(data, scales, x, 1, N, K, 32)
+    assert np.abs(got - exact).max() < 0.02 * np.abs(x).max() * np.abs(W).max() * np.sqrt(K)
+
+
+def test_gemv_pool_dispatch_is_n_split_invariant(oracle):
+    """GemvPool.dispatch (quant.zig:139-198): outputs are split over min(workers, N*K / 2^20, 16) threads in chunks
+    rounded up to 4; every split gives the single-thread result bit for bit. 4096 x 1024 is the smallest power-of-two
+    shape that activates 4 workers (useful = N*K / 2^20)."""
+    K, N = 1024, 4096
+    rng = np.random.default_rng(7)
+    data = rng.integers(-127, 128, K * N, dtype=np.int8)
+    scales = (rng.random(K * N // 32, dtype=np.float32) * 0.01 + 0.001).astype(np.float32)
+    x = rng.standard_normal(K).astype(np.float32)
+    t_data, t_scales = oracle.prepare_transposed(data, scales, K, N, 32)
+    one = oracle.gemv(t_data, t_scales, x, N, K, 32)
+    for workers in (1, 3, 4, 16, 64):  # 64 is clamped to GemvPool.max_workers = 16
+        assert np.array_equal(oracle.gemv(t_data, t_scales, x, N, K, 32, workers=workers), one), workers
+
+
+def test_gemv_pool_small_problem_runs_inline(oracle):
+    """N*K below min_work_per_thread (2^20, quant.zig:150) -> n_active = 1 -> the caller's thread (same numbers)."""
+    K, N = 64, 48
+    rng = np.random.default_rng(3)
+    W = rng.standard_normal(K * N).astype(np.float32)
+    x = rng.standard_normal(K).astype(np.float32)
+    data, scales = oracle.quantize_from_slice(W, K, N, 32)
+    t_data, t_scales = oracle.prepare_transposed(data, scales, K, N, 32)
+    assert np.array_equal(oracle.gemv(t_data, t_scales, x, N, K, 32, workers=8), oracle.gemv(t_data, t_scales, x, N, K, 32))

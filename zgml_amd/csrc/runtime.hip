@@ -143,6 +143,10 @@ struct zgml_hip_program {
     bool plan_batched = false;       // plan was built from dependency levels
     bool batching_safe = true;       // cleared when a refresh leaves the assumed dynamic bounds
     std::vector<uint64_t> barriers;  // op indices nothing may be moved across (multi-GPU harness)
+    // per attention op: the largest seq_kv the caller ever handed over (compile time or a refresh). The schedule
+    // takes the attention's K/V read extent from here, never from the last refreshed value, so a plan rebuilt
+    // after a small-seq_kv refresh cannot put a KV store and the attention that reads it on one level.
+    std::vector<uint32_t> seq_kv_bound;
     std::vector<void*> param_blobs;  // device parameter arrays of batched launches
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
@@ -237,6 +241,12 @@ bool program_supported(const zgml_device_program* pr) {
     std::vector<uint16_t> ids;
     for (uint64_t i = 0; i < pr->n_ops; i++) {
         const zgml_device_op& op = pr->ops[i];
+        if (op.kind == ZGML_DOP_FUSED_ELEMENTWISE && op.u.fused_elementwise.n_steps && !op.u.fused_elementwise.steps) return false;
+        if (op.kind == ZGML_DOP_FUSED_ELEMENTWISE && op.u.fused_elementwise.n_steps > (uint32_t)kMaxFusedSteps) return false;
+        ids.clear(); // buffer ids first: the per-kind checks below index buffer_sizes with them
+        op_buffers(op, ids);
+        for (uint16_t id : ids)
+            if ((uint64_t)id >= pr->n_buffer_sizes) return false;
         switch (op.kind) {
             case ZGML_DOP_ELEMENTWISE:
                 if (!elementwise_op_ok(op.u.elementwise.op)) return false;
@@ -290,10 +300,6 @@ bool program_supported(const zgml_device_program* pr) {
             }
             default: return false;
         }
-        ids.clear();
-        op_buffers(op, ids);
-        for (uint16_t id : ids)
-            if ((uint64_t)id >= pr->n_buffer_sizes) return false;
     }
     return true;
 }
@@ -312,11 +318,16 @@ __global__ void gather_words_kernel(const IoTableDev* table, uint32_t* stage) {
     for (uint32_t i = threadIdx.x; i < e.n_words; i += blockDim.x) dst[i] = src[i];
 }
 
+void free_resident_graph(zgml_hip_program* p); // below (zgml_resident is defined there)
+
+// Drop every captured graph of the program: both bake the plan's kernel nodes and the device parameter arrays
+// build_plan() is about to free, so a plan rebuild must never leave one behind (the resident graph included).
 void free_graph(zgml_hip_program* p) {
     if (p->graph_exec) hipGraphExecDestroy(p->graph_exec);
     if (p->graph) hipGraphDestroy(p->graph);
     p->graph_exec = nullptr;
     p->graph = nullptr;
+    free_resident_graph(p);
 }
 
 bool ensure_stage(zgml_hip_program* p, uint64_t bytes) {
@@ -1679,7 +1690,7 @@ void build_plan(zgml_hip_program* p) {
     p->split_pos = UINT64_MAX - 1, p->split_input = nullptr, p->qmm_group = nullptr, p->f16_group = nullptr;
     p->plan_batched = p->ctx->opt_fusion && p->batching_safe;
     if (p->plan_batched) {
-        p->sched = build_schedule(p->ops, p->sizes, p->barriers);
+        p->sched = build_schedule(p->ops, p->sizes, p->barriers, &p->seq_kv_bound);
         if (!dynamic_fields_in_bounds(p->sched, p->ops)) p->plan_batched = false;
     }
     if (p->plan_batched) {
@@ -1714,7 +1725,21 @@ void set_dyn_from_ops(zgml_hip_program* p) {
 }
 
 // copy ops (and their fused steps) into program-owned storage
+void note_seq_kv_bounds(zgml_hip_program* p) {
+    p->seq_kv_bound.resize(p->ops.size(), 0);
+    for (size_t i = 0; i < p->ops.size(); i++) {
+        uint32_t v = 0;
+        if (p->ops[i].kind == ZGML_DOP_ATTENTION) v = p->ops[i].u.attention.seq_kv;
+        if (p->ops[i].kind == ZGML_DOP_ATTENTION_KVQ) v = p->ops[i].u.attention_kvq.seq_kv;
+        p->seq_kv_bound[i] = std::max(p->seq_kv_bound[i], v);
+    }
+}
+
 void own_ops(zgml_hip_program* p, const zgml_device_op* ops, uint64_t n_ops) {
+    // a static refresh may change an op's kind: bounds of ops that are no longer the same attention start over
+    if (p->seq_kv_bound.size() == n_ops && p->ops.size() == n_ops)
+        for (uint64_t i = 0; i < n_ops; i++)
+            if (p->ops[i].kind != ops[i].kind) p->seq_kv_bound[i] = 0;
     p->ops.assign(ops, ops + n_ops);
     p->steps.assign(n_ops, {});
     for (uint64_t i = 0; i < n_ops; i++) {
@@ -1724,6 +1749,7 @@ void own_ops(zgml_hip_program* p, const zgml_device_op* ops, uint64_t n_ops) {
             p->ops[i].u.fused_elementwise.steps = p->steps[i].data();
         }
     }
+    note_seq_kv_bounds(p);
 }
 
 // true when the static part of two ops is identical (dynamic fields and step pointers ignored)
@@ -1890,11 +1916,18 @@ struct zgml_resident {
 using Resident = zgml_resident;
 namespace {
 
-void free_resident(zgml_hip_program* p) {
+void free_resident_graph(zgml_hip_program* p) {
     Resident* r = p->resident;
     if (!r) return;
     if (r->graph_exec) hipGraphExecDestroy(r->graph_exec);
     if (r->graph) hipGraphDestroy(r->graph);
+    r->graph_exec = nullptr, r->graph = nullptr;
+}
+
+void free_resident(zgml_hip_program* p) {
+    Resident* r = p->resident;
+    if (!r) return;
+    free_resident_graph(p);
     hipFree(r->embed);
     hipFree(r->cos);
     hipFree(r->sin);
@@ -2402,6 +2435,7 @@ void zgml_hip_refresh_program(zgml_hip_ctx* ctx, zgml_hip_program* p, const zgml
             if (ops[i].kind == ZGML_DOP_ATTENTION_KVQ) p->ops[i].u.attention_kvq.seq_kv = ops[i].u.attention_kvq.seq_kv;
         }
         set_dyn_from_ops(p);
+        note_seq_kv_bounds(p);
         if (p->plan_batched && !dynamic_fields_in_bounds(p->sched, p->ops)) {
             // a dynamic field left the span the level schedule assumed: the reordered plan is no
             // longer provably equivalent, fall back to program order for good
@@ -3023,15 +3057,33 @@ int zgml_hip_resident_decode(zgml_hip_ctx* ctx, zgml_hip_program* p, uint32_t fi
         free_graph(p);
         build_plan(p);
     }
+    if (p->plan_batched && n_steps) {
+        // the device patches slice_assign offsets / seq_kv itself (resident_prep_kernel): check the first and
+        // last position of this call against the bounds the batched plan assumed, as refresh_program does
+        bool ok = true;
+        std::vector<zgml_device_op> probe = p->ops;
+        for (uint32_t pos : {start_pos, start_pos + n_steps - 1}) {
+            for (auto& o : probe) {
+                if (o.kind == ZGML_DOP_SLICE_ASSIGN && o.u.slice_assign.patch_stride)
+                    o.u.slice_assign.dst_offset = o.u.slice_assign.dst_base_offset + pos * o.u.slice_assign.patch_stride;
+                if (o.kind == ZGML_DOP_ATTENTION) o.u.attention.seq_kv = pos + 1;
+                if (o.kind == ZGML_DOP_ATTENTION_KVQ) o.u.attention_kvq.seq_kv = pos + 1;
+            }
+            ok = ok && dynamic_fields_in_bounds(p->sched, probe);
+        }
+        if (!ok) { // fall back to program order for good, like refresh_program
+            p->batching_safe = false;
+            free_graph(p);
+            build_plan(p);
+        }
+    }
     if (r->tokens_cap < n_steps) {
         hipStreamSynchronize(s);
         hipFree(r->tokens);
         r->tokens = nullptr;
         if (!CTX_CHECK(ctx, hipMalloc((void**)&r->tokens, (size_t)n_steps * 8))) return -1;
         r->tokens_cap = n_steps;
-        if (r->graph_exec) hipGraphExecDestroy(r->graph_exec); // the graph baked the old pointer/cap
-        if (r->graph) hipGraphDestroy(r->graph);
-        r->graph_exec = nullptr, r->graph = nullptr;
+        free_resident_graph(p); // the graph baked the old pointer/cap
     }
     ResidentPrepArgs a{r->embed, r->cos, r->sin, r->tok_in, r->mask, r->rope_bufs, r->dyn_kind, r->dyn_base, r->dyn_stride,
                        p->dyn_dev, r->state, r->d, r->max_seq, r->dh, r->n_rope, (uint32_t)p->ops.size()};

@@ -48,8 +48,10 @@ struct Schedule {
 
 // `barriers`: sorted op indices; ops before a barrier index never move after it and vice versa
 // (used by the multi-GPU harness, whose collectives sit at those indices).
+// `seq_kv_bound` (optional, one entry per op): the attention read extents come from max(op's seq_kv, bound)
+// rather than from the op's current (possibly refreshed-down) value.
 Schedule build_schedule(const std::vector<zgml_device_op>& ops, const std::vector<uint64_t>& buffer_sizes,
-                        const std::vector<uint64_t>& barriers);
+                        const std::vector<uint64_t>& barriers, const std::vector<uint32_t>* seq_kv_bound = nullptr);
 
 // Levels of an arbitrary list of items with access lists (used for fused macro-ops). `position[i]`
 // is the program-order op index the item stands at (for barrier placement); items must be sorted

@@ -134,7 +134,7 @@ inline bool overlap(const Span& x, const Span& y) { return spans_overlap(x, y); 
 } // namespace
 
 Schedule build_schedule(const std::vector<zgml_device_op>& ops, const std::vector<uint64_t>& buffer_sizes,
-                        const std::vector<uint64_t>& barriers) {
+                        const std::vector<uint64_t>& barriers, const std::vector<uint32_t>* seq_kv_bound) {
     Schedule s;
     const size_t n = ops.size();
     s.bounds.resize(n);
@@ -157,9 +157,11 @@ Schedule build_schedule(const std::vector<zgml_device_op>& ops, const std::vecto
         } else if (ops[i].kind == ZGML_DOP_ATTENTION) {
             s.bounds[i].kind = 2;
             s.bounds[i].max_seq_kv = ops[i].u.attention.seq_kv;
+            if (seq_kv_bound && i < seq_kv_bound->size()) s.bounds[i].max_seq_kv = std::max(s.bounds[i].max_seq_kv, (*seq_kv_bound)[i]);
         } else if (ops[i].kind == ZGML_DOP_ATTENTION_KVQ) {
             s.bounds[i].kind = 3;
             s.bounds[i].max_seq_kv = ops[i].u.attention_kvq.seq_kv;
+            if (seq_kv_bound && i < seq_kv_bound->size()) s.bounds[i].max_seq_kv = std::max(s.bounds[i].max_seq_kv, (*seq_kv_bound)[i]);
         }
     }
     s.access.resize(n);
