@@ -457,6 +457,12 @@ int zgml_hip_resident_decode(zgml_hip_ctx* ctx, zgml_hip_program* handle, uint32
  * error). `bytes_per_launch` receives the algorithmic bytes (K*N/32*{18|34} + 4K + 4N). */
 double zgml_hip_qmatvec_bench(zgml_hip_ctx* ctx, uint32_t K, uint32_t N, int q4, uint32_t n_matrices,
                               uint32_t warmup, uint32_t iters, uint64_t* bytes_per_launch);
+/* A CHAIN of square (K x K) mat-vecs with a true data dependency: launch i computes y_i = (x_i^T W_i) * c (an
+ * epilogue multiply by a constant vector keeps magnitudes bounded) and launch i + 1 reads y_i as its x (ping-pong
+ * vectors; n_matrices even). The roofline figure of bench.py: launches are ordered by DATA, not only by the stream.
+ * Microseconds per launch (< 0 on error). */
+double zgml_hip_qmatvec_chain_bench(zgml_hip_ctx* ctx, uint32_t K, int q4, uint32_t n_matrices, uint32_t warmup, uint32_t iters,
+                                    uint64_t* bytes_per_launch);
 /* Same ring with M input rows (M > 1 runs the f32-MFMA tile kernel used by prefill plans);
  * bytes = weights + 4*M*K + 4*M*N, flops = 2*M*K*N. */
 double zgml_hip_qmatmul_bench(zgml_hip_ctx* ctx, uint32_t M, uint32_t K, uint32_t N, int q4, uint32_t n_matrices,

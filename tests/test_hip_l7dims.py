@@ -41,6 +41,11 @@ def check_probe(logits, want, tol=2e-4):
 
 @pytest.mark.parametrize("kvq", [0, 32])
 def test_decode_two_layers_matches_oracle_and_fixture(hip_backend, oracle, kvq):
+    """f32 KV: 2e-4 of the logit range. int8 KV: storeColumn TRUNCATES x * 127 / max to an integer, so a 1-ulp f32
+    difference in a projected key / value (summation order of the mat-vec) that straddles an integer moves the cached
+    value by a whole quantisation step (1/127 of its block's maximum); over 2 x 32 heads x 128 dims x 12 positions a
+    few such flips happen, hence 1e-3 there (measured 2.1e-4; the f16-promoted path has the same kind of bound)."""
+    tol = 1e-3 if kvq else 2e-4
     gold = GOLD["decode_int8kv" if kvq else "decode_f32kv"]
     oracle.set_threads(16)
     m = llama.Model(l7cfg(2, kvq=kvq), llama.Q4_0, threads=16)
@@ -50,11 +55,11 @@ def test_decode_two_layers_matches_oracle_and_fixture(hip_backend, oracle, kvq):
     for pos in range(len(gold["tokens"])):
         t_hip, l_hip = s_hip.step(tok, pos)
         assert not hip_backend.last_error(), hip_backend.last_error()
-        check_probe(l_hip, gold["probes"][pos])
+        check_probe(l_hip, gold["probes"][pos], tol)
         assert t_hip == gold["tokens"][pos]
         if pos < 4:  # full logits against the oracle run here
             t_ref, l_ref = s_ref.step(tok, pos)
-            assert np.abs(l_hip - l_ref).max() <= 2e-4 * np.abs(l_ref).max() and t_hip == t_ref
+            assert np.abs(l_hip - l_ref).max() <= tol * np.abs(l_ref).max() and t_hip == t_ref
         tok = t_hip
     # the device-resident loop (what bench.py times) produces the same tokens at these shapes
     s_hip.resident_setup(hip_backend)

@@ -1395,16 +1395,6 @@ void launch_packed(hipStream_t s, QMVArgs& a, const QWeightDev& w0, uint32_t tot
     uint32_t waves = qmv_waves(w0, total_blocks);
     if (!xd && a.pro.kind != QMV_PRO_NONE) // a staged prologue keeps all of x in the register window: 16 floats per thread
         while (waves < (uint32_t)kMaxWaves && waves * 64 * 4 * kXRegs < a.K) waves++;
-    dim3 grid(total_blocks, M);
-    const size_t lds = xd ? (size_t)kMaxWaves * 16 * sizeof(float) : qmv_lds_bytes(w0);
-    const uint32_t n_steps = cdiv(a.U, waves * 4);
-    const int depth_sel = n_steps >= 4 ? 2 : (n_steps >= 2 ? 1 : 0); // DEPTH 4 / 2 / 1
-    const bool pro = a.pro.kind != QMV_PRO_NONE, grp = a.n_parts > 1;
-    const bool nt = w0.stream_nt != 0;
-    const KernelFn fn = w0.scale_f16 ? pick_kernel<__half>(xvec, q4, pro, grp, depth_sel, xd, nt)
-                                     : pick_kernel<float>(xvec, q4, pro, grp, depth_sel, xd, nt);
-    if (lds > 64 * 1024) // > 64 KiB of dynamic LDS needs an explicit opt-in per kernel (idempotent)
-        hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
     // parts back to back in the weight arenas (and <= 4 of them): the kernel needs no argument-block fetch to find them
     static const bool contig_ok = !(getenv("ZGML_QMV_CONTIG") && atoi(getenv("ZGML_QMV_CONTIG")) == 0);
     bool contig = a.n_parts > 1 && contig_ok;
@@ -1415,6 +1405,16 @@ void launch_packed(hipStream_t s, QMVArgs& a, const QWeightDev& w0, uint32_t tot
                  (const char*)pt.sc == (const char*)pv.sc + (size_t)(pv.NB2 / 2) * a.U * 16 * sc_elem &&
                  pt.block_begin == pv.block_begin + pv.NB2;
     }
+    dim3 grid(total_blocks, M);
+    const size_t lds = xd ? (size_t)kMaxWaves * 16 * sizeof(float) : qmv_lds_bytes(w0);
+    const uint32_t n_steps = cdiv(a.U, waves * 4);
+    const int depth_sel = n_steps >= 4 ? 2 : (n_steps >= 2 ? 1 : 0); // DEPTH 4 / 2 / 1
+    const bool pro = a.pro.kind != QMV_PRO_NONE, grp = a.n_parts > 1;
+    const bool nt = w0.stream_nt != 0;
+    const KernelFn fn = w0.scale_f16 ? pick_kernel<__half>(xvec, q4, pro, grp, depth_sel, xd, nt)
+                                     : pick_kernel<float>(xvec, q4, pro, grp, depth_sel, xd, nt);
+    if (lds > 64 * 1024) // > 64 KiB of dynamic LDS needs an explicit opt-in per kernel (idempotent)
+        hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
     if (a.n_parts > 1 && (a.parts[1].NB2 > 0xFFFFu || (a.n_parts > 2 && a.parts[2].NB2 > 0xFFFFu))) contig = false; // 16-bit fields
     const uint32_t nb2_12 = contig ? (a.parts[1].NB2 | (a.n_parts > 2 ? a.parts[2].NB2 << 16 : 0u)) : 0u;
     hipLaunchKernelGGL(fn, grid, dim3(waves * 64), lds, s, a.parts[0].qs, a.parts[0].sc, a.parts[0].out, a.pro.a, a.pro.b, a.in_rs, a.K,

@@ -2850,6 +2850,78 @@ double zgml_hip_qmatmul_bench(zgml_hip_ctx* ctx, uint32_t M, uint32_t K, uint32_
     return us;
 }
 
+// ── dependent CHAIN of square mat-vecs (true data dependency) ───────────────────────────────────────────────────
+// Launch i computes y_i = (x_i^T W_i) * c and launch i + 1 consumes y_i as its x (ping-pong vectors; the epilogue
+// multiply by a constant vector keeps the magnitudes bounded), so consecutive launches are ordered by DATA, not only by
+// the stream. (Round-2 experiments on top of this chain — an Infinity-Cache warmer kernel on a second graph branch,
+// per launch and as one progress-paced kernel per pass — made it slower or stalled it)
+double zgml_hip_qmatvec_chain_bench(zgml_hip_ctx* ctx, uint32_t K, int q4, uint32_t n_matrices, uint32_t warmup, uint32_t iters,
+                                    uint64_t* bytes_per_launch) {
+    const uint32_t N = K;
+    if (!ctx || N % 32 || n_matrices < 2 || n_matrices % 2 || !iters) return -1.0;
+    hipSetDevice(ctx->device);
+    std::vector<QWeightDev> ring(n_matrices);
+    bool ok = true;
+    for (uint32_t i = 0; ok && i < n_matrices; i++) ok = make_synth_weight(ctx, K, N, q4, i, &ring[i]);
+    if (ok && (ring[0].qs_bytes + ring[0].sc_bytes) * n_matrices >= (192ull << 20))
+        for (auto& w : ring) w.stream_nt = 1;
+    float *v0 = nullptr, *v1 = nullptr, *cvec = nullptr;
+    std::vector<float> xh(K), ch(N, 0.2f);
+    for (size_t i = 0; i < xh.size(); i++) xh[i] = ((int)(i % 17) - 8) * 0.03125f;
+    ok = ok && CTX_CHECK(ctx, hipMalloc((void**)&v0, K * 4)) && CTX_CHECK(ctx, hipMalloc((void**)&v1, K * 4)) &&
+         CTX_CHECK(ctx, hipMalloc((void**)&cvec, N * 4)) && CTX_CHECK(ctx, hipMemcpy(v0, xh.data(), K * 4, hipMemcpyHostToDevice)) &&
+         CTX_CHECK(ctx, hipMemcpy(cvec, ch.data(), N * 4, hipMemcpyHostToDevice));
+    double us = -1.0;
+    if (ok) {
+        auto one = [&](uint32_t i) { // launch i: x = (i even ? v0 : v1), y = the other (even ring: the wrap keeps the ping-pong)
+            QmvLaunch L;
+            L.n_parts = 1, L.K = K;
+            L.parts[0].w = ring[i];
+            L.parts[0].dst = (i & 1) ? v0 : v1;
+            L.parts[0].n_epi = 1;
+            L.parts[0].epi[0] = QmvEpiStep{ZGML_OP_MUL, 0, cvec, (i & 1) ? v0 : v1};
+            L.pro.kind = QMV_PRO_NONE, L.pro.a = (i & 1) ? v1 : v0;
+            launch_qmatvec_fused(ctx->stream, L);
+        };
+        for (uint32_t i = 0; i < warmup; i++) one(i % n_matrices);
+        hipGraph_t g = nullptr;
+        hipGraphExec_t ge = nullptr;
+        ok = CTX_CHECK(ctx, hipStreamSynchronize(ctx->stream)) && CTX_CHECK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+        if (ok) {
+            for (uint32_t i = 0; i < n_matrices; i++) one(i);
+            ok = CTX_CHECK(ctx, hipStreamEndCapture(ctx->stream, &g)) && CTX_CHECK(ctx, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        }
+        if (ok) {
+            const uint32_t reps = (iters + n_matrices - 1) / n_matrices;
+            hipGraphLaunch(ge, ctx->stream);
+            hipEvent_t e0, e1;
+            hipEventCreate(&e0);
+            hipEventCreate(&e1);
+            hipEventRecord(e0, ctx->stream);
+            for (uint32_t r = 0; r < reps; r++) hipGraphLaunch(ge, ctx->stream);
+            hipEventRecord(e1, ctx->stream);
+            if (CTX_CHECK(ctx, hipEventSynchronize(e1))) {
+                float ms = 0;
+                hipEventElapsedTime(&ms, e0, e1);
+                us = (double)ms * 1000.0 / ((double)reps * n_matrices);
+            }
+            hipEventDestroy(e0);
+            hipEventDestroy(e1);
+        }
+        if (ge) hipGraphExecDestroy(ge);
+        if (g) hipGraphDestroy(g);
+    }
+    if (bytes_per_launch) *bytes_per_launch = (uint64_t)K * N / 32 * (q4 ? 18 : 34) + 4ull * K + 4ull * N;
+    for (auto& w : ring) {
+        hipFree(w.qs);
+        hipFree(w.sc);
+    }
+    hipFree(v0);
+    hipFree(v1);
+    hipFree(cvec);
+    return us;
+}
+
 // The same ring of M = 1 mat-vecs, but as INDEPENDENT launches: the captured graph forks the ring over
 // `n_streams` branches (distinct outputs per branch), so consecutive launches may overlap on the device.
 // Not the decode path (there every mat-vec waits for its predecessor) — it separates what the kernel can
