@@ -43,20 +43,36 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def matvec_roofline(be, K=4096, N=4096, q4=1, ring=64, iters=2048):
+def _pmc_traffic(K, N, q4):
+    """HBM bytes per launch of the roofline kernel from the committed PMC pass (FETCH_SIZE x 2 on gfx950, calibrated on
+    the 1 GiB copy kernel of the same run), newest round first; stamped with the commit the pass was collected at."""
+    if (K, N, q4) != (4096, 4096, 1):
+        return None, None
+    for name in ("r02_qmatvec_pmc.json", "r01_qmatvec_pmc.json"):
+        f = ROOT / "profiles" / name
+        if f.exists():
+            d = json.loads(f.read_text())
+            e = d.get("4096x4096_q4_0", {})
+            return e.get("traffic_bytes_per_launch"), {"file": "profiles/" + name, "source_commit": d.get("source_commit", "round 1 (unstamped)")}
+    return None, None
+
+
+def matvec_roofline(be, K=4096, N=4096, q4=1, ring=64, iters=2048, chain=False):
+    """chain=True: launch i + 1 consumes y_i (ping-pong vectors, an epilogue multiply keeps magnitudes bounded) — a
+    true data dependency, the shape of the decode path; chain=False: the ring on one x / y, ordered by the stream only."""
     nbytes = C.c_uint64()
-    us = be._lib.zgml_hip_qmatvec_bench(be.ctx, K, N, q4, ring, 64, iters, C.byref(nbytes))
+    if chain:
+        us = be._lib.zgml_hip_qmatvec_chain_bench(be.ctx, K, q4, ring, 64, iters, C.byref(nbytes))
+    else:
+        us = be._lib.zgml_hip_qmatvec_bench(be.ctx, K, N, q4, ring, 64, iters, C.byref(nbytes))
     if us <= 0:
         raise RuntimeError("qmatvec_bench: " + be.last_error())
     gbps = nbytes.value / us / 1e3
-    # HBM bytes per launch from the committed PMC pass (FETCH_SIZE x 2 on gfx950, see the json)
-    traffic = None
-    pmc = ROOT / "profiles" / "r01_qmatvec_pmc.json"
-    if pmc.exists() and (K, N, q4) == (4096, 4096, 1):
-        traffic = json.loads(pmc.read_text())["4096x4096_q4_0"]["traffic_bytes_per_launch"]
+    traffic, src = _pmc_traffic(K, N, q4)
     return {"bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": traffic,
+            "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": src,
             "kernel": f"qmatvec_kernel<q4_0> {K}x{N} (single launch per mat-vec)",
+            "dependency": "data (y_i is x_{i+1}; epilogue multiply by a constant vector)" if chain else "stream order (one x / y)",
             "bytes_per_launch": nbytes.value, "us_per_launch": round(us, 3), "ring_matrices": ring,
             "launches": iters, "timing": "HIP events on the launch stream; ring captured in a hipGraph"}
 
@@ -100,6 +116,8 @@ def cpu_baseline(llama, cfg, kind, budget_s=7.0, max_tokens=64):
 
     run("B1_exact_1thread", 1, False, "exact-dequant f32 path (quant.zig:475-578), sequential")
     run("B2_exact_all_cores", min(cores, 64), False, "same arithmetic, output columns split over the host cores")
+    if cores > 16:  # the pool's per-op wake-up of 63 threads costs more than it buys on 576-wide layers: also the moderate split
+        run("B2_exact_16_threads", 16, False, "same arithmetic, output columns split over 16 threads")
     run("B3_w8a8_gemvpool", min(cores, 16), True, "quantizeInput + gemvRange over GemvPool (<= 16 workers, quant.zig:24-198,320-440)")
     O.set_threads(1)
     m.close()
@@ -191,8 +209,11 @@ def bench_single(args):
     sess.close()
     model.close()
 
-    roof = matvec_roofline(be)
-    log(f"[bench] 4096x4096 Q4_0 mat-vec: {roof['us_per_launch']} us, {roof['achieved']} GB/s")
+    roof = matvec_roofline(be, chain=True)
+    log(f"[bench] 4096x4096 Q4_0 mat-vec chain (data-dependent launches): {roof['us_per_launch']} us, {roof['achieved']} GB/s")
+    ring0 = matvec_roofline(be)
+    extra["matvec_q4_0_4096_stream_ordered_ring"] = {"us": ring0["us_per_launch"], "GBps": ring0["achieved"], "frac": ring0["frac"],
+                                                     "note": "the round-1 figure: same x / y for every launch, ordered by the stream only"}
     shapes = {}
     for (k, n) in ((4096, 11008), (11008, 4096), (4096, 32000)):
         r = matvec_roofline(be, k, n, 1, 32, 512)

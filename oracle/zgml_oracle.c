@@ -40,9 +40,16 @@ static struct {
     int inited;
 } g_pool = {.n_threads = 1};
 
+/* a worker starts at the generation current when it was spawned: after zo_set_threads() re-created the pool
+ * `generation` is no longer 0, and a worker starting from 0 would run the PREVIOUS dispatch's stale fn / ctx */
+static struct {
+    int id;
+    uint64_t gen;
+} g_worker_args[ZO_MAX_THREADS];
+
 static void* zo_worker(void* arg) {
-    int id = (int)(intptr_t)arg;
-    uint64_t my_gen = 0;
+    int id = ((int*)arg)[0];
+    uint64_t my_gen = g_worker_args[id].gen;
     for (;;) {
         pthread_mutex_lock(&g_pool.mutex);
         while (g_pool.generation == my_gen && !g_pool.shutdown)
@@ -99,7 +106,9 @@ static void zo_pool_ensure(void) {
     }
     while (g_pool.spawned < g_pool.n_threads - 1) {
         int id = g_pool.spawned + 1;
-        if (pthread_create(&g_pool.threads[id], NULL, zo_worker, (void*)(intptr_t)id) != 0) break;
+        g_worker_args[id].id = id;
+        g_worker_args[id].gen = g_pool.generation; /* only this (dispatching) thread ever bumps it */
+        if (pthread_create(&g_pool.threads[id], NULL, zo_worker, &g_worker_args[id]) != 0) break;
         g_pool.spawned = id;
     }
 }

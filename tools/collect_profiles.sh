@@ -4,11 +4,13 @@
 #   --pmc FETCH_SIZE pass of the mat-vec ring. Summaries land under gpurun_out/prof_<tag>/ ; copy the
 #   ones to be judged into profiles/ (tools/summarise_profiles.py does that).
 set -e -o pipefail
-TAG=${1:-r01}
+TAG=${1:-r02}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-export ZGML_HIP_GRAPH=0   # rocprofv3 (ROCm 7.2) crashes inside hipGraphLaunch of the per-token graph
+# The decode loops are profiled on the GRAPH path (what bench.py times). Round 1 ran them with ZGML_HIP_GRAPH=0 because
+# rocprofv3 crashed inside hipGraphLaunch of the per-token graph; that was the runtime's own use-after-free (the resident
+# graph outlived a plan rebuild that freed its parameter arrays — fixed in round 2), not the profiler.
 run() { # name, command...
   local name=$1; shift
   echo "== $name"
@@ -18,6 +20,7 @@ run() { # name, command...
 run smollm135m_decode python3 tools/decode_run.py smollm-135m 64
 run llama2_7b_decode python3 tools/decode_run.py llama2-7b 32
 run qmatvec_bench python3 tools/bench_matvec.py --shapes 4096x4096 --iters 512
+run qmatvec_chain python3 tools/chain_bench.py 4096 1024
 run llama2_7b_prefill32 python3 tools/prefill_run.py llama2-7b --T 32 --reps 6 --kinds q4,f16
 echo "== pmc"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc -- python3 tools/bench_matvec.py --shapes 4096x4096 --iters 128 > $OUT/pmc.log 2>&1

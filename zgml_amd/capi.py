@@ -256,8 +256,9 @@ def _bind_hip(lib: C.CDLL) -> None:
     lib.zgml_hip_qmatmul_bench.argtypes = [vp, u32, u32, u32, i32, u32, u32, u32, C.POINTER(u64)]
     lib.zgml_hip_qmatvec_overlap_bench.restype = C.c_double
     lib.zgml_hip_qmatvec_overlap_bench.argtypes = [vp, u32, u32, i32, u32, u32, u32, C.POINTER(u64)]
-    lib.zgml_hip_qmatvec_chain_bench.restype = C.c_double
-    lib.zgml_hip_qmatvec_chain_bench.argtypes = [vp, u32, i32, u32, u32, u32, C.POINTER(u64)]
+    if hasattr(lib, "zgml_hip_qmatvec_chain_bench"):  # absent from an older build loaded through ZGML_HIP_LIB (diagnostics)
+        lib.zgml_hip_qmatvec_chain_bench.restype = C.c_double
+        lib.zgml_hip_qmatvec_chain_bench.argtypes = [vp, u32, i32, u32, u32, u32, C.POINTER(u64)]
     lib.zgml_hip_qmatvec_synth.restype = i32
     lib.zgml_hip_qmatvec_synth.argtypes = [vp, u32, u32, i32, u32, vp, vp]
     lib.zgml_hip_resident_setup.restype = i32

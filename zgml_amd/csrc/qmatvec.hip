@@ -1408,7 +1408,7 @@ void launch_packed(hipStream_t s, QMVArgs& a, const QWeightDev& w0, uint32_t tot
     dim3 grid(total_blocks, M);
     const size_t lds = xd ? (size_t)kMaxWaves * 16 * sizeof(float) : qmv_lds_bytes(w0);
     const uint32_t n_steps = cdiv(a.U, waves * 4);
-    const int depth_sel = n_steps >= 4 ? 2 : (n_steps >= 2 ? 1 : 0); // DEPTH 4 / 2 / 1
+    const int depth_sel = n_steps >= 4 ? 2 : (n_steps >= 2 ? 1 : 0); // DEPTH 4 / 2 / 1 (DEPTH 8 for the staged-prologue launches of a 7B model: -9 % tok/s, round 2)
     const bool pro = a.pro.kind != QMV_PRO_NONE, grp = a.n_parts > 1;
     const bool nt = w0.stream_nt != 0;
     const KernelFn fn = w0.scale_f16 ? pick_kernel<__half>(xvec, q4, pro, grp, depth_sel, xd, nt)

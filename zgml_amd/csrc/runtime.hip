@@ -320,6 +320,36 @@ __global__ void gather_words_kernel(const IoTableDev* table, uint32_t* stage) {
 
 void free_resident_graph(zgml_hip_program* p); // below (zgml_resident is defined there)
 
+// Diagnostics: ZGML_HIP_GRAPH_DUMP=<dir> writes <dir>/<tag>.dot (hipGraphDebugDotPrint) and prints the node-type
+// histogram of every graph the runtime instantiates (how the rocprofv3 crash inside hipGraphLaunch of the per-token
+// graph was narrowed down: DESIGN.md section 5).
+void dump_graph(hipGraph_t g, const char* tag) {
+    const char* dir = getenv("ZGML_HIP_GRAPH_DUMP");
+    if (!dir || !g) return;
+    size_t n = 0;
+    if (hipGraphGetNodes(g, nullptr, &n) != hipSuccess) return;
+    std::vector<hipGraphNode_t> nodes(n);
+    if (n && hipGraphGetNodes(g, nodes.data(), &n) != hipSuccess) return;
+    std::map<int, size_t> hist;
+    size_t max_shmem = 0, n_kernel = 0;
+    for (hipGraphNode_t nd : nodes) {
+        hipGraphNodeType t;
+        if (hipGraphNodeGetType(nd, &t) != hipSuccess) continue;
+        hist[(int)t]++;
+        if (t == hipGraphNodeTypeKernel) {
+            hipKernelNodeParams kp{};
+            if (hipGraphKernelNodeGetParams(nd, &kp) == hipSuccess) max_shmem = std::max<size_t>(max_shmem, kp.sharedMemBytes), n_kernel++;
+        }
+    }
+    fprintf(stderr, "[zgml_hip] graph %s: %zu nodes;", tag, n);
+    for (auto& kv : hist) fprintf(stderr, " type%d=%zu", kv.first, kv.second);
+    fprintf(stderr, " (kernel=%d memcpy=%d memset=%d host=%d empty=%d event_record=%d wait_event=%d); max dynamic LDS %zu B over %zu kernel nodes\n",
+            (int)hipGraphNodeTypeKernel, (int)hipGraphNodeTypeMemcpy, (int)hipGraphNodeTypeMemset, (int)hipGraphNodeTypeHost,
+            (int)hipGraphNodeTypeEmpty, (int)hipGraphNodeTypeEventRecord, (int)hipGraphNodeTypeWaitEvent, max_shmem, n_kernel);
+    const std::string path = std::string(dir) + "/" + tag + ".dot";
+    hipGraphDebugDotPrint(g, path.c_str(), 0);
+}
+
 // Drop every captured graph of the program: both bake the plan's kernel nodes and the device parameter arrays
 // build_plan() is about to free, so a plan rebuild must never leave one behind (the resident graph included).
 void free_graph(zgml_hip_program* p) {
@@ -1863,6 +1893,7 @@ void enqueue(zgml_hip_program* p) {
             if (CTX_CHECK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal))) {
                 run_plan(p, ctx->stream, 0, p->plan.size());
                 if (CTX_CHECK(ctx, hipStreamEndCapture(ctx->stream, &g)) && g) {
+                    dump_graph(g, "program");
                     hipGraphExec_t ge = nullptr;
                     if (CTX_CHECK(ctx, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0))) {
                         p->graph = g;
@@ -2816,8 +2847,9 @@ double zgml_hip_qmatmul_bench(zgml_hip_ctx* ctx, uint32_t M, uint32_t K, uint32_
         ok = CTX_CHECK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
         if (ok) {
             for (uint32_t i = 0; i < n_matrices; i++) launch_qmatmul(ctx->stream, ring[i], qp, scratch);
-            ok = CTX_CHECK(ctx, hipStreamEndCapture(ctx->stream, &g)) &&
-                 CTX_CHECK(ctx, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+            ok = CTX_CHECK(ctx, hipStreamEndCapture(ctx->stream, &g));
+            if (ok) dump_graph(g, "ring");
+            ok = ok && CTX_CHECK(ctx, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
         }
         if (ok) {
             const uint32_t reps = (iters + n_matrices - 1) / n_matrices;
@@ -3178,6 +3210,7 @@ int zgml_hip_resident_decode(zgml_hip_ctx* ctx, zgml_hip_program* p, uint32_t fi
         if (CTX_CHECK(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal))) {
             one_token(s);
             if (CTX_CHECK(ctx, hipStreamEndCapture(s, &g)) && g) {
+                dump_graph(g, "resident");
                 if (CTX_CHECK(ctx, hipGraphInstantiate(&r->graph_exec, g, nullptr, nullptr, 0)))
                     r->graph = g;
                 else
