@@ -478,11 +478,13 @@ def bench_llama7b_single(be, llama, args):
 
 
 def bench_sharded(args):
-    import numpy as np
+    """N > 1: one process per GPU; the data path (op ranges + RCCL all-gathers + argmax, one graph per token) runs
+    behind the C ABI (zgml_hip_shard_*); torch.distributed (gloo) is only the control plane here: it carries the
+    128-byte communicator id, the barriers around the timed region and the max over ranks."""
     import torch
     import torch.distributed as dist
     from zgml_amd import Backend, llama
-    from zgml_amd.sharded import HipExecutor, ShardedDecoder
+    from zgml_amd.sharded import NativeShardedDecoder
 
     # RCCL prints a version banner on stdout at init; the contract is ONE JSON line there, so
     # everything until the final print goes to stderr
@@ -493,72 +495,46 @@ def bench_sharded(args):
     local = int(os.environ.get("LOCAL_RANK", rank))
     if ws != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={ws}")
-    torch.cuda.set_device(local)
-    torch.cuda.init()  # torch's HIP runtime must be up before libzgml_hip.so is loaded (it then binds to it)
     if "MASTER_ADDR" not in os.environ:  # single-process rehearsal (ZGML_BENCH_FORCE_SHARDED)
         os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29533"
-    dist.init_process_group("nccl", rank=rank, world_size=ws, device_id=torch.device("cuda", local))
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
     be = Backend(local)
-    from zgml_amd import capi
-    be.set_option(capi.OPT_GRAPH, 0)  # op ranges are launched directly between collectives
+
+    def exchange_id(mine: bytes) -> bytes:
+        t = torch.tensor(list(mine), dtype=torch.uint8)
+        dist.broadcast(t, 0)
+        return bytes(t.tolist())
+
     cfg = llama.preset("llama2-7b", 2048)
     cfg.shard_rank, cfg.shard_world = rank, ws
     model = llama.Model(cfg, llama.Q4_0, threads=max(2, 16 // max(1, ws // 2)))
-    ex = HipExecutor(be, model, local)
-    dec = ShardedDecoder(model, ex)
-    buf_logits = model.buf("logits")
-
-    def step_eager(tok, pos):
-        dec.step(tok, pos, download=False)
-        return be.argmax(ex.handle, buf_logits, 0, cfg.vocab_size)
-
+    dec = NativeShardedDecoder(be, model, rank, ws, exchange_id if ws > 1 else None)
     K = min(args.steps, 256)
-    tok = 1
     W = max(2, args.warmup)
-    for pos in range(W - 1):
-        tok = step_eager(tok, pos)
-    # One graph per token (ops + RCCL all-gathers + argmax recorded once, replayed per token) unless
-    # ZGML_SHARD_GRAPH=0. The first replay is checked against the eager step of the same token; any
-    # failure falls back to the eager loop, so the line is always produced.
-    mode, step = "eager", step_eager
-    if os.environ.get("ZGML_SHARD_GRAPH", "1") != "0":
-        captured = 1
-        try:
-            dec.capture(buf_logits)
-        except Exception as e:  # capture unsupported here: keep the eager loop
-            captured = 0
-            log(f"[bench] rank {rank}: graph capture failed ({type(e).__name__}: {str(e)[:160]}); eager loop")
-        flag = torch.tensor([captured], device="cuda")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # every rank replays, or none does
-        checked = False
-        if int(flag.item()) == 1:
-            same = 1
-            for pos in (W - 1, W):  # two consecutive positions: inputs and dynamic words must follow the replays
-                t_graph = dec.step_graph(tok, pos)
-                t_eager = step_eager(tok, pos)  # same token and position again: idempotent for the KV cache
-                same &= int(t_graph == t_eager)
-                tok = t_eager
-            checked = True
-            flag = torch.tensor([same], device="cuda")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 1:
-                mode, step = "graph", dec.step_graph
-            else:
-                log(f"[bench] rank {rank}: graph replay disagreed with the eager step; eager loop")
-        if not checked:
-            for pos in (W - 1, W):
-                tok = step_eager(tok, pos)
-    else:
-        for pos in (W - 1, W):
-            tok = step_eager(tok, pos)
+    tok = 1
+    toks = []
+    for pos in range(W):
+        tok = dec.step(tok, pos)
+        toks.append(tok)
+    # every rank must have produced the same greedy tokens (replicated logits), and with the whole model on the ranks
+    # they are the oracle's (tests/golden/l7full.json: the unsharded 32-layer program)
+    t = torch.tensor(toks, dtype=torch.int64)
+    gathered = [torch.empty_like(t) for _ in range(ws)]
+    dist.all_gather(gathered, t)
+    if not all(torch.equal(g, gathered[0]) for g in gathered):
+        raise SystemExit("sharded decode: ranks disagree on the greedy tokens")
+    gold = json.loads((ROOT / "tests" / "golden" / "l7full.json").read_text())["tokens"]
+    n_chk = min(len(gold), len(toks))
+    if toks[:n_chk] != gold[:n_chk]:
+        raise SystemExit(f"PARITY FAILURE: sharded decode tokens {toks[:n_chk]} != oracle {gold[:n_chk]}")
     dist.barrier()
-    torch.cuda.synchronize()
+    be.synchronize()
     t0 = time.perf_counter()
     for i in range(K):
-        tok = step(tok, W + 1 + i)
-    torch.cuda.synchronize()
+        tok = dec.step(tok, W + i)
+    be.synchronize()
     dist.barrier()
-    dt = torch.tensor([time.perf_counter() - t0], device="cuda")
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     dt = float(dt.item())
     qb, _ = model.quant_bytes()
@@ -571,7 +547,9 @@ def bench_sharded(args):
                                    "(BASELINE configs[3])",
                        "weights": "synthetic Q4_0", "max_seq": cfg.max_seq_len,
                        "parallelism": f"tp{ws} (N-split weights, replicated activations, head-sharded KV)",
-                       "collectives_per_token": len(model.gather_points()) if ws > 1 else 0, "step_mode": mode,
+                       "collectives_per_token": dec.n_points if ws > 1 else 0, "rccl_ranks": ws, "step_mode": dec.mode,
+                       "data_path": "zgml_hip_shard_step (C ABI): op ranges + in-place ncclAllGather + argmax, one graph per token",
+                       "verified": f"first {n_chk} greedy tokens equal the oracle's for the unsharded 32-layer program; all ranks agree",
                        "compare_with": "extra.llama2_7b.tok_s of the --gpus 1 line (same model, unsharded)"},
             "roofline": None, "cpu_baseline": None,
             "extra": {"q4_0_weight_bytes_per_rank": qb},
@@ -580,7 +558,7 @@ def bench_sharded(args):
         os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)
-    ex.close()
+    dec.close()
     model.close()
     be.close()
     dist.destroy_process_group()

@@ -427,6 +427,34 @@ void zgml_hip_download_outputs(zgml_hip_ctx* ctx, zgml_hip_program* handle, cons
 int64_t zgml_hip_argmax(zgml_hip_ctx* ctx, zgml_hip_program* handle, uint16_t buf_idx,
                         uint64_t offset, uint64_t n);
 
+/* ── Row-shard (N-split) execution across the GPUs of one node (the reference has no distributed code) ──
+ * One process and one context per GPU. Every quantized weight of the per-rank program is split along N (whole 32-column
+ * scale blocks), activations are replicated, KV caches are head-sharded; between op ranges the replicated activation is
+ * restored by ONE in-place all-gather (RCCL over xGMI, enqueued on the context stream). librccl.so is opened at run time
+ * by these entry points only. Typical use (the host side of zgml_amd/host builds the per-rank program and its gather
+ * points): rank 0 calls shard_unique_id and hands the 128 bytes to the other ranks by any channel; every rank calls
+ * shard_init, compile_program, shard_attach, then per token refresh_program + shard_step. */
+typedef struct zgml_shard_point {
+    uint64_t op_end;       /* ops [previous op_end, op_end) run before this gather */
+    uint16_t buf_idx;      /* program buffer holding the replicated vector */
+    uint16_t _pad;
+    uint32_t offset;       /* f32 elements: the vector is [offset, offset + world * len_per_rank) */
+    uint32_t len_per_rank; /* rank r owns [offset + r * len_per_rank, ...) before the gather */
+} zgml_shard_point;
+int zgml_hip_shard_unique_id(unsigned char id_out[128]);                 /* ncclGetUniqueId; 0 on success */
+int zgml_hip_shard_init(zgml_hip_ctx* ctx, const unsigned char id[128], int rank, int world); /* ncclCommInitRank on the context's device */
+void zgml_hip_shard_destroy(zgml_hip_ctx* ctx);                            /* also done by zgml_hip_destroy */
+/* Declare the program's all-gather points (ascending op_end) and the logits the greedy token is taken from
+ * (after the last gather every rank holds the full vocabulary). Also sets the plan barriers at those op indices. */
+int zgml_hip_shard_attach(zgml_hip_ctx* ctx, zgml_hip_program* program, const zgml_shard_point* points, uint64_t n_points,
+                          uint16_t logits_buf, uint64_t vocab);
+/* One decode step on this rank: stage + upload the inputs, run the op ranges with the all-gathers between them, argmax
+ * of the gathered logits; blocking. The device side is recorded into one graph on the first call and replayed
+ * afterwards (ZGML_SHARD_GRAPH=0 or a failed capture: issued eagerly). Returns the greedy token, < 0 on error. Every
+ * rank must call it for every step (the collectives are collective). */
+int64_t zgml_hip_shard_step(zgml_hip_ctx* ctx, zgml_hip_program* program, const zgml_program_io* inputs, uint64_t n_inputs);
+int zgml_hip_shard_step_mode(zgml_hip_program* program); /* 1: steps replay one graph per token, 0: eager */
+
 /* Device-resident greedy decode for LLaMA-shaped programs (measurement protocol: inputs already
  * in HBM when the timed region starts). The reference's per-token host work — embedding-row
  * copy, causal-mask column, RoPE row, KV position / seq_kv patching, logits download + argmax

@@ -16,3 +16,12 @@ def test_sharded_driver_world_size_one():
     worker = Path(__file__).parent / "sharded_ws1_worker.py"
     r = subprocess.run([sys.executable, str(worker)], capture_output=True, text=True, timeout=580)
     assert r.returncode == 0 and "SHARDED_WS1_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.timeout(600)
+def test_native_shard_path_world_size_one():
+    """The same step behind the C ABI (zgml_hip_shard_*: the library owns the RCCL communicator and enqueues the
+    all-gathers itself; graph and eager forms) — what `bench.py --gpus N` runs on every rank."""
+    worker = Path(__file__).parent / "sharded_native_worker.py"
+    r = subprocess.run([sys.executable, str(worker)], capture_output=True, text=True, timeout=580)
+    assert r.returncode == 0 and "SHARDED_NATIVE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -193,7 +193,14 @@ HIP_SYMBOLS = [
     "zgml_hip_enqueue_ops", "zgml_hip_program_set_barriers", "zgml_hip_synchronize", "zgml_hip_upload_inputs", "zgml_hip_download_outputs", "zgml_hip_argmax", "zgml_hip_qmatvec_bench",
     "zgml_hip_qmatmul_bench", "zgml_hip_qmatvec_overlap_bench", "zgml_hip_qmatvec_chain_bench", "zgml_hip_dense_f16_bench", "zgml_hip_dense_cache_invalidate", "zgml_hip_dense_cache_stats",
     "zgml_hip_qmatvec_synth", "zgml_hip_copy_bench", "zgml_hip_resident_setup", "zgml_hip_resident_decode",
+    "zgml_hip_shard_unique_id", "zgml_hip_shard_init", "zgml_hip_shard_destroy", "zgml_hip_shard_attach", "zgml_hip_shard_step", "zgml_hip_shard_step_mode",
 ]
+
+class ShardPointC(C.Structure):
+    """zgml_shard_point (include/zgml_hip.h)."""
+    _fields_ = [("op_end", C.c_uint64), ("buf_idx", C.c_uint16), ("_pad", C.c_uint16), ("offset", C.c_uint32),
+                ("len_per_rank", C.c_uint32)]
+
 
 OPT_FUSION, OPT_GRAPH, OPT_PROFILE, OPT_SKIP_DEAD_UPLOADS, OPT_F16_DENSE_WEIGHTS, OPT_DENSE_WEIGHT_CACHE = 1, 2, 3, 4, 5, 6
 OPT_ATTN_SPLIT_MIN_KEYS = 7
@@ -256,6 +263,14 @@ def _bind_hip(lib: C.CDLL) -> None:
     lib.zgml_hip_qmatmul_bench.argtypes = [vp, u32, u32, u32, i32, u32, u32, u32, C.POINTER(u64)]
     lib.zgml_hip_qmatvec_overlap_bench.restype = C.c_double
     lib.zgml_hip_qmatvec_overlap_bench.argtypes = [vp, u32, u32, i32, u32, u32, u32, C.POINTER(u64)]
+    if hasattr(lib, "zgml_hip_shard_init"):
+        lib.zgml_hip_shard_unique_id.restype, lib.zgml_hip_shard_unique_id.argtypes = i32, [vp]
+        lib.zgml_hip_shard_init.restype, lib.zgml_hip_shard_init.argtypes = i32, [vp, vp, i32, i32]
+        lib.zgml_hip_shard_destroy.restype, lib.zgml_hip_shard_destroy.argtypes = None, [vp]
+        lib.zgml_hip_shard_attach.restype = i32
+        lib.zgml_hip_shard_attach.argtypes = [vp, vp, C.POINTER(ShardPointC), u64, C.c_uint16, u64]
+        lib.zgml_hip_shard_step.restype, lib.zgml_hip_shard_step.argtypes = C.c_int64, [vp, vp, C.POINTER(ProgramIOC), u64]
+        lib.zgml_hip_shard_step_mode.restype, lib.zgml_hip_shard_step_mode.argtypes = i32, [vp]
     if hasattr(lib, "zgml_hip_qmatvec_chain_bench"):  # absent from an older build loaded through ZGML_HIP_LIB (diagnostics)
         lib.zgml_hip_qmatvec_chain_bench.restype = C.c_double
         lib.zgml_hip_qmatvec_chain_bench.argtypes = [vp, u32, i32, u32, u32, u32, C.POINTER(u64)]

@@ -66,6 +66,7 @@ struct IoPlan {
 
 } // namespace
 
+struct ShardState;
 struct zgml_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -92,6 +93,7 @@ struct zgml_hip_ctx {
     int64_t* arg_idx = nullptr;
     int64_t* arg_out = nullptr;
     int64_t* arg_out_host = nullptr; // pinned
+    struct ShardState* shard = nullptr; // RCCL communicator of the row-shard path (zgml_hip_shard_*), else nullptr
 
     void fail(const std::string& what) {
         if (err.empty()) err = what;
@@ -158,6 +160,14 @@ struct zgml_hip_program {
     uint64_t staged_bytes = 0, staged_n = 0; // zgml_hip_stage_inputs / enqueue_staged
     zgml_runtime_profile profile{};
     zgml_resident* resident = nullptr;
+    // row-shard path (zgml_hip_shard_attach): all-gather points in op order, the logits for the greedy token, and the
+    // captured graph of one whole step (staged inputs, op ranges, all-gathers, argmax)
+    std::vector<zgml_shard_point> shard_points;
+    uint16_t shard_logits_buf = 0;
+    uint64_t shard_vocab = 0;
+    hipGraph_t shard_graph = nullptr;
+    hipGraphExec_t shard_graph_exec = nullptr;
+    bool shard_capture_failed = false;
 };
 
 namespace {
@@ -357,6 +367,9 @@ void free_graph(zgml_hip_program* p) {
     if (p->graph) hipGraphDestroy(p->graph);
     p->graph_exec = nullptr;
     p->graph = nullptr;
+    if (p->shard_graph_exec) hipGraphExecDestroy(p->shard_graph_exec);
+    if (p->shard_graph) hipGraphDestroy(p->shard_graph);
+    p->shard_graph_exec = nullptr, p->shard_graph = nullptr;
     free_resident_graph(p);
 }
 
@@ -2065,8 +2078,10 @@ zgml_hip_ctx* zgml_hip_create(int device_ordinal) {
     return ctx;
 }
 
+void zgml_hip_shard_destroy(zgml_hip_ctx* ctx);
 void zgml_hip_destroy(zgml_hip_ctx* ctx) {
     if (!ctx) return;
+    zgml_hip_shard_destroy(ctx);
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     ctx->drop_b_cache();
@@ -3235,5 +3250,181 @@ int zgml_hip_resident_decode(zgml_hip_ctx* ctx, zgml_hip_program* p, uint32_t fi
     p->profile.backend_dispatch_count += (uint64_t)n_steps * (p->plan.size() + 4);
     return ok ? 0 : -1;
 }
+
+
+// ── row-shard (N-split) path behind the C ABI: RCCL all-gathers between op ranges ─────────────────────
+// One process per GPU (the caller's launcher decides ranks). librccl.so is opened at run time by zgml_hip_shard_*
+// only, so single-GPU users of the library carry no dependency on it. The communicator lives in the context; a step's
+// whole device side (H2D of the staged inputs, op ranges, in-place ncclAllGather of the replicated activations, argmax)
+// is recorded once into a graph on the context stream and replayed per token — the messages are 2-44 KB, so the step is
+// bound by launch and collective latency, not by xGMI bandwidth.
+} // extern "C"
+#include <dlfcn.h>
+struct ShardState {
+    void* lib = nullptr;
+    void* comm = nullptr;
+    int rank = 0, world = 1;
+    int (*get_unique_id)(void*) = nullptr;
+    int (*comm_init_rank)(void**, int, /* ncclUniqueId by value: 128 bytes */ struct Id128, int) = nullptr;
+    int (*all_gather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*comm_destroy)(void*) = nullptr;
+    const char* (*get_error_string)(int) = nullptr;
+};
+struct Id128 {
+    char b[128];
+};
+namespace {
+constexpr int kNcclFloat = 7; // ncclFloat32 (rccl.h ncclDataType_t)
+bool shard_load(zgml_hip_ctx* ctx, ShardState* st) {
+    if (st->lib) return true;
+    for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+        st->lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (st->lib) break;
+    }
+    if (!st->lib) {
+        if (ctx) ctx->fail(std::string("shard: cannot open librccl.so: ") + dlerror());
+        return false;
+    }
+    st->get_unique_id = (int (*)(void*))dlsym(st->lib, "ncclGetUniqueId");
+    st->comm_init_rank = (int (*)(void**, int, Id128, int))dlsym(st->lib, "ncclCommInitRank");
+    st->all_gather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(st->lib, "ncclAllGather");
+    st->comm_destroy = (int (*)(void*))dlsym(st->lib, "ncclCommDestroy");
+    st->get_error_string = (const char* (*)(int))dlsym(st->lib, "ncclGetErrorString");
+    if (!st->get_unique_id || !st->comm_init_rank || !st->all_gather || !st->comm_destroy) {
+        if (ctx) ctx->fail("shard: librccl.so lacks an expected entry point");
+        return false;
+    }
+    return true;
+}
+ShardState g_shard_loader; // for zgml_hip_shard_unique_id (no context yet)
+
+// the device side of one sharded step on stream order: op ranges separated by in-place all-gathers
+bool shard_segments(zgml_hip_ctx* ctx, zgml_hip_program* p) {
+    ShardState* st = ctx->shard;
+    uint64_t prev = 0;
+    for (const zgml_shard_point& gp : p->shard_points) {
+        if (gp.op_end > prev) zgml_hip_enqueue_ops(ctx, p, prev, gp.op_end - prev);
+        float* full = p->bufs[gp.buf_idx] + gp.offset;
+        const int rc = st->all_gather(full + (uint64_t)st->rank * gp.len_per_rank, full, gp.len_per_rank, kNcclFloat, st->comm, ctx->stream);
+        if (rc != 0) {
+            ctx->fail(std::string("shard: ncclAllGather: ") + (st->get_error_string ? st->get_error_string(rc) : "error"));
+            return false;
+        }
+        prev = gp.op_end;
+    }
+    if (p->ops.size() > prev) zgml_hip_enqueue_ops(ctx, p, prev, p->ops.size() - prev);
+    return ctx->err.empty();
+}
+} // namespace
+extern "C" {
+
+int zgml_hip_shard_unique_id(unsigned char id_out[128]) {
+    if (!id_out || !shard_load(nullptr, &g_shard_loader)) return -1;
+    return g_shard_loader.get_unique_id(id_out) == 0 ? 0 : -1;
+}
+
+int zgml_hip_shard_init(zgml_hip_ctx* ctx, const unsigned char id[128], int rank, int world) {
+    if (!ctx || !id || world < 1 || rank < 0 || rank >= world) return -1;
+    hipSetDevice(ctx->device);
+    if (ctx->shard) return -1; // one communicator per context
+    ShardState* st = new ShardState();
+    if (!shard_load(ctx, st)) {
+        delete st;
+        return -1;
+    }
+    Id128 uid;
+    memcpy(uid.b, id, 128);
+    st->rank = rank, st->world = world;
+    const int rc = st->comm_init_rank(&st->comm, world, uid, rank);
+    if (rc != 0) {
+        ctx->fail(std::string("shard: ncclCommInitRank: ") + (st->get_error_string ? st->get_error_string(rc) : "error"));
+        delete st;
+        return -1;
+    }
+    ctx->shard = st;
+    return 0;
+}
+
+void zgml_hip_shard_destroy(zgml_hip_ctx* ctx) {
+    if (!ctx || !ctx->shard) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    if (ctx->shard->comm) ctx->shard->comm_destroy(ctx->shard->comm);
+    delete ctx->shard;
+    ctx->shard = nullptr;
+}
+
+int zgml_hip_shard_attach(zgml_hip_ctx* ctx, zgml_hip_program* p, const zgml_shard_point* points, uint64_t n_points, uint16_t logits_buf,
+                          uint64_t vocab) {
+    if (!ctx || !p || (n_points && !points)) return -1;
+    const uint32_t world = ctx->shard ? (uint32_t)ctx->shard->world : 1u;
+    std::vector<uint64_t> bars;
+    uint64_t prev = 0;
+    for (uint64_t i = 0; i < n_points; i++) {
+        const zgml_shard_point& gp = points[i];
+        if (gp.op_end < prev || gp.op_end > p->ops.size() || gp.buf_idx >= p->bufs.size() || !p->bufs[gp.buf_idx] ||
+            (uint64_t)gp.offset + (uint64_t)world * gp.len_per_rank > p->sizes[gp.buf_idx]) {
+            ctx->fail("shard_attach: gather point " + std::to_string(i) + " out of range");
+            return -1;
+        }
+        prev = gp.op_end;
+        bars.push_back(gp.op_end);
+    }
+    if (logits_buf >= p->bufs.size() || !p->bufs[logits_buf] || vocab > p->sizes[logits_buf]) {
+        ctx->fail("shard_attach: bad logits buffer");
+        return -1;
+    }
+    p->shard_points.assign(points, points + n_points);
+    p->shard_logits_buf = logits_buf, p->shard_vocab = vocab;
+    p->shard_capture_failed = false;
+    return zgml_hip_program_set_barriers(ctx, p, bars.data(), bars.size()); // batched launches never straddle a collective
+}
+
+int64_t zgml_hip_shard_step(zgml_hip_ctx* ctx, zgml_hip_program* p, const zgml_program_io* inputs, uint64_t n_inputs) {
+    if (!ctx || !p || !ctx->shard) return -1;
+    hipSetDevice(ctx->device);
+    hipStream_t s = ctx->stream;
+    if (p->plan_dirty) {
+        free_graph(p);
+        build_plan(p);
+    }
+    if (zgml_hip_stage_inputs(ctx, p, inputs, n_inputs) != 0) return -1;
+    static const bool want_graph = !(getenv("ZGML_SHARD_GRAPH") && atoi(getenv("ZGML_SHARD_GRAPH")) == 0);
+    if (want_graph && ctx->opt_graph && !p->shard_graph_exec && !p->shard_capture_failed) {
+        // relaxed capture: RCCL may touch its own (already created) resources while it enqueues
+        hipGraph_t g = nullptr;
+        bool ok = hipStreamSynchronize(s) == hipSuccess && hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) == hipSuccess;
+        if (ok) {
+            zgml_hip_enqueue_staged(ctx, p);
+            const bool seg = shard_segments(ctx, p);
+            launch_argmax(s, p->bufs[p->shard_logits_buf], p->shard_vocab, ctx->arg_val, ctx->arg_idx, ctx->arg_out);
+            hipMemcpyAsync(ctx->arg_out_host, ctx->arg_out, sizeof(int64_t), hipMemcpyDeviceToHost, s);
+            ok = hipStreamEndCapture(s, &g) == hipSuccess && g && seg;
+        }
+        if (ok) ok = hipGraphInstantiate(&p->shard_graph_exec, g, nullptr, nullptr, 0) == hipSuccess;
+        if (ok) {
+            p->shard_graph = g;
+        } else {
+            if (g) hipGraphDestroy(g);
+            p->shard_graph_exec = nullptr;
+            p->shard_capture_failed = true; // eager from now on (all ranks decide alike: same program, same runtime)
+            (void)hipGetLastError();
+            if (!ctx->err.empty()) return -1;
+        }
+    }
+    if (p->shard_graph_exec) {
+        if (!CTX_CHECK(ctx, hipGraphLaunch(p->shard_graph_exec, s))) return -1;
+    } else {
+        zgml_hip_enqueue_staged(ctx, p);
+        if (!shard_segments(ctx, p)) return -1;
+        launch_argmax(s, p->bufs[p->shard_logits_buf], p->shard_vocab, ctx->arg_val, ctx->arg_idx, ctx->arg_out);
+        hipMemcpyAsync(ctx->arg_out_host, ctx->arg_out, sizeof(int64_t), hipMemcpyDeviceToHost, s);
+    }
+    if (!CTX_CHECK(ctx, hipStreamSynchronize(s))) return -1;
+    p->profile.call_count++;
+    return *ctx->arg_out_host;
+}
+
+int zgml_hip_shard_step_mode(zgml_hip_program* p) { return !p ? -1 : (p->shard_graph_exec ? 1 : 0); } // 1 = one graph per token
 
 } // extern "C"

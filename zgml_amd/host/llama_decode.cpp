@@ -1,6 +1,8 @@
 // llama_decode.cpp — see llama_decode.hpp for the reference map.
 #include "llama_decode.hpp"
 
+#include <cstdlib>
+
 #include <algorithm>
 #include <functional>
 #include <cmath>
@@ -288,7 +290,11 @@ std::unique_ptr<DecodeProgram> build_decode_program(const LlamaModel& model, boo
     const uint32_t H_loc = H / ws, KV_loc = KV / ws, h0 = r * H_loc, kv0 = r * KV_loc;
     const uint32_t d_loc = d / ws, kvd_loc = c.kv_dim() / ws, ff_loc = ff / ws;
     const float attn_scale = 1.0f / std::sqrt((float)dh);
-    const bool sharded = ws > 1;
+    // rehearsal switch (tests): mark the gather points also at world size 1 (token_len 1, untied head), so a single
+    // GPU exercises every collective call of the N > 1 path as a 1-rank in-place all-gather
+    const bool rehearse = ws == 1 && token_len <= 1 && !c.tied_lm_head && getenv("ZGML_HOST_SHARD_POINTS_WORLD1") &&
+                          atoi(getenv("ZGML_HOST_SHARD_POINTS_WORLD1")) != 0;
+    const bool sharded = ws > 1 || rehearse;
     const uint32_t T = token_len ? token_len : 1; // tokens per execution: 1 = decode plan, N = prefill plan
     dp.token_len = T;
 

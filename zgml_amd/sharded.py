@@ -22,6 +22,56 @@ from . import capi
 from .llama import Model
 
 
+class NativeShardedDecoder:
+    """The row-shard step behind the C ABI (zgml_hip_shard_*): the library owns the RCCL communicator and enqueues the
+    all-gathers itself, one graph per token. Python only patches the per-token leaves (the host mirror of
+    LlamaDeviceSession) and hands the 128-byte communicator id around — `exchange_id` is any callable that returns
+    rank 0's bytes on every rank (bench.py broadcasts it over a gloo control plane; world size 1 needs none)."""
+
+    def __init__(self, backend, model: Model, rank: int, world: int, exchange_id=None):
+        self.be, self.model, self.lib = backend, model, capi.load_hip()
+        uid = (C.c_ubyte * 128)()
+        if rank == 0 and self.lib.zgml_hip_shard_unique_id(uid) != 0:
+            raise RuntimeError("shard_unique_id failed (librccl.so?)")
+        if exchange_id is not None:
+            raw = exchange_id(bytes(uid))
+            uid = (C.c_ubyte * 128)(*raw)
+        if self.lib.zgml_hip_shard_init(backend.ctx, uid, rank, world) != 0:
+            raise RuntimeError("shard_init: " + backend.last_error())
+        prog = model.program
+        self.handle = self.lib.zgml_hip_compile_program(backend.ctx, C.byref(prog))
+        if not self.handle:
+            raise RuntimeError("compile failed: " + backend.last_error())
+        pts = model.gather_points()
+        arr = (capi.ShardPointC * max(1, len(pts)))()
+        for i, gp in enumerate(pts):
+            arr[i] = capi.ShardPointC(gp.op_end, gp.buf, 0, gp.offset, gp.len_per_rank)
+        if self.lib.zgml_hip_shard_attach(backend.ctx, self.handle, arr, len(pts), model.buf("logits"), model.cfg.vocab_size) != 0:
+            raise RuntimeError("shard_attach: " + backend.last_error())
+        self.n_points = len(pts)
+        n = C.c_uint64()
+        self._in = model.lib.zh_model_step_inputs(model.ptr, C.byref(n)), n.value
+
+    def step(self, token: int, pos: int) -> int:
+        self.model.patch(token, pos)
+        prog = self.model.program
+        self.lib.zgml_hip_refresh_program(self.be.ctx, self.handle, prog.ops, prog.n_ops)
+        tok = int(self.lib.zgml_hip_shard_step(self.be.ctx, self.handle, self._in[0], self._in[1]))
+        if tok < 0:
+            raise RuntimeError("shard_step: " + self.be.last_error())
+        return tok
+
+    @property
+    def mode(self) -> str:
+        return "graph" if self.lib.zgml_hip_shard_step_mode(self.handle) == 1 else "eager"
+
+    def close(self):
+        if self.handle:
+            self.lib.zgml_hip_free_program(self.be.ctx, self.handle)
+            self.handle = None
+        self.lib.zgml_hip_shard_destroy(self.be.ctx)
+
+
 class _DevArray:
     """Minimal __cuda_array_interface__ holder so torch can wrap a raw device pointer."""
 
