@@ -478,6 +478,14 @@ int zgml_hip_resident_setup(zgml_hip_ctx* ctx, zgml_hip_program* handle, const z
 int zgml_hip_resident_decode(zgml_hip_ctx* ctx, zgml_hip_program* handle, uint32_t first_token,
                              uint32_t start_pos, uint32_t n_steps, int64_t* tokens_out);
 
+/* The same for a token_len = T plan (a prefill chunk: LlamaInferenceSession.prefill, src/llama_inference.zig:474,
+ * src/llm/device_prefill.zig): zgml_hip_resident_setup on the T-token program (T is read off token_input's size), then per
+ * chunk only the T token ids cross PCIe — the T embedding rows, the T causal-mask columns, the T RoPE rows per layer,
+ * the KV store offsets / seq_kv = start_pos + T and the argmax of the last position's logits are produced on the
+ * device. Blocking. Returns the greedy next token (< 0 on error); results equal execute_program on host-patched inputs. */
+int64_t zgml_hip_resident_prefill(zgml_hip_ctx* ctx, zgml_hip_program* handle, const uint32_t* tokens, uint32_t n_tokens,
+                                  uint32_t start_pos);
+
 /* Mat-vec roofline micro-benchmark: builds `n_matrices` distinct K x N quantized
  * matrices on the device from the deterministic synthetic generator (q4: nibbles in [-8,7];
  * otherwise int8), runs `warmup` + `iters` launches round-robin over the ring and returns the

@@ -345,3 +345,67 @@ def test_fused_plan_equals_serial_plan(hip_backend, kvq, token_len):
             t_s, l_s = s_s.prefill(toks, chunk * token_len)
             check(t_f, l_f, t_s, l_s, chunk)
     s_f.close(), s_s.close(), m.close()
+
+
+def _download(hip_backend, handle, buf, n):
+    """Raw f32 image of a program buffer (zgml_hip_download_outputs: the read half of execute_program)."""
+    import ctypes as C
+    out = np.zeros(n, np.float32)
+    io = (capi.ProgramIOC * 1)(capi.ProgramIOC(buf, 0, 0, out.ctypes.data, 4 * n, 0))
+    capi.load_hip().zgml_hip_download_outputs(hip_backend.ctx, handle, io, 1)
+    return out
+
+
+@pytest.mark.parametrize("kind", [llama.Q4_0, llama.Q8_0])
+def test_prefill_chunk_of_128_tokens(hip_backend, oracle, kind):
+    """The reference's prefill chunk size (LlamaInferenceSession.prefill, src/llama_inference.zig:474: chunks of 128):
+    a token_len = 128 plan (8 m-tiles per matmul, 128 query columns per attention) against the oracle's execution of the
+    same program and against 128 sequential decode steps ('prefill == sequential', src/llama_inference.zig:983-1034)."""
+    cfg = llama.preset("tiny", 256)
+    T = 128
+    toks = [(7 * i + 3) % cfg.vocab_size for i in range(T)]
+    oracle.set_threads(8)
+    mN = llama.Model(cfg, kind, token_len=T)
+    s_ref = llama.Session(mN, oracle.backend_fns())
+    s_hip = llama.Session(mN, llama.hip_backend_fns(hip_backend))
+    t_ref, l_ref = s_ref.prefill(toks, 0)
+    t_hip, l_hip = s_hip.prefill(toks, 0)
+    assert not hip_backend.last_error(), hip_backend.last_error()
+    assert np.abs(l_hip - l_ref).max() / np.abs(l_ref).max() < 2e-4 and t_hip == t_ref
+    toks2 = [(5 * i + 11) % cfg.vocab_size for i in range(T)]  # second chunk: queries 128..255 over 256 cached keys
+    t_ref2, l_ref2 = s_ref.prefill(toks2, T)
+    t_hip2, l_hip2 = s_hip.prefill(toks2, T)
+    assert np.abs(l_hip2 - l_ref2).max() / np.abs(l_ref2).max() < 2e-4 and t_hip2 == t_ref2
+    s_ref.close(), s_hip.close(), mN.close()
+    m1 = llama.Model(cfg, kind)
+    s1 = llama.Session(m1, llama.hip_backend_fns(hip_backend))
+    for p, t in enumerate(toks + toks2):
+        t_seq, l_seq = s1.step(t, p, want_logits=(p == 2 * T - 1))
+    assert np.abs(l_seq - l_hip2).max() / np.abs(l_seq).max() < 2e-4 and t_seq == t_hip2
+    s1.close(), m1.close()
+
+
+@pytest.mark.parametrize("name,T", [("tiny", 5), ("tiny", 32), ("smollm-135m", 128)])
+def test_resident_prefill_equals_vtable_prefill(hip_backend, name, T):
+    """zgml_hip_resident_prefill (only the T token ids cross PCIe; embedding gather, causal-mask columns, RoPE rows, KV
+    positions and the argmax on the device) leaves the same KV caches and returns the same token as execute_program on
+    host-patched inputs, for two consecutive chunks; and the program stays usable through the vtable afterwards."""
+    cfg = llama.preset(name, 512 if name != "tiny" else 0)
+    m = llama.Model(cfg, llama.Q4_0, threads=16, token_len=T)
+    a = llama.Session(m, llama.hip_backend_fns(hip_backend))
+    b = llama.Session(m, llama.hip_backend_fns(hip_backend))
+    b.resident_setup(hip_backend)
+    n_cache = cfg.max_seq_len * cfg.d_head * cfg.n_kv_heads
+    for chunk in range(2):
+        toks = [(7 * (i + chunk * T) + 3) % cfg.vocab_size for i in range(T)]
+        t_a, _ = a.prefill(toks, chunk * T)
+        t_b = b.resident_prefill(toks, chunk * T)
+        assert not hip_backend.last_error(), hip_backend.last_error()
+        assert t_a == t_b, (chunk, t_a, t_b)
+        for which in ("k_cache", "v_cache"):
+            ca = _download(hip_backend, a.handle, m.buf(which, cfg.n_layers - 1), n_cache)
+            cb = _download(hip_backend, b.handle, m.buf(which, cfg.n_layers - 1), n_cache)
+            assert np.array_equal(ca, cb), (chunk, which)
+    toks = [(3 * i + 1) % cfg.vocab_size for i in range(T)]  # the resident program through the vtable again (position 0)
+    assert b.prefill(toks, 0)[0] == a.prefill(toks, 0)[0]
+    a.close(), b.close(), m.close()

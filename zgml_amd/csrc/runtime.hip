@@ -1952,6 +1952,8 @@ struct zgml_resident {
     uint32_t* dyn_base = nullptr;
     uint32_t* dyn_stride = nullptr;
     uint32_t* state = nullptr;     // [0] token, [1] pos, [2] produced count
+    uint32_t token_len = 1;        // T of the plan (token_input holds T rows): 1 = decode, > 1 = prefill chunk
+    uint32_t* tok_dev = nullptr;   // prefill: the chunk's T token ids (the only per-chunk host -> device traffic)
     int64_t* tokens = nullptr;     // produced tokens (device)
     uint32_t tokens_cap = 0;
     hipGraph_t graph = nullptr;
@@ -1980,6 +1982,7 @@ void free_resident(zgml_hip_program* p) {
     hipFree(r->dyn_base);
     hipFree(r->dyn_stride);
     hipFree(r->state);
+    hipFree(r->tok_dev);
     hipFree(r->tokens);
     delete r;
     p->resident = nullptr;
@@ -1992,32 +1995,37 @@ struct ResidentPrepArgs {
     const uint32_t *dyn_kind, *dyn_base, *dyn_stride;
     uint32_t* dyn;
     const uint32_t* state;
-    uint32_t d, max_seq, dh, n_rope, n_ops;
+    const uint32_t* tokens; // T token ids (decode: &state[0])
+    uint32_t d, max_seq, dh, n_rope, n_ops, T;
 };
 
-// Everything LlamaInferencePlan.execute patches on the host per token, as one flat index space.
+// Everything LlamaInferencePlan.execute patches on the host per execution (src/llama_inference.zig:405-446; for T > 1
+// patch_tokens of zgml_amd/host/llama_decode.cpp), as one flat index space: T embedding rows, T causal-mask columns,
+// T RoPE rows per layer leaf, the dynamic words (KV store offsets at `pos`, seq_kv = pos + T).
 __global__ void __launch_bounds__(256) resident_prep_kernel(ResidentPrepArgs a) {
-    const uint32_t token = a.state[0], pos = a.state[1];
+    const uint32_t pos = a.state[1];
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i < a.d) {
-        a.tok_in[i] = a.embed[(uint64_t)token * a.d + i];
+    if (i < a.T * a.d) {
+        const uint32_t j = i / a.d, e = i - j * a.d;
+        a.tok_in[i] = a.embed[(uint64_t)a.tokens[j] * a.d + e];
         return;
     }
-    i -= a.d;
-    if (i < a.max_seq) {
-        a.mask[i] = i <= pos ? 0.0f : -INFINITY;
+    i -= a.T * a.d;
+    if (i < a.T * a.max_seq) {
+        const uint32_t j = i / a.max_seq, sidx = i - j * a.max_seq;
+        a.mask[i] = sidx <= pos + j ? 0.0f : -INFINITY;
         return;
     }
-    i -= a.max_seq;
-    if (i < a.n_rope * 2 * a.dh) {
-        const uint32_t l = i / (2 * a.dh), j = i % (2 * a.dh);
-        a.rope_bufs[l][j] = j < a.dh ? a.cos[(uint64_t)pos * a.dh + j] : a.sin[(uint64_t)pos * a.dh + j - a.dh];
+    i -= a.T * a.max_seq;
+    if (i < a.n_rope * a.T * 2 * a.dh) {
+        const uint32_t l = i / (a.T * 2 * a.dh), rem = i - l * (a.T * 2 * a.dh), j = rem / (2 * a.dh), e = rem - j * 2 * a.dh;
+        a.rope_bufs[l][rem] = e < a.dh ? a.cos[(uint64_t)(pos + j) * a.dh + e] : a.sin[(uint64_t)(pos + j) * a.dh + e - a.dh];
         return;
     }
-    i -= a.n_rope * 2 * a.dh;
+    i -= a.n_rope * a.T * 2 * a.dh;
     if (i < a.n_ops) {
         if (a.dyn_kind[i] == 1) a.dyn[i] = a.dyn_base[i] + pos * a.dyn_stride[i];
-        if (a.dyn_kind[i] == 2) a.dyn[i] = pos + 1;
+        if (a.dyn_kind[i] == 2) a.dyn[i] = pos + a.T;
     }
 }
 
@@ -3111,20 +3119,27 @@ int zgml_hip_resident_setup(zgml_hip_ctx* ctx, zgml_hip_program* p, const zgml_r
     hipSetDevice(ctx->device);
     free_resident(p);
     auto live = [&](uint16_t b) { return b < p->bufs.size() && p->bufs[b]; };
-    if (!live(d->buf_token_input) || !live(d->buf_attn_mask) || !live(d->buf_logits) ||
+    if (!live(d->buf_token_input) || !live(d->buf_attn_mask) || !live(d->buf_logits) || !d->d_model ||
         p->sizes[d->buf_token_input] < d->d_model || p->sizes[d->buf_attn_mask] < d->max_seq ||
         p->sizes[d->buf_logits] < d->vocab) {
         ctx->fail("resident_setup: bad buffer ids");
         return -1;
     }
+    // token_len of the plan: token_input holds T embedding rows (T = 1: decode plan, T > 1: prefill chunk)
+    const uint32_t T = (uint32_t)(p->sizes[d->buf_token_input] / d->d_model);
+    if (T > 1 && (p->sizes[d->buf_attn_mask] < (uint64_t)T * d->max_seq || p->sizes[d->buf_logits] < (uint64_t)T * d->vocab)) {
+        ctx->fail("resident_setup: attn_mask / logits smaller than token_len columns / rows");
+        return -1;
+    }
     Resident* r = new Resident();
     p->resident = r;
+    r->token_len = T;
     r->vocab = d->vocab, r->d = d->d_model, r->max_seq = d->max_seq, r->dh = d->d_head, r->n_rope = d->n_rope;
     r->tok_in = p->bufs[d->buf_token_input], r->mask = p->bufs[d->buf_attn_mask], r->logits = p->bufs[d->buf_logits];
     const size_t n_ops = p->ops.size();
     std::vector<float*> ropes(d->n_rope);
     for (uint32_t l = 0; l < d->n_rope; l++) {
-        if (!live(d->buf_rope[l]) || p->sizes[d->buf_rope[l]] < 2 * d->d_head) {
+        if (!live(d->buf_rope[l]) || p->sizes[d->buf_rope[l]] < (uint64_t)T * 2 * d->d_head) {
             ctx->fail("resident_setup: bad rope buffer");
             return -1;
         }
@@ -3147,7 +3162,7 @@ int zgml_hip_resident_setup(zgml_hip_ctx* ctx, zgml_hip_program* p, const zgml_r
               CTX_CHECK(ctx, hipMalloc((void**)&r->dyn_kind, (n_ops + 1) * 4)) &&
               CTX_CHECK(ctx, hipMalloc((void**)&r->dyn_base, (n_ops + 1) * 4)) &&
               CTX_CHECK(ctx, hipMalloc((void**)&r->dyn_stride, (n_ops + 1) * 4)) &&
-              CTX_CHECK(ctx, hipMalloc((void**)&r->state, 4 * 4)) &&
+              CTX_CHECK(ctx, hipMalloc((void**)&r->state, 4 * 4)) && CTX_CHECK(ctx, hipMalloc((void**)&r->tok_dev, (size_t)T * 4)) &&
               CTX_CHECK(ctx, hipMemcpy(r->embed, d->token_embed, emb, hipMemcpyHostToDevice)) &&
               CTX_CHECK(ctx, hipMemcpy(r->cos, d->cos_table, tab, hipMemcpyHostToDevice)) &&
               CTX_CHECK(ctx, hipMemcpy(r->sin, d->sin_table, tab, hipMemcpyHostToDevice)) &&
@@ -3166,6 +3181,10 @@ int zgml_hip_resident_decode(zgml_hip_ctx* ctx, zgml_hip_program* p, uint32_t fi
                              uint32_t n_steps, int64_t* tokens_out) {
     if (!ctx || !p || !p->resident || !tokens_out) return -1;
     Resident* r = p->resident;
+    if (r->token_len != 1) {
+        ctx->fail("resident_decode: the program is a token_len > 1 plan (use zgml_hip_resident_prefill)");
+        return -1;
+    }
     if (first_token >= r->vocab || (uint64_t)start_pos + n_steps > r->max_seq) {
         ctx->fail("resident_decode: token or position out of range");
         return -1;
@@ -3205,7 +3224,7 @@ int zgml_hip_resident_decode(zgml_hip_ctx* ctx, zgml_hip_program* p, uint32_t fi
         free_resident_graph(p); // the graph baked the old pointer/cap
     }
     ResidentPrepArgs a{r->embed, r->cos, r->sin, r->tok_in, r->mask, r->rope_bufs, r->dyn_kind, r->dyn_base, r->dyn_stride,
-                       p->dyn_dev, r->state, r->d, r->max_seq, r->dh, r->n_rope, (uint32_t)p->ops.size()};
+                       p->dyn_dev, r->state, r->state /* the token is state[0] */, r->d, r->max_seq, r->dh, r->n_rope, (uint32_t)p->ops.size(), 1};
     const uint32_t total = r->d + r->max_seq + r->n_rope * 2 * r->dh + (uint32_t)p->ops.size();
     auto one_token = [&](hipStream_t st) {
         resident_prep_kernel<<<(total + 255) / 256, 256, 0, st>>>(a);
@@ -3251,6 +3270,66 @@ int zgml_hip_resident_decode(zgml_hip_ctx* ctx, zgml_hip_program* p, uint32_t fi
     return ok ? 0 : -1;
 }
 
+
+// One execution of a token_len = T plan (a prefill chunk) with everything but the T token ids produced on the device.
+int64_t zgml_hip_resident_prefill(zgml_hip_ctx* ctx, zgml_hip_program* p, const uint32_t* tokens, uint32_t n_tokens, uint32_t start_pos) {
+    if (!ctx || !p || !p->resident || !tokens) return -1;
+    Resident* r = p->resident;
+    if (n_tokens != r->token_len || (uint64_t)start_pos + n_tokens > r->max_seq) {
+        ctx->fail("resident_prefill: n_tokens must equal the plan's token_len and the chunk must fit max_seq");
+        return -1;
+    }
+    for (uint32_t j = 0; j < n_tokens; j++)
+        if (tokens[j] >= r->vocab) {
+            ctx->fail("resident_prefill: token out of range");
+            return -1;
+        }
+    hipSetDevice(ctx->device);
+    hipStream_t s = ctx->stream;
+    if (p->plan_dirty) {
+        free_graph(p);
+        build_plan(p);
+    }
+    if (p->plan_batched) { // the device patches offsets / seq_kv itself: same bound check as refresh_program
+        std::vector<zgml_device_op> probe = p->ops;
+        for (auto& o : probe) {
+            if (o.kind == ZGML_DOP_SLICE_ASSIGN && o.u.slice_assign.patch_stride)
+                o.u.slice_assign.dst_offset = o.u.slice_assign.dst_base_offset + start_pos * o.u.slice_assign.patch_stride;
+            if (o.kind == ZGML_DOP_ATTENTION) o.u.attention.seq_kv = start_pos + n_tokens;
+            if (o.kind == ZGML_DOP_ATTENTION_KVQ) o.u.attention_kvq.seq_kv = start_pos + n_tokens;
+        }
+        if (!dynamic_fields_in_bounds(p->sched, probe)) {
+            p->batching_safe = false;
+            free_graph(p);
+            build_plan(p);
+        }
+    }
+    set_dyn_from_ops(p); // static dyn words from the host mirror; the prep kernel rewrites the position-dependent ones
+    p->dyn_dirty = true;
+    flush_dyn(p);
+    const uint32_t st0[4] = {0, start_pos, 0, 0};
+    if (!CTX_CHECK(ctx, hipMemcpyAsync(r->state, st0, sizeof(st0), hipMemcpyHostToDevice, s)) ||
+        !CTX_CHECK(ctx, hipMemcpyAsync(r->tok_dev, tokens, (size_t)n_tokens * 4, hipMemcpyHostToDevice, s)))
+        return -1;
+    ResidentPrepArgs a{r->embed, r->cos, r->sin, r->tok_in, r->mask, r->rope_bufs, r->dyn_kind, r->dyn_base, r->dyn_stride,
+                       p->dyn_dev, r->state, r->tok_dev, r->d, r->max_seq, r->dh, r->n_rope, (uint32_t)p->ops.size(), n_tokens};
+    const uint64_t total = (uint64_t)n_tokens * r->d + (uint64_t)n_tokens * r->max_seq + (uint64_t)r->n_rope * n_tokens * 2 * r->dh + p->ops.size();
+    resident_prep_kernel<<<(uint32_t)((total + 255) / 256), 256, 0, s>>>(a);
+    p->dyn_dirty = false;
+    enqueue(p); // the plan (graph replay when enabled); flush_dyn is a no-op: the device words are current
+    // the logits buffer holds one row per token: the greedy token comes from the LAST position's row
+    launch_argmax(s, r->logits + (uint64_t)(n_tokens - 1) * r->vocab, r->vocab, ctx->arg_val, ctx->arg_idx, ctx->arg_out);
+    hipMemcpyAsync(ctx->arg_out_host, ctx->arg_out, sizeof(int64_t), hipMemcpyDeviceToHost, s);
+    const bool ok = CTX_CHECK(ctx, hipStreamSynchronize(s));
+    // the device rewrote the dyn block behind the host mirror's back: force a re-upload next time
+    memset(p->dyn_host, 0xFF, p->ops.size() * sizeof(uint32_t));
+    set_dyn_from_ops(p);
+    p->dyn_dirty = true;
+    p->profile.call_count++;
+    p->profile.backend_op_count += p->ops.size();
+    p->profile.backend_dispatch_count += p->plan.size() + 3;
+    return ok ? *ctx->arg_out_host : -1;
+}
 
 // ── row-shard (N-split) path behind the C ABI: RCCL all-gathers between op ranges ─────────────────────
 // One process per GPU (the caller's launcher decides ranks). librccl.so is opened at run time by zgml_hip_shard_*

@@ -195,6 +195,15 @@ class Session:
             raise RuntimeError("resident_decode: " + self._backend.last_error())
         return toks
 
+    def resident_prefill(self, tokens, start_pos: int) -> int:
+        """One chunk of a token_len = N plan with on-device embedding gather / mask / RoPE rows / argmax."""
+        toks = np.ascontiguousarray(tokens, dtype=np.uint32)
+        nxt = int(capi.load_hip().zgml_hip_resident_prefill(self._backend.ctx, self.handle, toks.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                            toks.size, start_pos))
+        if nxt < 0:
+            raise RuntimeError("resident_prefill: " + self._backend.last_error())
+        return nxt
+
     def close(self):
         if self.ptr:
             self.lib.zh_session_free(self.ptr)
