@@ -297,7 +297,7 @@ def bench_single(args):
 def verify_l7_prefill(be, llama, kind, T=32):
     """The tile kernels at 7B shapes (2 layers, one token_len = 32 chunk at position 0 and one at 32) against the
     oracle's fixture; f16 promotion is compared at 2e-3 (a 1-ulp f32 difference in A can flip its f16 rounding)."""
-    gold = json.loads((ROOT / "tests" / "golden" / "l7dims.json").read_text())["prefill32_" + kind]
+    gold = json.loads((ROOT / "tests" / "golden" / "l7dims.json").read_text())[f"prefill{T}_" + kind]
     dense = kind == "f16"
     cfg = llama.preset("llama2-7b", 512)
     cfg.n_layers = gold["n_layers"]
@@ -325,7 +325,9 @@ def prefill_leg(be, llama, kind, T=32, reps=8, max_seq=512):
     dense = kind == "f16"
     be.set_option(capi.OPT_F16_DENSE_WEIGHTS, int(dense))
     try:
-        verify_l7_prefill(be, llama, kind, T)  # ParityError: no number is reported for this leg
+        has_fixture = f"prefill{T}_{kind}" in json.loads((ROOT / "tests" / "golden" / "l7dims.json").read_text())
+        if has_fixture:
+            verify_l7_prefill(be, llama, kind, T)  # ParityError: no number is reported for this leg
         t0 = time.perf_counter()
         m = llama.Model(llama.preset("llama2-7b", max_seq), llama.F32_DENSE if dense else llama.Q4_0, threads=16, token_len=T)
         s = llama.Session(m, llama.hip_backend_fns(be))
@@ -340,6 +342,20 @@ def prefill_leg(be, llama, kind, T=32, reps=8, max_seq=512):
             be._lib.zgml_hip_enqueue_program(be.ctx, s.handle)
         be.synchronize()
         dt = (time.perf_counter() - t0) / reps
+        # the device-resident chunk (only the T token ids cross PCIe; embedding gather, mask, RoPE rows, argmax on the
+        # device): consecutive chunks of one prompt, blocking per chunk
+        resident = None
+        if not dense:
+            s.resident_setup(be)
+            nxt_r = s.resident_prefill(toks, 0)
+            if nxt_r != nxt:
+                raise ParityError(f"resident prefill token {nxt_r} != vtable prefill token {nxt}")
+            n_chunks = min(reps, max_seq // T)
+            be.synchronize()
+            t0 = time.perf_counter()
+            for c in range(n_chunks):
+                s.resident_prefill(toks, c * T)
+            resident = round(T * n_chunks / (time.perf_counter() - t0), 1)
         dec = None
         if dense:  # the same f16-promoted weights at token_len 1, for the "fp16 dense vs Q4_0" comparison at batch 1
             s.close()
@@ -355,8 +371,8 @@ def prefill_leg(be, llama, kind, T=32, reps=8, max_seq=512):
             dec = round(48 / (time.perf_counter() - t0), 1)
         s.close()
         m.close()
-        return {"verified_against_oracle": "tests/golden/l7dims.json prefill32_" + kind + " (2 layers at 7B shapes, both chunks)",
-                "decode_tok_s_batch1": dec, "prefill_tok_s": round(T / dt, 1), "ms_per_chunk": round(dt * 1e3, 3), "token_len": T, "first_token": int(nxt),
+        return {"verified_against_oracle": f"tests/golden/l7dims.json prefill{T}_{kind} (2 layers at 7B shapes, both chunks)" if has_fixture else None,
+                "verified": has_fixture, "resident_prefill_tok_s": resident, "decode_tok_s_batch1": dec, "prefill_tok_s": round(T / dt, 1), "ms_per_chunk": round(dt * 1e3, 3), "token_len": T, "first_token": int(nxt),
                 "logits_finite": finite, "build_s": round(build_s, 1)}
     finally:
         be.set_option(capi.OPT_F16_DENSE_WEIGHTS, 0)
@@ -471,6 +487,12 @@ def bench_llama7b_single(be, llama, args):
             except Exception as e:
                 prefill[kind] = {"error": str(e)[:200]}
         prefill["workload"] = "Llama-2-7B prefill, one chunk of 32 tokens, Q4_0 vs dense f16 (BASELINE configs[4])"
+        try:  # the reference's own chunk size (llama_inference.zig:474): 128 tokens per execution, M > 32 tile kernel
+            prefill["chunk128_q4_0"] = prefill_leg(be, llama, "q4_0", T=128, reps=4)
+        except ParityError as e:
+            prefill["chunk128_q4_0"] = {"error": "PARITY FAILURE: " + str(e)[:300]}
+        except Exception as e:
+            prefill["chunk128_q4_0"] = {"error": str(e)[:200]}
     return {"verified_against_oracle": verified, "prefill_batch32": prefill, "tok_s": round(tok_s, 1), "long_context_pos1900_tok_s": long_ctx, "long_context_pos1900_int8_kv_tok_s": kvq_long, "ms_per_token": round(1e3 * dt / K, 3), "steps": K, "build_s": round(build_s, 1),
             "q4_0_weight_bytes": qb, "weight_stream_GBps": round(qb * tok_s / 1e9, 1),
             "frac_of_hbm_peak": round(qb * tok_s / 1e9 / HBM_PEAK_GBPS, 4),

@@ -100,6 +100,27 @@ def test_decode_past_the_attention_split_threshold(hip_backend):
         assert t == t2 and np.abs(logits - logits2).max() <= 1e-5 * np.abs(logits2).max()
 
 
+def test_prefill_chunk128_q4_0_matches_fixture(hip_backend):
+    """The reference's prefill chunk (128 tokens, llama_inference.zig:474) at 7B shapes: the M > 32 tile kernel
+    (qmatmul_xdl4_kernel: 8 m-tiles per workgroup, K split with a last-arriver fan-in on the 4096-wide projections)
+    and 128-query attention, two chunks (the second reads 256 cached keys), against the oracle's fixture; the
+    device-resident chunk returns the same tokens."""
+    gold = GOLD["prefill128_q4_0"]
+    T = gold["T"]
+    m = llama.Model(l7cfg(2), llama.Q4_0, threads=16, token_len=T)
+    s = llama.Session(m, llama.hip_backend_fns(hip_backend))
+    r = llama.Session(m, llama.hip_backend_fns(hip_backend))
+    r.resident_setup(hip_backend)
+    for ci, ch in enumerate(gold["chunks"]):
+        toks = [(7 * (i + ci * T) + 3) % m.cfg.vocab_size for i in range(T)]
+        t_hip, l_hip = s.prefill(toks, ch["pos"])
+        assert not hip_backend.last_error(), hip_backend.last_error()
+        check_probe(l_hip, ch["probe"])
+        assert t_hip == ch["token"]
+        assert r.resident_prefill(toks, ch["pos"]) == ch["token"]
+    s.close(), r.close(), m.close()
+
+
 @pytest.mark.parametrize("kind", ["q4_0", "f16"])
 def test_prefill_chunk32_matches_oracle_and_fixture(hip_backend, oracle, kind):
     """BASELINE configs[4] at its shapes: one token_len = 32 chunk at position 0 and a second at 32 through the tile

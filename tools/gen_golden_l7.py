@@ -104,9 +104,22 @@ def full_model():
     print("wrote", dst, round(time.time() - t0, 1), "s", res["tokens"])
 
 
+def add_prefill128():
+    """--prefill128: add the token_len = 128 chunk case (the reference's prefill chunk size) to l7dims.json."""
+    O.set_threads(8)
+    dst = ROOT / "tests" / "golden" / "l7dims.json"
+    out = json.loads(dst.read_text())
+    t0 = time.time()
+    out["prefill128_q4_0"] = dict(n_layers=2, **prefill_case(l7cfg(2), "q4_0", 128))
+    dst.write_text(json.dumps(out, indent=1))
+    print("prefill128_q4_0", round(time.time() - t0, 1), "s; wrote", dst)
+
+
 def main():
     if "--full" in sys.argv:
         return full_model()
+    if "--prefill128" in sys.argv:
+        return add_prefill128()
     O.set_threads(8)
     out = {"generator": "tools/gen_golden_l7.py", "dims": {"d_model": 4096, "n_heads": 32, "n_kv_heads": 32, "d_ff": 11008,
                                                             "vocab": 32000, "max_seq": 512}}

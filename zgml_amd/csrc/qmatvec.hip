@@ -1128,6 +1128,180 @@ __global__ void __launch_bounds__(512) qmatmul_xdl2_kernel(QMM2Args a) {
     }
 }
 
+// ── XDL tile kernel for M > 32 (prefill chunks of 64 .. 128+ tokens): RT m-tiles per workgroup ────────────────────
+// At M = 32 the per-weight preparation of B (convert, scale, exact two-way bf16 split, packs: 5 VALU instructions per
+// weight, independent of M) costs 3.3 VALU instructions per MFMA and does not hide under the matrix pipe (a 16x16x32
+// MFMA holds the SIMD's vector issue for 8 of its 16 cycles): every M = 32 form measured lands at ~32 cycles per MFMA
+// per SIMD (profiles/r02_exp_stream_kernel.txt). The preparation is per WEIGHT, so with RT = 8 m-tiles (128 rows) per
+// workgroup one prepared B operand feeds 48 MFMAs (0.8 VALU per MFMA) and the kernel is paced by the matrix pipe.
+// What grows with M is A: a workgroup that owns all of K pulls all of A (M K 6 B as bf16 pieces) through L2, so here
+//   * a workgroup owns ONE scale block-column (C = 2 column groups, 32 columns), RT m-tiles and a SLICE of the K steps;
+//     its 8 waves take whole steps (128 k);
+//   * per 8-k group J the wave holds the A pieces of the RT tiles in registers (12 RT VGPRs, fetched half a group ahead
+//     in two halves of RT / 2 tiles) and uses them for both column groups: 12 RT MFMAs per prepared B pair, chained on one
+//     accumulator per (column group, m-tile) (a dependent 16x16x32 chain issues at the full rate);
+//   * waves fold through LDS in wave order; a K split publishes partial tiles (write-through stores, drained, one
+//     agent-scope add on the block's counter) and the LAST arriver sums the slices in slice order, scales, stores.
+struct QMM4Args {
+    QMM2Part parts[kMaxQmmParts]; // NB2 / block_begin in scale BLOCK-COLUMNS (pairs of groups) here
+    const uint4* ap;              // split_a_kernel output (tiles padded to a multiple of RT)
+    float* partial;               // [tile group][block-column][slice][2 RT 256] f32 (split-K only)
+    uint32_t* counter;            // one word per (tile group, block-column), zero between launches
+    uint32_t n_parts, M, U, S, SK, steps_per_slice;
+};
+constexpr int kX4Waves = 8;
+
+template <int RT, int CB, bool NT>
+__global__ void __launch_bounds__(512, 2) qmatmul_xdl4_kernel(QMM4Args a) {
+    constexpr int C = 2, H = RT / 2; // H tiles per half
+    constexpr uint32_t KW = kX4Waves / CB; // waves that split the K steps of one block-column
+    extern __shared__ float smem[];
+    const uint32_t cbx = blockIdx.x / a.SK, slice = blockIdx.x - cbx * a.SK; // launch-wide block-column, K slice
+    uint32_t pi = 0;
+#pragma unroll
+    for (uint32_t t = 1; t < (uint32_t)kMaxQmmParts; t++)
+        if (t < a.n_parts && cbx >= a.parts[t].block_begin) pi = t;
+    const QMM2Part& P = a.parts[pi];
+    const uint32_t lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // CB block-columns per workgroup: waves (kw, kw + KW, ...) take the SAME K steps on neighbouring block-columns, so
+    // the second reader of a step's A pieces mostly hits this CU's L1 (A through L2 / CB)
+    const uint32_t bcw = w / KW, kw = w - bcw * KW;
+    const uint32_t cb = (cbx - P.block_begin) * CB + bcw, g0 = cb * C, t0 = blockIdx.y * RT;
+    const uint32_t row = lane >> 4, i = lane & 15;
+    const uint4* qs = P.qs + (uint64_t)g0 * a.U * 16 + i;
+    const uint32_t* scd = (const uint32_t*)P.sc + (uint64_t)cb * a.U * 16 + i;
+    const uint4* ap = a.ap + (uint64_t)t0 * a.S * 12 * 64 + lane;
+    const uint64_t tile_stride = (uint64_t)a.S * 12 * 64;
+    const uint32_t s_begin = slice * a.steps_per_slice, s_end = min(s_begin + a.steps_per_slice, a.S);
+
+    mfma_f4 acc[C][RT];
+#pragma unroll
+    for (int g = 0; g < C; g++)
+#pragma unroll
+        for (int t = 0; t < RT; t++) acc[g][t] = mfma_f4{0.f, 0.f, 0.f, 0.f};
+
+    struct AHalf {
+        uint4 v[H][3];
+    };
+    auto load_a = [&](AHalf& x, uint32_t s, int J, int half) {
+#pragma unroll
+        for (int t = 0; t < H; t++)
+#pragma unroll
+            for (int p = 0; p < 3; p++) x.v[t][p] = ap[(uint64_t)(half * H + t) * tile_stride + (((uint64_t)s * 4 + J) * 3 + p) * 64];
+    };
+    for (uint32_t s = s_begin + kw; s < s_end; s += KW) { // (scalar loop: kw, s are in SGPRs)
+        const uint32_t u = min(4 * s + row, a.U - 1); // units past the end: A is zero there
+        uint4 wq[C];
+#pragma unroll
+        for (int g = 0; g < C; g++) wq[g] = wload<NT>(qs + ((uint64_t)g * a.U + u) * 16);
+        const uint32_t sd = scd[(uint64_t)u * 16];
+        AHalf a0, a1;
+        load_a(a0, s, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        const __half2 hh = __builtin_bit_cast(__half2, sd);
+        const int sb_lo = __float_as_int(__half2float(hh.x)), sb_hi = __float_as_int(__half2float(hh.y)); // scales of k_local i, 16 + i
+        bf16x8_t b1[C], b2[C];
+        auto prep = [&](auto jc) {
+            constexpr int J = decltype(jc)::value;
+            const int sbits = J >> 1 ? sb_hi : sb_lo;
+#pragma unroll
+            for (int g = 0; g < C; g++) {
+                const uint32_t lo = J == 0 ? wq[g].x : J == 1 ? wq[g].y : J == 2 ? wq[g].z : wq[g].w, hi = lo >> 4;
+                float wv[8];
+                constexpr int C0 = 0x150 + 8 * (J & 1); // the scale of k_local 8 J + e sits in lane 8 (J & 1) + e of this row
+#define XDL4_W(E, SRC, BYTE) wv[E] = row_bcast<C0 + E>(sbits) * __builtin_amdgcn_cvt_off_f32_i4((int)((SRC) >> (8 * BYTE)))
+                XDL4_W(0, lo, 0), XDL4_W(1, lo, 1), XDL4_W(2, lo, 2), XDL4_W(3, lo, 3);
+                XDL4_W(4, hi, 0), XDL4_W(5, hi, 1), XDL4_W(6, hi, 2), XDL4_W(7, hi, 3);
+#undef XDL4_W
+                float lo2[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) lo2[e] = wv[e] - __uint_as_float(__float_as_uint(wv[e]) & 0xFFFF0000u);
+                b1[g] = as_bf16x8(make_uint4(pack_hi16(wv[0], wv[1]), pack_hi16(wv[2], wv[3]), pack_hi16(wv[4], wv[5]), pack_hi16(wv[6], wv[7])));
+                b2[g] = as_bf16x8(make_uint4(pack_hi16(lo2[0], lo2[1]), pack_hi16(lo2[2], lo2[3]), pack_hi16(lo2[4], lo2[5]), pack_hi16(lo2[6], lo2[7])));
+            }
+        };
+        auto mfmas = [&](const AHalf& x, int half) {
+#pragma unroll
+            for (int g = 0; g < C; g++)
+#pragma unroll
+                for (int t = 0; t < H; t++)
+#pragma unroll
+                    for (int p = 0; p < 3; p++) {
+                        acc[g][half * H + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(x.v[t][p]), b1[g], acc[g][half * H + t], 0, 0, 0);
+                        acc[g][half * H + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(x.v[t][p]), b2[g], acc[g][half * H + t], 0, 0, 0);
+                    }
+        };
+        // eight half-groups: the A pieces of the next half are requested before the MFMAs of the current one
+#define XDL4_HALF(CUR, NXT, J, HALF, NJ, NHALF, PREP)          \
+    do {                                                       \
+        load_a(NXT, s, NJ, NHALF);                             \
+        __builtin_amdgcn_sched_barrier(0);                     \
+        PREP;                                                  \
+        mfmas(CUR, HALF);                                      \
+        __builtin_amdgcn_sched_barrier(0);                     \
+    } while (0)
+        XDL4_HALF(a0, a1, 0, 0, 0, 1, prep(std::integral_constant<int, 0>{}));
+        XDL4_HALF(a1, a0, 0, 1, 1, 0, (void)0);
+        XDL4_HALF(a0, a1, 1, 0, 1, 1, prep(std::integral_constant<int, 1>{}));
+        XDL4_HALF(a1, a0, 1, 1, 2, 0, (void)0);
+        XDL4_HALF(a0, a1, 2, 0, 2, 1, prep(std::integral_constant<int, 2>{}));
+        XDL4_HALF(a1, a0, 2, 1, 3, 0, (void)0);
+        XDL4_HALF(a0, a1, 3, 0, 3, 1, prep(std::integral_constant<int, 3>{}));
+        mfmas(a1, 1);
+#undef XDL4_HALF
+    }
+
+    // D[m = 4 * row + v][n = i] in acc[g][t][v]; fold the KW waves of each block-column in wave order
+    constexpr uint32_t TILE = C * RT * 256; // floats of one block-column's tile
+#pragma unroll
+    for (int g = 0; g < C; g++)
+#pragma unroll
+        for (int t = 0; t < RT; t++)
+#pragma unroll
+            for (int v = 0; v < 4; v++) smem[((bcw * KW + kw) * (C * RT) + g * RT + t) * 256 + v * 64 + lane] = acc[g][t][v];
+    __syncthreads();
+    uint32_t* const flag = (uint32_t*)(smem + (size_t)kX4Waves * TILE);
+    constexpr uint32_t NQ = CB * TILE / 512; // values per thread: the workgroup's CB tiles over 512 threads
+    float sum[NQ];
+#pragma unroll
+    for (uint32_t q = 0; q < NQ; q++) {
+        const uint32_t idx = threadIdx.x + q * 512, bc = idx / TILE, e = idx - bc * TILE;
+        float v = smem[(bc * KW) * TILE + e];
+        for (uint32_t ww = 1; ww < KW; ww++) v += smem[(bc * KW + ww) * TILE + e];
+        sum[q] = v;
+    }
+    if (a.SK > 1) {
+        using gf32 = __attribute__((address_space(1))) float;
+        using gu32 = __attribute__((address_space(1))) unsigned int;
+        float* const mine = a.partial + ((uint64_t)blockIdx.y * gridDim.x + blockIdx.x) * (CB * TILE); // [tile group][column block][slice]
+#pragma unroll
+        for (uint32_t q = 0; q < NQ; q++) __hip_atomic_store((gf32*)(mine + threadIdx.x + q * 512), sum[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains before the count
+        __syncthreads();
+        uint32_t* const cnt = a.counter + blockIdx.y * (gridDim.x / a.SK) + cbx;
+        if (threadIdx.x == 0) *flag = __hip_atomic_fetch_add((gu32*)cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (*flag != a.SK - 1) return; // not the last slice of this block-column
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // compiler only: the loads below stay below the count
+        const float* const base = a.partial + ((uint64_t)blockIdx.y * gridDim.x + (uint64_t)cbx * a.SK) * (CB * TILE);
+#pragma unroll
+        for (uint32_t q = 0; q < NQ; q++) {
+            float v = 0.f;
+            for (uint32_t sl = 0; sl < a.SK; sl++) // slice order, not arrival order
+                v += __hip_atomic_load((gf32*)(base + (uint64_t)sl * (CB * TILE) + threadIdx.x + q * 512), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sum[q] = v;
+        }
+        if (threadIdx.x == 0) __hip_atomic_store((gu32*)cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // re-arm
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < NQ; q++) {
+        const uint32_t idx = threadIdx.x + q * 512, bc = idx / TILE, e = idx - bc * TILE, gt = e >> 8, v = (e >> 6) & 3, l = e & 63;
+        const uint32_t g = gt / RT, t = gt % RT;
+        const uint32_t m = (t0 + t) * 16 + 4 * (l >> 4) + v, n = (((cbx - P.block_begin) * CB + bc) * C + g) * 16 + (l & 15);
+        if (m < a.M) P.out[(uint64_t)m * P.out_rs + n] = sum[q] * 16.0f; // the tile carries q/16
+    }
+}
+
 // Raw layout (any block size, any N): one thread per (m, n), k sequential — exactly the
 // reference's loop order, coalesced along n. Used for odd shapes (e.g. the bs=4 conformance case).
 __global__ void __launch_bounds__(kBlock) qmatmul_raw_kernel(const int8_t* __restrict__ data,
@@ -1319,10 +1493,27 @@ static bool xdl2_enabled() {
 static bool xdl2_applies(const QWeightDev& w, uint32_t M) { // K <= 12288: a wave's weights (<= 12 steps) are preloaded into LDS
     return M > 1 && w.format == QW_Q4 && w.scale_f16 && xdl2_enabled() && (w.KC + 3) / 4 <= 8 * 12;
 }
+// scratch of an M > 1 launch: [A pieces][split-K partial tiles of the M > 32 form][its arrival counters]. The partial and
+// counter regions are sized for a grouped launch of kMaxQmmParts weights of this shape (the runtime allocates the
+// maximum over a program's weights, so the widest weight bounds every group it is part of).
+static uint32_t xdl_tile_pad(uint32_t M) { return M > 64 ? 8 : (M > 32 ? 4 : (M > 16 ? 2 : 1)); } // m-tiles per workgroup
+static uint64_t xdl_a_bytes(const QWeightDev& w, uint32_t M) {
+    const uint64_t S = (w.KC + 3) / 4, tiles = (M + 15) / 16, R = xdl_tile_pad(M);
+    return (tiles + R - 1) / R * R * S * 12 * 1024;
+}
+static uint64_t xdl4_partial_bytes(const QWeightDev& w, uint32_t M) { // one part, at most 4 K slices
+    if (M <= 32) return 0;
+    const uint64_t RT = xdl_tile_pad(M), groups = ((M + 15) / 16 + RT - 1) / RT;
+    return groups * (w.N / 32) * 4 * (2 * RT * 256 * 4);
+}
+static uint64_t xdl4_counter_bytes(const QWeightDev& w, uint32_t M) {
+    if (M <= 32) return 0;
+    const uint64_t RT = xdl_tile_pad(M), groups = ((M + 15) / 16 + RT - 1) / RT;
+    return (groups * (w.N / 32) * 4 + 255) / 256 * 256;
+}
 uint64_t qmatmul_scratch_bytes(const QWeightDev& w, uint32_t M) {
     if (!xdl2_applies(w, M)) return 0;
-    const uint64_t S = (w.KC + 3) / 4, tiles = (M + 15) / 16, R = M > 16 ? 2 : 1;
-    return (tiles + R - 1) / R * R * S * 12 * 1024;
+    return xdl_a_bytes(w, M) + (uint64_t)kMaxQmmParts * (xdl4_partial_bytes(w, M) + xdl4_counter_bytes(w, M));
 }
 
 bool qweight_packable(uint64_t K, uint64_t N, uint64_t bs) {
@@ -1445,9 +1636,56 @@ void launch_xdl2_rg(hipStream_t s, const QMM2Args& a, uint32_t G, dim3 grid, uin
 
 // second XDL form: split x once, then the B-scaled tile kernel (Q4_0, f16 scales); n >= 1 weights that
 // read the same rows share one launch (blockIdx.x ranges)
+// M > 32: RT = 4 or 8 m-tiles per workgroup, one scale block-column wide, K split to fill the chip
+void launch_xdl4(hipStream_t s, const QWeightDev* w, const QMatmulParams* p, uint32_t n, float* scratch, uint32_t S, uint32_t RT, uint32_t tiles) {
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+    }
+    QMM4Args a{};
+    uint32_t blocks = 0;
+    uint64_t part_max = 0, cnt_max = 0;
+    // block-columns per workgroup (kernel template CB): pairing waves on neighbouring block-columns so that the second
+    // reader of a step's A pieces hits L1 was measured SLOWER (128 x 4096 x 4096: 47.4 vs 32.5 us) — one per workgroup
+    constexpr uint32_t CB = 1;
+    for (uint32_t t = 0; t < n; t++) {
+        a.parts[t] = {(const uint4*)w[t].qs, (const uint4*)w[t].sc, p[t].dst, p[t].dst_rs, p[t].N / 32 / CB, blocks};
+        blocks += p[t].N / 32 / CB;
+        part_max = std::max(part_max, xdl4_partial_bytes(w[t], p[0].M)), cnt_max = std::max(cnt_max, xdl4_counter_bytes(w[t], p[0].M));
+    }
+    const uint32_t groups = tiles / RT, KW = kX4Waves / CB;
+    // K split: at least one workgroup per CU, at most 4 slices (the scratch regions are sized for 4), whole steps per wave
+    static const int env_sk = getenv("ZGML_QMM_XDL4_SK") ? atoi(getenv("ZGML_QMM_XDL4_SK")) : 0;
+    uint32_t SK = env_sk > 0 ? (uint32_t)env_sk : cdiv((uint32_t)n_cu, blocks * groups);
+    SK = std::max(1u, std::min({SK, 4u, cdiv(S, KW)}));
+    const uint32_t steps_per_slice = cdiv(S, SK);
+    SK = cdiv(S, steps_per_slice);
+    const uint64_t a_bytes = xdl_a_bytes(w[0], p[0].M);
+    a.ap = (const uint4*)scratch;
+    a.partial = (float*)((char*)scratch + a_bytes);
+    a.counter = (uint32_t*)((char*)scratch + a_bytes + (uint64_t)kMaxQmmParts * part_max);
+    a.n_parts = n, a.M = p[0].M, a.U = w[0].KC, a.S = S, a.SK = SK, a.steps_per_slice = steps_per_slice;
+    const dim3 grid(blocks * SK, groups);
+    const size_t lds = (size_t)kX4Waves * 2 * RT * 256 * sizeof(float) + 64;
+    const bool nt = w[0].stream_nt != 0 && groups == 1;
+    using Fn4 = void (*)(QMM4Args);
+    const Fn4 fn = RT == 8 ? (nt ? (Fn4)qmatmul_xdl4_kernel<8, 1, true> : (Fn4)qmatmul_xdl4_kernel<8, 1, false>)
+                           : (nt ? (Fn4)qmatmul_xdl4_kernel<4, 1, true> : (Fn4)qmatmul_xdl4_kernel<4, 1, false>);
+    if (lds > 64 * 1024) hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(fn, grid, dim3(kX4Waves * 64), lds, s, a);
+}
+
 void launch_xdl2(hipStream_t s, const QWeightDev* w, const QMatmulParams* p, uint32_t n, float* scratch) {
-    const uint32_t U = w[0].KC, S = cdiv(U, 4), R = p[0].M > 16 ? 2 : 1, tiles = cdiv(cdiv(p[0].M, 16), R) * R;
+    const uint32_t U = w[0].KC, S = cdiv(U, 4), R = xdl_tile_pad(p[0].M), tiles = cdiv(cdiv(p[0].M, 16), R) * R;
     if (!p[0].reuse_split) hipLaunchKernelGGL(split_a_kernel, dim3(S, tiles), dim3(256), 0, s, p[0].input, p[0].M, p[0].K, p[0].in_rs, (uint4*)scratch, S);
+    static const bool xdl4_on = !(getenv("ZGML_QMM_XDL4") && atoi(getenv("ZGML_QMM_XDL4")) == 0);
+    if (R >= 4 && xdl4_on) {
+        launch_xdl4(s, w, p, n, scratch, S, R, tiles);
+        return;
+    }
+    const uint32_t R2 = std::min(R, 2u); // (switch off: the M = 32 form over pairs of tiles; the A pieces are laid out per tile)
     static const int env_g = getenv("ZGML_QMM_XDL2_G") ? atoi(getenv("ZGML_QMM_XDL2_G")) : 0;
     uint32_t total_nb2 = 0;
     for (uint32_t t = 0; t < n; t++) total_nb2 += p[t].N / 16;
@@ -1465,10 +1703,10 @@ void launch_xdl2(hipStream_t s, const QWeightDev* w, const QMatmulParams* p, uin
         blocks += p[t].N / 16 / Gs;
     }
     a.ap = (const uint4*)scratch, a.n_parts = n, a.M = p[0].M, a.U = U, a.S = S, a.spw_max = spw_max;
-    const dim3 grid(blocks, tiles / R);
-    const size_t lds = std::max((size_t)waves * Gs * R * 256 * sizeof(float), b_bytes(Gs));
-    const bool nt = w[0].stream_nt != 0 && tiles / R == 1;
-    if (R == 2)
+    const dim3 grid(blocks, tiles / R2);
+    const size_t lds = std::max((size_t)waves * Gs * R2 * 256 * sizeof(float), b_bytes(Gs));
+    const bool nt = w[0].stream_nt != 0 && tiles / R2 == 1;
+    if (R2 == 2)
         nt ? launch_xdl2_rg<2, true>(s, a, Gs, grid, waves, lds) : launch_xdl2_rg<2, false>(s, a, Gs, grid, waves, lds);
     else
         nt ? launch_xdl2_rg<1, true>(s, a, Gs, grid, waves, lds) : launch_xdl2_rg<1, false>(s, a, Gs, grid, waves, lds);
