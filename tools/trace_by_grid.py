@@ -9,7 +9,8 @@ agg = collections.defaultdict(list)
 for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"]
-        short = name.split("(")[0].replace("zgml::(anonymous namespace)::", "").replace("void ", "")
+        short = name.replace("zgml::(anonymous namespace)::", "").replace("(anonymous namespace)::", "").replace("void ", "")
+        short = short.split("(")[0] if not short.startswith("(") else short
         agg[(short[:88], r.get("Grid_Size", r.get("Grid_Size_X", "?")), r.get("Workgroup_Size", r.get("Workgroup_Size_X", "?")))].append(
             int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 rows = sorted(agg.items(), key=lambda kv: -sum(kv[1]))
