@@ -266,7 +266,10 @@ __device__ __forceinline__ uint32_t column_group(uint32_t b, uint32_t NB2) {
 }
 
 // the part's elementwise epilogue on one output value (residual add, SiLU chain, ...)
-__device__ __forceinline__ void run_epilogue(const QMVPartDev& part, uint32_t n, float v, const float* out_row) {
+// `pre0` / `have_pre0`: the operand of step 0, fetched at kernel start under the weight stream (non-grouped launches:
+// the residual add of the O / down projections) instead of by a dependent load behind the reduction.
+__device__ __forceinline__ void run_epilogue(const QMVPartDev& part, uint32_t n, float v, const float* out_row, float pre0 = 0.f,
+                                             bool have_pre0 = false) {
     const float raw = v; // an operand that is this part's own output (SiLU's final gate * sigmoid) stays in the register
     // fully unrolled: `part.epi[e]` with a run-time e is a scalar load from the argument block inside
     // the loop, i.e. one dependent ~0.3 us round trip per step at the very end of the kernel
@@ -275,10 +278,10 @@ __device__ __forceinline__ void run_epilogue(const QMVPartDev& part, uint32_t n,
         if (e >= part.n_epi) break;
         const QmvEpiStep st = part.epi[e];
         if (st.op == ZGML_OP_ADD) {
-            const float o = st.operand == out_row ? raw : st.operand[n];
+            const float o = st.operand == out_row ? raw : (e == 0 && have_pre0 ? pre0 : st.operand[n]);
             v = st.swapped ? o + v : v + o;
         } else if (st.op == ZGML_OP_MUL) {
-            const float o = st.operand == out_row ? raw : st.operand[n];
+            const float o = st.operand == out_row ? raw : (e == 0 && have_pre0 ? pre0 : st.operand[n]);
             v = st.swapped ? o * v : v * o;
         } else {
             v = epi_unary(st.op, v);
@@ -293,7 +296,8 @@ __device__ __forceinline__ void run_epilogue(const QMVPartDev& part, uint32_t n,
 // a run-time index into the argument block is a dependent scalar load that costs ~1 us at the
 // start and again in the tail of a 5 us kernel.
 template <bool GROUPED>
-__device__ __forceinline__ void reduce_store(float acc, float* red, const QMVArgs& a, uint32_t pi, float* out0, uint32_t g, uint32_t m) {
+__device__ __forceinline__ void reduce_store(float acc, float* red, const QMVArgs& a, uint32_t pi, float* out0, uint32_t g, uint32_t m,
+                                             float pre0 = 0.f, bool have_pre0 = false) {
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     acc += __shfl_xor(acc, 16, 64);
     acc += __shfl_xor(acc, 32, 64);
@@ -315,7 +319,7 @@ __device__ __forceinline__ void reduce_store(float acc, float* red, const QMVArg
         }
         out_row[n] = v;
         if (!GROUPED || pi == 0)
-            run_epilogue(a.parts[0], n, v, out_row);
+            run_epilogue(a.parts[0], n, v, out_row, pre0, !GROUPED && have_pre0);
         else if (pi == 1)
             run_epilogue(a.parts[1], n, v, out_row);
         else if (pi == 2)
@@ -616,6 +620,16 @@ __global__ void __launch_bounds__(1024) qmatvec_kernel(QMV_HEAD_PARAMS, QMVArgs 
         QMV_STAMP(3); // x staged
     }
 
+    // single-matrix launches (O / down projection): the operand of the first epilogue step (the residual) is requested
+    // now, under the weight stream, by every lane for its column (unconditional: a load under a branch would degrade
+    // the counted waits); the 16 owning lanes use it behind the reduction instead of a dependent ~0.5 us load
+    float pre0 = 0.f;
+    bool have_pre0 = false;
+    if (!GROUPED) {
+        const float* const op0 = a.parts[0].epi[0].operand;
+        have_pre0 = m == 0 && a.parts[0].n_epi != 0 && op0 != nullptr && op0 != out0;
+        pre0 = (have_pre0 ? op0 : xa_row)[have_pre0 ? g * 16 + i : 0];
+    }
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
     for (uint32_t gi = 1; gi < n_groups; gi++) {
         Group nxt;
@@ -626,7 +640,7 @@ __global__ void __launch_bounds__(1024) qmatvec_kernel(QMV_HEAD_PARAMS, QMVArgs 
     }
     cur.compute(xs, u, stride, U, i, acc0, acc1, acc2, acc3, xd);
     QMV_STAMP(4); // weights streamed
-    reduce_store<GROUPED>((acc0 + acc1) + (acc2 + acc3), red, a, pi, out0, g, m);
+    reduce_store<GROUPED>((acc0 + acc1) + (acc2 + acc3), red, a, pi, out0, g, m, pre0, have_pre0);
     QMV_STAMP(5);
 #undef QMV_STAMP
 }
