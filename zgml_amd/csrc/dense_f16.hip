@@ -258,7 +258,11 @@ __global__ void __launch_bounds__(kBlock) pack_a_f16_kernel(const float* __restr
 
 template <int R, bool NT>
 __global__ void __launch_bounds__(512) dense_f16_tile2_kernel(F16Args2 a) {
-    constexpr int DEPTH = 4; // chunks in flight per wave, (1 + R) x 16 B per lane each (8 measured no faster)
+    // chunks in flight per wave, (1 + R) x 16 B per lane each (8 measured no faster at R = 2). R = 4 / 8 (prefill chunks of
+    // 64 / 128 tokens): all m-tiles in one workgroup, so the weights are read ONCE per matmul instead of once per tile pair
+    // (Llama-2-7B at 128 tokens: 13.5 GB of f16 weights per chunk instead of 54 GB); 3 / 2 chunks in flight keep the ring
+    // within the register budget of two waves per SIMD
+    constexpr int DEPTH = R >= 8 ? 2 : (R >= 4 ? 3 : 4);
     extern __shared__ float smem[];
     // w in an SGPR: the chunk guard below must be a scalar branch — a v_mfma ignores EXEC, so a predicated
     // (if-converted) guard would still accumulate the clamped duplicate chunks
@@ -353,15 +357,19 @@ void launch_pack_f16(hipStream_t s, const float* b, uint32_t b_rs, uint32_t b_cs
     pack_f16_kernel<<<2048, kBlock, 0, s>>>(b, b_rs, b_cs, K, N, (K + 31) / 32, (uint4*)out);
 }
 
+static uint32_t f16_tiles_per_wg(uint32_t M) { // m-tiles a workgroup of the A-pre-laid-out kernel carries
+    static const bool wide = !(getenv("ZGML_F16_TILE2_WIDE") && atoi(getenv("ZGML_F16_TILE2_WIDE")) == 0);
+    return M > 64 && wide ? 8 : (M > 32 && wide ? 4 : (M > 16 ? 2 : 1));
+}
 uint64_t dense_f16_scratch_bytes(uint32_t M, uint32_t K) {
     static const bool on = !(getenv("ZGML_F16_TILE2") && atoi(getenv("ZGML_F16_TILE2")) == 0);
     if (!on || M <= 1) return 0;
-    const uint64_t tiles = (M + 15) / 16, R = M > 16 ? 2 : 1;
+    const uint64_t tiles = (M + 15) / 16, R = f16_tiles_per_wg(M);
     return (tiles + R - 1) / R * R * ((K + 31) / 32) * 1024;
 }
 
 static void launch_dense_f16_tile2(hipStream_t s, const DenseF16Params* p, uint32_t n) {
-    const uint32_t KC = (p[0].K + 31) / 32, R = p[0].M > 16 ? 2 : 1, tiles = cdiv(cdiv(p[0].M, 16), R) * R;
+    const uint32_t KC = (p[0].K + 31) / 32, R = f16_tiles_per_wg(p[0].M), tiles = cdiv(cdiv(p[0].M, 16), R) * R;
     if (!p[0].reuse_a) {
         const uint64_t items = (uint64_t)tiles * KC * 64;
         pack_a_f16_kernel<<<(uint32_t)std::min<uint64_t>(2048, (items + kBlock - 1) / kBlock), kBlock, 0, s>>>(p[0].a, p[0].M, p[0].K, p[0].a_rs, KC,
@@ -380,8 +388,11 @@ static void launch_dense_f16_tile2(hipStream_t s, const DenseF16Params* p, uint3
     const size_t lds = (size_t)waves * R * 256 * sizeof(float);
     const bool nt = p[0].stream_nt != 0 && tiles / R == 1;
     using Fn2 = void (*)(F16Args2);
-    const Fn2 fn = R == 2 ? (nt ? (Fn2)dense_f16_tile2_kernel<2, true> : (Fn2)dense_f16_tile2_kernel<2, false>)
-                          : (nt ? (Fn2)dense_f16_tile2_kernel<1, true> : (Fn2)dense_f16_tile2_kernel<1, false>);
+    const Fn2 fn = R == 8   ? (nt ? (Fn2)dense_f16_tile2_kernel<8, true> : (Fn2)dense_f16_tile2_kernel<8, false>)
+                   : R == 4 ? (nt ? (Fn2)dense_f16_tile2_kernel<4, true> : (Fn2)dense_f16_tile2_kernel<4, false>)
+                   : R == 2 ? (nt ? (Fn2)dense_f16_tile2_kernel<2, true> : (Fn2)dense_f16_tile2_kernel<2, false>)
+                            : (nt ? (Fn2)dense_f16_tile2_kernel<1, true> : (Fn2)dense_f16_tile2_kernel<1, false>);
+    if (lds > 64 * 1024) hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(fn, grid, dim3(waves * 64), lds, s, a);
 }
 
