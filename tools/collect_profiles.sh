@@ -8,9 +8,9 @@ TAG=${1:-r02}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-# The decode loops are profiled on the GRAPH path (what bench.py times). Round 1 ran them with ZGML_HIP_GRAPH=0 because
-# rocprofv3 crashed inside hipGraphLaunch of the per-token graph; that was the runtime's own use-after-free (the resident
-# graph outlived a plan rebuild that freed its parameter arrays — fixed in round 2), not the profiler.
+# The decode loops are profiled on the GRAPH path (what bench.py times). Round 1 ran them with ZGML_HIP_GRAPH=0 after
+# rocprofv3 crashed inside hipGraphLaunch of the per-token graph; the crash did not reproduce in round 2 (current or
+# rebuilt round-1 library), see DESIGN.md section 5.
 run() { # name, command...
   local name=$1; shift
   echo "== $name"
@@ -22,6 +22,7 @@ run llama2_7b_decode python3 tools/decode_run.py llama2-7b 32
 run qmatvec_bench python3 tools/bench_matvec.py --shapes 4096x4096 --iters 512
 run qmatvec_chain python3 tools/chain_bench.py 4096 1024
 run llama2_7b_prefill32 python3 tools/prefill_run.py llama2-7b --T 32 --reps 6 --kinds q4,f16
+run llama2_7b_prefill128 python3 tools/prefill_run.py llama2-7b --T 128 --reps 4 --kinds q4,f16
 echo "== pmc"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc -- python3 tools/bench_matvec.py --shapes 4096x4096 --iters 128 > $OUT/pmc.log 2>&1
 f=$(find $OUT/pmc -name "*counter_collection.csv" | head -1); test -n "$f" && cp "$f" $OUT/pmc_counter_collection.csv

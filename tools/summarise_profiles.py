@@ -8,9 +8,9 @@ import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src, dst = ROOT / "gpurun_out" / f"prof_{tag}", ROOT / "profiles"
-for name in ("smollm135m_decode", "llama2_7b_decode", "qmatvec_bench", "llama2_7b_prefill32"):
+for name in ("smollm135m_decode", "llama2_7b_decode", "qmatvec_bench", "qmatvec_chain", "llama2_7b_prefill32", "llama2_7b_prefill128"):
     f = src / f"{name}_kernel_stats.csv"
     if f.exists():
         shutil.copy(f, dst / f"{tag}_{name}_kernel_stats.csv")
@@ -40,7 +40,10 @@ if pmc.exists():
         k, v = max(q4, key=lambda kv: len(kv[1]))
         kb = sum(v) / len(v)
         cal = sum(copy[0]) / len(copy[0])
-        js = {"4096x4096_q4_0": {
+        import subprocess
+        commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=ROOT).stdout.strip()
+        js = {"source_commit": commit + " (HEAD when the summary was written; the kernel of the pass is the tree's)",
+              "4096x4096_q4_0": {
             "FETCH_SIZE_KB_avg": round(kb, 3), "traffic_bytes_per_launch": int(round(kb * 1024 * 2)),
             "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request for wide coalesced streams -> x2 "
                           f"(MI355X_MICROARCH.md, HBM); calibrated in the same run: copy_f4_kernel of 1 GiB reads FETCH_SIZE = {cal:.0f} KB = 0.5 GiB",
