@@ -306,7 +306,11 @@ bool qweight_packable(uint64_t K, uint64_t N, uint64_t bs);
 void packed_bytes(QWFormat format, uint32_t scale_f16, uint64_t K, uint64_t N, uint64_t* qs_bytes,
                   uint64_t* sc_bytes);
 void launch_pack_qweight(hipStream_t s, const int8_t* raw_data, const float* raw_scales, const QWeightDev& out);
-// Bytes of split-K scratch a qmatmul launch may need (f32 partial slabs).
+// Bytes of scratch a qmatmul launch may need behind its `scratch` pointer (A pieces, split-K partial tiles). In addition
+// the kQmmScratchHead bytes IN FRONT of that pointer belong to the launchers: fan-in counters of the K-split tile kernel,
+// zero at allocation and re-armed by every launch. Whoever allocates the block allocates kQmmScratchHead + bytes,
+// zeroes the head and passes base + kQmmScratchHead.
+constexpr uint64_t kQmmScratchHead = 4096;
 uint64_t qmatmul_scratch_bytes(const QWeightDev& w, uint32_t M);
 void launch_qmatmul(hipStream_t s, const QWeightDev& w, const QMatmulParams& p, float* scratch);
 // M > 1: up to qmatmul_max_group() quantized matmuls over the same rows in one launch (qmatmul_can_group pairwise)

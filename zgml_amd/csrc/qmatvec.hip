@@ -1507,9 +1507,12 @@ static bool xdl2_enabled() {
 static bool xdl2_applies(const QWeightDev& w, uint32_t M) { // K <= 12288: a wave's weights (<= 12 steps) are preloaded into LDS
     return M > 1 && w.format == QW_Q4 && w.scale_f16 && xdl2_enabled() && (w.KC + 3) / 4 <= 8 * 12;
 }
-// scratch of an M > 1 launch: [A pieces][split-K partial tiles of the M > 32 form][its arrival counters]. The partial and
-// counter regions are sized for a grouped launch of kMaxQmmParts weights of this shape (the runtime allocates the
-// maximum over a program's weights, so the widest weight bounds every group it is part of).
+// scratch of an M > 1 launch: [A pieces][split-K partial tiles of the M > 32 form]; the partial region is sized for a
+// grouped launch of kMaxQmmParts weights of this shape (the runtime allocates the maximum over a program's weights, so
+// the widest weight bounds every group it is part of). The arrival counters of the K split live in the kQmmScratchHead
+// bytes in FRONT of the scratch pointer (kernels.h): a fixed place, so launches of different shapes that share the block
+// can never scribble partial tiles or A pieces over each other's counters. A launch only splits K when it has fewer
+// (tile group, block-column) pairs than counter words.
 static uint32_t xdl_tile_pad(uint32_t M) { return M > 64 ? 8 : (M > 32 ? 4 : (M > 16 ? 2 : 1)); } // m-tiles per workgroup
 static uint64_t xdl_a_bytes(const QWeightDev& w, uint32_t M) {
     const uint64_t S = (w.KC + 3) / 4, tiles = (M + 15) / 16, R = xdl_tile_pad(M);
@@ -1520,14 +1523,9 @@ static uint64_t xdl4_partial_bytes(const QWeightDev& w, uint32_t M) { // one par
     const uint64_t RT = xdl_tile_pad(M), groups = ((M + 15) / 16 + RT - 1) / RT;
     return groups * (w.N / 32) * 4 * (2 * RT * 256 * 4);
 }
-static uint64_t xdl4_counter_bytes(const QWeightDev& w, uint32_t M) {
-    if (M <= 32) return 0;
-    const uint64_t RT = xdl_tile_pad(M), groups = ((M + 15) / 16 + RT - 1) / RT;
-    return (groups * (w.N / 32) * 4 + 255) / 256 * 256;
-}
 uint64_t qmatmul_scratch_bytes(const QWeightDev& w, uint32_t M) {
     if (!xdl2_applies(w, M)) return 0;
-    return xdl_a_bytes(w, M) + (uint64_t)kMaxQmmParts * (xdl4_partial_bytes(w, M) + xdl4_counter_bytes(w, M));
+    return xdl_a_bytes(w, M) + (uint64_t)kMaxQmmParts * xdl4_partial_bytes(w, M);
 }
 
 bool qweight_packable(uint64_t K, uint64_t N, uint64_t bs) {
@@ -1660,26 +1658,25 @@ void launch_xdl4(hipStream_t s, const QWeightDev* w, const QMatmulParams* p, uin
     }
     QMM4Args a{};
     uint32_t blocks = 0;
-    uint64_t part_max = 0, cnt_max = 0;
     // block-columns per workgroup (kernel template CB): pairing waves on neighbouring block-columns so that the second
     // reader of a step's A pieces hits L1 was measured SLOWER (128 x 4096 x 4096: 47.4 vs 32.5 us) — one per workgroup
     constexpr uint32_t CB = 1;
     for (uint32_t t = 0; t < n; t++) {
         a.parts[t] = {(const uint4*)w[t].qs, (const uint4*)w[t].sc, p[t].dst, p[t].dst_rs, p[t].N / 32 / CB, blocks};
         blocks += p[t].N / 32 / CB;
-        part_max = std::max(part_max, xdl4_partial_bytes(w[t], p[0].M)), cnt_max = std::max(cnt_max, xdl4_counter_bytes(w[t], p[0].M));
     }
     const uint32_t groups = tiles / RT, KW = kX4Waves / CB;
     // K split: at least one workgroup per CU, at most 4 slices (the scratch regions are sized for 4), whole steps per wave
     static const int env_sk = getenv("ZGML_QMM_XDL4_SK") ? atoi(getenv("ZGML_QMM_XDL4_SK")) : 0;
     uint32_t SK = env_sk > 0 ? (uint32_t)env_sk : cdiv((uint32_t)n_cu, blocks * groups);
     SK = std::max(1u, std::min({SK, 4u, cdiv(S, KW)}));
+    if ((uint64_t)blocks * groups * sizeof(uint32_t) > kQmmScratchHead) SK = 1; // one counter word per (tile group, block-column)
     const uint32_t steps_per_slice = cdiv(S, SK);
     SK = cdiv(S, steps_per_slice);
     const uint64_t a_bytes = xdl_a_bytes(w[0], p[0].M);
     a.ap = (const uint4*)scratch;
     a.partial = (float*)((char*)scratch + a_bytes);
-    a.counter = (uint32_t*)((char*)scratch + a_bytes + (uint64_t)kMaxQmmParts * part_max);
+    a.counter = (uint32_t*)((char*)scratch - kQmmScratchHead);
     a.n_parts = n, a.M = p[0].M, a.U = w[0].KC, a.S = S, a.SK = SK, a.steps_per_slice = steps_per_slice;
     const dim3 grid(blocks * SK, groups);
     const size_t lds = (size_t)kX4Waves * 2 * RT * 256 * sizeof(float) + 64;

@@ -2456,7 +2456,12 @@ zgml_hip_program* zgml_hip_compile_program(zgml_hip_ctx* ctx, const zgml_device_
             uint64_t b = dense_f16_scratch_bytes((uint32_t)op.u.matmul.geom.M, (uint32_t)op.u.matmul.geom.K); // pre-rounded A operand
             if (b > p->scratch_bytes) p->scratch_bytes = b;
         }
-    if (ok && p->scratch_bytes) ok = CTX_CHECK(ctx, hipMalloc((void**)&p->scratch, p->scratch_bytes));
+    // the head in front of the block holds the K-split fan-in counters: zero once, every launch re-arms them (kernels.h)
+    if (ok && p->scratch_bytes) {
+        char* base = nullptr;
+        ok = CTX_CHECK(ctx, hipMalloc((void**)&base, kQmmScratchHead + p->scratch_bytes)) && CTX_CHECK(ctx, hipMemsetAsync(base, 0, kQmmScratchHead, ctx->stream));
+        if (base) p->scratch = (float*)(base + kQmmScratchHead);
+    }
 
     const size_t n_dyn = p->ops.empty() ? 1 : p->ops.size();
     if (ok)
@@ -2672,7 +2677,7 @@ void zgml_hip_free_program(zgml_hip_ctx* ctx, zgml_hip_program* p) {
     if (p->arena) hipFree(p->arena);
     if (p->zero_word) hipFree(p->zero_word);
     for (void* d : p->owned) hipFree(d);
-    if (p->scratch) hipFree(p->scratch);
+    if (p->scratch) hipFree((char*)p->scratch - kQmmScratchHead);
     if (p->dyn_dev) hipFree(p->dyn_dev);
     if (p->dyn_host) hipHostFree(p->dyn_host);
     if (p->stage_host) hipHostFree(p->stage_host);
@@ -2853,12 +2858,14 @@ double zgml_hip_qmatmul_bench(zgml_hip_ctx* ctx, uint32_t M, uint32_t K, uint32_
     if (ok && (ring[0].qs_bytes + ring[0].sc_bytes) * n_matrices >= (192ull << 20)) // the ring stands for a model beyond the cache
         for (auto& w : ring) w.stream_nt = 1;
     float *x = nullptr, *y = nullptr, *scratch = nullptr;
+    char* scratch_base = nullptr;
     std::vector<float> xh((size_t)M * K);
     for (size_t i = 0; i < xh.size(); i++) xh[i] = ((int)(i % 17) - 8) * 0.03125f;
     uint64_t sb = ok ? qmatmul_scratch_bytes(ring[0], M) : 0;
     ok = ok && CTX_CHECK(ctx, hipMalloc((void**)&x, xh.size() * 4)) && CTX_CHECK(ctx, hipMalloc((void**)&y, (size_t)M * N * 4)) &&
-         (!sb || CTX_CHECK(ctx, hipMalloc((void**)&scratch, sb))) &&
+         (!sb || (CTX_CHECK(ctx, hipMalloc((void**)&scratch_base, kQmmScratchHead + sb)) && CTX_CHECK(ctx, hipMemsetAsync(scratch_base, 0, kQmmScratchHead, ctx->stream)))) &&
          CTX_CHECK(ctx, hipMemcpy(x, xh.data(), xh.size() * 4, hipMemcpyHostToDevice));
+    if (scratch_base) scratch = (float*)(scratch_base + kQmmScratchHead);
     double us = -1.0;
     if (ok) {
         QMatmulParams qp{y, x, M, N, K, K, N};
@@ -2901,7 +2908,7 @@ double zgml_hip_qmatmul_bench(zgml_hip_ctx* ctx, uint32_t M, uint32_t K, uint32_
     }
     hipFree(x);
     hipFree(y);
-    hipFree(scratch);
+    hipFree(scratch_base);
     return us;
 }
 
@@ -3066,11 +3073,13 @@ int zgml_hip_qmatvec_synth(zgml_hip_ctx* ctx, uint32_t K, uint32_t N, int q4, ui
     hipSetDevice(ctx->device);
     QWeightDev w{};
     float *x = nullptr, *y = nullptr, *scratch = nullptr;
+    char* scratch_base = nullptr;
     bool ok = make_synth_weight(ctx, K, N, q4, matrix_id, &w);
     uint64_t sb = ok ? qmatmul_scratch_bytes(w, 1) : 0;
     ok = ok && CTX_CHECK(ctx, hipMalloc((void**)&x, K * 4)) && CTX_CHECK(ctx, hipMalloc((void**)&y, N * 4)) &&
-         (!sb || CTX_CHECK(ctx, hipMalloc((void**)&scratch, sb))) &&
+         (!sb || (CTX_CHECK(ctx, hipMalloc((void**)&scratch_base, kQmmScratchHead + sb)) && CTX_CHECK(ctx, hipMemsetAsync(scratch_base, 0, kQmmScratchHead, ctx->stream)))) &&
          CTX_CHECK(ctx, hipMemcpyAsync(x, x_host, K * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (scratch_base) scratch = (float*)(scratch_base + kQmmScratchHead);
     if (ok) {
         QMatmulParams qp{y, x, 1, N, K, K, N};
         launch_qmatmul(ctx->stream, w, qp, scratch);
@@ -3081,7 +3090,7 @@ int zgml_hip_qmatvec_synth(zgml_hip_ctx* ctx, uint32_t K, uint32_t N, int q4, ui
     hipFree(w.sc);
     hipFree(x);
     hipFree(y);
-    hipFree(scratch);
+    hipFree(scratch_base);
     return ok ? 0 : -1;
 }
 
