@@ -271,10 +271,14 @@ def test_refresh_beyond_assumed_bounds_falls_back_correctly(hip_backend, oracle)
         np.testing.assert_allclose(g, r, atol=2e-5, rtol=0)
 
 
-@pytest.mark.parametrize("dh,sq,n_heads,skv,has_mask", [(128, 64, 8, 300, False), (64, 33, 3, 90, True), (32, 40, 8, 1030, True)])
+@pytest.mark.parametrize("dh,sq,n_heads,skv,has_mask", [(128, 64, 8, 300, False), (64, 33, 3, 90, True), (32, 40, 8, 1030, True),
+                                                         (128, 20, 2, 37, True), (64, 128, 4, 128, True), (128, 16, 1, 5, True),
+                                                         (128, 128, 32, 256, True), (128, 32, 2, 2040, True), (64, 17, 2, 17, False)])
 def test_attention_many_queries_batched_heads(hip_backend, oracle, dh, sq, n_heads, skv, has_mask):
-    """seq_q > 1 over several heads in one dependency level (the prefill shape): the streaming kernel with 4-wave
-    workgroups when (queries x heads) fills the chip, 16-wave ones otherwise; causal-style masks, multi-step contexts."""
+    """seq_q > 1 over several heads in one dependency level (the prefill shape). d_head 64 / 128 with >= 16 queries:
+    attention_tiles_kernel (16-query tiles on the f32 matrix cores; ragged query and key tiles, causal tiles skipped,
+    4- and 8-wave workgroups, key tiles split over waves and merged); otherwise the streaming kernel. Causal-style masks,
+    multi-step contexts."""
     rng = np.random.default_rng(dh * 1000 + sq + skv)
     bufs, ups, ops = [], [], []
     mask = np.zeros(skv * sq, f32)

@@ -284,6 +284,10 @@ void launch_attention_decode_batch(hipStream_t s, const AttnDecodeParams* dev_pa
                                    const AttnSplit& sp, bool kvq = false); // kvq: every head reads quantised caches (block 32)
 void launch_kvq_attention_batch(hipStream_t s, const KvqAttentionParams* dev_params, uint32_t n_ops, uint32_t max_seq_q, uint32_t d_head,
                                 const AttnSplit& sp = AttnSplit{}); // split applies to seq_q == 1 launches only
+// seq_q >= 16, dense layouts, d_head 64 / 128: query tiles on the matrix cores (attention_tiles.hip)
+bool attention_tiles_applies(uint32_t max_seq_q, uint32_t d_head);
+void launch_attention_tiles(hipStream_t s, const AttentionParams* dev_params, uint32_t n_ops, uint32_t max_seq_q, uint32_t d_head,
+                            const float* zero_word);
 void launch_attention_batch(hipStream_t s, const AttentionParams* dev_params, uint32_t n_ops, uint32_t max_seq_q, bool all_dense,
                             uint32_t rows_d_head = 0, const float* zero_word = nullptr); // rows_d_head: the common d_head when every op is dense (else 0)
 void launch_dense_matmul(hipStream_t s, const DenseMatmulParams& p);

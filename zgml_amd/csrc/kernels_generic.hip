@@ -1541,6 +1541,10 @@ void launch_attention_batch(hipStream_t s, const AttentionParams* dev_params, ui
                             bool all_dense, uint32_t rows_d_head, const float* zero_word) {
     if (!n_ops || !max_seq_q) return;
     static const bool rows_on = !(getenv("ZGML_HIP_ATTN_ROWS") && atoi(getenv("ZGML_HIP_ATTN_ROWS")) == 0);
+    if (all_dense && rows_d_head && zero_word && rows_on && attention_tiles_applies(max_seq_q, rows_d_head)) {
+        launch_attention_tiles(s, dev_params, n_ops, max_seq_q, rows_d_head, zero_word);
+        return;
+    }
     if (all_dense && rows_d_head && zero_word && rows_on) { // every op dense with this d_head: the streaming kernel
         const dim3 grid(max_seq_q, n_ops);
         // enough (query, head) workgroups to fill the chip: 4 waves each (a 16-wave workgroup whose context needs 2
