@@ -209,6 +209,34 @@ __device__ __forceinline__ void x_commit(float* xs, const XRegs& ra, const XRegs
             *(float4*)(xs + i) = zero_tail(load_x4<XVEC>(xa_row, i, K), i, K);
 }
 
+// all 64 lanes get the sum of the wave's 4 DPP rows, (r0 + r1) + (r2 + r3), by gfx950's row swaps (no LDS round trip)
+__device__ __forceinline__ float rows_sum4(float v) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+// every lane of a DPP row gets the sum of the row's 16 lanes (quad swaps, half mirror, mirror)
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xF, 0xF, true));
+    return v;
+}
+// workgroup total of one value per thread, the same on every thread, fixed order: lanes, rows, then the (<= 16) waves
+// with ONE LDS read per lane and a row fold (a serial loop over the waves is one dependent LDS round trip per wave)
+__device__ __forceinline__ float block_total(float v, float* red) {
+    v = rows_sum4(row16_sum(v));
+    const uint32_t n_waves = blockDim.x >> 6, slot = threadIdx.x & 15;
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const float t = red[min(slot, n_waves - 1)];
+    const float total = row16_sum(slot < n_waves ? t : 0.f);
+    __syncthreads();
+    return total;
+}
+
 // sum of squares of the (zero-tailed) register window, fixed reduction order: lanes, then waves
 __device__ __forceinline__ float block_sumsq(const XRegs& r, uint32_t K, float* red) {
     float ss = 0.f;
@@ -221,19 +249,7 @@ __device__ __forceinline__ float block_sumsq(const XRegs& r, uint32_t K, float* 
         ss += v.z * v.z;
         ss += v.w * v.w;
     }
-    // row of 16 by DPP (quad swaps, half mirror, mirror), then the 4 rows by two LDS shuffles
-    ss += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(ss), 0xB1, 0xF, 0xF, true));
-    ss += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(ss), 0x4E, 0xF, 0xF, true));
-    ss += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(ss), 0x141, 0xF, 0xF, true));
-    ss += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(ss), 0x140, 0xF, 0xF, true));
-    ss += __shfl_xor(ss, 16, 64);
-    ss += __shfl_xor(ss, 32, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
-    __syncthreads();
-    float t = 0.f;
-    for (uint32_t w = 0; w < (blockDim.x >> 6); w++) t += red[w];
-    __syncthreads();
-    return t;
+    return block_total(ss, red);
 }
 
 __device__ __forceinline__ float epi_unary(uint32_t op, float a) {
@@ -295,17 +311,29 @@ __device__ __forceinline__ void run_epilogue(const QMVPartDev& part, uint32_t n,
 // `a.parts[...]` below is a COMPILE-TIME index so the kernel-argument loads are issued up front —
 // a run-time index into the argument block is a dependent scalar load that costs ~1 us at the
 // start and again in the tail of a 5 us kernel.
+// The waves' rows are folded by wave 0 with 4 independent LDS reads per lane (row r of the wave takes waves r, r + 4,
+// r + 8, r + 12) and one more row fold: the serial loop over the waves it replaces was one dependent LDS round trip per
+// wave (in-kernel stamps: 0.64 us of tail with 9-16 waves; SmolLM-135M +3.0 %, Llama-2-7B +1.1 % on the same box).
+// Measured with it and NOT kept: requesting the operands of all epilogue steps at kernel start (the SiLU chain's constant
+// vector; -1 %: two more loads per lane and the part selects cost more than the one dependent load they save), and the
+// prologue kind / x alignment from the preloaded head instead of the argument block (+0.7 % / -0.9 %).
 template <bool GROUPED>
 __device__ __forceinline__ void reduce_store(float acc, float* red, const QMVArgs& a, uint32_t pi, float* out0, uint32_t g, uint32_t m,
                                              float pre0 = 0.f, bool have_pre0 = false) {
-    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
-    acc += __shfl_xor(acc, 16, 64);
-    acc += __shfl_xor(acc, 32, 64);
+    const uint32_t lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n_waves = blockDim.x >> 6;
+    acc = rows_sum4(acc);
     if (lane < 16) red[w * 16 + lane] = acc;
     __syncthreads();
-    if (threadIdx.x < 16) {
-        float v = red[threadIdx.x];
-        for (uint32_t ww = 1; ww < n_waves; ww++) v += red[ww * 16 + threadIdx.x];
+    if (w != 0) return;
+    const uint32_t r = lane >> 4, col = lane & 15;
+    float part[4];
+#pragma unroll
+    for (uint32_t j = 0; j < 4; j++) part[j] = red[min(r + 4 * j, n_waves - 1) * 16 + col]; // clamped, unconditional
+    float v = 0.f;
+#pragma unroll
+    for (uint32_t j = 0; j < 4; j++) v += r + 4 * j < n_waves ? part[j] : 0.f;
+    v = rows_sum4(v);
+    if (lane < 16) {
         const uint32_t n = g * 16 + threadIdx.x;
         // part 0's output pointer is a preloaded argument; further parts' come from the argument block
         // (static indices), long arrived by now; the row stride only matters for M > 1
@@ -414,19 +442,7 @@ __device__ __forceinline__ float block_sumsq_direct(const SumsqRegs& r, const fl
             if (threadIdx.x + j * T < K) s[j] += r.v[j].x * r.v[j].x;
         for (uint32_t k = threadIdx.x + 4 * T; k < K; k += T) s[0] += x[k] * x[k];
     }
-    float ss = (s[0] + s[1]) + (s[2] + s[3]);
-    ss += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(ss), 0xB1, 0xF, 0xF, true));
-    ss += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(ss), 0x4E, 0xF, 0xF, true));
-    ss += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(ss), 0x141, 0xF, 0xF, true));
-    ss += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(ss), 0x140, 0xF, 0xF, true));
-    ss += __shfl_xor(ss, 16, 64);
-    ss += __shfl_xor(ss, 32, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
-    __syncthreads();
-    float t = 0.f;
-    for (uint32_t w = 0; w < (blockDim.x >> 6); w++) t += red[w];
-    __syncthreads();
-    return t;
+    return block_total((s[0] + s[1]) + (s[2] + s[3]), red);
 }
 
 template <typename ST, int DEPTH, bool XD, bool PROMUL, bool NT>
