@@ -607,15 +607,36 @@ __device__ __forceinline__ float score_of(float dot, float mk, float scale) {
 // Lane layout: a key is handled by LPK = d_head/4 adjacent lanes holding one float4 of the head
 // dimension each (one coalesced row read per key); a wave streams 64/LPK keys per step.
 
-// allreduce (sum) over groups of LPK adjacent lanes; DPP inside a 16-lane row, ds_bpermute above
+// v + (v of lane ^ 16) and v + (v of lane ^ 32) without the LDS crossbar (ds_bpermute: ~100 cycles and an lgkmcnt wait
+// per exchange): gfx950's row swaps. permlane16_swap(v, v) = (rows 0 0 2 2 | rows 1 1 3 3), so their sum (max) is the
+// xor-16 exchange's on every lane; permlane32_swap pairs the wave's halves the same way. Same values as the shuffles
+// (a + b == b + a exactly).
+__device__ __forceinline__ float xor16_sum(float v) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor32_sum(float v) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor16_max(float v) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor32_max(float v) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+// allreduce (sum) over groups of LPK adjacent lanes; DPP inside a 16-lane row, row swaps above
 template <int LPK>
 __device__ __forceinline__ float group_sum(float v) {
     if (LPK >= 2) v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
     if (LPK >= 4) v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));  // quad_perm [2,3,0,1]
     if (LPK >= 8) v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xF, 0xF, true)); // row_half_mirror
     if (LPK >= 16) v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xF, 0xF, true)); // row_mirror
-    if (LPK >= 32) v += __shfl_xor(v, 16, 64);
-    if (LPK >= 64) v += __shfl_xor(v, 32, 64);
+    if (LPK >= 32) v = xor16_sum(v);
+    if (LPK >= 64) v = xor32_sum(v);
     return v;
 }
 
@@ -656,18 +677,22 @@ __device__ __forceinline__ void split_get(const float* p, float& a, float& b) {
 template <int LPK>
 __device__ __forceinline__ void slots_sum(SoftState& s) {
 #pragma unroll
-    for (int off = LPK; off < 64; off <<= 1) {
+    for (int off = LPK; off < 16; off <<= 1) {
         s.l += __shfl_xor(s.l, off, 64);
         s.acc.x += __shfl_xor(s.acc.x, off, 64), s.acc.y += __shfl_xor(s.acc.y, off, 64);
         s.acc.z += __shfl_xor(s.acc.z, off, 64), s.acc.w += __shfl_xor(s.acc.w, off, 64);
     }
+    if (LPK <= 16) s.l = xor16_sum(s.l), s.acc.x = xor16_sum(s.acc.x), s.acc.y = xor16_sum(s.acc.y), s.acc.z = xor16_sum(s.acc.z), s.acc.w = xor16_sum(s.acc.w);
+    if (LPK <= 32) s.l = xor32_sum(s.l), s.acc.x = xor32_sum(s.acc.x), s.acc.y = xor32_sum(s.acc.y), s.acc.z = xor32_sum(s.acc.z), s.acc.w = xor32_sum(s.acc.w);
 }
 // merge the slots' online-softmax states: common max, one rescale each, sums
 template <int LPK>
 __device__ __forceinline__ void slots_merge(SoftState& s) {
     float M = s.m;
 #pragma unroll
-    for (int off = LPK; off < 64; off <<= 1) M = fmaxf(M, __shfl_xor(M, off, 64));
+    for (int off = LPK; off < 16; off <<= 1) M = fmaxf(M, __shfl_xor(M, off, 64));
+    if (LPK <= 16) M = xor16_max(M);
+    if (LPK <= 32) M = xor32_max(M);
     const float f = s.m > -INFINITY ? expf(s.m - M) : 0.0f;
     s.l *= f;
     s.acc = make_float4(s.acc.x * f, s.acc.y * f, s.acc.z * f, s.acc.w * f);
