@@ -636,6 +636,21 @@ __global__ void __launch_bounds__(1024) qmatvec_kernel(QMV_HEAD_PARAMS, QMVArgs 
         QMV_STAMP(3); // x staged
     }
 
+    // Touch every 64-byte line of the argument block now (one scalar dword each, consumed after the stream). The epilogue's
+    // step descriptors are read from it behind the reduction, under the part selects, where hipcc issues their s_loads
+    // late — each a miss in the kernel's tail; with the lines already in the scalar cache they hit (SmolLM-135M +1 %,
+    // Llama-2-7B unchanged). Unconditional: under `if (K <= 2048)` the scalar loads sit behind a branch and the counted
+    // waits of the whole kernel degrade (-5 %). Fetching the whole descriptor block into SGPRs with three
+    // s_load_dwordx16 under the cross-wave fold gave nothing on top of this.
+    uint32_t arg_touch = 0;
+#if defined(__HIP_DEVICE_COMPILE__) // (the builtin's pointer type differs in the host pass)
+    {
+        const auto kargs = (const __attribute__((address_space(4))) uint32_t*)__builtin_amdgcn_kernarg_segment_ptr();
+        constexpr uint32_t kArgDwords = (56 + sizeof(QMVArgs)) / 4; // QMV_HEAD_PARAMS (5 pointers + 4 dwords), then QMVArgs
+#pragma unroll
+        for (uint32_t o = 16; o < kArgDwords; o += 16) arg_touch |= kargs[o];
+    }
+#endif
     // single-matrix launches (O / down projection): the operand of the first epilogue step (the residual) is requested
     // now, under the weight stream, by every lane for its column (unconditional: a load under a branch would degrade
     // the counted waits); the 16 owning lanes use it behind the reduction instead of a dependent ~0.5 us load
@@ -655,6 +670,9 @@ __global__ void __launch_bounds__(1024) qmatvec_kernel(QMV_HEAD_PARAMS, QMVArgs 
         u += DEPTH * stride;
     }
     cur.compute(xs, u, stride, U, i, acc0, acc1, acc2, acc3, xd);
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" ::"s"(arg_touch)); // (keeps the touches alive; long arrived)
+#endif
     QMV_STAMP(4); // weights streamed
     reduce_store<GROUPED>((acc0 + acc1) + (acc2 + acc3), red, a, pi, out0, g, m, pre0, have_pre0);
     QMV_STAMP(5);
