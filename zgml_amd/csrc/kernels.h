@@ -265,7 +265,18 @@ struct RowChainParams {
     float* mul_dst = nullptr;
     uint32_t cols = 0;
     float eps = 0.f;
+    // Optional side output for an M > 1 quantized matmul that consumes the chain's result (mul_dst, else norm_dst): the
+    // rows' exact bf16 pieces in the tile kernels' A-operand layout (qmatvec.hip: split_a_kernel), written here instead of
+    // by a launch of their own. ap_S = the matmul's K steps (cols / 128); only for rows % 16 == 0 and cols % 128 == 0.
+    uint16_t* ap = nullptr;
+    uint32_t ap_S = 0;
 };
+// element (row m, column j) of an activation matrix in the A-operand layout of the XDL tile kernels: index of its bf16 in
+// units of 2 bytes for piece 0; pieces 1 and 2 follow at + 512 and + 1024 (64 lanes x 8 bf16 each)
+__host__ __device__ inline uint64_t a_piece_index(uint32_t S, uint32_t m, uint32_t j) {
+    const uint64_t t = m >> 4, i = m & 15, s = j >> 7, r = (j >> 5) & 3, jj = (j >> 3) & 3, e = j & 7;
+    return ((((t * S + s) * 4 + jj) * 3) * 64 + (i + 16 * r)) * 8 + e;
+}
 void launch_row_chain(hipStream_t s, const RowChainParams& p, uint32_t rows);
 void launch_reduce(hipStream_t s, uint32_t op, float* dst, const float* src, uint32_t n_out, uint32_t reduce_size);
 // batched: dev_params = device array of n_ops records; one launch covers all of them

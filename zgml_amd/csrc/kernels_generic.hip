@@ -184,6 +184,16 @@ __global__ void __launch_bounds__(kBlock) rmsnorm_kernel(float* __restrict__ dst
 // form. NPT > 0: the row fits NPT elements per thread — everything is loaded up front with independent loads
 // (a row is one dependent chain otherwise: 32 rows x 4096 columns took ~25 us) and kept in registers between
 // the two passes. NPT == 0: any width, looping.
+// x = h1 + h2 + h3 exactly, each piece a bf16 (truncation split, 8 + 8 + 8 significant bits: split_a_kernel's arithmetic)
+__device__ __forceinline__ void store_a_pieces(uint16_t* ap, uint32_t S, uint32_t m, uint32_t j, float v) {
+    const uint32_t h1 = __float_as_uint(v) & 0xFFFF0000u;
+    const float r1 = v - __uint_as_float(h1);
+    const uint32_t h2 = __float_as_uint(r1) & 0xFFFF0000u;
+    const float r2 = r1 - __uint_as_float(h2);
+    uint16_t* const d = ap + a_piece_index(S, m, j);
+    d[0] = (uint16_t)(h1 >> 16), d[512] = (uint16_t)(h2 >> 16), d[1024] = (uint16_t)(__float_as_uint(r2) >> 16);
+}
+
 template <int NPT>
 __global__ void __launch_bounds__(kBlock) row_chain_kernel(RowChainParams p) {
     __shared__ float red[8];
@@ -193,6 +203,7 @@ __global__ void __launch_bounds__(kBlock) row_chain_kernel(RowChainParams p) {
     float ss = 0;
     if (NPT > 0) {
         constexpr int N = NPT > 0 ? NPT : 1;
+        __shared__ __attribute__((aligned(16))) uint16_t pl[3 * N * kBlock]; // A pieces of the row (RowChainParams::ap)
         float v[N], mo[N];
         const uint32_t last = p.cols - 1;
         if (p.add_dst) {
@@ -228,7 +239,24 @@ __global__ void __launch_bounds__(kBlock) row_chain_kernel(RowChainParams p) {
             if (j < p.cols) {
                 const float nv = v[k] * inv;
                 nd[j] = nv;
-                if (p.mul_dst) p.mul_dst[base + j] = nv * mo[k];
+                const float xv = p.mul_dst ? nv * mo[k] : nv;
+                if (p.mul_dst) p.mul_dst[base + j] = xv;
+                if (p.ap) { // the three bf16 pieces, transposed through LDS so that they leave as 16-byte stores
+                    const uint32_t h1 = __float_as_uint(xv) & 0xFFFF0000u;
+                    const float r1 = xv - __uint_as_float(h1);
+                    const uint32_t h2 = __float_as_uint(r1) & 0xFFFF0000u;
+                    const float r2 = r1 - __uint_as_float(h2);
+                    pl[j] = (uint16_t)(h1 >> 16), pl[N * kBlock + j] = (uint16_t)(h2 >> 16), pl[2 * N * kBlock + j] = (uint16_t)(__float_as_uint(r2) >> 16);
+                }
+            }
+        }
+        if (p.ap) { // (uniform) cols % 128 == 0 here (planner)
+            __syncthreads();
+            const uint32_t groups = p.cols / 8;
+            for (uint32_t u = threadIdx.x; u < 3 * groups; u += kBlock) {
+                const uint32_t piece = u / groups, j0 = (u - piece * groups) * 8;
+                const uint4 val = *(const uint4*)(pl + piece * (N * kBlock) + j0);
+                *(uint4*)(p.ap + a_piece_index(p.ap_S, blockIdx.x, j0) + piece * 512) = val;
             }
         }
         return;
@@ -254,9 +282,13 @@ __global__ void __launch_bounds__(kBlock) row_chain_kernel(RowChainParams p) {
             const float nv = s[j] * inv;
             nd[j] = nv;
             md[j] = nv * mo[j];
+            if (p.ap) store_a_pieces(p.ap, p.ap_S, blockIdx.x, j, nv * mo[j]);
         }
     } else {
-        for (uint32_t j = threadIdx.x; j < p.cols; j += kBlock) nd[j] = s[j] * inv;
+        for (uint32_t j = threadIdx.x; j < p.cols; j += kBlock) {
+            nd[j] = s[j] * inv;
+            if (p.ap) store_a_pieces(p.ap, p.ap_S, blockIdx.x, j, s[j] * inv);
+        }
     }
 }
 

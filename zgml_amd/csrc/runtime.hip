@@ -36,11 +36,21 @@ namespace {
 
 std::string g_create_error;
 
+// A launch that can also emit its result rows as the A pieces of an M > 1 quantized matmul (kernels.h: RowChainParams::ap):
+// the planner arms it when the matmul that consumes exactly these rows follows with no other splitting launch in between.
+struct SplitHook {
+    const float* out = nullptr; // the rows the launch produces (dense: row stride == cols)
+    uint32_t rows = 0, cols = 0;
+    uint16_t** ap = nullptr;    // fields of the launch's (shared) parameter block
+    uint32_t* ap_S = nullptr;
+};
+
 struct Launch {
     uint32_t kind;           // DeviceOp tag the launch is accounted to
     uint32_t n_ops;          // DeviceOps covered (batching folds several)
     uint32_t op_lo, op_hi;   // smallest / largest op index covered
     std::function<void(hipStream_t)> run;
+    std::shared_ptr<SplitHook> hook; // (after `run` so the aggregate initialisers elsewhere stay valid)
     uint64_t prof_ns = 0;    // ZGML_HIP_OPT_PROFILE: accumulated event time of this launch
     uint32_t prof_calls = 0;
 };
@@ -617,6 +627,20 @@ bool make_single(zgml_hip_program* p, size_t i, Launch& L) {
             const bool splits = scratch && qmatmul_scratch_bytes(w, qp.M) != 0;
             qp.reuse_split = splits && p->split_pos + 1 == pos && p->split_input == qp.input && p->split_M == qp.M && p->split_K == qp.K &&
                              p->split_in_rs == qp.in_rs && p->split_kind == 1;
+            // ... or finds them written by the launch that produced the rows (a row chain right in front of it, no other
+            // splitting launch in between): that launch is armed and this one skips its split_a_kernel launch
+            static const bool fuse_split = !(getenv("ZGML_HIP_FUSE_SPLIT") && atoi(getenv("ZGML_HIP_FUSE_SPLIT")) == 0);
+            if (splits && !qp.reuse_split && fuse_split && qp.M % 16 == 0 && qp.K % 128 == 0 && qp.in_rs == qp.K) {
+                for (size_t back = p->plan.size(); back-- > 0;) {
+                    const Launch& prev = p->plan[back];
+                    if (prev.hook && prev.hook->out == qp.input && prev.hook->rows == qp.M && prev.hook->cols == qp.K) {
+                        *prev.hook->ap = (uint16_t*)scratch, *prev.hook->ap_S = qp.K / 128;
+                        qp.reuse_split = 1;
+                        break;
+                    }
+                    if (prev.kind == ZGML_DOP_QMATMUL || prev.kind == ZGML_DOP_MATMUL) break; // may own the scratch
+                }
+            }
             if (splits)
                 p->split_pos = pos, p->split_input = qp.input, p->split_M = qp.M, p->split_K = qp.K, p->split_in_rs = qp.in_rs, p->split_kind = 1;
             // ... and joins its launch when the kernel can take another part (same rows, same K: q/k/v, gate/up)
@@ -1647,8 +1671,11 @@ void build_fused_plan(zgml_hip_program* p) {
                     rc.mul_dst = buf_at(p, e.dst, e.dst_offset);
                 }
                 const uint32_t rows = rn.rows;
-                chains.push_back({ZGML_DOP_RMSNORM, (uint32_t)m.members.size(), m.members.front(), m.members.back(),
-                                  [=](hipStream_t s) { launch_row_chain(s, rc, rows); }});
+                auto rcp = std::make_shared<RowChainParams>(rc); // shared: a later matmul may arm its A-piece output
+                Launch L{ZGML_DOP_RMSNORM, (uint32_t)m.members.size(), m.members.front(), m.members.back(),
+                         [=](hipStream_t s) { launch_row_chain(s, *rcp, rows); }};
+                L.hook = std::make_shared<SplitHook>(SplitHook{rcp->mul_dst ? rcp->mul_dst : rcp->norm_dst, rows, rcp->cols, &rcp->ap, &rcp->ap_S});
+                chains.push_back(std::move(L));
                 continue;
             }
             if (macros[mi].elt_chain) {
