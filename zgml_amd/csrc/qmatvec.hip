@@ -548,7 +548,7 @@ struct Q8Group {
 // epilogues, non-contiguous parts), needed late or rarely.
 #define QMV_HEAD_PARAMS                                                                                                 \
     const uint4 *__restrict__ qs0, const void *__restrict__ sc0, float *__restrict__ out0, const float *__restrict__ xa_base, \
-        const float *__restrict__ xb_base, uint32_t in_rs, uint32_t K, uint32_t nb2_0_flags /* NB2_0 | n_parts << 24 | contiguous << 28 */, \
+        const float *__restrict__ xb_base, uint32_t in_rs, uint32_t K, uint32_t nb2_0_flags /* NB2_0 | n_parts << 24 | contiguous << 28 | rmsnorm prologue << 29 | x_vec << 30 */, \
         uint32_t nb2_12 /* NB2_1 | NB2_2 << 16 */
 template <typename ST, bool XVEC, int DEPTH, bool Q4, bool PRO, bool GROUPED, bool XD, bool NT>
 __global__ void __launch_bounds__(1024) qmatvec_kernel(QMV_HEAD_PARAMS, QMVArgs a) {
@@ -573,11 +573,10 @@ __global__ void __launch_bounds__(1024) qmatvec_kernel(QMV_HEAD_PARAMS, QMVArgs 
     const uint32_t NB2_0 = nb2_0_flags & 0xFFFFFFu, n_parts = (nb2_0_flags >> 24) & 0xF, NB2_1 = nb2_12 & 0xFFFFu, NB2_2 = nb2_12 >> 16;
     uint32_t NB2 = NB2_0, block_begin = 0;
     if (GROUPED) {
-        if (nb2_0_flags >> 28) { // contiguous parts: everything from preloaded scalars
-            const uint32_t b1 = NB2_0, b2 = b1 + NB2_1, b3 = b2 + NB2_2;
+        if ((nb2_0_flags >> 28) & 1) { // contiguous parts: everything from preloaded scalars
+            const uint32_t b1 = NB2_0, b2 = b1 + NB2_1; // (<= 3 parts: a fourth part's size would be an argument-block load in front of the first load)
             if (n_parts > 1 && blockIdx.x >= b1) pi = 1, block_begin = b1, NB2 = NB2_1;
             if (n_parts > 2 && blockIdx.x >= b2) pi = 2, block_begin = b2, NB2 = NB2_2;
-            if (n_parts > 3 && blockIdx.x >= b3) pi = 3, block_begin = b3, NB2 = a.parts[3].NB2;
             qs_base = qs0 + (uint64_t)block_begin * U * 16;
             sc_base = (const ScaleT*)sc0 + (uint64_t)(block_begin >> 1) * U * 16;
         } else {
@@ -604,17 +603,22 @@ __global__ void __launch_bounds__(1024) qmatvec_kernel(QMV_HEAD_PARAMS, QMVArgs 
     const float* xa_row = xa_base + (uint64_t)m * in_rs;
     uint32_t u = 4 * w + row; // this row's unit in step 0
     const bool pro_owner = XD && PRO && blockIdx.x == 0 && blockIdx.y == 0;
-    XDirect xd{xa_row, xb_base, pro_owner ? a.pro.store_x : nullptr, pro_owner ? a.pro.store_mid : nullptr, K, 1.0f, false};
+    XDirect xd{xa_row, xb_base, nullptr, nullptr, K, 1.0f, false};
     Group cur;
+    // prologue kind and x alignment come with the preloaded head (bits 29 / 30), and the owner's side-output pointers are
+    // read after the loads are issued: anything taken from the argument block before that is an s_load round trip
+    // (~0.7 us on its first line) in front of the kernel's first load
+    const bool norm = PRO && ((nb2_0_flags >> 29) & 1) != 0;
+    const bool x_vec = ((nb2_0_flags >> 30) & 1) != 0;
     if (XD) {
-        const bool norm = PRO && a.pro.kind == QMV_PRO_RMSNORM_MUL;
         SumsqRegs sq;
-        if (norm) sq = sumsq_fetch(xa_row, K, a.x_vec != 0); // before the weights (in-order vmcnt)
+        if (norm) sq = sumsq_fetch(xa_row, K, x_vec); // before the weights (in-order vmcnt)
         cur.load(qs, sc, u, stride, u_last, xd, i);
         QMV_STAMP(1); // loads issued
         __builtin_amdgcn_sched_barrier(0); // argument-block reads below wait while the loads above fly
+        if (pro_owner) xd.store_x = a.pro.store_x, xd.store_mid = a.pro.store_mid;
         if (norm) { // the weights are in flight while the vector is reduced
-            const float ss = block_sumsq_direct(sq, xa_row, K, red, a.x_vec != 0);
+            const float ss = block_sumsq_direct(sq, xa_row, K, red, x_vec);
             xd.inv = 1.0f / sqrtf(ss / (float)K + a.pro.eps); // reference.zig:365
             xd.norm = true;
         }
@@ -626,7 +630,7 @@ __global__ void __launch_bounds__(1024) qmatvec_kernel(QMV_HEAD_PARAMS, QMVArgs 
         cur.load(qs, sc, u, stride, u_last, xd, i);
         QMV_STAMP(1); // loads issued
         float inv = 1.0f;
-        if (PRO && a.pro.kind == QMV_PRO_RMSNORM_MUL) {
+        if (norm) {
             const float ss = block_sumsq(xa, K, red);
             inv = 1.0f / sqrtf(ss / (float)K + a.pro.eps); // reference.zig:365
         }
@@ -1634,7 +1638,7 @@ void launch_packed(hipStream_t s, QMVArgs& a, const QWeightDev& w0, uint32_t tot
         while (waves < (uint32_t)kMaxWaves && waves * 64 * 4 * kXRegs < a.K) waves++;
     // parts back to back in the weight arenas (and <= 4 of them): the kernel needs no argument-block fetch to find them
     static const bool contig_ok = !(getenv("ZGML_QMV_CONTIG") && atoi(getenv("ZGML_QMV_CONTIG")) == 0);
-    bool contig = a.n_parts > 1 && contig_ok;
+    bool contig = a.n_parts > 1 && a.n_parts <= 3 && contig_ok;
     const size_t sc_elem = (q4 ? 2 : 1) * (w0.scale_f16 ? 2 : 4);
     for (uint32_t t = 1; t < a.n_parts && contig; t++) {
         const QMVPartDev &pv = a.parts[t - 1], &pt = a.parts[t];
@@ -1655,7 +1659,9 @@ void launch_packed(hipStream_t s, QMVArgs& a, const QWeightDev& w0, uint32_t tot
     if (a.n_parts > 1 && (a.parts[1].NB2 > 0xFFFFu || (a.n_parts > 2 && a.parts[2].NB2 > 0xFFFFu))) contig = false; // 16-bit fields
     const uint32_t nb2_12 = contig ? (a.parts[1].NB2 | (a.n_parts > 2 ? a.parts[2].NB2 << 16 : 0u)) : 0u;
     hipLaunchKernelGGL(fn, grid, dim3(waves * 64), lds, s, a.parts[0].qs, a.parts[0].sc, a.parts[0].out, a.pro.a, a.pro.b, a.in_rs, a.K,
-                       a.parts[0].NB2 | (a.n_parts << 24) | (contig ? 1u << 28 : 0u), nb2_12, a);
+                       a.parts[0].NB2 | (a.n_parts << 24) | (contig ? 1u << 28 : 0u) | (a.pro.kind == QMV_PRO_RMSNORM_MUL ? 1u << 29 : 0u) |
+                           (a.x_vec ? 1u << 30 : 0u),
+                       nb2_12, a);
 }
 
 using TileFn = void (*)(QMMArgs);
