@@ -166,10 +166,10 @@ __device__ __forceinline__ float4 zero_tail(float4 v, uint32_t i, uint32_t K) {
 }
 
 template <bool XVEC>
-__device__ __forceinline__ XRegs x_fetch(const float* x, uint32_t K) {
+__device__ __forceinline__ XRegs x_fetch(const float* x, uint32_t K, uint32_t bdim) {
     XRegs r;
 #pragma unroll
-    for (int j = 0; j < kXRegs; j++) r.v[j] = load_x4<XVEC>(x, (threadIdx.x + j * blockDim.x) * 4, K);
+    for (int j = 0; j < kXRegs; j++) r.v[j] = load_x4<XVEC>(x, (threadIdx.x + j * bdim) * 4, K);
     return r;
 }
 
@@ -182,11 +182,11 @@ __device__ __forceinline__ float4 scale4(float4 a, float s) { return make_float4
 // the absorbed ops hold what the unfused plan would have written.
 template <bool XVEC, bool PRO>
 __device__ __forceinline__ void x_commit(float* xs, const XRegs& ra, const XRegs& rb, const QmvPrologue& pro, float inv,
-                                         uint32_t k_count, uint32_t K, const float* xa_row) {
+                                         uint32_t k_count, uint32_t K, const float* xa_row, uint32_t bdim) {
     const bool owner = PRO && blockIdx.x == 0 && blockIdx.y == 0;
 #pragma unroll
     for (int j = 0; j < kXRegs; j++) {
-        const uint32_t i = (threadIdx.x + j * blockDim.x) * 4;
+        const uint32_t i = (threadIdx.x + j * bdim) * 4;
         float4 v = zero_tail(ra.v[j], i, K);
         if (PRO && pro.kind == QMV_PRO_RMSNORM_MUL) {
             v = scale4(v, inv);
@@ -205,7 +205,7 @@ __device__ __forceinline__ void x_commit(float* xs, const XRegs& ra, const XRegs
         *(float4*)(xs + (i < k_count ? i : k_count)) = v;
     }
     if (!PRO) // only for K > 16 * blockDim (prologues are limited to the register window)
-        for (uint32_t i = (threadIdx.x + kXRegs * blockDim.x) * 4; i < k_count; i += blockDim.x * 4)
+        for (uint32_t i = (threadIdx.x + kXRegs * bdim) * 4; i < k_count; i += bdim * 4)
             *(float4*)(xs + i) = zero_tail(load_x4<XVEC>(xa_row, i, K), i, K);
 }
 
@@ -226,9 +226,9 @@ __device__ __forceinline__ float row16_sum(float v) {
 }
 // workgroup total of one value per thread, the same on every thread, fixed order: lanes, rows, then the (<= 16) waves
 // with ONE LDS read per lane and a row fold (a serial loop over the waves is one dependent LDS round trip per wave)
-__device__ __forceinline__ float block_total(float v, float* red) {
+__device__ __forceinline__ float block_total(float v, float* red, uint32_t bdim) {
     v = rows_sum4(row16_sum(v));
-    const uint32_t n_waves = blockDim.x >> 6, slot = threadIdx.x & 15;
+    const uint32_t n_waves = bdim >> 6, slot = threadIdx.x & 15;
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
     const float t = red[min(slot, n_waves - 1)];
@@ -238,18 +238,18 @@ __device__ __forceinline__ float block_total(float v, float* red) {
 }
 
 // sum of squares of the (zero-tailed) register window, fixed reduction order: lanes, then waves
-__device__ __forceinline__ float block_sumsq(const XRegs& r, uint32_t K, float* red) {
+__device__ __forceinline__ float block_sumsq(const XRegs& r, uint32_t K, float* red, uint32_t bdim) {
     float ss = 0.f;
 #pragma unroll
     for (int j = 0; j < kXRegs; j++) {
-        const uint32_t i = (threadIdx.x + j * blockDim.x) * 4;
+        const uint32_t i = (threadIdx.x + j * bdim) * 4;
         const float4 v = zero_tail(r.v[j], i, K);
         ss += v.x * v.x;
         ss += v.y * v.y;
         ss += v.z * v.z;
         ss += v.w * v.w;
     }
-    return block_total(ss, red);
+    return block_total(ss, red, bdim);
 }
 
 __device__ __forceinline__ float epi_unary(uint32_t op, float a) {
@@ -319,8 +319,8 @@ __device__ __forceinline__ void run_epilogue(const QMVPartDev& part, uint32_t n,
 // prologue kind / x alignment from the preloaded head instead of the argument block (+0.7 % / -0.9 %).
 template <bool GROUPED>
 __device__ __forceinline__ void reduce_store(float acc, float* red, const QMVArgs& a, uint32_t pi, float* out0, uint32_t g, uint32_t m,
-                                             float pre0 = 0.f, bool have_pre0 = false) {
-    const uint32_t lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n_waves = blockDim.x >> 6;
+                                             float pre0, bool have_pre0, uint32_t n_waves) {
+    const uint32_t lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     acc = rows_sum4(acc);
     if (lane < 16) red[w * 16 + lane] = acc;
     __syncthreads();
@@ -408,9 +408,8 @@ struct XDirect {
 struct SumsqRegs {
     float4 v[4];
 };
-__device__ __forceinline__ SumsqRegs sumsq_fetch(const float* x, uint32_t K, bool vec) {
+__device__ __forceinline__ SumsqRegs sumsq_fetch(const float* x, uint32_t K, bool vec, uint32_t T) {
     SumsqRegs r;
-    const uint32_t T = blockDim.x;
     if (vec) {
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -423,9 +422,8 @@ __device__ __forceinline__ SumsqRegs sumsq_fetch(const float* x, uint32_t K, boo
     }
     return r;
 }
-__device__ __forceinline__ float block_sumsq_direct(const SumsqRegs& r, const float* x, uint32_t K, float* red, bool vec) {
+__device__ __forceinline__ float block_sumsq_direct(const SumsqRegs& r, const float* x, uint32_t K, float* red, bool vec, uint32_t T) {
     float s[4] = {0.f, 0.f, 0.f, 0.f};
-    const uint32_t T = blockDim.x;
     if (vec) {
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -442,7 +440,7 @@ __device__ __forceinline__ float block_sumsq_direct(const SumsqRegs& r, const fl
             if (threadIdx.x + j * T < K) s[j] += r.v[j].x * r.v[j].x;
         for (uint32_t k = threadIdx.x + 4 * T; k < K; k += T) s[0] += x[k] * x[k];
     }
-    return block_total((s[0] + s[1]) + (s[2] + s[3]), red);
+    return block_total((s[0] + s[1]) + (s[2] + s[3]), red, T);
 }
 
 template <typename ST, int DEPTH, bool XD, bool PROMUL, bool NT>
@@ -548,7 +546,7 @@ struct Q8Group {
 // epilogues, non-contiguous parts), needed late or rarely.
 #define QMV_HEAD_PARAMS                                                                                                 \
     const uint4 *__restrict__ qs0, const void *__restrict__ sc0, float *__restrict__ out0, const float *__restrict__ xa_base, \
-        const float *__restrict__ xb_base, uint32_t in_rs, uint32_t K, uint32_t nb2_0_flags /* NB2_0 | n_parts << 24 | contiguous << 28 | rmsnorm prologue << 29 | x_vec << 30 */, \
+        const float *__restrict__ xb_base, uint32_t in_rs, uint32_t K, uint32_t nb2_0_flags /* NB2_0 (20 bits) | (waves - 1) << 20 | n_parts << 24 | contiguous << 28 | rmsnorm prologue << 29 | x_vec << 30 */, \
         uint32_t nb2_12 /* NB2_1 | NB2_2 << 16 */
 template <typename ST, bool XVEC, int DEPTH, bool Q4, bool PRO, bool GROUPED, bool XD, bool NT>
 __global__ void __launch_bounds__(1024) qmatvec_kernel(QMV_HEAD_PARAMS, QMVArgs a) {
@@ -570,7 +568,10 @@ __global__ void __launch_bounds__(1024) qmatvec_kernel(QMV_HEAD_PARAMS, QMVArgs 
     uint32_t pi = 0;
     const uint4* qs_base = qs0;
     const void* sc_base = sc0;
-    const uint32_t NB2_0 = nb2_0_flags & 0xFFFFFFu, n_parts = (nb2_0_flags >> 24) & 0xF, NB2_1 = nb2_12 & 0xFFFFu, NB2_2 = nb2_12 >> 16;
+    // the workgroup size comes with the preloaded head too: blockDim is a hidden kernel argument, i.e. one more scalar-load
+    // round trip in front of the first load
+    const uint32_t n_waves = ((nb2_0_flags >> 20) & 0xFu) + 1, bdim = n_waves * 64;
+    const uint32_t NB2_0 = nb2_0_flags & 0xFFFFFu, n_parts = (nb2_0_flags >> 24) & 0xF, NB2_1 = nb2_12 & 0xFFFFu, NB2_2 = nb2_12 >> 16;
     uint32_t NB2 = NB2_0, block_begin = 0;
     if (GROUPED) {
         if ((nb2_0_flags >> 28) & 1) { // contiguous parts: everything from preloaded scalars
@@ -594,7 +595,7 @@ __global__ void __launch_bounds__(1024) qmatvec_kernel(QMV_HEAD_PARAMS, QMVArgs 
     const uint32_t g = column_group(blockIdx.x - block_begin, NB2), m = blockIdx.y;
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint32_t row = lane >> 4, i = lane & 15;
-    const uint32_t stride = (blockDim.x >> 6) * 4; // units per step (4 rows per wave)
+    const uint32_t stride = n_waves * 4; // units per step (4 rows per wave)
     const uint4* qs = qs_base + (uint64_t)g * U * 16 + i;
     const ScaleT* sc = (const ScaleT*)sc_base + (uint64_t)(g >> 1) * U * 16 + i;
     const uint32_t n_groups = (U + stride * DEPTH - 1) / (stride * DEPTH);
@@ -612,30 +613,30 @@ __global__ void __launch_bounds__(1024) qmatvec_kernel(QMV_HEAD_PARAMS, QMVArgs 
     const bool x_vec = ((nb2_0_flags >> 30) & 1) != 0;
     if (XD) {
         SumsqRegs sq;
-        if (norm) sq = sumsq_fetch(xa_row, K, x_vec); // before the weights (in-order vmcnt)
+        if (norm) sq = sumsq_fetch(xa_row, K, x_vec, bdim); // before the weights (in-order vmcnt)
         cur.load(qs, sc, u, stride, u_last, xd, i);
         QMV_STAMP(1); // loads issued
         __builtin_amdgcn_sched_barrier(0); // argument-block reads below wait while the loads above fly
         if (pro_owner) xd.store_x = a.pro.store_x, xd.store_mid = a.pro.store_mid;
         if (norm) { // the weights are in flight while the vector is reduced
-            const float ss = block_sumsq_direct(sq, xa_row, K, red, x_vec);
+            const float ss = block_sumsq_direct(sq, xa_row, K, red, x_vec, bdim);
             xd.inv = 1.0f / sqrtf(ss / (float)K + a.pro.eps); // reference.zig:365
             xd.norm = true;
         }
         QMV_STAMP(2); // (+ sum of squares)
         QMV_STAMP(3);
     } else {
-        const XRegs xa = x_fetch<XVEC>(xa_row, K);
-        const XRegs xb = PRO ? x_fetch<XVEC>(xb_base, K) : xa;
+        const XRegs xa = x_fetch<XVEC>(xa_row, K, bdim);
+        const XRegs xb = PRO ? x_fetch<XVEC>(xb_base, K, bdim) : xa;
         cur.load(qs, sc, u, stride, u_last, xd, i);
         QMV_STAMP(1); // loads issued
         float inv = 1.0f;
         if (norm) {
-            const float ss = block_sumsq(xa, K, red);
+            const float ss = block_sumsq(xa, K, red, bdim);
             inv = 1.0f / sqrtf(ss / (float)K + a.pro.eps); // reference.zig:365
         }
         QMV_STAMP(2); // x arrived (+ sum of squares)
-        x_commit<XVEC, PRO>(xs, xa, xb, a.pro, inv, U * UNIT_X, K, xa_row);
+        x_commit<XVEC, PRO>(xs, xa, xb, a.pro, inv, U * UNIT_X, K, xa_row, bdim);
         __syncthreads();
         QMV_STAMP(3); // x staged
     }
@@ -678,7 +679,7 @@ __global__ void __launch_bounds__(1024) qmatvec_kernel(QMV_HEAD_PARAMS, QMVArgs 
     asm volatile("" ::"s"(arg_touch)); // (keeps the touches alive; long arrived)
 #endif
     QMV_STAMP(4); // weights streamed
-    reduce_store<GROUPED>((acc0 + acc1) + (acc2 + acc3), red, a, pi, out0, g, m, pre0, have_pre0);
+    reduce_store<GROUPED>((acc0 + acc1) + (acc2 + acc3), red, a, pi, out0, g, m, pre0, have_pre0, n_waves);
     QMV_STAMP(5);
 #undef QMV_STAMP
 }
@@ -1567,7 +1568,7 @@ uint64_t qmatmul_scratch_bytes(const QWeightDev& w, uint32_t M) {
 }
 
 bool qweight_packable(uint64_t K, uint64_t N, uint64_t bs) {
-    if (bs != 32 || N == 0 || K == 0 || N % 32 != 0) return false;
+    if (bs != 32 || N == 0 || K == 0 || N % 32 != 0 || N / 16 >= (1u << 20)) return false; // (the mat-vec head carries N / 16 in 20 bits)
     // x (padded K) must fit the workgroup's LDS next to the reduction area
     const uint64_t KC = (K + 31) / 32;
     return (KC * 32 + 4 + kMaxWaves * 16) * sizeof(float) <= kMaxLds;
@@ -1659,7 +1660,7 @@ void launch_packed(hipStream_t s, QMVArgs& a, const QWeightDev& w0, uint32_t tot
     if (a.n_parts > 1 && (a.parts[1].NB2 > 0xFFFFu || (a.n_parts > 2 && a.parts[2].NB2 > 0xFFFFu))) contig = false; // 16-bit fields
     const uint32_t nb2_12 = contig ? (a.parts[1].NB2 | (a.n_parts > 2 ? a.parts[2].NB2 << 16 : 0u)) : 0u;
     hipLaunchKernelGGL(fn, grid, dim3(waves * 64), lds, s, a.parts[0].qs, a.parts[0].sc, a.parts[0].out, a.pro.a, a.pro.b, a.in_rs, a.K,
-                       a.parts[0].NB2 | (a.n_parts << 24) | (contig ? 1u << 28 : 0u) | (a.pro.kind == QMV_PRO_RMSNORM_MUL ? 1u << 29 : 0u) |
+                       a.parts[0].NB2 | ((waves - 1) << 20) | (a.n_parts << 24) | (contig ? 1u << 28 : 0u) | (a.pro.kind == QMV_PRO_RMSNORM_MUL ? 1u << 29 : 0u) |
                            (a.x_vec ? 1u << 30 : 0u),
                        nb2_12, a);
 }
