@@ -16,6 +16,21 @@ namespace {
 
 constexpr int kBlock = 256;
 
+// Loads / stores through GLOBAL-address-space pointers. A pointer taken from a parameter record is a generic pointer to
+// hipcc, and a generic access is a FLAT instruction: it counts on vmcnt AND lgkmcnt, so every `s_waitcnt lgkmcnt(0)` in
+// front of a scalar-load result (the records are read with scalar loads, round after round) also waits for every vector
+// load issued so far — the phases of a latency-chain kernel serialise. global_load / global_store only count on vmcnt.
+typedef float f4v_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ldg4(const float* p) {
+    const f4v_t v = *(const __attribute__((address_space(1))) f4v_t*)p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float ldg1(const float* p) { return *(const __attribute__((address_space(1))) float*)p; }
+__device__ __forceinline__ uint32_t ldgu(const uint32_t* p) { return *(const __attribute__((address_space(1))) uint32_t*)p; }
+__device__ __forceinline__ void stg4(float* p, float4 v) { *(__attribute__((address_space(1))) f4v_t*)p = f4v_t{v.x, v.y, v.z, v.w}; }
+__device__ __forceinline__ void stg1(float* p, float v) { *(__attribute__((address_space(1))) float*)p = v; }
+__device__ __forceinline__ void stgu(uint32_t* p, uint32_t v) { *(__attribute__((address_space(1))) uint32_t*)p = v; }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -792,13 +807,13 @@ __global__ void __launch_bounds__(kAttnBlock) attention_decode_kernel(const Attn
     const bool is_hi = d0 >= (uint32_t)HALF;
     // ---- phase A: dynamic words (scalar) and everything the ropes need (vector), one round
     // quantised KV: the stores' dynamic words are column indices, the caches are int8 rows + f32 block scales
-    const uint32_t seq_kv = KVQ ? min(*p.dyn_seq_kv, P.kvq_cols) : *p.dyn_seq_kv, dk = *P.dyn_k_off, dv = *P.dyn_v_off;
-    const uint32_t d2_off = p.dst2 ? *p.dyn_dst2_off : 0; // scalar, with the other dynamic words
-    const float4 q_own = *(const float4*)(P.q_src + d0), q_par = *(const float4*)(P.q_src + (d0 ^ HALF));
-    const float4 q_c = *(const float4*)(P.q_cs + pair), q_s = *(const float4*)(P.q_cs + HALF + pair);
-    const float4 k_own = *(const float4*)(P.k_src + d0), k_par = *(const float4*)(P.k_src + (d0 ^ HALF));
-    const float4 k_c = *(const float4*)(P.k_cs + pair), k_s = *(const float4*)(P.k_cs + HALF + pair);
-    const float4 v_new = *(const float4*)(P.v_src + d0);
+    const uint32_t seq_kv = KVQ ? min(ldgu(p.dyn_seq_kv), P.kvq_cols) : ldgu(p.dyn_seq_kv), dk = ldgu(P.dyn_k_off), dv = ldgu(P.dyn_v_off);
+    const uint32_t d2_off = p.dst2 ? ldgu(p.dyn_dst2_off) : 0; // scalar, with the other dynamic words
+    const float4 q_own = ldg4(P.q_src + d0), q_par = ldg4(P.q_src + (d0 ^ HALF));
+    const float4 q_c = ldg4(P.q_cs + pair), q_s = ldg4(P.q_cs + HALF + pair);
+    const float4 k_own = ldg4(P.k_src + d0), k_par = ldg4(P.k_src + (d0 ^ HALF));
+    const float4 k_c = ldg4(P.k_cs + pair), k_s = ldg4(P.k_cs + HALF + pair);
+    const float4 v_new = ldg4(P.v_src + d0);
     ATTN_STAMP(1);
     // this workgroup's keys [k_begin, k_end)
     const uint32_t sp = blockIdx.y;
@@ -824,15 +839,15 @@ __global__ void __launch_bounds__(kAttnBlock) attention_decode_kernel(const Attn
     const float* const vsc = P.v_cache + (uint64_t)P.kvq_cols * DH / 4 + d0 / 32;
     auto load_k = [&](uint32_t s) -> Row {
         if constexpr (KVQ)
-            return Row{*(const uint32_t*)(kq + (uint64_t)s * DH), ksc[(uint64_t)s * BPC]};
+            return Row{ldgu((const uint32_t*)(kq + (uint64_t)s * DH)), ldg1(ksc + (uint64_t)s * BPC)};
         else
-            return Row{*(const float4*)(p.k + (uint64_t)s * p.k_cs + d0)};
+            return Row{ldg4(p.k + (uint64_t)s * p.k_cs + d0)};
     };
     auto load_v = [&](uint32_t s) -> Row {
         if constexpr (KVQ)
-            return Row{*(const uint32_t*)(vq + (uint64_t)s * DH), vsc[(uint64_t)s * BPC]};
+            return Row{ldgu((const uint32_t*)(vq + (uint64_t)s * DH)), ldg1(vsc + (uint64_t)s * BPC)};
         else
-            return Row{*(const float4*)(p.v + (uint64_t)s * p.v_cs + d0)};
+            return Row{ldg4(p.v + (uint64_t)s * p.v_cs + d0)};
     };
     Row kv[U], vv[U];
     float mk[U];
@@ -841,7 +856,7 @@ __global__ void __launch_bounds__(kAttnBlock) attention_decode_kernel(const Attn
         const uint32_t s = min(k_begin + j * keys_per_iter + w * KPW + slot, last);
         kv[j] = load_k(s);
         vv[j] = load_v(s);
-        mk[j] = p.mask[(uint64_t)s * p.mask_rs]; // host passes a zero word with stride 0 when there is no mask
+        mk[j] = ldg1(p.mask + (uint64_t)s * p.mask_rs); // host passes a zero word with stride 0 when there is no mask
     }
     ATTN_STAMP(2);
     // ---- ropes; side outputs and the cache stores (one lane group writes each value)
@@ -857,21 +872,21 @@ __global__ void __launch_bounds__(kAttnBlock) attention_decode_kernel(const Attn
         k_col = Row{k_new}, v_col = Row{v_new};
     }
     if (w == 0 && slot == 0 && sp == 0) {
-        *(float4*)(P.q_rot + d0) = qv;
+        stg4(P.q_rot + d0, qv);
         if (P.owner) {
-            *(float4*)(P.k_rot + d0) = k_new;
+            stg4(P.k_rot + d0, k_new);
             if constexpr (KVQ) { // never outside the cache (kvq_store_kernel's guard)
                 if (col_k < P.kvq_cols) {
-                    *(uint32_t*)((int8_t*)P.k_cache + (uint64_t)col_k * DH + d0) = k_col.w;
-                    if ((li & 7) == 0) P.k_cache[(uint64_t)P.kvq_cols * DH / 4 + (uint64_t)col_k * BPC + d0 / 32] = k_col.sc;
+                    stgu((uint32_t*)((int8_t*)P.k_cache + (uint64_t)col_k * DH + d0), k_col.w);
+                    if ((li & 7) == 0) stg1(P.k_cache + (uint64_t)P.kvq_cols * DH / 4 + (uint64_t)col_k * BPC + d0 / 32, k_col.sc);
                 }
                 if (col_v < P.kvq_cols) {
-                    *(uint32_t*)((int8_t*)P.v_cache + (uint64_t)col_v * DH + d0) = v_col.w;
-                    if ((li & 7) == 0) P.v_cache[(uint64_t)P.kvq_cols * DH / 4 + (uint64_t)col_v * BPC + d0 / 32] = v_col.sc;
+                    stgu((uint32_t*)((int8_t*)P.v_cache + (uint64_t)col_v * DH + d0), v_col.w);
+                    if ((li & 7) == 0) stg1(P.v_cache + (uint64_t)P.kvq_cols * DH / 4 + (uint64_t)col_v * BPC + d0 / 32, v_col.sc);
                 }
             } else {
-                *(float4*)(P.k_cache + dk + d0) = k_new;
-                *(float4*)(P.v_cache + dv + d0) = v_new;
+                stg4(P.k_cache + dk + d0, k_new);
+                stg4(P.v_cache + dv + d0, v_new);
             }
         }
     }
@@ -917,7 +932,7 @@ __global__ void __launch_bounds__(kAttnBlock) attention_decode_kernel(const Attn
                 const uint32_t s = min(base + step_keys + j * keys_per_iter + w * KPW + slot, last);
                 kn[j] = load_k(s);
                 vn[j] = load_v(s);
-                mn[j] = p.mask[(uint64_t)s * p.mask_rs];
+                mn[j] = ldg1(p.mask + (uint64_t)s * p.mask_rs);
             }
             step(base);
 #pragma unroll
@@ -1002,10 +1017,10 @@ __global__ void __launch_bounds__(kAttnBlock) attention_decode_kernel(const Attn
         if (lane < LPK) {
             const float inv_l = r.l > 0.f ? 1.0f / r.l : 0.0f;
             const float o[4] = {r.acc.x * inv_l, r.acc.y * inv_l, r.acc.z * inv_l, r.acc.w * inv_l};
-            *(float4*)(p.dst + 4 * lane) = make_float4(o[0], o[1], o[2], o[3]); // dst_rs == 1, 16-byte aligned (planner)
+            stg4(p.dst + 4 * lane, make_float4(o[0], o[1], o[2], o[3])); // dst_rs == 1, 16-byte aligned (planner)
             if (p.dst2)
 #pragma unroll
-                for (int e = 0; e < 4; e++) p.dst2[(uint64_t)d2_off + (uint64_t)(4 * lane + e) * p.d2_rs] = o[e];
+                for (int e = 0; e < 4; e++) stg1(p.dst2 + (uint64_t)d2_off + (uint64_t)(4 * lane + e) * p.d2_rs, o[e]);
         }
     }
     ATTN_STAMP(7);
