@@ -791,7 +791,33 @@ __global__ void __launch_bounds__(kAttnBlock) attention_decode_kernel(const Attn
                                                                       uint32_t* split_cnt, uint32_t split_min_keys) {
     constexpr int DH = 4 * LPK, KPW = 64 / LPK, U = kAttnUnroll, HALF = DH / 2;
     using Row = AttnRow<KVQ>;
-    const AttnDecodeParams& P = params[blockIdx.x];
+    // The head's parameter record in ONE scalar round trip: read through a reference, hipcc fetches it field by field where
+    // the fields are used — three dependent rounds of s_load + s_waitcnt before the kernel's first vector load.
+    static_assert(sizeof(AttnDecodeParams) == 248, "the bulk fetch below covers exactly 62 dwords");
+    AttnDecodeParams P;
+    {
+        typedef uint32_t u32x16_t __attribute__((ext_vector_type(16)));
+        typedef uint32_t u32x8_t __attribute__((ext_vector_type(8)));
+        typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+        typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+        u32x16_t ra, rb, rc;
+        u32x8_t rd;
+        u32x4_t re;
+        u32x2_t rf;
+#if defined(__HIP_DEVICE_COMPILE__)
+        const AttnDecodeParams* const rec = params + blockIdx.x;
+        asm volatile("s_load_dwordx16 %0, %6, 0x0\n\ts_load_dwordx16 %1, %6, 0x40\n\ts_load_dwordx16 %2, %6, 0x80\n\t"
+                     "s_load_dwordx8 %3, %6, 0xc0\n\ts_load_dwordx4 %4, %6, 0xe0\n\ts_load_dwordx2 %5, %6, 0xf0\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(ra), "=&s"(rb), "=&s"(rc), "=&s"(rd), "=&s"(re), "=&s"(rf)
+                     : "s"(rec)
+                     : "memory");
+#else
+        ra = rb = rc = u32x16_t{}, rd = u32x8_t{}, re = u32x4_t{}, rf = u32x2_t{};
+#endif
+        char* const dst = (char*)&P;
+        __builtin_memcpy(dst, &ra, 64), __builtin_memcpy(dst + 64, &rb, 64), __builtin_memcpy(dst + 128, &rc, 64);
+        __builtin_memcpy(dst + 192, &rd, 32), __builtin_memcpy(dst + 224, &re, 16), __builtin_memcpy(dst + 240, &rf, 8);
+    }
     const AttentionParams& p = P.att;
 #ifdef ZGML_TRACE // build with -DZGML_TRACE (ZGML_HIP_ATTN_TRACE=1 then prints the stamps)
     unsigned long long* const trace = P.trace;
