@@ -38,6 +38,10 @@ struct EltChainParams {
     const float* src;
     uint32_t n, n_steps;
     ChainStepDev steps[kMaxChainSteps];
+    // optional side output of the chain's final value for an M > 1 quantized matmul over dense rows of `ap_cols` columns
+    // (RowChainParams::ap): set by the planner when that matmul follows
+    uint16_t* ap = nullptr;
+    uint32_t ap_S = 0, ap_cols = 0;
 };
 void launch_eltwise_chain(hipStream_t s, const EltChainParams& p);
 

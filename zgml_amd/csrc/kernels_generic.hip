@@ -121,6 +121,16 @@ __global__ void __launch_bounds__(kBlock) fused_elementwise_kernel(FusedParams p
 }
 
 // several elementwise / fused_elementwise ops in a row (same arithmetic, same order, per element)
+// x = h1 + h2 + h3 exactly, each piece a bf16 (truncation split, 8 + 8 + 8 significant bits: split_a_kernel's arithmetic)
+__device__ __forceinline__ void store_a_pieces(uint16_t* ap, uint32_t S, uint32_t m, uint32_t j, float v) {
+    const uint32_t h1 = __float_as_uint(v) & 0xFFFF0000u;
+    const float r1 = v - __uint_as_float(h1);
+    const uint32_t h2 = __float_as_uint(r1) & 0xFFFF0000u;
+    const float r2 = r1 - __uint_as_float(h2);
+    uint16_t* const d = ap + a_piece_index(S, m, j);
+    d[0] = (uint16_t)(h1 >> 16), d[512] = (uint16_t)(h2 >> 16), d[1024] = (uint16_t)(__float_as_uint(r2) >> 16);
+}
+
 __global__ void __launch_bounds__(kBlock) eltwise_chain_kernel(EltChainParams p) {
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= p.n) return;
@@ -138,6 +148,10 @@ __global__ void __launch_bounds__(kBlock) eltwise_chain_kernel(EltChainParams p)
             v = apply_unary(op, v);
         }
         if (p.steps[s].store) p.steps[s].store[i] = v;
+    }
+    if (p.ap) { // 64 consecutive lanes = 64 consecutive k: 128 contiguous bytes per piece and wave
+        const uint32_t m = i / p.ap_cols;
+        store_a_pieces(p.ap, p.ap_S, m, i - m * p.ap_cols, v);
     }
 }
 
@@ -199,16 +213,6 @@ __global__ void __launch_bounds__(kBlock) rmsnorm_kernel(float* __restrict__ dst
 // form. NPT > 0: the row fits NPT elements per thread — everything is loaded up front with independent loads
 // (a row is one dependent chain otherwise: 32 rows x 4096 columns took ~25 us) and kept in registers between
 // the two passes. NPT == 0: any width, looping.
-// x = h1 + h2 + h3 exactly, each piece a bf16 (truncation split, 8 + 8 + 8 significant bits: split_a_kernel's arithmetic)
-__device__ __forceinline__ void store_a_pieces(uint16_t* ap, uint32_t S, uint32_t m, uint32_t j, float v) {
-    const uint32_t h1 = __float_as_uint(v) & 0xFFFF0000u;
-    const float r1 = v - __uint_as_float(h1);
-    const uint32_t h2 = __float_as_uint(r1) & 0xFFFF0000u;
-    const float r2 = r1 - __uint_as_float(h2);
-    uint16_t* const d = ap + a_piece_index(S, m, j);
-    d[0] = (uint16_t)(h1 >> 16), d[512] = (uint16_t)(h2 >> 16), d[1024] = (uint16_t)(__float_as_uint(r2) >> 16);
-}
-
 template <int NPT>
 __global__ void __launch_bounds__(kBlock) row_chain_kernel(RowChainParams p) {
     __shared__ float red[8];

@@ -40,9 +40,11 @@ std::string g_create_error;
 // the planner arms it when the matmul that consumes exactly these rows follows with no other splitting launch in between.
 struct SplitHook {
     const float* out = nullptr; // the rows the launch produces (dense: row stride == cols)
-    uint32_t rows = 0, cols = 0;
+    uint32_t rows = 0, cols = 0; // rows == 0: a flat launch over `n` elements, any rows x cols = n of dense rows
+    uint32_t n = 0;
     uint16_t** ap = nullptr;    // fields of the launch's (shared) parameter block
     uint32_t* ap_S = nullptr;
+    uint32_t* ap_cols = nullptr; // flat launches: the row length is filled in too
 };
 
 struct Launch {
@@ -633,8 +635,11 @@ bool make_single(zgml_hip_program* p, size_t i, Launch& L) {
             if (splits && !qp.reuse_split && fuse_split && qp.M % 16 == 0 && qp.K % 128 == 0 && qp.in_rs == qp.K) {
                 for (size_t back = p->plan.size(); back-- > 0;) {
                     const Launch& prev = p->plan[back];
-                    if (prev.hook && prev.hook->out == qp.input && prev.hook->rows == qp.M && prev.hook->cols == qp.K) {
+                    const bool fits = prev.hook && prev.hook->out == qp.input &&
+                                      (prev.hook->rows ? prev.hook->rows == qp.M && prev.hook->cols == qp.K : (uint64_t)qp.M * qp.K == prev.hook->n);
+                    if (fits) {
                         *prev.hook->ap = (uint16_t*)scratch, *prev.hook->ap_S = qp.K / 128;
+                        if (prev.hook->ap_cols) *prev.hook->ap_cols = qp.K;
                         qp.reuse_split = 1;
                         break;
                     }
@@ -1674,15 +1679,18 @@ void build_fused_plan(zgml_hip_program* p) {
                 auto rcp = std::make_shared<RowChainParams>(rc); // shared: a later matmul may arm its A-piece output
                 Launch L{ZGML_DOP_RMSNORM, (uint32_t)m.members.size(), m.members.front(), m.members.back(),
                          [=](hipStream_t s) { launch_row_chain(s, *rcp, rows); }};
-                L.hook = std::make_shared<SplitHook>(SplitHook{rcp->mul_dst ? rcp->mul_dst : rcp->norm_dst, rows, rcp->cols, &rcp->ap, &rcp->ap_S});
+                L.hook = std::make_shared<SplitHook>(SplitHook{rcp->mul_dst ? rcp->mul_dst : rcp->norm_dst, rows, rcp->cols, 0, &rcp->ap, &rcp->ap_S, nullptr});
                 chains.push_back(std::move(L));
                 continue;
             }
             if (macros[mi].elt_chain) {
                 const Macro& m = macros[mi];
-                const EltChainParams ec = m.elt;
-                chains.push_back({ZGML_DOP_FUSED_ELEMENTWISE, (uint32_t)m.members.size(), m.members.front(), m.members.back(),
-                                  [=](hipStream_t s) { launch_eltwise_chain(s, ec); }});
+                auto ecp = std::make_shared<EltChainParams>(m.elt); // shared: a later matmul may arm its A-piece output
+                Launch L{ZGML_DOP_FUSED_ELEMENTWISE, (uint32_t)m.members.size(), m.members.front(), m.members.back(),
+                         [=](hipStream_t s) { launch_eltwise_chain(s, *ecp); }};
+                if (ecp->n_steps && ecp->steps[ecp->n_steps - 1].store)
+                    L.hook = std::make_shared<SplitHook>(SplitHook{ecp->steps[ecp->n_steps - 1].store, 0, 0, ecp->n, &ecp->ap, &ecp->ap_S, &ecp->ap_cols});
+                chains.push_back(std::move(L));
                 continue;
             }
             if (macros[mi].qmv)
