@@ -56,7 +56,8 @@ __device__ __forceinline__ float rows_sum(float v) { // (r0 + r1) + (r2 + r3) on
 constexpr int kTileWavesMax = 8;
 
 template <int DH>
-__global__ void __launch_bounds__(kTileWavesMax * 64) attention_tiles_kernel(const AttentionParams* __restrict__ params, const float* __restrict__ zero_word) {
+__global__ void __launch_bounds__(kTileWavesMax * 64) attention_tiles_kernel(const AttentionParams* __restrict__ params, const float* __restrict__ zero_word,
+                                                                             AttnPieceSink sink) {
     constexpr int NI = DH / 16;  // float4 loads per K / Q row slice of a lane = MFMA steps / 4 of the score tile
     constexpr int NH = DH / 64;  // float4 loads per V row slice of a lane; 4 dim tiles each
     constexpr int NT = DH / 16;  // output dim tiles
@@ -213,11 +214,23 @@ __global__ void __launch_bounds__(kTileWavesMax * 64) attention_tiles_kernel(con
         const float il = linv[qq];
         const uint32_t qo = q0 + qq, d0 = 64 * h + 16 * gg + 4 * v;
         if (qo >= p.seq_q) continue;
+        uint32_t h1[4], h2[4], h3[4];
 #pragma unroll
         for (int c = 0; c < 4; c++) {
             const float val = o[c] * il;
             p.dst[(uint64_t)qo * p.dst_cs + (uint64_t)(d0 + c) * p.dst_rs] = val;
             if (p.dst2) p.dst2[(uint64_t)d2_off + (uint64_t)(d0 + c) * p.d2_rs + (uint64_t)qo * p.d2_cs] = val;
+            // exact three-way bf16 split (split_a_kernel's arithmetic) for the piece sink below
+            h1[c] = __float_as_uint(val) & 0xFFFF0000u;
+            const float r1 = val - __uint_as_float(h1[c]);
+            h2[c] = __float_as_uint(r1) & 0xFFFF0000u;
+            h3[c] = __float_as_uint(r1 - __uint_as_float(h2[c]));
+        }
+        if (sink.ap && p.dst2) { // the row store fills row qo, columns d2_off + d0 .. + 3 of the next matmul's input (planner-checked)
+            uint16_t* const dp = sink.ap + a_piece_index(sink.S, qo, d2_off + d0);
+            *(uint2*)dp = make_uint2((h1[0] >> 16) | h1[1], (h1[2] >> 16) | h1[3]);
+            *(uint2*)(dp + 512) = make_uint2((h2[0] >> 16) | h2[1], (h2[2] >> 16) | h2[3]);
+            *(uint2*)(dp + 1024) = make_uint2((h3[0] >> 16) | (h3[1] & 0xFFFF0000u), (h3[2] >> 16) | (h3[3] & 0xFFFF0000u));
         }
     }
 }
@@ -231,7 +244,7 @@ bool attention_tiles_applies(uint32_t max_seq_q, uint32_t d_head) {
 
 // every op dense (q/k/v rows contiguous, 16-byte aligned, strides % 4 == 0 — the planner's `dense`) with this d_head
 void launch_attention_tiles(hipStream_t s, const AttentionParams* dev_params, uint32_t n_ops, uint32_t max_seq_q, uint32_t d_head,
-                            const float* zero_word) {
+                            const float* zero_word, const AttnPieceSink& sink) {
     const uint32_t q_tiles = (max_seq_q + 15) / 16;
     const uint64_t units = (uint64_t)q_tiles * n_ops;
     static const int env_w = getenv("ZGML_HIP_ATTN_TILES_WAVES") ? atoi(getenv("ZGML_HIP_ATTN_TILES_WAVES")) : 0;
@@ -242,9 +255,9 @@ void launch_attention_tiles(hipStream_t s, const AttentionParams* dev_params, ui
     const dim3 grid(q_tiles, n_ops);
     if (d_head == 128) {
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)attention_tiles_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL(attention_tiles_kernel<128>, grid, dim3(waves * 64), lds, s, dev_params, zero_word);
+        hipLaunchKernelGGL(attention_tiles_kernel<128>, grid, dim3(waves * 64), lds, s, dev_params, zero_word, sink);
     } else {
-        hipLaunchKernelGGL(attention_tiles_kernel<64>, grid, dim3(waves * 64), lds, s, dev_params, zero_word);
+        hipLaunchKernelGGL(attention_tiles_kernel<64>, grid, dim3(waves * 64), lds, s, dev_params, zero_word, sink);
     }
 }
 

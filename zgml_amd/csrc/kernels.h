@@ -301,10 +301,16 @@ void launch_kvq_attention_batch(hipStream_t s, const KvqAttentionParams* dev_par
                                 const AttnSplit& sp = AttnSplit{}); // split applies to seq_q == 1 launches only
 // seq_q >= 16, dense layouts, d_head 64 / 128: query tiles on the matrix cores (attention_tiles.hip)
 bool attention_tiles_applies(uint32_t max_seq_q, uint32_t d_head);
+// A-piece side output of a batched attention launch whose row stores (dst2) fill the dense rows an M > 1 quantized matmul
+// reads (the concatenated head outputs in front of the O projection): RowChainParams::ap for the tile kernel's stores
+struct AttnPieceSink {
+    uint16_t* ap = nullptr;
+    uint32_t S = 0, cols = 0;
+};
 void launch_attention_tiles(hipStream_t s, const AttentionParams* dev_params, uint32_t n_ops, uint32_t max_seq_q, uint32_t d_head,
-                            const float* zero_word);
+                            const float* zero_word, const AttnPieceSink& sink = AttnPieceSink{});
 void launch_attention_batch(hipStream_t s, const AttentionParams* dev_params, uint32_t n_ops, uint32_t max_seq_q, bool all_dense,
-                            uint32_t rows_d_head = 0, const float* zero_word = nullptr); // rows_d_head: the common d_head when every op is dense (else 0)
+                            uint32_t rows_d_head = 0, const float* zero_word = nullptr, const AttnPieceSink& sink = AttnPieceSink{}); // rows_d_head: the common d_head when every op is dense (else 0)
 void launch_dense_matmul(hipStream_t s, const DenseMatmulParams& p);
 void launch_argmax(hipStream_t s, const float* v, uint64_t n, float* scratch_val, int64_t* scratch_idx, int64_t* out);
 void launch_copy_f4(hipStream_t s, void* dst, const void* src, uint64_t bytes);

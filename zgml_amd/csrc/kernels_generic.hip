@@ -1640,11 +1640,11 @@ void launch_attention_decode_batch(hipStream_t s, const AttnDecodeParams* dev_pa
 }
 
 void launch_attention_batch(hipStream_t s, const AttentionParams* dev_params, uint32_t n_ops, uint32_t max_seq_q,
-                            bool all_dense, uint32_t rows_d_head, const float* zero_word) {
+                            bool all_dense, uint32_t rows_d_head, const float* zero_word, const AttnPieceSink& sink) {
     if (!n_ops || !max_seq_q) return;
     static const bool rows_on = !(getenv("ZGML_HIP_ATTN_ROWS") && atoi(getenv("ZGML_HIP_ATTN_ROWS")) == 0);
     if (all_dense && rows_d_head && zero_word && rows_on && attention_tiles_applies(max_seq_q, rows_d_head)) {
-        launch_attention_tiles(s, dev_params, n_ops, max_seq_q, rows_d_head, zero_word);
+        launch_attention_tiles(s, dev_params, n_ops, max_seq_q, rows_d_head, zero_word, sink);
         return;
     }
     if (all_dense && rows_d_head && zero_word && rows_on) { // every op dense with this d_head: the streaming kernel

@@ -641,6 +641,7 @@ bool make_single(zgml_hip_program* p, size_t i, Launch& L) {
                         *prev.hook->ap = (uint16_t*)scratch, *prev.hook->ap_S = qp.K / 128;
                         if (prev.hook->ap_cols) *prev.hook->ap_cols = qp.K;
                         qp.reuse_split = 1;
+                        if (getenv("ZGML_HIP_DEBUG_PLAN")) fprintf(stderr, "[zgml_hip] A pieces of op %u (M %u, K %u) written by the launch of kind %u at plan[%zu]\n", (unsigned)i, qp.M, qp.K, prev.kind, back);
                         break;
                     }
                     if (prev.kind == ZGML_DOP_QMATMUL || prev.kind == ZGML_DOP_MATMUL) break; // may own the scratch
@@ -727,6 +728,7 @@ void emit_batches(zgml_hip_program* p, const std::vector<PlanItem>& group) {
     std::vector<RepeatParams> reps;
     std::vector<MoveParams> moves;
     std::vector<AttentionParams> atts;
+    std::vector<int64_t> att_store_off; // per attention: the static offset of its folded row store (else -1)
     std::vector<KvqStoreParams> kstores;
     std::map<uint32_t, std::vector<KvqAttentionParams>> katts; // by d_head
     uint32_t kst_lo = UINT32_MAX, kst_hi = 0, kat_lo = UINT32_MAX, kat_hi = 0, kat_max_q = 0;
@@ -783,6 +785,9 @@ void emit_batches(zgml_hip_program* p, const std::vector<PlanItem>& group) {
                     ap.dyn_dst2_off = p->dyn_dev + it.store;
                     ap.d2_rs = sa.dst_row_stride, ap.d2_cs = sa.dst_col_stride;
                     n_att++;
+                    att_store_off.push_back(sa.patch_stride == 0 ? (int64_t)sa.dst_offset : -1); // -1: moves with the position
+                } else {
+                    att_store_off.push_back(-1);
                 }
                 atts.push_back(ap);
                 att_max = std::max(att_max, op.u.attention.seq_q);
@@ -856,7 +861,19 @@ void emit_batches(zgml_hip_program* p, const std::vector<PlanItem>& group) {
         const float* zero = p->zero_word;
         const AttentionParams* d = upload_params(p, atts);
         const uint32_t n = (uint32_t)atts.size(), mx = att_max;
-        p->plan.push_back({ZGML_DOP_ATTENTION, n_att, lo[2], hi[2], [=](hipStream_t s) { launch_attention_batch(s, d, n, mx, dense, rows_dh, zero); }});
+        auto sink = std::make_shared<AttnPieceSink>(); // armed by the matmul that reads the heads' row stores, if one follows
+        Launch L{ZGML_DOP_ATTENTION, n_att, lo[2], hi[2], [=](hipStream_t s) { launch_attention_batch(s, d, n, mx, dense, rows_dh, zero, *sink); }};
+        // every head stores its rows into one dense [seq_q x cols] matrix (d2_rs == 1, a common row stride) and the tile
+        // kernel will run: that matrix may be the next quantized matmul's input
+        bool one_matrix = dense && rows_dh && zero && attention_tiles_applies(mx, rows_dh) && atts[0].dst2 && atts[0].d2_rs == 1;
+        for (const AttentionParams& a : atts)
+            one_matrix = one_matrix && a.dst2 == atts[0].dst2 && a.d2_rs == 1 && a.d2_cs == atts[0].d2_cs && a.seq_q == mx;
+        std::vector<int64_t> offs = att_store_off;
+        std::sort(offs.begin(), offs.end());
+        for (size_t h = 0; h < offs.size(); h++) one_matrix = one_matrix && offs[h] == (int64_t)(h * rows_dh); // head h's columns, statically
+        if (one_matrix && (uint64_t)rows_dh * n == atts[0].d2_cs) // the heads tile the whole row
+            L.hook = std::make_shared<SplitHook>(SplitHook{atts[0].dst2, mx, atts[0].d2_cs, 0, &sink->ap, &sink->S, &sink->cols});
+        p->plan.push_back(std::move(L));
     }
 }
 
