@@ -19,6 +19,7 @@
 // LDS in wave order (deterministic). A key tile whose 16 x 16 mask block is entirely -inf (the causal upper triangle) or
 // past seq_kv is skipped before its MFMAs.
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 
 #include <cmath>
 #include <cstdint>
@@ -226,7 +227,11 @@ __global__ void __launch_bounds__(kTileWavesMax * 64) attention_tiles_kernel(con
             h2[c] = __float_as_uint(r1) & 0xFFFF0000u;
             h3[c] = __float_as_uint(r1 - __uint_as_float(h2[c]));
         }
-        if (sink.ap && p.dst2) { // the row store fills row qo, columns d2_off + d0 .. + 3 of the next matmul's input (planner-checked)
+        if (sink.ap && p.dst2 && (sink.S & kApF16)) { // ... of an f16-promoted matmul: four halves, round to nearest even
+            uint16_t* const dp = sink.ap + a_f16_index(sink.S & ~kApF16, qo, d2_off + d0);
+            *(uint2*)dp = make_uint2((uint32_t)__half_as_ushort(__float2half_rn(o[0] * il)) | ((uint32_t)__half_as_ushort(__float2half_rn(o[1] * il)) << 16),
+                                     (uint32_t)__half_as_ushort(__float2half_rn(o[2] * il)) | ((uint32_t)__half_as_ushort(__float2half_rn(o[3] * il)) << 16));
+        } else if (sink.ap && p.dst2) { // the row store fills row qo, columns d2_off + d0 .. + 3 of the next matmul's input (planner-checked)
             uint16_t* const dp = sink.ap + a_piece_index(sink.S, qo, d2_off + d0);
             *(uint2*)dp = make_uint2((h1[0] >> 16) | h1[1], (h1[2] >> 16) | h1[3]);
             *(uint2*)(dp + 512) = make_uint2((h2[0] >> 16) | h2[1], (h2[2] >> 16) | h2[3]);

@@ -361,6 +361,11 @@ static uint32_t f16_tiles_per_wg(uint32_t M) { // m-tiles a workgroup of the A-p
     static const bool wide = !(getenv("ZGML_F16_TILE2_WIDE") && atoi(getenv("ZGML_F16_TILE2_WIDE")) == 0);
     return M > 64 && wide ? 8 : (M > 32 && wide ? 4 : (M > 16 ? 2 : 1));
 }
+// the pre-laid-out A operand of an M x K matmul has no padding rows / columns (a producer may then write it in place of
+// pack_a_f16_kernel: kernels.h a_f16_index)
+bool dense_f16_a_unpadded(uint32_t M, uint32_t K) {
+    return M > 1 && M % 16 == 0 && K % 32 == 0 && (M / 16) % f16_tiles_per_wg(M) == 0 && dense_f16_scratch_bytes(M, K) != 0;
+}
 uint64_t dense_f16_scratch_bytes(uint32_t M, uint32_t K) {
     static const bool on = !(getenv("ZGML_F16_TILE2") && atoi(getenv("ZGML_F16_TILE2")) == 0);
     if (!on || M <= 1) return 0;

@@ -170,6 +170,7 @@ struct DenseF16Params {
     uint32_t reuse_a = 0;
 };
 uint64_t dense_f16_scratch_bytes(uint32_t M, uint32_t K);
+bool dense_f16_a_unpadded(uint32_t M, uint32_t K);
 // M > 1: up to dense_f16_max_group() promoted matmuls over the same rows in one launch
 bool dense_f16_can_group(const DenseF16Params& a, const DenseF16Params& b);
 uint32_t dense_f16_max_group();
@@ -280,6 +281,13 @@ struct RowChainParams {
 __host__ __device__ inline uint64_t a_piece_index(uint32_t S, uint32_t m, uint32_t j) {
     const uint64_t t = m >> 4, i = m & 15, s = j >> 7, r = (j >> 5) & 3, jj = (j >> 3) & 3, e = j & 7;
     return ((((t * S + s) * 4 + jj) * 3) * 64 + (i + 16 * r)) * 8 + e;
+}
+// the same for the f16-promoted matmuls' A operand (dense_f16.hip: pack_a_f16_kernel): index of the element's half. A
+// producer is told the format by the top bit of its ap_S field: kApF16 | KC (32-k chunks) instead of the 128-k step count.
+constexpr uint32_t kApF16 = 0x80000000u;
+__host__ __device__ inline uint64_t a_f16_index(uint32_t KC, uint32_t m, uint32_t j) {
+    const uint64_t t = m >> 4, i = m & 15, c = j >> 5, r = (j >> 3) & 3, e = j & 7;
+    return (((t * KC + c) * 64) + 16 * r + i) * 8 + e;
 }
 void launch_row_chain(hipStream_t s, const RowChainParams& p, uint32_t rows);
 void launch_reduce(hipStream_t s, uint32_t op, float* dst, const float* src, uint32_t n_out, uint32_t reduce_size);

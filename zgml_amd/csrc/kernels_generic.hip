@@ -123,6 +123,10 @@ __global__ void __launch_bounds__(kBlock) fused_elementwise_kernel(FusedParams p
 // several elementwise / fused_elementwise ops in a row (same arithmetic, same order, per element)
 // x = h1 + h2 + h3 exactly, each piece a bf16 (truncation split, 8 + 8 + 8 significant bits: split_a_kernel's arithmetic)
 __device__ __forceinline__ void store_a_pieces(uint16_t* ap, uint32_t S, uint32_t m, uint32_t j, float v) {
+    if (S & kApF16) { // f16-promoted matmul: one half, round to nearest even (pack_a_f16_kernel's rounding)
+        ap[a_f16_index(S & ~kApF16, m, j)] = __half_as_ushort(__float2half_rn(v));
+        return;
+    }
     const uint32_t h1 = __float_as_uint(v) & 0xFFFF0000u;
     const float r1 = v - __uint_as_float(h1);
     const uint32_t h2 = __float_as_uint(r1) & 0xFFFF0000u;
@@ -260,7 +264,9 @@ __global__ void __launch_bounds__(kBlock) row_chain_kernel(RowChainParams p) {
                 nd[j] = nv;
                 const float xv = p.mul_dst ? nv * mo[k] : nv;
                 if (p.mul_dst) p.mul_dst[base + j] = xv;
-                if (p.ap) { // the three bf16 pieces, transposed through LDS so that they leave as 16-byte stores
+                if (p.ap && (p.ap_S & kApF16)) { // f16 A operand: one half per element
+                    pl[j] = __half_as_ushort(__float2half_rn(xv));
+                } else if (p.ap) { // the three bf16 pieces, transposed through LDS so that they leave as 16-byte stores
                     const uint32_t h1 = __float_as_uint(xv) & 0xFFFF0000u;
                     const float r1 = xv - __uint_as_float(h1);
                     const uint32_t h2 = __float_as_uint(r1) & 0xFFFF0000u;
@@ -272,10 +278,12 @@ __global__ void __launch_bounds__(kBlock) row_chain_kernel(RowChainParams p) {
         if (p.ap) { // (uniform) cols % 128 == 0 here (planner)
             __syncthreads();
             const uint32_t groups = p.cols / 8;
-            for (uint32_t u = threadIdx.x; u < 3 * groups; u += kBlock) {
+            const bool f16 = (p.ap_S & kApF16) != 0;
+            for (uint32_t u = threadIdx.x; u < (f16 ? 1u : 3u) * groups; u += kBlock) {
                 const uint32_t piece = u / groups, j0 = (u - piece * groups) * 8;
                 const uint4 val = *(const uint4*)(pl + piece * (N * kBlock) + j0);
-                *(uint4*)(p.ap + a_piece_index(p.ap_S, blockIdx.x, j0) + piece * 512) = val;
+                uint16_t* const d = f16 ? p.ap + a_f16_index(p.ap_S & ~kApF16, blockIdx.x, j0) : p.ap + a_piece_index(p.ap_S, blockIdx.x, j0) + piece * 512;
+                *(uint4*)d = val;
             }
         }
         return;

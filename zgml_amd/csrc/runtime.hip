@@ -591,6 +591,22 @@ bool make_single(zgml_hip_program* p, size_t i, Launch& L) {
                     fp.scratch = p->scratch;
                     fp.reuse_a = p->split_pos + 1 == pos && p->split_input == dp.a && p->split_M == dp.M && p->split_K == dp.K &&
                                  p->split_in_rs == dp.a_rs && p->split_kind == 2;
+                    // ... or the launch that produced the rows wrote the operand itself (as for the quantized split below)
+                    static const bool fuse_pack = !(getenv("ZGML_HIP_FUSE_SPLIT") && atoi(getenv("ZGML_HIP_FUSE_SPLIT")) == 0);
+                    if (!fp.reuse_a && fuse_pack && dense_f16_a_unpadded(dp.M, dp.K) && dp.a_rs == dp.K) {
+                        for (size_t back = p->plan.size(); back-- > 0;) {
+                            const Launch& prev = p->plan[back];
+                            const bool fits = prev.hook && prev.hook->out == dp.a &&
+                                              (prev.hook->rows ? prev.hook->rows == dp.M && prev.hook->cols == dp.K : (uint64_t)dp.M * dp.K == prev.hook->n);
+                            if (fits) {
+                                *prev.hook->ap = (uint16_t*)p->scratch, *prev.hook->ap_S = kApF16 | (dp.K / 32);
+                                if (prev.hook->ap_cols) *prev.hook->ap_cols = dp.K;
+                                fp.reuse_a = 1;
+                                break;
+                            }
+                            if (prev.kind == ZGML_DOP_QMATMUL || prev.kind == ZGML_DOP_MATMUL) break; // may own the scratch
+                        }
+                    }
                     p->split_pos = pos, p->split_input = dp.a, p->split_M = dp.M, p->split_K = dp.K, p->split_in_rs = dp.a_rs, p->split_kind = 2;
                     bool joins = fp.reuse_a && p->f16_group && p->f16_group->size() < dense_f16_max_group();
                     for (size_t t = 0; joins && t < p->f16_group->size(); t++) joins = dense_f16_can_group((*p->f16_group)[t], fp);
