@@ -125,7 +125,15 @@ struct QMVPartDev {
     uint32_t out_rs;
     uint32_t n_epi;
     QmvEpiStep epi[kMaxEpiSteps];
+    uint32_t epi_kind; // kEpiGeneric, or a recognised chain that runs as straight-line code (same operations, same order)
 };
+// NEG, EXP [store], ADD operand, RECIP, MUL by the part's own output [store] — the gate projection's SiLU chain
+// (silu = nn.zig:38-44 as zgml_amd/host/llama_decode.cpp emits it). The generic interpreter spends ~0.2 us per step on
+// scalar loads, compares and branches at the very end of the kernel (in-kernel stamps: 1.5 us of tail against 0.5).
+constexpr uint32_t kEpiGeneric = 0, kEpiSilu = 1;
+// ADD vector [store]: the residual add behind the O / down projections (single-matrix launches; the vector is the operand
+// the kernel requests at its start, `pre0`)
+constexpr uint32_t kEpiResidual = 2;
 
 struct QMVArgs {
     QMVPartDev parts[kMaxQmvParts];
@@ -207,6 +215,14 @@ __device__ __forceinline__ void x_commit(float* xs, const XRegs& ra, const XRegs
     if (!PRO) // only for K > 16 * blockDim (prologues are limited to the register window)
         for (uint32_t i = (threadIdx.x + kXRegs * bdim) * 4; i < k_count; i += bdim * 4)
             *(float4*)(xs + i) = zero_tail(load_x4<XVEC>(xa_row, i, K), i, K);
+}
+
+// kEpiSilu: the five steps of the interpreter above for exactly that chain (the host checked the pattern)
+__device__ __forceinline__ void run_epilogue_silu(const QMVPartDev& part, uint32_t n, float raw, float ones) {
+    const float e = expf(-raw);  // NEG, EXP
+    part.epi[1].store[n] = e;
+    const float s = 1.0f / (e + ones); // ADD (commutative), RECIP
+    part.epi[4].store[n] = s * raw;    // MUL by the part's own output (commutative)
 }
 
 // all 64 lanes get the sum of the wave's 4 DPP rows, (r0 + r1) + (r2 + r3), by gfx950's row swaps (no LDS round trip)
@@ -323,6 +339,18 @@ __device__ __forceinline__ void reduce_store(float acc, float* red, const QMVArg
     const uint32_t lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     acc = rows_sum4(acc);
     if (lane < 16) red[w * 16 + lane] = acc;
+    // a recognised chain's vector operand is requested before the barrier (the stream is over: a load under a branch
+    // costs nothing here) so that it lands under the cross-wave fold
+    // (grouped launches only — gate / up: single-matrix launches carry residual adds, and every scalar load in this tail counts)
+    uint32_t kind = kEpiGeneric;
+    float ones = 0.f;
+    if (GROUPED) {
+        kind = pi == 1 ? a.parts[1].epi_kind : pi == 2 ? a.parts[2].epi_kind : pi == 3 ? a.parts[3].epi_kind : a.parts[0].epi_kind;
+        if (kind == kEpiSilu && w == 0) {
+            const float* const ones_p = pi == 1 ? a.parts[1].epi[2].operand : pi == 2 ? a.parts[2].epi[2].operand : pi == 3 ? a.parts[3].epi[2].operand : a.parts[0].epi[2].operand;
+            ones = ones_p[g * 16 + (lane & 15)];
+        }
+    }
     __syncthreads();
     if (w != 0) return;
     const uint32_t r = lane >> 4, col = lane & 15;
@@ -346,7 +374,18 @@ __device__ __forceinline__ void reduce_store(float acc, float* red, const QMVArg
             out_row = out + (uint64_t)m * out_rs;
         }
         out_row[n] = v;
-        if (!GROUPED || pi == 0)
+        if (GROUPED && kind == kEpiSilu) {
+            if (pi == 0)
+                run_epilogue_silu(a.parts[0], n, v, ones);
+            else if (pi == 1)
+                run_epilogue_silu(a.parts[1], n, v, ones);
+            else if (pi == 2)
+                run_epilogue_silu(a.parts[2], n, v, ones);
+            else
+                run_epilogue_silu(a.parts[3], n, v, ones);
+        } else if (!GROUPED && have_pre0 && a.parts[0].epi_kind == kEpiResidual) {
+            a.parts[0].epi[0].store[n] = v + pre0; // (commutative: the interpreter's swapped flag does not matter)
+        } else if (!GROUPED || pi == 0)
             run_epilogue(a.parts[0], n, v, out_row, pre0, !GROUPED && have_pre0);
         else if (pi == 1)
             run_epilogue(a.parts[1], n, v, out_row);
@@ -1858,6 +1897,15 @@ void launch_qmatvec_fused(hipStream_t s, const QmvLaunch& L) {
         d.out_rs = pt.w.N;
         d.n_epi = pt.n_epi;
         for (uint32_t e = 0; e < pt.n_epi; e++) d.epi[e] = pt.epi[e];
+        { // the SiLU chain, exactly: NEG, EXP [store], ADD vector, RECIP, MUL by this part's output [store]; M == 1
+            const QmvEpiStep* st = pt.epi;
+            const bool silu = pt.n_epi == 5 && st[0].op == ZGML_OP_NEG && !st[0].store && st[1].op == ZGML_OP_EXP && st[1].store &&
+                              st[2].op == ZGML_OP_ADD && st[2].operand && st[2].operand != pt.dst && st[2].operand != st[1].store && !st[2].store &&
+                              st[3].op == ZGML_OP_RECIP && !st[3].store && st[4].op == ZGML_OP_MUL && st[4].operand == pt.dst && st[4].store;
+            static const bool silu_on = !(getenv("ZGML_QMV_EPI_SILU") && atoi(getenv("ZGML_QMV_EPI_SILU")) == 0);
+            const bool residual = pt.n_epi == 1 && st[0].op == ZGML_OP_ADD && st[0].operand && st[0].operand != pt.dst && st[0].store;
+            d.epi_kind = !silu_on ? kEpiGeneric : (silu ? kEpiSilu : (residual ? kEpiResidual : kEpiGeneric));
+        }
         blocks += d.NB2;
     }
     a.pro = L.pro;
