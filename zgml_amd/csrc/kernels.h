@@ -320,7 +320,15 @@ void launch_attention_tiles(hipStream_t s, const AttentionParams* dev_params, ui
 void launch_attention_batch(hipStream_t s, const AttentionParams* dev_params, uint32_t n_ops, uint32_t max_seq_q, bool all_dense,
                             uint32_t rows_d_head = 0, const float* zero_word = nullptr, const AttnPieceSink& sink = AttnPieceSink{}); // rows_d_head: the common d_head when every op is dense (else 0)
 void launch_dense_matmul(hipStream_t s, const DenseMatmulParams& p);
-void launch_argmax(hipStream_t s, const float* v, uint64_t n, float* scratch_val, int64_t* scratch_idx, int64_t* out);
+// `adv` (device-resident decode): the final stage also appends the token — state[0] = token, state[1] += 1 (position),
+// tokens[state[2]++] = token — instead of a one-thread launch of its own behind it
+struct ArgmaxAdvance {
+    uint32_t* state = nullptr;
+    int64_t* tokens = nullptr;
+    uint32_t cap = 0;
+};
+void launch_argmax(hipStream_t s, const float* v, uint64_t n, float* scratch_val, int64_t* scratch_idx, int64_t* out,
+                   const ArgmaxAdvance& adv = ArgmaxAdvance{});
 void launch_copy_f4(hipStream_t s, void* dst, const void* src, uint64_t bytes);
 void launch_f32_to_f16(hipStream_t s, void* dst, const float* src, uint64_t n);
 

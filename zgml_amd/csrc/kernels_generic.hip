@@ -1485,7 +1485,7 @@ __global__ void __launch_bounds__(kBlock) argmax_stage1(const float* __restrict_
 }
 
 __global__ void __launch_bounds__(kBlock) argmax_stage2(const float* vals, const int64_t* idxs, int nblk,
-                                                        int64_t* out) {
+                                                        int64_t* out, ArgmaxAdvance adv) {
     __shared__ float sv[kBlock];
     __shared__ int64_t si[kBlock];
     float bv = -INFINITY;
@@ -1515,7 +1515,17 @@ __global__ void __launch_bounds__(kBlock) argmax_stage2(const float* vals, const
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) *out = si[0] == INT64_MAX ? -1 : si[0];
+    if (threadIdx.x == 0) {
+        const int64_t next = si[0] == INT64_MAX ? -1 : si[0];
+        *out = next;
+        if (adv.state) { // the resident loop's advance step
+            const uint32_t n = adv.state[2];
+            if (n < adv.cap) adv.tokens[n] = next;
+            adv.state[0] = (uint32_t)next;
+            adv.state[1] += 1;
+            adv.state[2] = n + 1;
+        }
+    }
 }
 
 __global__ void __launch_bounds__(kBlock) copy_f4_kernel(float4* __restrict__ dst, const float4* __restrict__ src,
@@ -1712,11 +1722,11 @@ void launch_dense_matmul(hipStream_t s, const DenseMatmulParams& p) {
     }
 }
 
-void launch_argmax(hipStream_t s, const float* v, uint64_t n, float* scratch_val, int64_t* scratch_idx, int64_t* out) {
+void launch_argmax(hipStream_t s, const float* v, uint64_t n, float* scratch_val, int64_t* scratch_idx, int64_t* out, const ArgmaxAdvance& adv) {
     int nblk = (int)(n / (kBlock * 4) + 1);
     if (nblk > kArgBlocks) nblk = kArgBlocks;
     argmax_stage1<<<nblk, kBlock, 0, s>>>(v, n, scratch_val, scratch_idx);
-    argmax_stage2<<<1, kBlock, 0, s>>>(scratch_val, scratch_idx, nblk, out);
+    argmax_stage2<<<1, kBlock, 0, s>>>(scratch_val, scratch_idx, nblk, out, adv);
 }
 
 void launch_copy_f4(hipStream_t s, void* dst, const void* src, uint64_t bytes) {

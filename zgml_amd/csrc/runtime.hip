@@ -2097,15 +2097,6 @@ __global__ void __launch_bounds__(256) resident_prep_kernel(ResidentPrepArgs a) 
     }
 }
 
-__global__ void resident_advance_kernel(const int64_t* arg_out, uint32_t* state, int64_t* tokens, uint32_t cap) {
-    const int64_t next = *arg_out;
-    const uint32_t n = state[2];
-    if (n < cap) tokens[n] = next;
-    state[0] = (uint32_t)next;
-    state[1] += 1;
-    state[2] = n + 1;
-}
-
 } // namespace
 
 // ════════════════════════════════ C ABI ════════════════════════════════
@@ -3306,8 +3297,7 @@ int zgml_hip_resident_decode(zgml_hip_ctx* ctx, zgml_hip_program* p, uint32_t fi
     auto one_token = [&](hipStream_t st) {
         resident_prep_kernel<<<(total + 255) / 256, 256, 0, st>>>(a);
         run_plan(p, st, 0, p->plan.size());
-        launch_argmax(st, r->logits, r->vocab, ctx->arg_val, ctx->arg_idx, ctx->arg_out);
-        resident_advance_kernel<<<1, 1, 0, st>>>(ctx->arg_out, r->state, r->tokens, r->tokens_cap);
+        launch_argmax(st, r->logits, r->vocab, ctx->arg_val, ctx->arg_idx, ctx->arg_out, ArgmaxAdvance{r->state, r->tokens, r->tokens_cap});
     };
     // static dyn words (row stores with patch_stride 0) come from the host mirror; the prep kernel
     // only rewrites the position-dependent ones
@@ -3343,7 +3333,7 @@ int zgml_hip_resident_decode(zgml_hip_ctx* ctx, zgml_hip_program* p, uint32_t fi
     p->dyn_dirty = true;
     p->profile.call_count += n_steps;
     p->profile.backend_op_count += (uint64_t)n_steps * p->ops.size();
-    p->profile.backend_dispatch_count += (uint64_t)n_steps * (p->plan.size() + 4);
+    p->profile.backend_dispatch_count += (uint64_t)n_steps * (p->plan.size() + 3);
     return ok ? 0 : -1;
 }
 
