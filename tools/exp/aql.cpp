@@ -83,7 +83,7 @@ int main(int argc, char** argv) {
     hsa_signal_t done;
     CK(hsa_signal_create(1, 0, nullptr, &done));
 
-    const uint32_t WGS = 256, WG = 256; // one workgroup per CU
+    const uint32_t WGS = argc > 2 ? (uint32_t)atoi(argv[2]) : 256, WG = 256; // default: one workgroup per CU (the buffers below hold 256 x 256 words: WGS <= 256 for the bump / rotate kernels)
     unsigned* words = nullptr;
     CK(hsa_amd_memory_pool_allocate(g_coarse, (size_t)WGS * WG * 4, 0, (void**)&words));
     CK(hsa_amd_agents_allow_access(1, &g_gpu, nullptr, words));
@@ -168,6 +168,11 @@ int main(int argc, char** argv) {
     const uint32_t N = 2000;
     for (int barrier = 1; barrier >= 0; barrier--)
         for (int scope = 0; scope <= 2; scope++) run("empty kernel", k_empty, N, barrier, scope, scope, false);
+    if (WGS != 256) { // grid-size sweep: empty kernels only
+        hsa_queue_destroy(q);
+        hsa_shut_down();
+        return 0;
+    }
     for (int scope = 0; scope <= 2; scope++) run("bump kernel (dependent)", k_bump, N, true, scope, scope, true);
     run("bump kernel, no barrier", k_bump, N, false, 1, 1, true);
     const Kernel k_bump1 = symbol(ex, "bump_sc1_kernel.kd"), k_rot = symbol(ex, "rotate_kernel.kd"), k_rot1 = symbol(ex, "rotate_sc1_kernel.kd");
