@@ -162,3 +162,65 @@ def test_tile_kernel_rows_equal_matvec_full_size(hip_backend, oracle, kind):
         assert np.all(np.abs(Y.reshape(M, N)[m] - y) <= 2 * TOL * bound + 1e-30), m
     assert np.all(Y.reshape(M, N)[5] == 0)
     hip_backend.freeProgram(h)
+
+
+def _q4_weight(rng, K, N):
+    data = rng.integers(-8, 8, K * N).astype(np.int8)
+    scales = (rng.random(K * N // 32).astype(np.float16) * 0.05 + 0.001).astype(f32)
+    return QuantizedWeightUpload(data, scales, K, N, 32)
+
+
+@pytest.mark.parametrize("K,N", [(576, 576), (4096, 1024)])
+def test_matvec_prologues_and_epilogue_chains_store_every_intermediate(hip_backend, oracle, K, N):
+    """The planner folds the ops around an M = 1 quantized mat-vec into its launch (prologue: rmsnorm -> mul gamma or a
+    plain mul; epilogue: element-wise consumers) and the kernel still writes every intermediate buffer. Chains here:
+    the residual add and the SiLU chain exactly as the LLaMA lowering emits them (straight-line fast paths), the SiLU
+    chain with its steps regrouped (must NOT match the fast path's pattern), and a chain no fast path knows
+    (relu, mul by a vector, swapped add, abs, neg) through the generic step interpreter. Every buffer against the oracle."""
+    from zgml_amd import FusedEwStep
+    rng = np.random.default_rng(K * 7 + N)
+    x = rng.standard_normal(K).astype(f32)
+    gamma = (rng.random(K).astype(f32) + 0.5)
+    vec = rng.standard_normal(N).astype(f32)
+    one = np.ones(N, f32)
+    # buffers: 0 x, 1 gamma, 2 normed, 3 xg (mat-vec input), 4 vecN, 5 ones, 6.. outputs
+    B = dict(x=0, gamma=1, normed=2, xg=3, vec=4, one=5, gate=6, up=7, exp_neg=8, silu=9, resid=10, y=11, t1=12, t2=13, t3=14, t4=15, t5=16,
+             g2=17, e2=18, s2=19, s3=20, s4=21)
+    sizes = [K, K, K, K, N, N] + [N] * 16
+    ops = [
+        DeviceOp.rmsnorm(B["normed"], B["x"], 1, K, 1e-5),
+        DeviceOp.elementwise("mul", B["xg"], B["normed"], B["gamma"], K),
+        # gate / up over the same input: a grouped launch; gate carries the LLaMA SiLU chain
+        DeviceOp.qmatmul(B["gate"], B["xg"], 0, 1, N, K),
+        DeviceOp.qmatmul(B["up"], B["xg"], 1, 1, N, K),
+        DeviceOp.fused_elementwise([FusedEwStep("neg"), FusedEwStep("exp")], N, B["exp_neg"], B["gate"]),
+        DeviceOp.fused_elementwise([FusedEwStep("add", False, B["one"], 0), FusedEwStep("recip"), FusedEwStep("mul", True, B["gate"], 0)], N,
+                                   B["silu"], B["exp_neg"]),
+        # a single-matrix launch with the residual add
+        DeviceOp.qmatmul(B["y"], B["xg"], 2, 1, N, K),
+        DeviceOp.elementwise("add", B["resid"], B["vec"], B["y"], N),
+        # a chain no fast path knows
+        DeviceOp.qmatmul(B["t1"], B["xg"], 3, 1, N, K),
+        DeviceOp.elementwise("relu", B["t2"], B["t1"], B["t1"], N),
+        DeviceOp.elementwise("mul", B["t3"], B["t2"], B["vec"], N),
+        DeviceOp.elementwise("add", B["t4"], B["vec"], B["t3"], N),
+        DeviceOp.fused_elementwise([FusedEwStep("abs"), FusedEwStep("neg")], N, B["t5"], B["t4"]),
+        # the SiLU arithmetic grouped differently (neg alone, then exp + add, then recip, then mul): not the fast path's pattern
+        DeviceOp.qmatmul(B["g2"], B["xg"], 4, 1, N, K),
+        DeviceOp.elementwise("neg", B["e2"], B["g2"], B["g2"], N),
+        DeviceOp.fused_elementwise([FusedEwStep("exp"), FusedEwStep("add", True, B["one"], 0)], N, B["s2"], B["e2"]),
+        DeviceOp.elementwise("recip", B["s3"], B["s2"], B["s2"], N),
+        DeviceOp.elementwise("mul", B["s4"], B["g2"], B["s3"], N),
+    ]
+    prog = DeviceProgram(ops=ops, buffer_sizes=sizes,
+                         initial_uploads=[ProgramIO(B["x"], x), ProgramIO(B["gamma"], gamma), ProgramIO(B["vec"], vec), ProgramIO(B["one"], one)],
+                         qweights=[_q4_weight(rng, K, N) for _ in range(5)])
+    for name in ("normed", "xg", "gate", "up", "exp_neg", "silu", "y", "resid", "t1", "t2", "t3", "t4", "t5", "g2", "e2", "s2", "s3", "s4"):
+        n = sizes[B[name]]
+        want = oracle.run_program(prog, B[name], n)
+        got = oracle.run_program(prog, B[name], n, backend=hip_backend)
+        assert not hip_backend.last_error(), hip_backend.last_error()
+        # summation order only — but exp() turns the mat-vec's absolute difference (~1e-4 at K = 4096: the oracle adds 4096
+        # f32 products sequentially) into a relative one, hence 1e-3 here: the test is about structure, not the last bit
+        scale = max(1.0, float(np.abs(want).max()))
+        np.testing.assert_allclose(got, want, rtol=1e-3, atol=1e-4 * scale, err_msg=name)
