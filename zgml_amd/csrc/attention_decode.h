@@ -1,0 +1,531 @@
+// attention_decode.h — the decode-shaped attention of one head with everything that feeds it folded in (device code).
+// Included by kernels_generic.hip (the stand-alone launch) and by qmatvec.hip (so that a launch can hold both the q / k / v
+// projection's workgroups and the attention's: DESIGN.md section 8.0). Everything lives in an anonymous namespace: each
+// translation unit gets its own copy.
+#pragma once
+#include "kernels.h"
+
+#include <hip/hip_fp16.h>
+#include <math.h>
+
+namespace zgml {
+namespace {
+
+// Loads / stores through GLOBAL-address-space pointers. A pointer taken from a parameter record is a generic pointer to
+// hipcc, and a generic access is a FLAT instruction: it counts on vmcnt AND lgkmcnt, so every `s_waitcnt lgkmcnt(0)` in
+// front of a scalar-load result (the records are read with scalar loads, round after round) also waits for every vector
+// load issued so far — the phases of a latency-chain kernel serialise. global_load / global_store only count on vmcnt.
+typedef float f4v_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ldg4(const float* p) {
+    const f4v_t v = *(const __attribute__((address_space(1))) f4v_t*)p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float ldg1(const float* p) { return *(const __attribute__((address_space(1))) float*)p; }
+__device__ __forceinline__ uint32_t ldgu(const uint32_t* p) { return *(const __attribute__((address_space(1))) uint32_t*)p; }
+__device__ __forceinline__ void stg4(float* p, float4 v) { *(__attribute__((address_space(1))) f4v_t*)p = f4v_t{v.x, v.y, v.z, v.w}; }
+__device__ __forceinline__ void stg1(float* p, float v) { *(__attribute__((address_space(1))) float*)p = v; }
+__device__ __forceinline__ void stgu(uint32_t* p, uint32_t v) { *(__attribute__((address_space(1))) uint32_t*)p = v; }
+
+constexpr int kAttnBlock = 1024;
+constexpr int kAttnUnroll = 4;
+
+// rope of 4 consecutive dims [d0, d0+4) of a head vector (reference.zig:457-478, DeviceOp
+// convention: sin at cs + pair + half_d); `own` = x[d0..], `par` = x[(d0 ^ half)..]. Same
+// expressions as rope_body so the fused path is bit-identical to the op-by-op one.
+__device__ __forceinline__ float4 rope4(float4 own, float4 par, float4 c, float4 s, bool is_hi) {
+    if (is_hi) // own = x_hi, par = x_lo: hi = x_hi * c + x_lo * s
+        return make_float4(own.x * c.x + par.x * s.x, own.y * c.y + par.y * s.y, own.z * c.z + par.z * s.z,
+                           own.w * c.w + par.w * s.w);
+    return make_float4(own.x * c.x - par.x * s.x, own.y * c.y - par.y * s.y, own.z * c.z - par.z * s.z,
+                       own.w * c.w - par.w * s.w); // lo = x_lo * c - x_hi * s
+}
+
+__device__ __forceinline__ float score_of(float dot, float mk, float scale) {
+    float score = -INFINITY;
+    if (isfinite(mk)) {
+        score = dot * scale + mk;
+        if (!isfinite(score)) score = -INFINITY;
+    }
+    return score;
+}
+
+// ── decode attention, one workgroup per head (seq_q == 1) ───────────────────────────────────
+// At decode lengths this kernel is not bandwidth: a launch keeps only n_heads CUs busy, so what
+// it costs is (a) the chain of dependent memory round trips and (b) the instruction stream of ONE
+// wave (a CU issues ~1 wave-instruction per 4-5 cycles per SIMD: 1000 instructions are ~2 us).
+// So: every load of a phase is issued back to back without branches (a conditional load makes
+// hipcc wait for everything before it), reductions inside a key's lane group use DPP instead of
+// LDS shuffles, there is no score buffer and a single barrier — each key slot (LPK lanes) runs its
+// own online softmax (m, l, acc) over the keys it streams, slots are merged at the end (within
+// the wave by shuffles, across waves through LDS) — and waves the context does not need retire at
+// the top (a retired wave no longer counts at s_barrier).
+// Lane layout: a key is handled by LPK = d_head/4 adjacent lanes holding one float4 of the head
+// dimension each (one coalesced row read per key); a wave streams 64/LPK keys per step.
+
+// v + (v of lane ^ 16) and v + (v of lane ^ 32) without the LDS crossbar (ds_bpermute: ~100 cycles and an lgkmcnt wait
+// per exchange): gfx950's row swaps. permlane16_swap(v, v) = (rows 0 0 2 2 | rows 1 1 3 3), so their sum (max) is the
+// xor-16 exchange's on every lane; permlane32_swap pairs the wave's halves the same way. Same values as the shuffles
+// (a + b == b + a exactly).
+__device__ __forceinline__ float xor16_sum(float v) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor32_sum(float v) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor16_max(float v) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor32_max(float v) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+// allreduce (sum) over groups of LPK adjacent lanes; DPP inside a 16-lane row, row swaps above
+template <int LPK>
+__device__ __forceinline__ float group_sum(float v) {
+    if (LPK >= 2) v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
+    if (LPK >= 4) v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));  // quad_perm [2,3,0,1]
+    if (LPK >= 8) v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xF, 0xF, true)); // row_half_mirror
+    if (LPK >= 16) v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xF, 0xF, true)); // row_mirror
+    if (LPK >= 32) v = xor16_sum(v);
+    if (LPK >= 64) v = xor32_sum(v);
+    return v;
+}
+
+struct SoftState { // online softmax of one key stream: running max, sum of weights, weighted V (4 dims)
+    float m, l;
+    float4 acc;
+};
+// merge stream `o` into `s` (either may be empty: m == -inf)
+__device__ __forceinline__ void soft_merge(SoftState& s, float om, float ol, float4 oacc) {
+    const float nm = fmaxf(s.m, om);
+    const float a = s.m > -INFINITY ? expf(s.m - nm) : 0.0f, b = om > -INFINITY ? expf(om - nm) : 0.0f;
+    s.l = s.l * a + ol * b;
+    s.acc = make_float4(s.acc.x * a + oacc.x * b, s.acc.y * a + oacc.y * b, s.acc.z * a + oacc.z * b, s.acc.w * a + oacc.w * b);
+    s.m = nm;
+}
+
+//
+// Long contexts (flash-decoding split): the launch has gridDim.y = S workgroups per head. While
+// seq_kv < 2 * split_min_keys only workgroup 0 works (the others retire after reading seq_kv) and
+// nothing below changes. Above that, n_active = min(S, seq_kv / split_min_keys) workgroups each
+// stream a contiguous chunk of the keys, publish their (m, l, acc) with write-through (sc1) stores,
+// drain, and add to the head's counter; the last arriver reads all partials with sc1 loads, merges
+// them in chunk order (so the result does not depend on arrival order), writes the output and
+// re-arms the counter. The guide's fan-in form: sc1 payload + vmcnt(0) drain + agent atomic, every
+// consumer load sc1, no fence.
+using gu64 = __attribute__((address_space(1))) unsigned long long;
+using gu32 = __attribute__((address_space(1))) unsigned int;
+__device__ __forceinline__ void split_put(float* p, float a, float b) {
+    const unsigned long long v = (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32);
+    __hip_atomic_store((gu64*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void split_get(const float* p, float& a, float& b) {
+    const unsigned long long v = __hip_atomic_load((gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    a = __uint_as_float((uint32_t)v), b = __uint_as_float((uint32_t)(v >> 32));
+}
+
+// sum l and acc over the 64 / LPK key slots of a wave (streams already on a common max)
+template <int LPK>
+__device__ __forceinline__ void slots_sum(SoftState& s) {
+#pragma unroll
+    for (int off = LPK; off < 16; off <<= 1) {
+        s.l += __shfl_xor(s.l, off, 64);
+        s.acc.x += __shfl_xor(s.acc.x, off, 64), s.acc.y += __shfl_xor(s.acc.y, off, 64);
+        s.acc.z += __shfl_xor(s.acc.z, off, 64), s.acc.w += __shfl_xor(s.acc.w, off, 64);
+    }
+    if (LPK <= 16) s.l = xor16_sum(s.l), s.acc.x = xor16_sum(s.acc.x), s.acc.y = xor16_sum(s.acc.y), s.acc.z = xor16_sum(s.acc.z), s.acc.w = xor16_sum(s.acc.w);
+    if (LPK <= 32) s.l = xor32_sum(s.l), s.acc.x = xor32_sum(s.acc.x), s.acc.y = xor32_sum(s.acc.y), s.acc.z = xor32_sum(s.acc.z), s.acc.w = xor32_sum(s.acc.w);
+}
+// merge the slots' online-softmax states: common max, one rescale each, sums
+template <int LPK>
+__device__ __forceinline__ void slots_merge(SoftState& s) {
+    float M = s.m;
+#pragma unroll
+    for (int off = LPK; off < 16; off <<= 1) M = fmaxf(M, __shfl_xor(M, off, 64));
+    if (LPK <= 16) M = xor16_max(M);
+    if (LPK <= 32) M = xor32_max(M);
+    const float f = s.m > -INFINITY ? expf(s.m - M) : 0.0f;
+    s.l *= f;
+    s.acc = make_float4(s.acc.x * f, s.acc.y * f, s.acc.z * f, s.acc.w * f);
+    s.m = M;
+    slots_sum<LPK>(s);
+}
+
+// One key's (value's) 4 dims as this lane holds them: f32 cache rows, or the quantised-KV form (4 int8 + the
+// block scale; QuantizedKVCache, src/quant.zig:645-700). The dot / accumulate expressions of the quantised form
+// are those of kvq_attention_kernel, the quantisation is kvq_store_kernel's (= storeColumn), so the fused launch
+// writes the same cache bytes and computes the same numbers as the op-by-op plan.
+template <bool KVQ>
+struct AttnRow {
+    float4 v;
+};
+template <>
+struct AttnRow<true> {
+    uint32_t w;
+    float sc;
+};
+__device__ __forceinline__ float row_dot(const float4& q, const AttnRow<false>& r) { return q.x * r.v.x + q.y * r.v.y + q.z * r.v.z + q.w * r.v.w; }
+__device__ __forceinline__ float row_dot(const float4& q, const AttnRow<true>& r) {
+    const uint32_t kw = r.w;
+    return (q.x * (float)(int8_t)(kw & 255) + q.y * (float)(int8_t)((kw >> 8) & 255) + q.z * (float)(int8_t)((kw >> 16) & 255) +
+            q.w * (float)(int8_t)(kw >> 24)) * r.sc;
+}
+__device__ __forceinline__ void row_axpy(float4& acc, float wgt, const AttnRow<false>& r) {
+    acc.x += wgt * r.v.x, acc.y += wgt * r.v.y, acc.z += wgt * r.v.z, acc.w += wgt * r.v.w;
+}
+__device__ __forceinline__ void row_axpy(float4& acc, float wgt, const AttnRow<true>& r) {
+    const float ws = wgt * r.sc;
+    const uint32_t vw = r.w;
+    acc.x += ws * (float)(int8_t)(vw & 255), acc.y += ws * (float)(int8_t)((vw >> 8) & 255);
+    acc.z += ws * (float)(int8_t)((vw >> 16) & 255), acc.w += ws * (float)(int8_t)(vw >> 24);
+}
+// storeColumn's arithmetic on the 4 dims of a lane; a block of 32 dims = 8 adjacent lanes
+__device__ __forceinline__ AttnRow<true> quantise_block32(float4 v) {
+    float mx = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mx), 0xB1, 0xF, 0xF, true)));  // quad_perm [1,0,3,2]
+    mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mx), 0x4E, 0xF, 0xF, true)));  // quad_perm [2,3,0,1]
+    mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(mx), 0x141, 0xF, 0xF, true))); // row_half_mirror
+    const float scale = mx > 0.f ? mx / 127.0f : 1.0f, inv = mx > 0.f ? 127.0f / mx : 0.0f;
+    auto q8 = [&](float x) { return (uint32_t)(uint8_t)(int8_t)(int)fminf(fmaxf(x * inv, -127.0f), 127.0f); }; // truncates toward zero
+    return AttnRow<true>{q8(v.x) | (q8(v.y) << 8) | (q8(v.z) << 16) | (q8(v.w) << 24), scale};
+}
+
+// A launch that also holds the workgroups of the q / k / v projection (qmatvec.hip: fused launch) hands the projections
+// over through agent-scope counters instead of a kernel boundary: one counter per 64-column... per head slice of each
+// projection, bumped once by every column group (16 columns) that has stored its outputs with write-through stores. The
+// attention issues everything that does not depend on the projections first, then waits (bounded) for its head's three
+// counters to pass `seen + need`, remembers the new values in its private `seen` words (kv heads have several consumers,
+// so the shared counters are never reset) and reads q / k / v with agent-scope loads.
+struct DecodeHandoff {
+    const uint32_t* cnt; // [n_heads | n_kv | n_kv] monotonic counters
+    uint32_t* seen;      // [workgroups of the attention part][3]
+    uint32_t n_heads, n_kv, group; // heads per kv head
+    uint32_t need;       // column groups per head slice = d_head / 16
+    uint32_t* timeout;   // bumped when a wait gives up
+};
+
+template <int LPK, bool KVQ>
+__device__ __forceinline__ void attention_decode_body(const AttnDecodeParams* __restrict__ params, float* split_buf, uint32_t* split_cnt,
+                                                      uint32_t split_min_keys, const uint32_t hx, const uint32_t sp_in, const uint32_t n_sp,
+                                                      const DecodeHandoff* ho) {
+    constexpr int DH = 4 * LPK, KPW = 64 / LPK, U = kAttnUnroll, HALF = DH / 2;
+    using Row = AttnRow<KVQ>;
+    // The head's parameter record in ONE scalar round trip: read through a reference, hipcc fetches it field by field where
+    // the fields are used — three dependent rounds of s_load + s_waitcnt before the kernel's first vector load.
+    static_assert(sizeof(AttnDecodeParams) == 248, "the bulk fetch below covers exactly 62 dwords");
+    AttnDecodeParams P;
+    {
+        typedef uint32_t u32x16_t __attribute__((ext_vector_type(16)));
+        typedef uint32_t u32x8_t __attribute__((ext_vector_type(8)));
+        typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+        typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+        u32x16_t ra, rb, rc;
+        u32x8_t rd;
+        u32x4_t re;
+        u32x2_t rf;
+#if defined(__HIP_DEVICE_COMPILE__)
+        const AttnDecodeParams* const rec = params + hx;
+        asm volatile("s_load_dwordx16 %0, %6, 0x0\n\ts_load_dwordx16 %1, %6, 0x40\n\ts_load_dwordx16 %2, %6, 0x80\n\t"
+                     "s_load_dwordx8 %3, %6, 0xc0\n\ts_load_dwordx4 %4, %6, 0xe0\n\ts_load_dwordx2 %5, %6, 0xf0\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(ra), "=&s"(rb), "=&s"(rc), "=&s"(rd), "=&s"(re), "=&s"(rf)
+                     : "s"(rec)
+                     : "memory");
+#else
+        ra = rb = rc = u32x16_t{}, rd = u32x8_t{}, re = u32x4_t{}, rf = u32x2_t{};
+#endif
+        char* const dst = (char*)&P;
+        __builtin_memcpy(dst, &ra, 64), __builtin_memcpy(dst + 64, &rb, 64), __builtin_memcpy(dst + 128, &rc, 64);
+        __builtin_memcpy(dst + 192, &rd, 32), __builtin_memcpy(dst + 224, &re, 16), __builtin_memcpy(dst + 240, &rf, 8);
+    }
+    const AttentionParams& p = P.att;
+#ifdef ZGML_TRACE // build with -DZGML_TRACE (ZGML_HIP_ATTN_TRACE=1 then prints the stamps)
+    unsigned long long* const trace = P.trace;
+#define ATTN_STAMP(i) do { if (trace && threadIdx.x == 0) trace[i] = wall_clock64(); } while (0)
+#else
+#define ATTN_STAMP(i) do { } while (0)
+#endif
+    ATTN_STAMP(0);
+    __shared__ __attribute__((aligned(8))) float part_ml[2 * (kAttnBlock / 64)];
+    __shared__ float4 part_acc[(kAttnBlock / 64) * LPK];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t slot = lane / LPK, li = lane % LPK, d0 = 4 * li, pair = d0 & (HALF - 1);
+    const bool is_hi = d0 >= (uint32_t)HALF;
+    // ---- phase A: dynamic words (scalar) and everything the ropes need (vector), one round
+    // quantised KV: the stores' dynamic words are column indices, the caches are int8 rows + f32 block scales
+    const uint32_t seq_kv = KVQ ? min(ldgu(p.dyn_seq_kv), P.kvq_cols) : ldgu(p.dyn_seq_kv), dk = ldgu(P.dyn_k_off), dv = ldgu(P.dyn_v_off);
+    const uint32_t d2_off = p.dst2 ? ldgu(p.dyn_dst2_off) : 0; // scalar, with the other dynamic words
+    // (a fused launch reads the projections' outputs only after the hand-off below; `ho` is a literal nullptr in the
+    // stand-alone kernel, so nothing here is a run-time branch there)
+    float4 q_own, q_par, k_own, k_par, v_new;
+    if (!ho) {
+        q_own = ldg4(P.q_src + d0), q_par = ldg4(P.q_src + (d0 ^ HALF));
+        k_own = ldg4(P.k_src + d0), k_par = ldg4(P.k_src + (d0 ^ HALF));
+        v_new = ldg4(P.v_src + d0);
+    }
+    const float4 q_c = ldg4(P.q_cs + pair), q_s = ldg4(P.q_cs + HALF + pair);
+    const float4 k_c = ldg4(P.k_cs + pair), k_s = ldg4(P.k_cs + HALF + pair);
+    ATTN_STAMP(1);
+    // this workgroup's keys [k_begin, k_end)
+    const uint32_t sp = sp_in;
+    uint32_t n_active = 1, k_begin = 0, k_end = seq_kv;
+    if (n_sp > 1) {
+        n_active = seq_kv / split_min_keys;
+        n_active = n_active < 1 ? 1 : (n_active > n_sp ? n_sp : n_active);
+        if (sp >= n_active) { // (a fused launch: an idle split still moves its private `seen` words with the counters)
+            if (ho && tid == 0) {
+                uint32_t* const seen = ho->seen + (hx * n_sp + sp) * 3;
+                seen[0] += ho->need, seen[1] += ho->need, seen[2] += ho->need;
+            }
+            return;
+        }
+        const uint32_t chunk = (seq_kv + n_active - 1) / n_active;
+        k_begin = min(sp * chunk, seq_kv), k_end = min(k_begin + chunk, seq_kv);
+    }
+    const uint32_t n_keys = k_end - k_begin;
+    // waves the chunk needs: one step of a wave covers KPW * U keys
+    uint32_t NW = (n_keys + KPW * U - 1) / (KPW * U);
+    NW = NW < 1 ? 1 : (NW > (uint32_t)(kAttnBlock / 64) ? (uint32_t)(kAttnBlock / 64) : NW);
+    if (w >= NW) return;
+    const uint32_t keys_per_iter = KPW * NW, step_keys = keys_per_iter * U, last = k_end ? k_end - 1 : 0;
+    // ---- phase B: first step's K / V / mask rows (clamped to live rows, unconditional)
+    constexpr uint32_t BPC = DH / 32; // quantised form: 32-dim blocks per column (the planner admits block size 32 only)
+    const int8_t* const kq = (const int8_t*)P.k_cache + d0;
+    const int8_t* const vq = (const int8_t*)P.v_cache + d0;
+    const float* const ksc = P.k_cache + (uint64_t)P.kvq_cols * DH / 4 + d0 / 32;
+    const float* const vsc = P.v_cache + (uint64_t)P.kvq_cols * DH / 4 + d0 / 32;
+    auto load_k = [&](uint32_t s) -> Row {
+        if constexpr (KVQ)
+            return Row{ldgu((const uint32_t*)(kq + (uint64_t)s * DH)), ldg1(ksc + (uint64_t)s * BPC)};
+        else
+            return Row{ldg4(p.k + (uint64_t)s * p.k_cs + d0)};
+    };
+    auto load_v = [&](uint32_t s) -> Row {
+        if constexpr (KVQ)
+            return Row{ldgu((const uint32_t*)(vq + (uint64_t)s * DH)), ldg1(vsc + (uint64_t)s * BPC)};
+        else
+            return Row{ldg4(p.v + (uint64_t)s * p.v_cs + d0)};
+    };
+    Row kv[U], vv[U];
+    float mk[U];
+#pragma unroll
+    for (int j = 0; j < U; j++) {
+        const uint32_t s = min(k_begin + j * keys_per_iter + w * KPW + slot, last);
+        kv[j] = load_k(s);
+        vv[j] = load_v(s);
+        mk[j] = ldg1(p.mask + (uint64_t)s * p.mask_rs); // host passes a zero word with stride 0 when there is no mask
+    }
+    uint32_t target[3] = {0, 0, 0}; // fused launch: the counter values this execution waits for (written back at the end)
+    if (ho) { // ---- hand-off: the q / k / v column groups of this head have been stored (DecodeHandoff)
+        const uint32_t kvh = hx / ho->group;
+        const uint32_t ci[3] = {hx, ho->n_heads + kvh, ho->n_heads + ho->n_kv + kvh};
+        const uint32_t* const seen = ho->seen + (hx * n_sp + sp) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; c++) target[c] = seen[c] + ho->need;
+        uint32_t spins = 0;
+        for (;;) {
+            bool ok = true;
+#pragma unroll
+            for (int c = 0; c < 3; c++) // (wrap-safe comparison)
+                ok = ok && (int32_t)(__hip_atomic_load((gu32*)ho->cnt + ci[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target[c]) >= 0;
+            if (ok) break;
+            if (++spins > 400000u) { // bounded: never hang the device; the caller sees the flag
+                if (tid == 0) atomicAdd(ho->timeout, 1u);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        auto ld_agent4 = [](const float* p) { // agent scope: never a stale line of this XCD's L2
+            float4 v;
+            split_get(p, v.x, v.y);
+            split_get(p + 2, v.z, v.w);
+            return v;
+        };
+        q_own = ld_agent4(P.q_src + d0), q_par = ld_agent4(P.q_src + (d0 ^ HALF));
+        k_own = ld_agent4(P.k_src + d0), k_par = ld_agent4(P.k_src + (d0 ^ HALF));
+        v_new = ld_agent4(P.v_src + d0);
+    }
+    ATTN_STAMP(2);
+    // ---- ropes; side outputs and the cache stores (one lane group writes each value)
+    const float4 qv = rope4(q_own, q_par, q_c, q_s, is_hi);
+    const float4 k_new = rope4(k_own, k_par, k_c, k_s, is_hi);
+    uint32_t col_k, col_v;
+    Row k_col, v_col; // the new column as the attention sees it (quantised KV: what storeColumn writes, dequantised on use)
+    if constexpr (KVQ) {
+        col_k = dk, col_v = dv;
+        k_col = quantise_block32(k_new), v_col = quantise_block32(v_new);
+    } else {
+        col_k = (dk - P.k_off) / p.k_cs, col_v = (dv - P.v_off) / p.v_cs;
+        k_col = Row{k_new}, v_col = Row{v_new};
+    }
+    if (w == 0 && slot == 0 && sp == 0) {
+        stg4(P.q_rot + d0, qv);
+        if (P.owner) {
+            stg4(P.k_rot + d0, k_new);
+            if constexpr (KVQ) { // never outside the cache (kvq_store_kernel's guard)
+                if (col_k < P.kvq_cols) {
+                    stgu((uint32_t*)((int8_t*)P.k_cache + (uint64_t)col_k * DH + d0), k_col.w);
+                    if ((li & 7) == 0) stg1(P.k_cache + (uint64_t)P.kvq_cols * DH / 4 + (uint64_t)col_k * BPC + d0 / 32, k_col.sc);
+                }
+                if (col_v < P.kvq_cols) {
+                    stgu((uint32_t*)((int8_t*)P.v_cache + (uint64_t)col_v * DH + d0), v_col.w);
+                    if ((li & 7) == 0) stg1(P.v_cache + (uint64_t)P.kvq_cols * DH / 4 + (uint64_t)col_v * BPC + d0 / 32, v_col.sc);
+                }
+            } else {
+                stg4(P.k_cache + dk + d0, k_new);
+                stg4(P.v_cache + dv + d0, v_new);
+            }
+        }
+    }
+    ATTN_STAMP(3);
+    SoftState st{-INFINITY, 0.f, make_float4(0.f, 0.f, 0.f, 0.f)};
+    // one step: scores of the slot's U keys, then the online-softmax update
+    auto step = [&](uint32_t base) {
+        float sc[U];
+        float bm = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < U; j++) {
+            const uint32_t t = base + j * keys_per_iter + w * KPW + slot;
+            const Row kk = t == col_k ? k_col : kv[j];
+            const float dot = group_sum<LPK>(row_dot(qv, kk));
+            sc[j] = t < k_end ? score_of(dot, mk[j], p.scale) : -INFINITY;
+            bm = fmaxf(bm, sc[j]);
+        }
+        const float nm = fmaxf(st.m, bm);
+        if (nm > -INFINITY) { // per key slot; lanes of a slot agree
+            const float alpha = st.m > -INFINITY ? expf(st.m - nm) : 0.0f;
+            st.l *= alpha;
+            st.acc = make_float4(st.acc.x * alpha, st.acc.y * alpha, st.acc.z * alpha, st.acc.w * alpha);
+#pragma unroll
+            for (int j = 0; j < U; j++) {
+                const uint32_t t = base + j * keys_per_iter + w * KPW + slot;
+                const float wgt = sc[j] > -INFINITY ? expf(sc[j] - nm) : 0.0f;
+                const Row x = t == col_v ? v_col : vv[j];
+                st.l += wgt;
+                if (sc[j] > -INFINITY) row_axpy(st.acc, wgt, x); // rows of dead slots are never touched
+            }
+            st.m = nm;
+        }
+    };
+    if (n_keys <= step_keys) { // the usual decode case: everything is already in registers
+        if (n_keys) step(k_begin);
+    } else {
+        for (uint32_t base = k_begin; base < k_end; base += step_keys) {
+            // prefetch the next step (clamped: the last step re-reads live rows, L2 hits)
+            Row kn[U], vn[U];
+            float mn[U];
+#pragma unroll
+            for (int j = 0; j < U; j++) {
+                const uint32_t s = min(base + step_keys + j * keys_per_iter + w * KPW + slot, last);
+                kn[j] = load_k(s);
+                vn[j] = load_v(s);
+                mn[j] = ldg1(p.mask + (uint64_t)s * p.mask_rs);
+            }
+            step(base);
+#pragma unroll
+            for (int j = 0; j < U; j++) kv[j] = kn[j], vv[j] = vn[j], mk[j] = mn[j];
+        }
+    }
+    ATTN_STAMP(4);
+    // ---- merge the key slots of the wave, then the waves. Every merge is two-pass (common max first,
+    // then ONE rescale per stream and plain sums): no chain of dependent exponentials.
+    slots_merge<LPK>(st);
+    SoftState r = st;
+    if (NW > 1) { // (uniform) a single wave has the workgroup's result already
+        if (lane < LPK) {
+            part_acc[w * LPK + lane] = st.acc;
+            if (lane == 0) part_ml[2 * w] = st.m, part_ml[2 * w + 1] = st.l;
+        }
+        ATTN_STAMP(5);
+        __syncthreads();
+        ATTN_STAMP(6);
+        if (w != 0) return;
+        // wave 0, all 64 lanes: lane ww < 16 fetches wave ww's max for the common max (DPP row reduction);
+        // slot g folds waves g, g + KPW, ... — every LDS read is issued up front, the exponentials are independent
+        constexpr int MAXW = kAttnBlock / 64, NPS = MAXW / KPW > 0 ? MAXW / KPW : 1;
+        static_assert(MAXW == 16, "lanes 0..15 (one DPP row) hold the waves' maxima");
+        float M = lane < NW ? part_ml[2 * lane] : -INFINITY;
+        float2 ml[NPS];
+        float4 pa[NPS];
+#pragma unroll
+        for (int i = 0; i < NPS; i++) {
+            const uint32_t ww = slot + i * KPW, wc = ww < NW ? ww : 0;
+            ml[i] = *(const float2*)&part_ml[2 * wc];
+            pa[i] = part_acc[wc * LPK + li];
+        }
+        M = fmaxf(M, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(M), 0xB1, 0xF, 0xF, true)));
+        M = fmaxf(M, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(M), 0x4E, 0xF, 0xF, true)));
+        M = fmaxf(M, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(M), 0x141, 0xF, 0xF, true)));
+        M = fmaxf(M, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(M), 0x140, 0xF, 0xF, true)));
+        M = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(M)));
+        r = SoftState{M, 0.f, make_float4(0.f, 0.f, 0.f, 0.f)};
+#pragma unroll
+        for (int i = 0; i < NPS; i++) {
+            const bool live = slot + i * KPW < NW && ml[i].x > -INFINITY;
+            const float f = live ? expf(ml[i].x - M) : 0.0f;
+            r.l += ml[i].y * f;
+            r.acc.x += pa[i].x * f, r.acc.y += pa[i].y * f, r.acc.z += pa[i].z * f, r.acc.w += pa[i].w * f;
+        }
+        slots_sum<LPK>(r);
+    } else {
+        ATTN_STAMP(5);
+        ATTN_STAMP(6);
+    }
+    { // wave 0 from here on
+        if (ho && lane == 0) { // every wave of this workgroup has passed the hand-off (merge barrier above / single wave)
+            uint32_t* const seen = ho->seen + (hx * n_sp + sp) * 3;
+            seen[0] = target[0], seen[1] = target[1], seen[2] = target[2];
+        }
+        if (n_active > 1) { // publish this chunk; the last arriver merges all of them
+            constexpr uint32_t REC = DH + 4; // m, l, pad, pad, acc[DH]
+            float* const head_buf = split_buf + (uint64_t)hx * n_sp * REC;
+            float* const mine = head_buf + (uint64_t)sp * REC;
+            if (lane < LPK) {
+                if (lane == 0) split_put(mine, r.m, r.l);
+                split_put(mine + 4 + 4 * lane, r.acc.x, r.acc.y);
+                split_put(mine + 4 + 4 * lane + 2, r.acc.z, r.acc.w);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the write-through stores have left before the count
+            uint32_t old = 0;
+            if (lane == 0) old = __hip_atomic_fetch_add((gu32*)(split_cnt + hx), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            old = __shfl(old, 0, 64);
+            if (old != n_active - 1) return;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // compiler only: the loads below stay below the count
+            // slot g folds chunks g, g + KPW, ... in chunk order (not arrival order), then the slots merge
+            r = SoftState{-INFINITY, 0.f, make_float4(0.f, 0.f, 0.f, 0.f)};
+            for (uint32_t c = slot; c < n_active; c += KPW) {
+                const float* rec = head_buf + (uint64_t)c * REC;
+                float om, ol;
+                float4 oa;
+                split_get(rec, om, ol);
+                split_get(rec + 4 + 4 * li, oa.x, oa.y);
+                split_get(rec + 4 + 4 * li + 2, oa.z, oa.w);
+                soft_merge(r, om, ol, oa);
+            }
+            slots_merge<LPK>(r);
+            if (lane == 0) __hip_atomic_store((gu32*)(split_cnt + hx), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // re-arm
+        }
+        if (lane < LPK) {
+            const float inv_l = r.l > 0.f ? 1.0f / r.l : 0.0f;
+            const float o[4] = {r.acc.x * inv_l, r.acc.y * inv_l, r.acc.z * inv_l, r.acc.w * inv_l};
+            stg4(p.dst + 4 * lane, make_float4(o[0], o[1], o[2], o[3])); // dst_rs == 1, 16-byte aligned (planner)
+            if (p.dst2)
+#pragma unroll
+                for (int e = 0; e < 4; e++) stg1(p.dst2 + (uint64_t)d2_off + (uint64_t)(4 * lane + e) * p.d2_rs, o[e]);
+        }
+    }
+    ATTN_STAMP(7);
+#undef ATTN_STAMP
+}
+
+template <int LPK, bool KVQ>
+__global__ void __launch_bounds__(kAttnBlock) attention_decode_kernel(const AttnDecodeParams* __restrict__ params, float* split_buf,
+                                                                      uint32_t* split_cnt, uint32_t split_min_keys) {
+    attention_decode_body<LPK, KVQ>(params, split_buf, split_cnt, split_min_keys, blockIdx.x, blockIdx.y, gridDim.y, nullptr);
+}
+
+} // namespace
+} // namespace zgml
