@@ -203,7 +203,8 @@ __device__ __forceinline__ AttnRow<true> quantise_block32(float4 v) {
 struct DecodeHandoff {
     const uint32_t* cnt; // [n_heads | n_kv | n_kv] monotonic counters
     uint32_t* seen;      // [workgroups of the attention part][3]
-    uint32_t n_heads, n_kv, group; // heads per kv head
+    const uint32_t* idx; // [records][3]: the q / k / v counters of each record's head (records need not be in head order)
+    uint32_t n_heads;
     uint32_t need;       // column groups per head slice = d_head / 16
     uint32_t* timeout;   // bumped when a wait gives up
 };
@@ -320,24 +321,26 @@ __device__ __forceinline__ void attention_decode_body(const AttnDecodeParams* __
     }
     uint32_t target[3] = {0, 0, 0}; // fused launch: the counter values this execution waits for (written back at the end)
     if (ho) { // ---- hand-off: the q / k / v column groups of this head have been stored (DecodeHandoff)
-        const uint32_t kvh = hx / ho->group;
-        const uint32_t ci[3] = {hx, ho->n_heads + kvh, ho->n_heads + ho->n_kv + kvh};
+        const uint32_t ci[3] = {ho->idx[3 * hx], ho->idx[3 * hx + 1], ho->idx[3 * hx + 2]};
         const uint32_t* const seen = ho->seen + (hx * n_sp + sp) * 3;
 #pragma unroll
         for (int c = 0; c < 3; c++) target[c] = seen[c] + ho->need;
-        uint32_t spins = 0;
-        for (;;) {
-            bool ok = true;
+        if (w == 0) { // one wave polls (the counters are 128 bytes apart; every poll is a trip to memory), the others wait at the barrier
+            uint32_t spins = 0;
+            for (;;) {
+                bool ok = true;
 #pragma unroll
-            for (int c = 0; c < 3; c++) // (wrap-safe comparison)
-                ok = ok && (int32_t)(__hip_atomic_load((gu32*)ho->cnt + ci[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target[c]) >= 0;
-            if (ok) break;
-            if (++spins > 400000u) { // bounded: never hang the device; the caller sees the flag
-                if (tid == 0) atomicAdd(ho->timeout, 1u);
-                break;
+                for (int c = 0; c < 3; c++) // (wrap-safe comparison)
+                    ok = ok && (int32_t)(__hip_atomic_load((gu32*)ho->cnt + 32 * ci[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target[c]) >= 0;
+                if (ok) break;
+                if (++spins > 400000u) { // bounded: never hang the device; the caller sees the flag
+                    if (tid == 0) atomicAdd(ho->timeout, 1u);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
             }
-            __builtin_amdgcn_s_sleep(1);
         }
+        if (NW > 1) __syncthreads(); // (waves >= NW have retired and do not count)
         auto ld_agent4 = [](const float* p) { // agent scope: never a stale line of this XCD's L2
             float4 v;
             split_get(p, v.x, v.y);

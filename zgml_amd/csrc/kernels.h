@@ -363,6 +363,12 @@ bool qmv_can_group(const QWeightDev& a, const QWeightDev& b);
 // Prologue kinds other than NONE keep the whole input in registers: K <= qmv_max_prologue_k(w).
 uint32_t qmv_max_prologue_k(const QWeightDev& w);
 void launch_qmatvec_fused(hipStream_t s, const QmvLaunch& L);
+// q / k / v projection (grouped, rmsnorm prologue, K <= 2048) + the decode attention of its heads in ONE launch; the
+// projection's outputs are handed over through `counters` ([n_heads + 2 n_kv] words; `idx` [n_heads][3] names each record's
+// q / k / v counter) with `seen` ([n_heads * splits * 3]) as the consumers' private progress words; counters and seen
+// zero-initialised by the caller. false: not fusable, nothing launched.
+bool launch_qkv_attention(hipStream_t s, const QmvLaunch& L, const AttnDecodeParams* dev_params, uint32_t n_heads, uint32_t n_kv, uint32_t d_head,
+                          const AttnSplit& sp, uint32_t* counters, const uint32_t* idx, uint32_t* seen, uint32_t* timeout);
 // Deterministic synthetic weights for the roofline micro-benchmark, generated on the device
 // directly in the packed layout (SURVEY §8d generator).
 void launch_synth_packed(hipStream_t s, const QWeightDev& w, uint32_t matrix_id);

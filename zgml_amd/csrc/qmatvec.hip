@@ -32,6 +32,7 @@
 // is staged in LDS. The two column groups of a scale block-column read the same scales; their
 // workgroups are placed 8 blocks apart so they share an XCD L2 (speed only, never correctness).
 #include "kernels.h"
+#include "attention_decode.h"
 
 #include <hip/hip_fp16.h>
 #include <math.h>
@@ -322,6 +323,15 @@ __device__ __forceinline__ void run_epilogue(const QMVPartDev& part, uint32_t n,
     }
 }
 
+// A launch that also holds the decode attention's workgroups (qkv_attn_kernel below) hands the projections over without a
+// kernel boundary: the 16 owning lanes store their outputs write-through (agent scope), the wave drains, and lane 0 bumps
+// the counter of the head slice this column group belongs to (attention_decode.h: DecodeHandoff).
+struct QmvPublish {
+    uint32_t* cnt;         // [n_heads | n_kv | n_kv]
+    uint32_t base[3];      // first counter of part 0 / 1 / 2 (q, k, v)
+    uint32_t groups_shift; // log2(d_head / 16): column group -> head slice
+};
+
 // Fold the 4 rows of each wave, then the waves, in fixed order; 16 outputs per workgroup. The 16
 // owning lanes then run the part's epilogue. `pi` is the (wave-uniform) part index: every use of
 // `a.parts[...]` below is a COMPILE-TIME index so the kernel-argument loads are issued up front —
@@ -335,7 +345,7 @@ __device__ __forceinline__ void run_epilogue(const QMVPartDev& part, uint32_t n,
 // prologue kind / x alignment from the preloaded head instead of the argument block (+0.7 % / -0.9 %).
 template <bool GROUPED>
 __device__ __forceinline__ void reduce_store(float acc, float* red, const QMVArgs& a, uint32_t pi, float* out0, uint32_t g, uint32_t m,
-                                             float pre0, bool have_pre0, uint32_t n_waves) {
+                                             float pre0, bool have_pre0, uint32_t n_waves, const QmvPublish* pub = nullptr) {
     const uint32_t lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     acc = rows_sum4(acc);
     if (lane < 16) red[w * 16 + lane] = acc;
@@ -373,7 +383,10 @@ __device__ __forceinline__ void reduce_store(float acc, float* red, const QMVArg
             if (GROUPED) out_rs = pi == 1 ? a.parts[1].out_rs : pi == 2 ? a.parts[2].out_rs : pi == 3 ? a.parts[3].out_rs : out_rs;
             out_row = out + (uint64_t)m * out_rs;
         }
-        out_row[n] = v;
+        if (pub) // (fused launches carry no epilogues on these parts: planner)
+            __hip_atomic_store((__attribute__((address_space(1))) float*)out_row + n, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else
+            out_row[n] = v;
         if (GROUPED && kind == kEpiSilu) {
             if (pi == 0)
                 run_epilogue_silu(a.parts[0], n, v, ones);
@@ -393,6 +406,14 @@ __device__ __forceinline__ void reduce_store(float acc, float* red, const QMVArg
             run_epilogue(a.parts[2], n, v, out_row);
         else
             run_epilogue(a.parts[3], n, v, out_row);
+    }
+    if (pub) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the write-through stores of this wave's 16 lanes have left
+#endif
+        if (lane == 0)
+            __hip_atomic_fetch_add((__attribute__((address_space(1))) uint32_t*)pub->cnt + 32 * (pub->base[pi < 3 ? pi : 2] + (g >> pub->groups_shift)), 1u,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -588,7 +609,7 @@ struct Q8Group {
         const float *__restrict__ xb_base, uint32_t in_rs, uint32_t K, uint32_t nb2_0_flags /* NB2_0 (20 bits) | (waves - 1) << 20 | n_parts << 24 | contiguous << 28 | rmsnorm prologue << 29 | x_vec << 30 */, \
         uint32_t nb2_12 /* NB2_1 | NB2_2 << 16 */
 template <typename ST, bool XVEC, int DEPTH, bool Q4, bool PRO, bool GROUPED, bool XD, bool NT>
-__global__ void __launch_bounds__(1024) qmatvec_kernel(QMV_HEAD_PARAMS, QMVArgs a) {
+__device__ __forceinline__ void qmatvec_body(QMV_HEAD_PARAMS, const QMVArgs& a, const QmvPublish* pub) {
     constexpr uint32_t UNIT_X = Q4 ? 32 : 16;
     using ScaleT = typename std::conditional<Q4, Pair<ST>, ST>::type;
     using Group = typename std::conditional<Q4, Q4Group<ST, DEPTH, XD, PRO, NT>, Q8Group<ST, DEPTH, XD, PRO, NT>>::type;
@@ -718,9 +739,39 @@ __global__ void __launch_bounds__(1024) qmatvec_kernel(QMV_HEAD_PARAMS, QMVArgs 
     asm volatile("" ::"s"(arg_touch)); // (keeps the touches alive; long arrived)
 #endif
     QMV_STAMP(4); // weights streamed
-    reduce_store<GROUPED>((acc0 + acc1) + (acc2 + acc3), red, a, pi, out0, g, m, pre0, have_pre0, n_waves);
+    reduce_store<GROUPED>((acc0 + acc1) + (acc2 + acc3), red, a, pi, out0, g, m, pre0, have_pre0, n_waves, pub);
     QMV_STAMP(5);
 #undef QMV_STAMP
+}
+
+template <typename ST, bool XVEC, int DEPTH, bool Q4, bool PRO, bool GROUPED, bool XD, bool NT>
+__global__ void __launch_bounds__(1024) qmatvec_kernel(QMV_HEAD_PARAMS, QMVArgs a) {
+    qmatvec_body<ST, XVEC, DEPTH, Q4, PRO, GROUPED, XD, NT>(qs0, sc0, out0, xa_base, xb_base, in_rs, K, nb2_0_flags, nb2_12, a, nullptr);
+}
+
+// The q / k / v projection and the decode attention that consumes it in ONE launch (DESIGN.md section 8.0,
+// tools/exp/localdep.hip): workgroups [0, n_mv) are the grouped mat-vec's, the rest the attention's (head-major, then
+// split). The attention's record fetch, dynamic words, rope tables and KV rows do not depend on the projection and
+// overlap it; the edge itself is a per-head-slice counter instead of a kernel boundary. 1024 threads per workgroup (the
+// attention's shape); the mat-vec half uses the waves its preloaded head asks for and retires the rest at once.
+struct QkvAttnArgs {
+    const AttnDecodeParams* params;
+    float* split_buf;
+    uint32_t* split_cnt;
+    uint32_t split_min_keys, n_mv, n_sp;
+    QmvPublish pub;
+    DecodeHandoff ho;
+};
+template <typename ST, int DEPTH, bool Q4, int LPK>
+__global__ void __launch_bounds__(1024) qkv_attn_kernel(QMV_HEAD_PARAMS, QMVArgs a, QkvAttnArgs f) {
+    if (blockIdx.x < f.n_mv) {
+        const uint32_t n_waves = ((nb2_0_flags >> 20) & 0xFu) + 1;
+        if (threadIdx.x >= n_waves * 64) return; // (whole waves: they no longer count at the barriers)
+        qmatvec_body<ST, false, DEPTH, Q4, true, true, true, false>(qs0, sc0, out0, xa_base, xb_base, in_rs, K, nb2_0_flags, nb2_12, a, &f.pub);
+    } else {
+        const uint32_t b = blockIdx.x - f.n_mv, n_heads = f.ho.n_heads; // head-major: the always-active split 0 of every head first
+        attention_decode_body<LPK, false>(f.params, f.split_buf, f.split_cnt, f.split_min_keys, b % n_heads, b / n_heads, f.n_sp, &f.ho);
+    }
 }
 
 // ── M > 1 (prefill): tile kernel on the f32 matrix cores ─────────────────────────────────────
@@ -1663,7 +1714,10 @@ KernelFn pick_kernel(bool xvec, bool q4, bool pro, bool grp, int depth_sel, bool
     return q4 ? pick_mode<ST, false, true, false>(pro, grp, depth_sel, nt) : pick_mode<ST, false, false, false>(pro, grp, depth_sel, nt);
 }
 
-void launch_packed(hipStream_t s, QMVArgs& a, const QWeightDev& w0, uint32_t total_blocks, uint32_t M, bool xvec) {
+// `fused` (optional): launch qkv_attn_kernel instead — the grouped mat-vec's workgroups followed by `extra_blocks` of the
+// decode attention. Returns false (nothing launched) when the mat-vec is not one of the shapes that kernel is built for.
+bool launch_packed(hipStream_t s, QMVArgs& a, const QWeightDev& w0, uint32_t total_blocks, uint32_t M, bool xvec, const QkvAttnArgs* fused = nullptr,
+                   uint32_t extra_blocks = 0, uint32_t d_head = 0) {
     const bool q4 = w0.format == QW_Q4;
     a.x_vec = xvec ? 1 : 0;
     // x direct (no LDS staging); the rmsnorm prologue reduces the vector while the weights fly
@@ -1698,10 +1752,27 @@ void launch_packed(hipStream_t s, QMVArgs& a, const QWeightDev& w0, uint32_t tot
         hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
     if (a.n_parts > 1 && (a.parts[1].NB2 > 0xFFFFu || (a.n_parts > 2 && a.parts[2].NB2 > 0xFFFFu))) contig = false; // 16-bit fields
     const uint32_t nb2_12 = contig ? (a.parts[1].NB2 | (a.n_parts > 2 ? a.parts[2].NB2 << 16 : 0u)) : 0u;
+    if (fused) {
+        if (!(xd && pro && grp && !nt && q4 && w0.scale_f16 && contig && M == 1 && a.n_parts == 3 && (d_head == 64 || d_head == 128))) return false;
+        QkvAttnArgs f = *fused;
+        f.n_mv = total_blocks;
+        using FusedFn = void (*)(const uint4*, const void*, float*, const float*, const float*, uint32_t, uint32_t, uint32_t, uint32_t, QMVArgs, QkvAttnArgs);
+        FusedFn ff = nullptr;
+        if (d_head == 64)
+            ff = depth_sel == 0 ? qkv_attn_kernel<__half, 1, true, 16> : depth_sel == 1 ? qkv_attn_kernel<__half, 2, true, 16> : qkv_attn_kernel<__half, 4, true, 16>;
+        else
+            ff = depth_sel == 0 ? qkv_attn_kernel<__half, 1, true, 32> : depth_sel == 1 ? qkv_attn_kernel<__half, 2, true, 32> : qkv_attn_kernel<__half, 4, true, 32>;
+        hipLaunchKernelGGL(ff, dim3(total_blocks + extra_blocks), dim3(1024), lds, s, a.parts[0].qs, a.parts[0].sc, a.parts[0].out, a.pro.a, a.pro.b, a.in_rs, a.K,
+                           a.parts[0].NB2 | ((waves - 1) << 20) | (a.n_parts << 24) | (1u << 28) | (a.pro.kind == QMV_PRO_RMSNORM_MUL ? 1u << 29 : 0u) |
+                               (a.x_vec ? 1u << 30 : 0u),
+                           nb2_12, a, f);
+        return true;
+    }
     hipLaunchKernelGGL(fn, grid, dim3(waves * 64), lds, s, a.parts[0].qs, a.parts[0].sc, a.parts[0].out, a.pro.a, a.pro.b, a.in_rs, a.K,
                        a.parts[0].NB2 | ((waves - 1) << 20) | (a.n_parts << 24) | (contig ? 1u << 28 : 0u) | (a.pro.kind == QMV_PRO_RMSNORM_MUL ? 1u << 29 : 0u) |
                            (a.x_vec ? 1u << 30 : 0u),
                        nb2_12, a);
+    return true;
 }
 
 using TileFn = void (*)(QMMArgs);
@@ -1880,8 +1951,8 @@ void launch_qmatmul(hipStream_t s, const QWeightDev& w, const QMatmulParams& p, 
     launch_packed(s, a, w, a.parts[0].NB2, p.M, xvec);
 }
 
-void launch_qmatvec_fused(hipStream_t s, const QmvLaunch& L) {
-    if (L.n_parts == 0) return;
+static bool launch_qmv(hipStream_t s, const QmvLaunch& L, const QkvAttnArgs* fused, uint32_t extra_blocks, uint32_t d_head) {
+    if (L.n_parts == 0) return false;
     const QWeightDev& w0 = L.parts[0].w;
     QMVArgs a{};
     a.n_parts = L.n_parts;
@@ -1916,7 +1987,23 @@ void launch_qmatvec_fused(hipStream_t s, const QmvLaunch& L) {
     bool xvec = ((uintptr_t)L.pro.a % 16 == 0) && (L.K % 4 == 0);
     if (L.pro.kind != QMV_PRO_NONE) xvec = xvec && ((uintptr_t)L.pro.b % 16 == 0);
     a.trace = L.trace;
-    launch_packed(s, a, w0, blocks, 1, xvec);
+    return launch_packed(s, a, w0, blocks, 1, xvec, fused, extra_blocks, d_head);
+}
+
+void launch_qmatvec_fused(hipStream_t s, const QmvLaunch& L) { launch_qmv(s, L, nullptr, 0, 0); }
+
+// the q / k / v projection + the decode attention of its heads in one launch (qkv_attn_kernel). `n_heads` x `n_sp`
+// attention workgroups follow the mat-vec's; false: shapes the fused kernel is not built for (launch the two separately)
+bool launch_qkv_attention(hipStream_t s, const QmvLaunch& L, const AttnDecodeParams* dev_params, uint32_t n_heads, uint32_t n_kv, uint32_t d_head,
+                          const AttnSplit& sp, uint32_t* counters, const uint32_t* idx, uint32_t* seen, uint32_t* timeout) {
+    QkvAttnArgs f{};
+    f.params = dev_params, f.split_buf = sp.buf, f.split_cnt = sp.cnt, f.split_min_keys = sp.min_keys;
+    f.n_sp = sp.splits ? sp.splits : 1;
+    uint32_t shift = 0;
+    while ((16u << shift) < d_head) shift++;
+    f.pub = QmvPublish{counters, {0, n_heads, n_heads + n_kv}, shift};
+    f.ho = DecodeHandoff{counters, seen, idx, n_heads, d_head / 16, timeout};
+    return launch_qmv(s, L, &f, n_heads * f.n_sp, d_head);
 }
 
 void launch_synth_packed(hipStream_t s, const QWeightDev& w, uint32_t matrix_id) {

@@ -47,12 +47,23 @@ struct SplitHook {
     uint32_t* ap_cols = nullptr; // flat launches: the row length is filled in too
 };
 
+struct AdecDesc {
+    std::vector<AttnDecodeParams> host; // the records as uploaded
+    const AttnDecodeParams* dev = nullptr;
+    uint32_t nh = 0, dh = 0;
+    AttnSplit sp;
+    bool kvq = false;
+};
+
 struct Launch {
     uint32_t kind;           // DeviceOp tag the launch is accounted to
     uint32_t n_ops;          // DeviceOps covered (batching folds several)
     uint32_t op_lo, op_hi;   // smallest / largest op index covered
     std::function<void(hipStream_t)> run;
     std::shared_ptr<SplitHook> hook; // (after `run` so the aggregate initialisers elsewhere stay valid)
+    // what a fused-launch pass needs to know about a grouped mat-vec launch / a decode-attention launch (fuse_qkv_attention)
+    std::shared_ptr<QmvLaunch> qmv_desc;
+    std::shared_ptr<struct AdecDesc> adec_desc;
     uint64_t prof_ns = 0;    // ZGML_HIP_OPT_PROFILE: accumulated event time of this launch
     uint32_t prof_calls = 0;
 };
@@ -139,6 +150,7 @@ struct zgml_hip_program {
     bool f16_stream_nt = false;     // promoted weights exceed the Infinity Cache: non-temporal loads
     std::vector<void*> f16_weights; // per buffer: MFMA-packed f16 copy of a promoted matmul B operand (else nullptr)
     std::vector<void*> owned; // other device allocations
+    std::vector<uint32_t*> handoff_timeouts; // fused launches: device words bumped when an in-launch wait gave up
     float* scratch = nullptr;
     uint64_t scratch_bytes = 0;
     // plan building: the last quantized matmul launch that split its input into the scratch (make_single)
@@ -974,6 +986,61 @@ bool anchor_ok(zgml_hip_program* p, uint32_t i) {
     return w.format != QW_RAW && (op.u.qmatmul.input_offset % 4) == 0;
 }
 
+// A grouped q / k / v projection launch directly followed by the decode-attention launch of exactly its heads becomes ONE
+// launch (qmatvec.hip: qkv_attn_kernel): the projection's outputs reach the attention through
+// per-head-slice counters instead of a kernel boundary, and everything the attention can do without them overlaps the
+// projection. Only for the shapes that kernel is built for (short K, Q4_0 with f16 scales, d_head 64 / 128, f32 KV).
+void fuse_qkv_attention(zgml_hip_program* p) {
+    static const bool on = !(getenv("ZGML_HIP_FUSE_QKV_ATTN") && atoi(getenv("ZGML_HIP_FUSE_QKV_ATTN")) == 0);
+    if (!on) return;
+    for (size_t i = 0; i + 1 < p->plan.size(); i++) {
+        const auto qd = p->plan[i].qmv_desc;
+        const auto ad = p->plan[i + 1].adec_desc;
+        if (!qd || !ad) continue;
+        const QmvLaunch& L = *qd;
+        if (L.n_parts != 3 || L.K > 2048 || L.pro.kind == QMV_PRO_NONE || ad->kvq || (ad->dh != 64 && ad->dh != 128) || L.trace) continue;
+        bool ok = true;
+        for (uint32_t t = 0; t < 3; t++) ok = ok && L.parts[t].n_epi == 0 && L.parts[t].w.format == QW_Q4 && L.parts[t].w.scale_f16;
+        const uint32_t nh = ad->nh, dh = ad->dh;
+        ok = ok && (uint64_t)nh * dh == L.parts[0].w.N && L.parts[1].w.N == L.parts[2].w.N && L.parts[1].w.N % dh == 0;
+        const uint32_t n_kv = ok ? (uint32_t)(L.parts[1].w.N / dh) : 0;
+        ok = ok && n_kv != 0 && nh % n_kv == 0;
+        std::vector<uint32_t> idx(3 * (size_t)nh);
+        std::vector<char> head_seen(nh, 0);
+        for (uint32_t r = 0; ok && r < nh; r++) { // the records are not in head order: each one's head from its pointers
+            const AttnDecodeParams& a = ad->host[r];
+            const ptrdiff_t qo = a.q_src - L.parts[0].dst, ko = a.k_src - L.parts[1].dst, vo = a.v_src - L.parts[2].dst;
+            ok = qo >= 0 && qo % dh == 0 && (uint64_t)qo < (uint64_t)nh * dh && ko >= 0 && ko % dh == 0 && (uint64_t)ko < (uint64_t)n_kv * dh && vo == ko && a.kvq_block == 0;
+            if (!ok) break;
+            const uint32_t h = (uint32_t)(qo / dh), kvh = (uint32_t)(ko / dh);
+            ok = !head_seen[h] && kvh == h / (nh / n_kv);
+            head_seen[h] = 1;
+            idx[3 * r] = h, idx[3 * r + 1] = nh + kvh, idx[3 * r + 2] = nh + n_kv + kvh;
+        }
+        if (!ok) continue;
+        const uint32_t n_sp = ad->sp.splits ? ad->sp.splits : 1;
+        const size_t n_cnt = 32 * ((size_t)nh + 2 * n_kv); // one counter per 128 bytes
+        const size_t words = n_cnt + (size_t)nh * n_sp * 3 + 1 + 3 * (size_t)nh;
+        uint32_t* block = nullptr;
+        if (hipMalloc((void**)&block, words * 4) != hipSuccess || hipMemset(block, 0, words * 4) != hipSuccess) continue;
+        p->owned.push_back(block);
+        uint32_t *counters = block, *seen = block + n_cnt, *timeout = seen + (size_t)nh * n_sp * 3, *idx_dev = timeout + 1;
+        if (hipMemcpy(idx_dev, idx.data(), idx.size() * 4, hipMemcpyHostToDevice) != hipSuccess) continue;
+        p->handoff_timeouts.push_back(timeout);
+        const AttnDecodeParams* d = ad->dev;
+        const AttnSplit sp = ad->sp;
+        Launch F{ZGML_DOP_QMATMUL, p->plan[i].n_ops + p->plan[i + 1].n_ops, std::min(p->plan[i].op_lo, p->plan[i + 1].op_lo),
+                 std::max(p->plan[i].op_hi, p->plan[i + 1].op_hi), [=](hipStream_t s) {
+                     if (!launch_qkv_attention(s, L, d, nh, n_kv, dh, sp, counters, idx_dev, seen, timeout)) {
+                         launch_qmatvec_fused(s, L);
+                         launch_attention_decode_batch(s, d, nh, dh, sp, false);
+                     }
+                 }};
+        p->plan[i] = std::move(F);
+        p->plan.erase(p->plan.begin() + (ptrdiff_t)i + 1);
+    }
+}
+
 void build_fused_plan(zgml_hip_program* p) {
     const auto& ops = p->ops;
     const size_t n = ops.size();
@@ -1742,7 +1809,9 @@ void build_fused_plan(zgml_hip_program* p) {
             uint32_t max_kv = 0;
             for (const auto& a : kv.second) max_kv = std::max(max_kv, a.max_kv);
             const AttnSplit sp = attn_split_for(p, nh, dh, max_kv);
-            p->plan.push_back({ZGML_DOP_ATTENTION, adec_ops, adec_lo, adec_hi, [=](hipStream_t s) { launch_attention_decode_batch(s, d, nh, dh, sp, kvq); }});
+            Launch AL{ZGML_DOP_ATTENTION, adec_ops, adec_lo, adec_hi, [=](hipStream_t s) { launch_attention_decode_batch(s, d, nh, dh, sp, kvq); }};
+            AL.adec_desc = std::make_shared<AdecDesc>(AdecDesc{kv.second, d, nh, dh, sp, kvq});
+            p->plan.push_back(std::move(AL));
             adec_ops = 0; // profile accounting: ops counted once
         }
         // group mat-vecs that stage the same vector
@@ -1788,9 +1857,12 @@ void build_fused_plan(zgml_hip_program* p) {
                     p->qmv_traces.push_back({t, L.n_parts, L.pro.kind, (uint32_t)w0.K, (uint32_t)w0.N});
                 }
             }
-            p->plan.push_back({ZGML_DOP_QMATMUL, n_ops, lo, hi, [=](hipStream_t s) { launch_qmatvec_fused(s, L); }});
+            Launch QL{ZGML_DOP_QMATMUL, n_ops, lo, hi, [=](hipStream_t s) { launch_qmatvec_fused(s, L); }};
+            QL.qmv_desc = std::make_shared<QmvLaunch>(L);
+            p->plan.push_back(std::move(QL));
         }
     }
+    fuse_qkv_attention(p);
 }
 
 void build_plan(zgml_hip_program* p) {
@@ -2704,6 +2776,11 @@ void zgml_hip_free_program(zgml_hip_ctx* ctx, zgml_hip_program* p) {
     if (ctx) {
         hipSetDevice(ctx->device);
         hipStreamSynchronize(ctx->stream);
+    }
+    for (uint32_t* t : p->handoff_timeouts) { // a bounded in-launch wait that expired is a bug: say so loudly
+        uint32_t v = 0;
+        if (hipMemcpy(&v, t, 4, hipMemcpyDeviceToHost) == hipSuccess && v)
+            fprintf(stderr, "[zgml_hip] ERROR: %u in-launch hand-off wait(s) of a fused q/k/v + attention launch timed out\n", v);
     }
     if (!p->attn_traces.empty()) { // stamps of the last execution, 100 MHz wall clock -> ns
         fprintf(stderr, "[zgml_hip] attention trace (ns since previous launch's end | start->params | ->dyn | ->rope | ->scores | ->max | ->pv | ->end)\n");
