@@ -207,6 +207,8 @@ struct DecodeHandoff {
     uint32_t n_heads;
     uint32_t need;       // column groups per head slice = d_head / 16
     uint32_t* timeout;   // bumped when a wait gives up
+    uint32_t* out_cnt;   // optional: bumped once per head when its output rows (dst2) are stored write-through — the O
+                         // projection's workgroups of the same launch wait for it (qmatvec.hip: QmvWait)
 };
 
 template <int LPK, bool KVQ>
@@ -515,9 +517,23 @@ __device__ __forceinline__ void attention_decode_body(const AttnDecodeParams* __
             const float inv_l = r.l > 0.f ? 1.0f / r.l : 0.0f;
             const float o[4] = {r.acc.x * inv_l, r.acc.y * inv_l, r.acc.z * inv_l, r.acc.w * inv_l};
             stg4(p.dst + 4 * lane, make_float4(o[0], o[1], o[2], o[3])); // dst_rs == 1, 16-byte aligned (planner)
-            if (p.dst2)
+            if (p.dst2) {
+                const bool through = ho && ho->out_cnt; // consumers in this launch: write-through (agent scope)
 #pragma unroll
-                for (int e = 0; e < 4; e++) stg1(p.dst2 + (uint64_t)d2_off + (uint64_t)(4 * lane + e) * p.d2_rs, o[e]);
+                for (int e = 0; e < 4; e++) {
+                    float* const d = p.dst2 + (uint64_t)d2_off + (uint64_t)(4 * lane + e) * p.d2_rs;
+                    if (through)
+                        __hip_atomic_store((__attribute__((address_space(1))) float*)d, o[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else
+                        stg1(d, o[e]);
+                }
+            }
+        }
+        if (ho && ho->out_cnt) { // the head's rows have left this wave: tell the O projection
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+            if (lane == 0) __hip_atomic_fetch_add((gu32*)ho->out_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     ATTN_STAMP(7);

@@ -508,18 +508,29 @@ struct Q4Group {
     uint4 wq[DEPTH];
     Pair<ST> s2[DEPTH];
     float xa[XD ? DEPTH : 1], xb[XD ? DEPTH : 1], ya[XD && PROMUL ? DEPTH : 1], yb[XD && PROMUL ? DEPTH : 1];
+    // WHAT: 0 = weights and x, 1 = weights only, 2 = x only; AGENT: x through agent-scope loads (a consumer of values
+    // stored earlier in the SAME launch: never a stale line of this XCD's L2)
+    template <int WHAT = 0, bool AGENT = false>
     __device__ __forceinline__ void load(const uint4* qs, const Pair<ST>* sc, uint32_t u, uint32_t stride, uint32_t u_last,
                                          const XDirect& xd, uint32_t i) {
+        using gf32 = const __attribute__((address_space(1))) float;
 #pragma unroll
         for (int d = 0; d < DEPTH; d++) { // clamped, unconditional
             const uint32_t ud = min(u + d * stride, u_last);
-            if (XD) {
+            if (XD && WHAT != 1) {
                 const uint32_t ka = min(ud * 32 + i, xd.K - 1), kb = min(ud * 32 + 16 + i, xd.K - 1);
-                xa[d] = xd.a[ka], xb[d] = xd.a[kb];
+                if (AGENT) {
+                    xa[d] = __hip_atomic_load((gf32*)xd.a + ka, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    xb[d] = __hip_atomic_load((gf32*)xd.a + kb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    xa[d] = xd.a[ka], xb[d] = xd.a[kb];
+                }
                 if (PROMUL) ya[d] = xd.b[ka], yb[d] = xd.b[kb];
             }
-            wq[d] = wload<NT>(qs + (uint64_t)ud * 16);
-            s2[d] = sc[(uint64_t)ud * 16];
+            if (WHAT != 2) {
+                wq[d] = wload<NT>(qs + (uint64_t)ud * 16);
+                s2[d] = sc[(uint64_t)ud * 16];
+            }
         }
     }
     __device__ __forceinline__ void compute(const float* xs, uint32_t u, uint32_t stride, uint32_t U, uint32_t i,
@@ -557,18 +568,22 @@ struct Q8Group {
     uint4 wq[DEPTH];
     ST s1[DEPTH];
     float xa[XD ? DEPTH : 1], ya[XD && PROMUL ? DEPTH : 1];
+    template <int WHAT = 0, bool AGENT = false>
     __device__ __forceinline__ void load(const uint4* qs, const ST* sc, uint32_t u, uint32_t stride, uint32_t u_last,
                                          const XDirect& xd, uint32_t i) {
+        using gf32 = const __attribute__((address_space(1))) float;
 #pragma unroll
         for (int d = 0; d < DEPTH; d++) {
             const uint32_t ud = min(u + d * stride, u_last);
-            if (XD) {
+            if (XD && WHAT != 1) {
                 const uint32_t ka = min(ud * 16 + i, xd.K - 1);
-                xa[d] = xd.a[ka];
+                xa[d] = AGENT ? __hip_atomic_load((gf32*)xd.a + ka, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : xd.a[ka];
                 if (PROMUL) ya[d] = xd.b[ka];
             }
-            wq[d] = wload<NT>(qs + (uint64_t)ud * 16);
-            s1[d] = sc[(uint64_t)ud * 16];
+            if (WHAT != 2) {
+                wq[d] = wload<NT>(qs + (uint64_t)ud * 16);
+                s1[d] = sc[(uint64_t)ud * 16];
+            }
         }
     }
     __device__ __forceinline__ void compute(const float* xs, uint32_t u, uint32_t stride, uint32_t U, uint32_t i,
@@ -608,14 +623,24 @@ struct Q8Group {
     const uint4 *__restrict__ qs0, const void *__restrict__ sc0, float *__restrict__ out0, const float *__restrict__ xa_base, \
         const float *__restrict__ xb_base, uint32_t in_rs, uint32_t K, uint32_t nb2_0_flags /* NB2_0 (20 bits) | (waves - 1) << 20 | n_parts << 24 | contiguous << 28 | rmsnorm prologue << 29 | x_vec << 30 */, \
         uint32_t nb2_12 /* NB2_1 | NB2_2 << 16 */
-template <typename ST, bool XVEC, int DEPTH, bool Q4, bool PRO, bool GROUPED, bool XD, bool NT>
-__device__ __forceinline__ void qmatvec_body(QMV_HEAD_PARAMS, const QMVArgs& a, const QmvPublish* pub) {
+// The consumer side of an in-launch hand-off (the O projection behind the decode attention, qkv_attn_o_kernel): the
+// weights do not depend on the producers and are requested first; then wave 0 waits (bounded) for the producers' counter
+// to pass this workgroup's private `seen` word + `need`, and x is read with agent-scope loads.
+struct QmvWait {
+    const uint32_t* cnt; // one monotonic counter, bumped once by every producer
+    uint32_t* seen;      // [workgroups of this part]
+    uint32_t need;
+    uint32_t* timeout;
+};
+
+template <typename ST, bool XVEC, int DEPTH, bool Q4, bool PRO, bool GROUPED, bool XD, bool NT, bool CONSUME = false>
+__device__ __forceinline__ void qmatvec_body(QMV_HEAD_PARAMS, const QMVArgs& a, const uint32_t bx, const QmvPublish* pub, const QmvWait* wt = nullptr) {
     constexpr uint32_t UNIT_X = Q4 ? 32 : 16;
     using ScaleT = typename std::conditional<Q4, Pair<ST>, ST>::type;
     using Group = typename std::conditional<Q4, Q4Group<ST, DEPTH, XD, PRO, NT>, Q8Group<ST, DEPTH, XD, PRO, NT>>::type;
     extern __shared__ float smem[];
 #ifdef ZGML_TRACE // build with -DZGML_TRACE: the stamps serialise the kernel-argument loads, so never in product builds
-#define QMV_STAMP(i) do { if (a.trace && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.trace[i] = wall_clock64(); } while (0)
+#define QMV_STAMP(i) do { if (a.trace && bx == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.trace[i] = wall_clock64(); } while (0)
 #else
 #define QMV_STAMP(i) do { } while (0)
 #endif
@@ -636,14 +661,14 @@ __device__ __forceinline__ void qmatvec_body(QMV_HEAD_PARAMS, const QMVArgs& a, 
     if (GROUPED) {
         if ((nb2_0_flags >> 28) & 1) { // contiguous parts: everything from preloaded scalars
             const uint32_t b1 = NB2_0, b2 = b1 + NB2_1; // (<= 3 parts: a fourth part's size would be an argument-block load in front of the first load)
-            if (n_parts > 1 && blockIdx.x >= b1) pi = 1, block_begin = b1, NB2 = NB2_1;
-            if (n_parts > 2 && blockIdx.x >= b2) pi = 2, block_begin = b2, NB2 = NB2_2;
+            if (n_parts > 1 && bx >= b1) pi = 1, block_begin = b1, NB2 = NB2_1;
+            if (n_parts > 2 && bx >= b2) pi = 2, block_begin = b2, NB2 = NB2_2;
             qs_base = qs0 + (uint64_t)block_begin * U * 16;
             sc_base = (const ScaleT*)sc0 + (uint64_t)(block_begin >> 1) * U * 16;
         } else {
 #pragma unroll
             for (uint32_t t = 1; t < (uint32_t)kMaxQmvParts; t++) {
-                const bool take = t < n_parts && blockIdx.x >= a.parts[t].block_begin;
+                const bool take = t < n_parts && bx >= a.parts[t].block_begin;
                 pi = take ? t : pi;
                 qs_base = take ? a.parts[t].qs : qs_base;
                 sc_base = take ? a.parts[t].sc : sc_base;
@@ -652,7 +677,7 @@ __device__ __forceinline__ void qmatvec_body(QMV_HEAD_PARAMS, const QMVArgs& a, 
             }
         }
     }
-    const uint32_t g = column_group(blockIdx.x - block_begin, NB2), m = blockIdx.y;
+    const uint32_t g = column_group(bx - block_begin, NB2), m = blockIdx.y;
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint32_t row = lane >> 4, i = lane & 15;
     const uint32_t stride = n_waves * 4; // units per step (4 rows per wave)
@@ -663,7 +688,7 @@ __device__ __forceinline__ void qmatvec_body(QMV_HEAD_PARAMS, const QMVArgs& a, 
 
     const float* xa_row = xa_base + (uint64_t)m * in_rs;
     uint32_t u = 4 * w + row; // this row's unit in step 0
-    const bool pro_owner = XD && PRO && blockIdx.x == 0 && blockIdx.y == 0;
+    const bool pro_owner = XD && PRO && bx == 0 && blockIdx.y == 0;
     XDirect xd{xa_row, xb_base, nullptr, nullptr, K, 1.0f, false};
     Group cur;
     // prologue kind and x alignment come with the preloaded head (bits 29 / 30), and the owner's side-output pointers are
@@ -674,7 +699,25 @@ __device__ __forceinline__ void qmatvec_body(QMV_HEAD_PARAMS, const QMVArgs& a, 
     if (XD) {
         SumsqRegs sq;
         if (norm) sq = sumsq_fetch(xa_row, K, x_vec, bdim); // before the weights (in-order vmcnt)
-        cur.load(qs, sc, u, stride, u_last, xd, i);
+        if (CONSUME) { // weights first, then the hand-off, then x (QmvWait); no prologue in this mode (planner)
+            cur.template load<1>(qs, sc, u, stride, u_last, xd, i);
+            const uint32_t target = wt->seen[bx] + wt->need;
+            if (w == 0) {
+                uint32_t spins = 0;
+                while ((int32_t)(__hip_atomic_load((const __attribute__((address_space(1))) uint32_t*)wt->cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+                    if (++spins > 400000u) { // bounded: never hang the device; the caller sees the flag
+                        if (threadIdx.x == 0) atomicAdd(wt->timeout, 1u);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+            if (n_waves > 1) __syncthreads();
+            if (threadIdx.x == 0) wt->seen[bx] = target; // (every wave read it before the barrier)
+            cur.template load<2, true>(qs, sc, u, stride, u_last, xd, i);
+        } else {
+            cur.load(qs, sc, u, stride, u_last, xd, i);
+        }
         QMV_STAMP(1); // loads issued
         __builtin_amdgcn_sched_barrier(0); // argument-block reads below wait while the loads above fly
         if (pro_owner) xd.store_x = a.pro.store_x, xd.store_mid = a.pro.store_mid;
@@ -729,7 +772,7 @@ __device__ __forceinline__ void qmatvec_body(QMV_HEAD_PARAMS, const QMVArgs& a, 
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
     for (uint32_t gi = 1; gi < n_groups; gi++) {
         Group nxt;
-        nxt.load(qs, sc, u + DEPTH * stride, stride, u_last, xd, i);
+        nxt.template load<0, CONSUME>(qs, sc, u + DEPTH * stride, stride, u_last, xd, i);
         cur.compute(xs, u, stride, U, i, acc0, acc1, acc2, acc3, xd);
         cur = nxt;
         u += DEPTH * stride;
@@ -746,7 +789,7 @@ __device__ __forceinline__ void qmatvec_body(QMV_HEAD_PARAMS, const QMVArgs& a, 
 
 template <typename ST, bool XVEC, int DEPTH, bool Q4, bool PRO, bool GROUPED, bool XD, bool NT>
 __global__ void __launch_bounds__(1024) qmatvec_kernel(QMV_HEAD_PARAMS, QMVArgs a) {
-    qmatvec_body<ST, XVEC, DEPTH, Q4, PRO, GROUPED, XD, NT>(qs0, sc0, out0, xa_base, xb_base, in_rs, K, nb2_0_flags, nb2_12, a, nullptr);
+    qmatvec_body<ST, XVEC, DEPTH, Q4, PRO, GROUPED, XD, NT>(qs0, sc0, out0, xa_base, xb_base, in_rs, K, nb2_0_flags, nb2_12, a, blockIdx.x, nullptr);
 }
 
 // The q / k / v projection and the decode attention that consumes it in ONE launch (DESIGN.md section 8.0,
@@ -767,10 +810,45 @@ __global__ void __launch_bounds__(1024) qkv_attn_kernel(QMV_HEAD_PARAMS, QMVArgs
     if (blockIdx.x < f.n_mv) {
         const uint32_t n_waves = ((nb2_0_flags >> 20) & 0xFu) + 1;
         if (threadIdx.x >= n_waves * 64) return; // (whole waves: they no longer count at the barriers)
-        qmatvec_body<ST, false, DEPTH, Q4, true, true, true, false>(qs0, sc0, out0, xa_base, xb_base, in_rs, K, nb2_0_flags, nb2_12, a, &f.pub);
+        qmatvec_body<ST, false, DEPTH, Q4, true, true, true, false>(qs0, sc0, out0, xa_base, xb_base, in_rs, K, nb2_0_flags, nb2_12, a, blockIdx.x, &f.pub);
     } else {
         const uint32_t b = blockIdx.x - f.n_mv, n_heads = f.ho.n_heads; // head-major: the always-active split 0 of every head first
         attention_decode_body<LPK, false>(f.params, f.split_buf, f.split_cnt, f.split_min_keys, b % n_heads, b / n_heads, f.n_sp, &f.ho);
+    }
+}
+
+// ... and the O projection behind the attention in the same launch (third range of workgroups): its weights are requested
+// at once, its x (the heads' row stores) is taken over through one counter that every head bumps when its rows are stored.
+struct QmvHead { // the leading arguments of a mat-vec launch (QMV_HEAD_PARAMS) as a value
+    const uint4* qs0;
+    const void* sc0;
+    float* out0;
+    const float* xa_base;
+    const float* xb_base;
+    uint32_t in_rs, K, nb2_0_flags, nb2_12;
+};
+struct QkvAttnOArgs {
+    QkvAttnArgs f;
+    QmvHead h2;
+    QmvWait wt;
+    uint32_t n_attn; // attention workgroups (heads x splits)
+};
+template <typename ST, bool Q4, int LPK>
+__global__ void __launch_bounds__(1024) qkv_attn_o_kernel(QMV_HEAD_PARAMS, QMVArgs a, QkvAttnOArgs fo, QMVArgs a2) {
+    const QkvAttnArgs& f = fo.f;
+    if (blockIdx.x < f.n_mv) {
+        const uint32_t n_waves = ((nb2_0_flags >> 20) & 0xFu) + 1;
+        if (threadIdx.x >= n_waves * 64) return;
+        qmatvec_body<ST, false, 1, Q4, true, true, true, false>(qs0, sc0, out0, xa_base, xb_base, in_rs, K, nb2_0_flags, nb2_12, a, blockIdx.x, &f.pub);
+    } else if (blockIdx.x < f.n_mv + fo.n_attn) {
+        const uint32_t b = blockIdx.x - f.n_mv, n_heads = f.ho.n_heads;
+        attention_decode_body<LPK, false>(f.params, f.split_buf, f.split_cnt, f.split_min_keys, b % n_heads, b / n_heads, f.n_sp, &f.ho);
+    } else {
+        const QmvHead& h = fo.h2;
+        const uint32_t n_waves = ((h.nb2_0_flags >> 20) & 0xFu) + 1;
+        if (threadIdx.x >= n_waves * 64) return;
+        qmatvec_body<ST, false, 1, Q4, false, false, true, false, true>(h.qs0, h.sc0, h.out0, h.xa_base, h.xb_base, h.in_rs, h.K, h.nb2_0_flags, h.nb2_12, a2,
+                                                                       blockIdx.x - f.n_mv - fo.n_attn, nullptr, &fo.wt);
     }
 }
 
@@ -1716,8 +1794,28 @@ KernelFn pick_kernel(bool xvec, bool q4, bool pro, bool grp, int depth_sel, bool
 
 // `fused` (optional): launch qkv_attn_kernel instead — the grouped mat-vec's workgroups followed by `extra_blocks` of the
 // decode attention. Returns false (nothing launched) when the mat-vec is not one of the shapes that kernel is built for.
+struct FusedO { // the O projection riding in a fused q/k/v + attention launch (qkv_attn_o_kernel)
+    QMVArgs a2;
+    QmvHead h2;
+    QmvWait wt;
+    uint32_t blocks2;
+};
 bool launch_packed(hipStream_t s, QMVArgs& a, const QWeightDev& w0, uint32_t total_blocks, uint32_t M, bool xvec, const QkvAttnArgs* fused = nullptr,
-                   uint32_t extra_blocks = 0, uint32_t d_head = 0) {
+                   uint32_t extra_blocks = 0, uint32_t d_head = 0, const FusedO* fo = nullptr);
+// the leading arguments of a single-matrix, prologue-free, x-direct launch with one load step (what the fused O projection
+// needs); false: not that shape
+static bool plain_head_depth1(const QMVArgs& a, const QWeightDev& w0, uint32_t blocks, QmvHead& h) {
+    static const bool xd_enabled = !(getenv("ZGML_QMV_XDIRECT") && atoi(getenv("ZGML_QMV_XDIRECT")) == 0);
+    if (!xd_enabled || a.n_parts != 1 || a.pro.kind != QMV_PRO_NONE || w0.format != QW_Q4 || !w0.scale_f16 || w0.stream_nt) return false;
+    const uint32_t waves = qmv_waves(w0, blocks);
+    if (cdiv(a.U, waves * 4) != 1 || a.parts[0].NB2 >= (1u << 20)) return false;
+    h = QmvHead{a.parts[0].qs, a.parts[0].sc, a.parts[0].out, a.pro.a, a.pro.b, a.in_rs, a.K,
+                a.parts[0].NB2 | ((waves - 1) << 20) | (1u << 24) | (a.x_vec ? 1u << 30 : 0u), 0u};
+    return true;
+}
+
+bool launch_packed(hipStream_t s, QMVArgs& a, const QWeightDev& w0, uint32_t total_blocks, uint32_t M, bool xvec, const QkvAttnArgs* fused,
+                   uint32_t extra_blocks, uint32_t d_head, const FusedO* fo) {
     const bool q4 = w0.format == QW_Q4;
     a.x_vec = xvec ? 1 : 0;
     // x direct (no LDS staging); the rmsnorm prologue reduces the vector while the weights fly
@@ -1756,6 +1854,20 @@ bool launch_packed(hipStream_t s, QMVArgs& a, const QWeightDev& w0, uint32_t tot
         if (!(xd && pro && grp && !nt && q4 && w0.scale_f16 && contig && M == 1 && a.n_parts == 3 && (d_head == 64 || d_head == 128))) return false;
         QkvAttnArgs f = *fused;
         f.n_mv = total_blocks;
+        if (fo && depth_sel == 0) { // ... and the O projection behind the attention
+            QkvAttnOArgs g{f, fo->h2, fo->wt, extra_blocks};
+            const dim3 grid3(total_blocks + extra_blocks + fo->blocks2);
+            if (d_head == 64)
+                hipLaunchKernelGGL((qkv_attn_o_kernel<__half, true, 16>), grid3, dim3(1024), lds, s, a.parts[0].qs, a.parts[0].sc, a.parts[0].out, a.pro.a, a.pro.b,
+                                   a.in_rs, a.K, a.parts[0].NB2 | ((waves - 1) << 20) | (a.n_parts << 24) | (1u << 28) | (a.pro.kind == QMV_PRO_RMSNORM_MUL ? 1u << 29 : 0u) | (a.x_vec ? 1u << 30 : 0u),
+                                   nb2_12, a, g, fo->a2);
+            else
+                hipLaunchKernelGGL((qkv_attn_o_kernel<__half, true, 32>), grid3, dim3(1024), lds, s, a.parts[0].qs, a.parts[0].sc, a.parts[0].out, a.pro.a, a.pro.b,
+                                   a.in_rs, a.K, a.parts[0].NB2 | ((waves - 1) << 20) | (a.n_parts << 24) | (1u << 28) | (a.pro.kind == QMV_PRO_RMSNORM_MUL ? 1u << 29 : 0u) | (a.x_vec ? 1u << 30 : 0u),
+                                   nb2_12, a, g, fo->a2);
+            return true;
+        }
+        if (fo) return false; // (the caller asked for the triple: let it fall back as a whole)
         using FusedFn = void (*)(const uint4*, const void*, float*, const float*, const float*, uint32_t, uint32_t, uint32_t, uint32_t, QMVArgs, QkvAttnArgs);
         FusedFn ff = nullptr;
         if (d_head == 64)
@@ -1951,12 +2063,11 @@ void launch_qmatmul(hipStream_t s, const QWeightDev& w, const QMatmulParams& p, 
     launch_packed(s, a, w, a.parts[0].NB2, p.M, xvec);
 }
 
-static bool launch_qmv(hipStream_t s, const QmvLaunch& L, const QkvAttnArgs* fused, uint32_t extra_blocks, uint32_t d_head) {
-    if (L.n_parts == 0) return false;
+static void build_qmv_args(const QmvLaunch& L, QMVArgs& a, uint32_t& blocks, bool& xvec_out) {
     const QWeightDev& w0 = L.parts[0].w;
-    QMVArgs a{};
+    a = QMVArgs{};
     a.n_parts = L.n_parts;
-    uint32_t blocks = 0;
+    blocks = 0;
     for (uint32_t i = 0; i < L.n_parts; i++) {
         const QmvPart& pt = L.parts[i];
         QMVPartDev& d = a.parts[i];
@@ -1987,7 +2098,16 @@ static bool launch_qmv(hipStream_t s, const QmvLaunch& L, const QkvAttnArgs* fus
     bool xvec = ((uintptr_t)L.pro.a % 16 == 0) && (L.K % 4 == 0);
     if (L.pro.kind != QMV_PRO_NONE) xvec = xvec && ((uintptr_t)L.pro.b % 16 == 0);
     a.trace = L.trace;
-    return launch_packed(s, a, w0, blocks, 1, xvec, fused, extra_blocks, d_head);
+    xvec_out = xvec;
+}
+
+static bool launch_qmv(hipStream_t s, const QmvLaunch& L, const QkvAttnArgs* fused, uint32_t extra_blocks, uint32_t d_head, const FusedO* fo = nullptr) {
+    if (L.n_parts == 0) return false;
+    QMVArgs a;
+    uint32_t blocks = 0;
+    bool xvec = false;
+    build_qmv_args(L, a, blocks, xvec);
+    return launch_packed(s, a, L.parts[0].w, blocks, 1, xvec, fused, extra_blocks, d_head, fo);
 }
 
 void launch_qmatvec_fused(hipStream_t s, const QmvLaunch& L) { launch_qmv(s, L, nullptr, 0, 0); }
@@ -1995,14 +2115,25 @@ void launch_qmatvec_fused(hipStream_t s, const QmvLaunch& L) { launch_qmv(s, L, 
 // the q / k / v projection + the decode attention of its heads in one launch (qkv_attn_kernel). `n_heads` x `n_sp`
 // attention workgroups follow the mat-vec's; false: shapes the fused kernel is not built for (launch the two separately)
 bool launch_qkv_attention(hipStream_t s, const QmvLaunch& L, const AttnDecodeParams* dev_params, uint32_t n_heads, uint32_t n_kv, uint32_t d_head,
-                          const AttnSplit& sp, uint32_t* counters, const uint32_t* idx, uint32_t* seen, uint32_t* timeout) {
+                          const AttnSplit& sp, uint32_t* counters, const uint32_t* idx, uint32_t* seen, uint32_t* timeout, const QmvLaunch* Lo,
+                          uint32_t* out_cnt, uint32_t* o_seen) {
     QkvAttnArgs f{};
     f.params = dev_params, f.split_buf = sp.buf, f.split_cnt = sp.cnt, f.split_min_keys = sp.min_keys;
     f.n_sp = sp.splits ? sp.splits : 1;
     uint32_t shift = 0;
     while ((16u << shift) < d_head) shift++;
     f.pub = QmvPublish{counters, {0, n_heads, n_heads + n_kv}, shift};
-    f.ho = DecodeHandoff{counters, seen, idx, n_heads, d_head / 16, timeout};
+    f.ho = DecodeHandoff{counters, seen, idx, n_heads, d_head / 16, timeout, nullptr};
+    if (Lo) { // the O projection rides along
+        FusedO fo;
+        bool xvec2 = false;
+        build_qmv_args(*Lo, fo.a2, fo.blocks2, xvec2);
+        fo.a2.x_vec = xvec2 ? 1 : 0;
+        if (!plain_head_depth1(fo.a2, Lo->parts[0].w, fo.blocks2, fo.h2)) return false;
+        fo.wt = QmvWait{out_cnt, o_seen, n_heads, timeout};
+        f.ho.out_cnt = out_cnt;
+        return launch_qmv(s, L, &f, n_heads * f.n_sp, d_head, &fo);
+    }
     return launch_qmv(s, L, &f, n_heads * f.n_sp, d_head);
 }
 

@@ -1019,8 +1019,25 @@ void fuse_qkv_attention(zgml_hip_program* p) {
         }
         if (!ok) continue;
         const uint32_t n_sp = ad->sp.splits ? ad->sp.splits : 1;
-        const size_t n_cnt = 32 * ((size_t)nh + 2 * n_kv); // one counter per 128 bytes
-        const size_t words = n_cnt + (size_t)nh * n_sp * 3 + 1 + 3 * (size_t)nh;
+        // ... and the single-matrix projection that reads exactly the heads' row stores (the O projection) rides along:
+        // no prologue, K = n_heads * d_head, every head's rows stored at its static offset h * d_head of that input
+        std::shared_ptr<QmvLaunch> od = i + 2 < p->plan.size() ? p->plan[i + 2].qmv_desc : nullptr;
+        // (measured: 93 launches per SmolLM-135M token instead of 123, parity green, and SLOWER — 1714-1734 against 1772 tok/s:
+        // this edge is all-to-all (every column group of the projection needs every head), its hand-off costs more than the
+        // boundary it replaces. Off unless ZGML_HIP_FUSE_QKV_ATTN_O=1.)
+        static const bool with_o = getenv("ZGML_HIP_FUSE_QKV_ATTN_O") && atoi(getenv("ZGML_HIP_FUSE_QKV_ATTN_O")) != 0;
+        bool o_ok = with_o && od && od->n_parts == 1 && od->pro.kind == QMV_PRO_NONE && od->K == nh * dh && od->K <= 2048 && !od->trace &&
+                    od->parts[0].w.format == QW_Q4 && od->parts[0].w.scale_f16;
+        for (uint32_t r = 0; o_ok && r < nh; r++) {
+            const AttnDecodeParams& a = ad->host[r];
+            o_ok = a.att.dst2 == od->pro.a && a.att.d2_rs == 1 && a.att.dyn_dst2_off >= p->dyn_dev && a.att.dyn_dst2_off < p->dyn_dev + p->ops.size();
+            if (!o_ok) break;
+            const zgml_device_op& so = p->ops[(size_t)(a.att.dyn_dst2_off - p->dyn_dev)];
+            o_ok = so.kind == ZGML_DOP_SLICE_ASSIGN && so.u.slice_assign.patch_stride == 0 && so.u.slice_assign.dst_offset == idx[3 * r] * dh;
+        }
+        const uint32_t o_blocks = o_ok ? (uint32_t)(od->parts[0].w.N / 16) : 0;
+        const size_t n_cnt = 32 * ((size_t)nh + 2 * n_kv + 1); // one counter per 128 bytes (the last: the heads' outputs)
+        const size_t words = n_cnt + (size_t)nh * n_sp * 3 + 1 + 3 * (size_t)nh + o_blocks;
         uint32_t* block = nullptr;
         if (hipMalloc((void**)&block, words * 4) != hipSuccess || hipMemset(block, 0, words * 4) != hipSuccess) continue;
         p->owned.push_back(block);
@@ -1029,15 +1046,21 @@ void fuse_qkv_attention(zgml_hip_program* p) {
         p->handoff_timeouts.push_back(timeout);
         const AttnDecodeParams* d = ad->dev;
         const AttnSplit sp = ad->sp;
-        Launch F{ZGML_DOP_QMATMUL, p->plan[i].n_ops + p->plan[i + 1].n_ops, std::min(p->plan[i].op_lo, p->plan[i + 1].op_lo),
-                 std::max(p->plan[i].op_hi, p->plan[i + 1].op_hi), [=](hipStream_t s) {
+        uint32_t *out_cnt = counters + 32 * ((size_t)nh + 2 * n_kv), *o_seen = idx_dev + 3 * (size_t)nh;
+        uint32_t n_ops = p->plan[i].n_ops + p->plan[i + 1].n_ops, lo = std::min(p->plan[i].op_lo, p->plan[i + 1].op_lo),
+                 hi = std::max(p->plan[i].op_hi, p->plan[i + 1].op_hi);
+        if (o_ok) n_ops += p->plan[i + 2].n_ops, lo = std::min(lo, p->plan[i + 2].op_lo), hi = std::max(hi, p->plan[i + 2].op_hi);
+        const QmvLaunch Lo = o_ok ? *od : QmvLaunch{};
+        Launch F{ZGML_DOP_QMATMUL, n_ops, lo, hi, [=](hipStream_t s) {
+                     if (o_ok && launch_qkv_attention(s, L, d, nh, n_kv, dh, sp, counters, idx_dev, seen, timeout, &Lo, out_cnt, o_seen)) return;
                      if (!launch_qkv_attention(s, L, d, nh, n_kv, dh, sp, counters, idx_dev, seen, timeout)) {
                          launch_qmatvec_fused(s, L);
                          launch_attention_decode_batch(s, d, nh, dh, sp, false);
                      }
+                     if (o_ok) launch_qmatvec_fused(s, Lo);
                  }};
         p->plan[i] = std::move(F);
-        p->plan.erase(p->plan.begin() + (ptrdiff_t)i + 1);
+        p->plan.erase(p->plan.begin() + (ptrdiff_t)i + 1, p->plan.begin() + (ptrdiff_t)i + (o_ok ? 3 : 2));
     }
 }
 
