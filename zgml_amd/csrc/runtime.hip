@@ -998,6 +998,12 @@ void fuse_qkv_attention(zgml_hip_program* p) {
         const auto ad = p->plan[i + 1].adec_desc;
         if (!qd || !ad) continue;
         const QmvLaunch& L = *qd;
+        { // a declared barrier (zgml_hip_program_set_barriers: a collective of the caller) between the two launches keeps them apart
+            const uint64_t lo_b = std::min(p->plan[i].op_lo, p->plan[i + 1].op_lo), hi_b = std::max(p->plan[i].op_hi, p->plan[i + 1].op_hi);
+            bool cut = false;
+            for (uint64_t b : p->barriers) cut = cut || (b > lo_b && b <= hi_b);
+            if (cut) continue;
+        }
         if (L.n_parts != 3 || L.K > 2048 || L.pro.kind == QMV_PRO_NONE || ad->kvq || (ad->dh != 64 && ad->dh != 128) || L.trace) continue;
         bool ok = true;
         for (uint32_t t = 0; t < 3; t++) ok = ok && L.parts[t].n_epi == 0 && L.parts[t].w.format == QW_Q4 && L.parts[t].w.scale_f16;
