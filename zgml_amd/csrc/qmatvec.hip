@@ -709,7 +709,7 @@ __device__ __forceinline__ void qmatvec_body(QMV_HEAD_PARAMS, const QMVArgs& a, 
                         if (threadIdx.x == 0) atomicAdd(wt->timeout, 1u);
                         break;
                     }
-                    __builtin_amdgcn_s_sleep(10); // ~0.3 us between polls: 36 workgroups polling ONE line back to back starve the line
+                    __builtin_amdgcn_s_sleep(10); // ~0.3 us between polls (2: 1724, 10: 1741, 40: 1728 tok/s): 36 workgroups polling ONE line back to back starve the line
                 }
             }
             if (n_waves > 1) __syncthreads();
