@@ -207,6 +207,7 @@ struct DecodeHandoff {
     uint32_t n_heads;
     uint32_t need;       // column groups per head slice = d_head / 16
     uint32_t* timeout;   // bumped when a wait gives up
+    uint32_t poll_sleep; // s_sleep(1) units (64 clocks) between two polls
     uint32_t* out_cnt;   // optional: bumped once per head when its output rows (dst2) are stored write-through — the O
                          // projection's workgroups of the same launch wait for it (qmatvec.hip: QmvWait)
 };
@@ -339,7 +340,7 @@ __device__ __forceinline__ void attention_decode_body(const AttnDecodeParams* __
                     if (tid == 0) atomicAdd(ho->timeout, 1u);
                     break;
                 }
-                __builtin_amdgcn_s_sleep(2);
+                for (uint32_t z = 0; z < ho->poll_sleep; z++) __builtin_amdgcn_s_sleep(1);
             }
         }
         if (NW > 1) __syncthreads(); // (waves >= NW have retired and do not count)

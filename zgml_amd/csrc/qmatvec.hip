@@ -2123,7 +2123,8 @@ bool launch_qkv_attention(hipStream_t s, const QmvLaunch& L, const AttnDecodePar
     uint32_t shift = 0;
     while ((16u << shift) < d_head) shift++;
     f.pub = QmvPublish{counters, {0, n_heads, n_heads + n_kv}, shift};
-    f.ho = DecodeHandoff{counters, seen, idx, n_heads, d_head / 16, timeout, nullptr};
+    static const uint32_t poll_sleep = getenv("ZGML_HIP_HANDOFF_SLEEP") ? (uint32_t)atoi(getenv("ZGML_HIP_HANDOFF_SLEEP")) : 2u;
+    f.ho = DecodeHandoff{counters, seen, idx, n_heads, d_head / 16, timeout, poll_sleep, nullptr};
     if (Lo) { // the O projection rides along
         FusedO fo;
         bool xvec2 = false;
