@@ -369,7 +369,7 @@ void launch_qmatvec_fused(hipStream_t s, const QmvLaunch& L);
 // zero-initialised by the caller. false: not fusable, nothing launched.
 bool launch_qkv_attention(hipStream_t s, const QmvLaunch& L, const AttnDecodeParams* dev_params, uint32_t n_heads, uint32_t n_kv, uint32_t d_head,
                           const AttnSplit& sp, uint32_t* counters, const uint32_t* idx, uint32_t* seen, uint32_t* timeout,
-                          const QmvLaunch* o_proj = nullptr, uint32_t* out_cnt = nullptr, uint32_t* o_seen = nullptr);
+                          const QmvLaunch* o_proj = nullptr, uint32_t* out_cnt = nullptr, uint32_t* o_seen = nullptr, bool kvq = false);
 // (o_proj: the single-matrix projection that reads the heads' row stores rides in the same launch; out_cnt: one zeroed
 // word, o_seen: one zeroed word per workgroup of that projection)
 // Deterministic synthetic weights for the roofline micro-benchmark, generated on the device

@@ -802,18 +802,20 @@ struct QkvAttnArgs {
     float* split_buf;
     uint32_t* split_cnt;
     uint32_t split_min_keys, n_mv, n_sp;
+    uint32_t kvq; // int8 KV caches (the attention half's template variant)
     QmvPublish pub;
     DecodeHandoff ho;
 };
-template <typename ST, int DEPTH, bool Q4, int LPK>
+template <typename ST, bool Q4, int LPK, bool KVQ>
 __global__ void __launch_bounds__(1024) qkv_attn_kernel(QMV_HEAD_PARAMS, QMVArgs a, QkvAttnArgs f) {
+    constexpr int DEPTH = 1; // K <= 2048 with up to 16 waves: one load step
     if (blockIdx.x < f.n_mv) {
         const uint32_t n_waves = ((nb2_0_flags >> 20) & 0xFu) + 1;
         if (threadIdx.x >= n_waves * 64) return; // (whole waves: they no longer count at the barriers)
         qmatvec_body<ST, false, DEPTH, Q4, true, true, true, false>(qs0, sc0, out0, xa_base, xb_base, in_rs, K, nb2_0_flags, nb2_12, a, blockIdx.x, &f.pub);
     } else {
         const uint32_t b = blockIdx.x - f.n_mv, n_heads = f.ho.n_heads; // head-major: the always-active split 0 of every head first
-        attention_decode_body<LPK, false>(f.params, f.split_buf, f.split_cnt, f.split_min_keys, b % n_heads, b / n_heads, f.n_sp, &f.ho);
+        attention_decode_body<LPK, KVQ>(f.params, f.split_buf, f.split_cnt, f.split_min_keys, b % n_heads, b / n_heads, f.n_sp, &f.ho);
     }
 }
 
@@ -1854,7 +1856,8 @@ bool launch_packed(hipStream_t s, QMVArgs& a, const QWeightDev& w0, uint32_t tot
         if (!(xd && pro && grp && !nt && q4 && w0.scale_f16 && contig && M == 1 && a.n_parts == 3 && (d_head == 64 || d_head == 128))) return false;
         QkvAttnArgs f = *fused;
         f.n_mv = total_blocks;
-        if (fo && depth_sel == 0) { // ... and the O projection behind the attention
+        const bool fused_kvq = f.kvq != 0;
+        if (fo && depth_sel == 0 && !fused_kvq) { // ... and the O projection behind the attention
             QkvAttnOArgs g{f, fo->h2, fo->wt, extra_blocks};
             const dim3 grid3(total_blocks + extra_blocks + fo->blocks2);
             if (d_head == 64)
@@ -1868,12 +1871,13 @@ bool launch_packed(hipStream_t s, QMVArgs& a, const QWeightDev& w0, uint32_t tot
             return true;
         }
         if (fo) return false; // (the caller asked for the triple: let it fall back as a whole)
+        if (depth_sel != 0) return false; // (one load step: K <= 2048)
         using FusedFn = void (*)(const uint4*, const void*, float*, const float*, const float*, uint32_t, uint32_t, uint32_t, uint32_t, QMVArgs, QkvAttnArgs);
         FusedFn ff = nullptr;
         if (d_head == 64)
-            ff = depth_sel == 0 ? qkv_attn_kernel<__half, 1, true, 16> : depth_sel == 1 ? qkv_attn_kernel<__half, 2, true, 16> : qkv_attn_kernel<__half, 4, true, 16>;
+            ff = fused_kvq ? qkv_attn_kernel<__half, true, 16, true> : qkv_attn_kernel<__half, true, 16, false>;
         else
-            ff = depth_sel == 0 ? qkv_attn_kernel<__half, 1, true, 32> : depth_sel == 1 ? qkv_attn_kernel<__half, 2, true, 32> : qkv_attn_kernel<__half, 4, true, 32>;
+            ff = fused_kvq ? qkv_attn_kernel<__half, true, 32, true> : qkv_attn_kernel<__half, true, 32, false>;
         hipLaunchKernelGGL(ff, dim3(total_blocks + extra_blocks), dim3(1024), lds, s, a.parts[0].qs, a.parts[0].sc, a.parts[0].out, a.pro.a, a.pro.b, a.in_rs, a.K,
                            a.parts[0].NB2 | ((waves - 1) << 20) | (a.n_parts << 24) | (1u << 28) | (a.pro.kind == QMV_PRO_RMSNORM_MUL ? 1u << 29 : 0u) |
                                (a.x_vec ? 1u << 30 : 0u),
@@ -2116,8 +2120,9 @@ void launch_qmatvec_fused(hipStream_t s, const QmvLaunch& L) { launch_qmv(s, L, 
 // attention workgroups follow the mat-vec's; false: shapes the fused kernel is not built for (launch the two separately)
 bool launch_qkv_attention(hipStream_t s, const QmvLaunch& L, const AttnDecodeParams* dev_params, uint32_t n_heads, uint32_t n_kv, uint32_t d_head,
                           const AttnSplit& sp, uint32_t* counters, const uint32_t* idx, uint32_t* seen, uint32_t* timeout, const QmvLaunch* Lo,
-                          uint32_t* out_cnt, uint32_t* o_seen) {
+                          uint32_t* out_cnt, uint32_t* o_seen, bool kvq) {
     QkvAttnArgs f{};
+    f.kvq = kvq ? 1 : 0;
     f.params = dev_params, f.split_buf = sp.buf, f.split_cnt = sp.cnt, f.split_min_keys = sp.min_keys;
     f.n_sp = sp.splits ? sp.splits : 1;
     uint32_t shift = 0;

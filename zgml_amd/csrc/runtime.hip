@@ -1004,7 +1004,8 @@ void fuse_qkv_attention(zgml_hip_program* p) {
             for (uint64_t b : p->barriers) cut = cut || (b > lo_b && b <= hi_b);
             if (cut) continue;
         }
-        if (L.n_parts != 3 || L.K > 2048 || L.pro.kind == QMV_PRO_NONE || ad->kvq || (ad->dh != 64 && ad->dh != 128) || L.trace) continue;
+        if (L.n_parts != 3 || L.K > 2048 || L.pro.kind == QMV_PRO_NONE || (ad->dh != 64 && ad->dh != 128) || L.trace) continue;
+        const bool kvq = ad->kvq;
         bool ok = true;
         for (uint32_t t = 0; t < 3; t++) ok = ok && L.parts[t].n_epi == 0 && L.parts[t].w.format == QW_Q4 && L.parts[t].w.scale_f16;
         const uint32_t nh = ad->nh, dh = ad->dh;
@@ -1016,7 +1017,8 @@ void fuse_qkv_attention(zgml_hip_program* p) {
         for (uint32_t r = 0; ok && r < nh; r++) { // the records are not in head order: each one's head from its pointers
             const AttnDecodeParams& a = ad->host[r];
             const ptrdiff_t qo = a.q_src - L.parts[0].dst, ko = a.k_src - L.parts[1].dst, vo = a.v_src - L.parts[2].dst;
-            ok = qo >= 0 && qo % dh == 0 && (uint64_t)qo < (uint64_t)nh * dh && ko >= 0 && ko % dh == 0 && (uint64_t)ko < (uint64_t)n_kv * dh && vo == ko && a.kvq_block == 0;
+            ok = qo >= 0 && qo % dh == 0 && (uint64_t)qo < (uint64_t)nh * dh && ko >= 0 && ko % dh == 0 && (uint64_t)ko < (uint64_t)n_kv * dh && vo == ko &&
+                 a.kvq_block == (kvq ? 32u : 0u);
             if (!ok) break;
             const uint32_t h = (uint32_t)(qo / dh), kvh = (uint32_t)(ko / dh);
             ok = !head_seen[h] && kvh == h / (nh / n_kv);
@@ -1032,7 +1034,7 @@ void fuse_qkv_attention(zgml_hip_program* p) {
         // this edge is all-to-all (every column group of the projection needs every head), its hand-off costs more than the
         // boundary it replaces. Off unless ZGML_HIP_FUSE_QKV_ATTN_O=1.)
         static const bool with_o = getenv("ZGML_HIP_FUSE_QKV_ATTN_O") && atoi(getenv("ZGML_HIP_FUSE_QKV_ATTN_O")) != 0;
-        bool o_ok = with_o && od && od->n_parts == 1 && od->pro.kind == QMV_PRO_NONE && od->K == nh * dh && od->K <= 2048 && !od->trace &&
+        bool o_ok = with_o && !kvq && od && od->n_parts == 1 && od->pro.kind == QMV_PRO_NONE && od->K == nh * dh && od->K <= 2048 && !od->trace &&
                     od->parts[0].w.format == QW_Q4 && od->parts[0].w.scale_f16;
         for (uint32_t r = 0; o_ok && r < nh; r++) {
             const AttnDecodeParams& a = ad->host[r];
@@ -1059,9 +1061,9 @@ void fuse_qkv_attention(zgml_hip_program* p) {
         const QmvLaunch Lo = o_ok ? *od : QmvLaunch{};
         Launch F{ZGML_DOP_QMATMUL, n_ops, lo, hi, [=](hipStream_t s) {
                      if (o_ok && launch_qkv_attention(s, L, d, nh, n_kv, dh, sp, counters, idx_dev, seen, timeout, &Lo, out_cnt, o_seen)) return;
-                     if (!launch_qkv_attention(s, L, d, nh, n_kv, dh, sp, counters, idx_dev, seen, timeout)) {
+                     if (!launch_qkv_attention(s, L, d, nh, n_kv, dh, sp, counters, idx_dev, seen, timeout, nullptr, nullptr, nullptr, kvq)) {
                          launch_qmatvec_fused(s, L);
-                         launch_attention_decode_batch(s, d, nh, dh, sp, false);
+                         launch_attention_decode_batch(s, d, nh, dh, sp, kvq);
                      }
                      if (o_ok) launch_qmatvec_fused(s, Lo);
                  }};
