@@ -150,7 +150,7 @@ struct zgml_hip_program {
     bool f16_stream_nt = false;     // promoted weights exceed the Infinity Cache: non-temporal loads
     std::vector<void*> f16_weights; // per buffer: MFMA-packed f16 copy of a promoted matmul B operand (else nullptr)
     std::vector<void*> owned; // other device allocations
-    std::vector<uint32_t*> handoff_timeouts; // fused launches: device words bumped when an in-launch wait gave up
+    uint32_t* handoff_timeout = nullptr; // fused launches: ONE device word bumped whenever an in-launch wait gave up
     float* scratch = nullptr;
     uint64_t scratch_bytes = 0;
     // plan building: the last quantized matmul launch that split its input into the scratch (make_single)
@@ -1045,13 +1045,16 @@ void fuse_qkv_attention(zgml_hip_program* p) {
         }
         const uint32_t o_blocks = o_ok ? (uint32_t)(od->parts[0].w.N / 16) : 0;
         const size_t n_cnt = 32 * ((size_t)nh + 2 * n_kv + 1); // one counter per 128 bytes (the last: the heads' outputs)
+        if (!p->handoff_timeout) { // one word for the whole program: checked after resident runs and when the program is freed
+            if (hipMalloc((void**)&p->handoff_timeout, 256) != hipSuccess || hipMemset(p->handoff_timeout, 0, 256) != hipSuccess) continue;
+            p->owned.push_back(p->handoff_timeout);
+        }
         const size_t words = n_cnt + (size_t)nh * n_sp * 3 + 1 + 3 * (size_t)nh + o_blocks;
         uint32_t* block = nullptr;
         if (hipMalloc((void**)&block, words * 4) != hipSuccess || hipMemset(block, 0, words * 4) != hipSuccess) continue;
         p->owned.push_back(block);
-        uint32_t *counters = block, *seen = block + n_cnt, *timeout = seen + (size_t)nh * n_sp * 3, *idx_dev = timeout + 1;
+        uint32_t *counters = block, *seen = block + n_cnt, *timeout = p->handoff_timeout, *idx_dev = seen + (size_t)nh * n_sp * 3 + 1;
         if (hipMemcpy(idx_dev, idx.data(), idx.size() * 4, hipMemcpyHostToDevice) != hipSuccess) continue;
-        p->handoff_timeouts.push_back(timeout);
         const AttnDecodeParams* d = ad->dev;
         const AttnSplit sp = ad->sp;
         uint32_t *out_cnt = counters + 32 * ((size_t)nh + 2 * n_kv), *o_seen = idx_dev + 3 * (size_t)nh;
@@ -2808,9 +2811,9 @@ void zgml_hip_free_program(zgml_hip_ctx* ctx, zgml_hip_program* p) {
         hipSetDevice(ctx->device);
         hipStreamSynchronize(ctx->stream);
     }
-    for (uint32_t* t : p->handoff_timeouts) { // a bounded in-launch wait that expired is a bug: say so loudly
+    if (p->handoff_timeout) { // a bounded in-launch wait that expired is a bug: say so loudly
         uint32_t v = 0;
-        if (hipMemcpy(&v, t, 4, hipMemcpyDeviceToHost) == hipSuccess && v)
+        if (hipMemcpy(&v, p->handoff_timeout, 4, hipMemcpyDeviceToHost) == hipSuccess && v)
             fprintf(stderr, "[zgml_hip] ERROR: %u in-launch hand-off wait(s) of a fused q/k/v + attention launch timed out\n", v);
     }
     if (!p->attn_traces.empty()) { // stamps of the last execution, 100 MHz wall clock -> ns
@@ -3434,7 +3437,14 @@ int zgml_hip_resident_decode(zgml_hip_ctx* ctx, zgml_hip_program* p, uint32_t fi
             one_token(s);
     }
     hipMemcpyAsync(tokens_out, r->tokens, (size_t)n_steps * 8, hipMemcpyDeviceToHost, s);
-    const bool ok = CTX_CHECK(ctx, hipStreamSynchronize(s));
+    bool ok = CTX_CHECK(ctx, hipStreamSynchronize(s));
+    if (ok && p->handoff_timeout) { // fused launches: a hand-off wait that gave up means wrong tokens — fail loudly
+        uint32_t v = 0;
+        if (hipMemcpy(&v, p->handoff_timeout, 4, hipMemcpyDeviceToHost) == hipSuccess && v) {
+            ctx->fail("resident_decode: an in-launch hand-off wait of a fused q/k/v + attention launch timed out");
+            ok = false;
+        }
+    }
     // the device rewrote the dyn block behind the host mirror's back: force a re-upload next time
     memset(p->dyn_host, 0xFF, p->ops.size() * sizeof(uint32_t));
     set_dyn_from_ops(p);
