@@ -185,6 +185,7 @@ enum QWFormat : uint32_t {
     QW_RAW = 0, // int8 [K*N] + f32 scale per `bs` flat elements (any bs, any N)
     QW_Q4 = 1,  // packed nibbles, lane-tiled (see qmatvec.hip)
     QW_Q8 = 2,  // packed int8, lane-tiled
+    QW_Q4K = 3, // packed offset-binary nibbles, K ON LANES (qmatvec.hip: qmatvec_kon_body): M = 1 mat-vecs only, f16 scales
 };
 
 struct QWeightDev {
@@ -218,6 +219,11 @@ enum QmvPrologueKind : uint32_t {
     QMV_PRO_NONE = 0,        // x = a
     QMV_PRO_MUL = 1,         // x = a * b                         (elementwise mul feeding the mat-vec)
     QMV_PRO_RMSNORM_MUL = 2, // mid = a / sqrt(mean(a^2) + eps); x = mid * b   (rmsnorm -> mul gamma)
+    // RMSNORM_MUL whose inputs the PRODUCING launch has prepared (QmvNextNorm below): `xg` = a * b elementwise and `ssq` =
+    // n_ssq partial sums of a^2, so this launch streams ONE vector and scales its finished sums by 1 / sqrt(sum / K + eps)
+    // (the mat-vec is linear in x). Only the K-on-lanes kernel consumes this form; a / b still name the original operands
+    // (the absorbed ops' own outputs are stored from them).
+    QMV_PRO_PRENORM = 3,
 };
 
 struct QmvPrologue {
@@ -227,6 +233,17 @@ struct QmvPrologue {
     const float* b = nullptr;
     float* store_mid = nullptr; // RMSNORM_MUL: the bare normalised vector
     float* store_x = nullptr;   // MUL / RMSNORM_MUL: the vector the mat-vec consumes
+    const float* xg = nullptr;  // PRENORM: a * b, written by the producing launch
+    const float* ssq = nullptr; // PRENORM: n_ssq partial sums of a^2 (one per 16 elements), same producer
+    uint32_t n_ssq = 0;
+};
+
+// What a launch with a residual-add epilogue (h = y + r) prepares for the rmsnorm -> mul(gamma) -> mat-vec launch that consumes
+// h next (runtime.hip: arm_prenorm): xg_out[n] = h[n] * gamma[n] and ssq_out[n / 16] = sum of h^2 over its 16 columns.
+struct QmvNextNorm {
+    const float* gamma = nullptr;
+    float* xg_out = nullptr; // nullptr: nothing to prepare
+    float* ssq_out = nullptr;
 };
 
 struct QmvPart {
@@ -240,6 +257,7 @@ struct QmvLaunch {
     uint32_t n_parts = 0;
     QmvPart parts[kMaxQmvParts];
     QmvPrologue pro;
+    QmvNextNorm next;
     uint32_t K = 0;
     unsigned long long* trace = nullptr; // diagnostics (ZGML_HIP_QMV_TRACE=1): 8 wall-clock stamps of block 0
 };

@@ -140,6 +140,7 @@ struct QMVArgs {
     QMVPartDev parts[kMaxQmvParts];
     uint32_t n_parts;
     QmvPrologue pro; // pro.a is the input vector for kind NONE
+    QmvNextNorm next; // residual-epilogue launches: side outputs for the next launch's rmsnorm prologue
     uint32_t M, K;
     uint32_t U;      // k-units per column group (Q4: KC, Q8: 2*KC)
     uint32_t in_rs;
@@ -343,12 +344,34 @@ struct QmvPublish {
 // Measured with it and NOT kept: requesting the operands of all epilogue steps at kernel start (the SiLU chain's constant
 // vector; -1 %: two more loads per lane and the part selects cost more than the one dependent load they save), and the
 // prologue kind / x alignment from the preloaded head instead of the argument block (+0.7 % / -0.9 %).
-template <bool GROUPED>
+// KON (the K-on-lanes body below): the caller has already folded its wave's lanes into red[w * 16 + column] (and the wave's sum of
+// squares into red[kMaxWaves * 16 + w]); the finished sums are scaled by `kon->post` (the fp8 converts' 2^9) and, with a
+// deferred rmsnorm prologue, by 1 / sqrt(mean(x^2) + eps); lanes 0-15 also store this workgroup's slice of the prologue's side
+// outputs (KonTail).
+struct KonTail {
+    float post;        // 512: the weights were accumulated as q * 2^-9
+    bool norm;         // rmsnorm prologue: scale by the factor computed from the folded sum of squares
+    float eps;
+    uint32_t K;
+    // the prologue's side outputs (the buffers of the absorbed ops): every workgroup stores `slice` elements from `k0`;
+    // lanes 0-15 hold a[k0 + lane] / b[k0 + lane] (requested at kernel start) when slice <= 16
+    float a_s, b_s;
+    uint32_t k0, slice;
+    bool has_pro;
+    // PRENORM: the factor comes from the producing launch's partial sums of squares; lane l of wave 0 holds partials
+    // l, l + 64, l + 128, l + 192 (requested at kernel start, zero beyond n_ssq)
+    bool prenorm;
+    float pp[4];
+};
+template <bool GROUPED, bool KON = false>
 __device__ __forceinline__ void reduce_store(float acc, float* red, const QMVArgs& a, uint32_t pi, float* out0, uint32_t g, uint32_t m,
-                                             float pre0, bool have_pre0, uint32_t n_waves, const QmvPublish* pub = nullptr) {
+                                             float pre0, bool have_pre0, uint32_t n_waves, const QmvPublish* pub = nullptr, const KonTail* kon = nullptr,
+                                             float pre_g = 0.f) {
     const uint32_t lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    acc = rows_sum4(acc);
-    if (lane < 16) red[w * 16 + lane] = acc;
+    if (!KON) {
+        acc = rows_sum4(acc);
+        if (lane < 16) red[w * 16 + lane] = acc;
+    }
     // a recognised chain's vector operand is requested before the barrier (the stream is over: a load under a branch
     // costs nothing here) so that it lands under the cross-wave fold
     // (grouped launches only — gate / up: single-matrix launches carry residual adds, and every scalar load in this tail counts)
@@ -371,6 +394,39 @@ __device__ __forceinline__ void reduce_store(float acc, float* red, const QMVArg
 #pragma unroll
     for (uint32_t j = 0; j < 4; j++) v += r + 4 * j < n_waves ? part[j] : 0.f;
     v = rows_sum4(v);
+    if (KON) {
+        v *= kon->post;
+        float inv = 1.0f;
+        if (kon->prenorm) { // the producer's partials, folded in a fixed order (the same value in every workgroup of the launch)
+            float s4 = (kon->pp[0] + kon->pp[1]) + (kon->pp[2] + kon->pp[3]);
+            for (uint32_t j = lane + 256; j < a.pro.n_ssq; j += 64) s4 += a.pro.ssq[j];
+            const float ss = rows_sum4(row16_sum(s4));
+            inv = 1.0f / sqrtf(ss / (float)kon->K + kon->eps); // reference.zig:365
+            v *= inv;
+        } else if (kon->norm) { // the waves' sums of squares, in wave order (the same value in every workgroup of the launch)
+            const float sv = red[kMaxWaves * 16 + min(col, n_waves - 1)];
+            const float ss = row16_sum(col < n_waves ? sv : 0.f);
+            inv = 1.0f / sqrtf(ss / (float)kon->K + kon->eps); // reference.zig:365
+            v *= inv;
+        }
+        if (kon->has_pro && lane < 16) { // this workgroup's slice of the absorbed ops' outputs (mid = a * inv, x = mid * b: reference order)
+            const QmvPrologue& pr = a.pro;
+            if (kon->slice <= 16) {
+                const uint32_t k = kon->k0 + lane;
+                if (lane < kon->slice && k < kon->K) {
+                    const float mid = kon->norm ? kon->a_s * inv : kon->a_s;
+                    if (kon->norm && pr.store_mid) pr.store_mid[k] = mid;
+                    if (pr.store_x) pr.store_x[k] = mid * kon->b_s;
+                }
+            } else { // few workgroups, long vector: a loop over the slice (not a shape the LLaMA plans produce)
+                for (uint32_t k = kon->k0 + lane; k < min(kon->k0 + kon->slice, kon->K); k += 16) {
+                    const float mid = kon->norm ? pr.a[k] * inv : pr.a[k];
+                    if (kon->norm && pr.store_mid) pr.store_mid[k] = mid;
+                    if (pr.store_x) pr.store_x[k] = mid * pr.b[k];
+                }
+            }
+        }
+    }
     if (lane < 16) {
         const uint32_t n = g * 16 + threadIdx.x;
         // part 0's output pointer is a preloaded argument; further parts' come from the argument block
@@ -397,7 +453,13 @@ __device__ __forceinline__ void reduce_store(float acc, float* red, const QMVArg
             else
                 run_epilogue_silu(a.parts[3], n, v, ones);
         } else if (!GROUPED && have_pre0 && a.parts[0].epi_kind == kEpiResidual) {
-            a.parts[0].epi[0].store[n] = v + pre0; // (commutative: the interpreter's swapped flag does not matter)
+            const float h = v + pre0; // (commutative: the interpreter's swapped flag does not matter)
+            a.parts[0].epi[0].store[n] = h;
+            if (a.next.xg_out) { // the next launch's rmsnorm -> mul(gamma) prologue, prepared here (QmvNextNorm)
+                a.next.xg_out[n] = h * pre_g;
+                const float sq = row16_sum(h * h);
+                if (lane == 0) a.next.ssq_out[g] = sq;
+            }
         } else if (!GROUPED || pi == 0)
             run_epilogue(a.parts[0], n, v, out_row, pre0, !GROUPED && have_pre0);
         else if (pi == 1)
@@ -762,12 +824,14 @@ __device__ __forceinline__ void qmatvec_body(QMV_HEAD_PARAMS, const QMVArgs& a, 
     // single-matrix launches (O / down projection): the operand of the first epilogue step (the residual) is requested
     // now, under the weight stream, by every lane for its column (unconditional: a load under a branch would degrade
     // the counted waits); the 16 owning lanes use it behind the reduction instead of a dependent ~0.5 us load
-    float pre0 = 0.f;
+    float pre0 = 0.f, pre_g = 0.f;
     bool have_pre0 = false;
     if (!GROUPED) {
         const float* const op0 = a.parts[0].epi[0].operand;
         have_pre0 = m == 0 && a.parts[0].n_epi != 0 && op0 != nullptr && op0 != out0;
         pre0 = (have_pre0 ? op0 : xa_row)[have_pre0 ? g * 16 + i : 0];
+        const float* const gp = a.next.xg_out ? a.next.gamma : nullptr; // (the next launch's gain, for the side outputs of reduce_store)
+        pre_g = (gp ? gp : xa_row)[gp ? g * 16 + i : 0];
     }
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
     for (uint32_t gi = 1; gi < n_groups; gi++) {
@@ -782,7 +846,7 @@ __device__ __forceinline__ void qmatvec_body(QMV_HEAD_PARAMS, const QMVArgs& a, 
     asm volatile("" ::"s"(arg_touch)); // (keeps the touches alive; long arrived)
 #endif
     QMV_STAMP(4); // weights streamed
-    reduce_store<GROUPED>((acc0 + acc1) + (acc2 + acc3), red, a, pi, out0, g, m, pre0, have_pre0, n_waves, pub);
+    reduce_store<GROUPED>((acc0 + acc1) + (acc2 + acc3), red, a, pi, out0, g, m, pre0, have_pre0, n_waves, pub, nullptr, pre_g);
     QMV_STAMP(5);
 #undef QMV_STAMP
 }
@@ -790,6 +854,228 @@ __device__ __forceinline__ void qmatvec_body(QMV_HEAD_PARAMS, const QMVArgs& a, 
 template <typename ST, bool XVEC, int DEPTH, bool Q4, bool PRO, bool GROUPED, bool XD, bool NT>
 __global__ void __launch_bounds__(1024) qmatvec_kernel(QMV_HEAD_PARAMS, QMVArgs a) {
     qmatvec_body<ST, XVEC, DEPTH, Q4, PRO, GROUPED, XD, NT>(qs0, sc0, out0, xa_base, xb_base, in_rs, K, nb2_0_flags, nb2_12, a, blockIdx.x, nullptr);
+}
+
+// ── K ON LANES (QW_Q4K, round 3): the M = 1 mat-vec of GGUF-Q4_0-sourced weights ───────────────────────────────────────
+// The form above pays two VALU instructions per weight (SDWA convert + DPP fmac) plus addressing: 3.26 per weight by the SQ
+// counters, and at one to three waves per SIMD that issue time shows (profiles/r02_qmatvec_pmc_series.csv: 45 % of the wave
+// cycles at 4096 x 11008 are issue stalls). Here a lane owns k instead of n:
+//   qs: uint4[NB2][P]  P = ceil(K / 2); item (g, p) = the 32 nibbles of k = 2p, 2p + 1 x the 16 columns of group g, stored
+//                      OFFSET-BINARY (q = w + 8 in 0..15: the GGUF nibble itself). dword dd: k = 2p + (dd >> 1), byte b holds
+//                      column 16g + 8 (dd & 1) + b in the low nibble and + 4 + b in the high nibble.
+//   sc: half2[NB][P]   { scale(2p, j), scale(2p + 1, j) }
+// so the multiplier t = scale * x is a per-lane scalar (no DPP broadcast), a byte 0x0N is the fp8 (e4m3) value N * 2^-9
+// (denormals and the first binade are linear), v_cvt_pk_f32_fp8 turns two masked bytes into two f32 and one v_pk_fma_f32
+// (t broadcast by op_sel) adds both products: 1 + 3/8 VALU instructions per weight instead of 2 + 1/8, ~1.8 with everything.
+// The -8 of the offset-binary form is taken out per lane, acc -= 8 * sum(t), mirroring the accumulation chain term by term
+// (an all-zero weight block gives exactly 0), before anything is folded across lanes. 64 consecutive lanes read 1 KiB of one
+// column group; a workgroup still owns 16 columns and all of K, so grid, epilogues, grouping and the in-launch publish are
+// those of the form above. The 16 per-lane column sums are folded across the wave by the gfx950 row swaps (16 values -> 8 ->
+// 4 registers), one row fold each, and land in LDS as red[wave][column].
+// The rmsnorm -> mul(gamma) prologue is DEFERRED: the mat-vec is linear in x, every k of the vector belongs to exactly one lane
+// of the workgroup, so the lanes sum x^2 beside the products and 1 / sqrt(mean + eps) scales the 16 finished sums — no second
+// pass over x, no barrier in front of the first FMA. The absorbed ops' own outputs (x * inv, x * inv * gamma) are stored in
+// slices, 1 / workgroups of the vector each, by the lanes that store the results.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <bool NT, bool PRO, bool XV>
+struct KonItem { // one lane's share of a step: k = 2p, 2p + 1 x 16 columns
+    uint4 wq;
+    uint32_t s2;
+    f32x2 xa, xb;
+    // unconditional, clamped (counted vmcnt waits need straight-line loads); XV: the vectors are 8-byte aligned and K is even
+    __device__ __forceinline__ void load(const uint4* qs, const uint32_t* sc, const float* a, const float* b, uint32_t p, uint32_t p_last, uint32_t K) {
+        const uint32_t pd = min(p, p_last);
+        if (XV) {
+            xa = *(const f32x2*)(a + 2 * pd);
+            if (PRO) xb = *(const f32x2*)(b + 2 * pd);
+        } else {
+            const uint32_t k1 = min(2 * pd + 1, K - 1);
+            xa = f32x2{a[2 * pd], a[k1]};
+            if (PRO) xb = f32x2{b[2 * pd], b[k1]};
+        }
+        s2 = sc[pd];
+        wq = wload<NT>(qs + pd);
+    }
+    __device__ __forceinline__ void compute(uint32_t pd, uint32_t P, uint32_t K, f32x2 (&acc)[8], float& T, float& SS) const {
+        const bool ok0 = pd < P, ok1 = ok0 && (XV || 2 * pd + 1 < K);
+        float x0 = ok0 ? xa.x : 0.f, x1 = ok1 ? xa.y : 0.f;
+        if (PRO) {
+            SS += x0 * x0;
+            SS += x1 * x1;
+            x0 *= xb.x, x1 *= xb.y;
+        }
+        const __half2 h = *(const __half2*)&s2;
+        const float t0 = __low2float(h) * x0, t1 = __high2float(h) * x1; // (scale * x as the reference rounds it, reference.zig:552)
+        T += t0;
+        T += t1;
+        const uint32_t dw[4] = {wq.x, wq.y, wq.z, wq.w};
+#pragma unroll
+        for (int dd = 0; dd < 4; dd++) {
+            const float t = dd < 2 ? t0 : t1;
+            const f32x2 tt = f32x2{t, t};
+            const uint32_t lo = dw[dd] & 0x0F0F0F0Fu, hi = (dw[dd] >> 4) & 0x0F0F0F0Fu;
+            const int c = 4 * (dd & 1);
+            acc[c + 0] = __builtin_elementwise_fma(__builtin_amdgcn_cvt_pk_f32_fp8((int)lo, false), tt, acc[c + 0]);
+            acc[c + 1] = __builtin_elementwise_fma(__builtin_amdgcn_cvt_pk_f32_fp8((int)lo, true), tt, acc[c + 1]);
+            acc[c + 2] = __builtin_elementwise_fma(__builtin_amdgcn_cvt_pk_f32_fp8((int)hi, false), tt, acc[c + 2]);
+            acc[c + 3] = __builtin_elementwise_fma(__builtin_amdgcn_cvt_pk_f32_fp8((int)hi, true), tt, acc[c + 3]);
+        }
+    }
+};
+
+// (a, b) -> lanes 0-31: a summed over lane ^ 32, lanes 32-63: b summed over lane ^ 32
+__device__ __forceinline__ float kon_fold32(float a, float b) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// rows 0 / 2: a summed over lane ^ 16, rows 1 / 3: b summed over lane ^ 16
+__device__ __forceinline__ float kon_fold16(float a, float b) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// PROM: 0 = no prologue, 1 = in-kernel (x = a * b, optionally the deferred rmsnorm), 2 = PRENORM (xa_base is the producer's a * b,
+// the factor comes from its partial sums of squares)
+template <int DEPTH, int PROM, bool GROUPED, bool XV, bool NT>
+__device__ __forceinline__ void qmatvec_kon_body(QMV_HEAD_PARAMS, const QMVArgs& a, const uint32_t bx, const uint32_t n_blocks, const QmvPublish* pub) {
+    constexpr bool PRO = PROM == 1;
+    extern __shared__ float smem[];
+    float* red = smem; // kMaxWaves * 16 column sums + kMaxWaves sums of squares
+#ifdef ZGML_TRACE
+#define QMV_STAMP(i) do { if (a.trace && (bx == 0 || bx == n_blocks - 1) && threadIdx.x == 0) a.trace[(bx ? 8 : 0) + i] = wall_clock64(); } while (0)
+#else
+#define QMV_STAMP(i) do { } while (0)
+#endif
+    QMV_STAMP(0);
+    const uint32_t P = (K + 1) >> 1; // units per column group
+    uint32_t pi = 0;
+    const uint4* qs_base = qs0;
+    const uint32_t* sc_base = (const uint32_t*)sc0;
+    const uint32_t n_waves = ((nb2_0_flags >> 20) & 0xFu) + 1, stride = n_waves * 64;
+    const uint32_t NB2_0 = nb2_0_flags & 0xFFFFFu, n_parts = (nb2_0_flags >> 24) & 0xF, NB2_1 = nb2_12 & 0xFFFFu, NB2_2 = nb2_12 >> 16;
+    uint32_t NB2 = NB2_0, block_begin = 0;
+    if (GROUPED) {
+        if ((nb2_0_flags >> 28) & 1) { // contiguous parts: everything from preloaded scalars (see the form above)
+            const uint32_t b1 = NB2_0, b2 = b1 + NB2_1;
+            if (n_parts > 1 && bx >= b1) pi = 1, block_begin = b1, NB2 = NB2_1;
+            if (n_parts > 2 && bx >= b2) pi = 2, block_begin = b2, NB2 = NB2_2;
+            qs_base = qs0 + (uint64_t)block_begin * P;
+            sc_base = (const uint32_t*)sc0 + (uint64_t)(block_begin >> 1) * P;
+        } else {
+#pragma unroll
+            for (uint32_t t = 1; t < (uint32_t)kMaxQmvParts; t++) {
+                const bool take = t < n_parts && bx >= a.parts[t].block_begin;
+                pi = take ? t : pi;
+                qs_base = take ? a.parts[t].qs : qs_base;
+                sc_base = take ? (const uint32_t*)a.parts[t].sc : sc_base;
+                NB2 = take ? a.parts[t].NB2 : NB2;
+                block_begin = take ? a.parts[t].block_begin : block_begin;
+            }
+        }
+    }
+    const uint32_t g = column_group(bx - block_begin, NB2);
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane >> 4, i = lane & 15;
+    const uint4* qs = qs_base + (uint64_t)g * P;
+    const uint32_t* sc = sc_base + (uint64_t)(g >> 1) * P;
+    const uint32_t n_groups = (P + stride * DEPTH - 1) / (stride * DEPTH), p_last = P - 1;
+    const bool norm = PROM == 2 || (PRO && ((nb2_0_flags >> 29) & 1) != 0);
+    uint32_t p = threadIdx.x;
+    // DEPTH items per lane in flight, refilled one by one: item d of the next group is requested into the registers item d of
+    // this group has just left (no second register set, and the stream never drains inside a workgroup)
+    KonItem<NT, PRO, XV> it[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++) it[d].load(qs, sc, xa_base, xb_base, p + d * stride, p_last, K);
+    // this workgroup's slice of the prologue's side outputs: its inputs are requested now, under the weight stream
+    KonTail tail{512.0f, norm, 0.f, K, 0.f, 0.f, 0u, 0u, PROM != 0, PROM == 2, {0.f, 0.f, 0.f, 0.f}};
+    if (PROM != 0) { // (PRENORM: xb_base carries the ORIGINAL vector a, a.pro.b the gain: the slices are stored from those)
+        tail.slice = (K + n_blocks - 1) / n_blocks;
+        tail.k0 = bx * tail.slice;
+        const uint32_t ks = min(tail.k0 + i, K - 1);
+        tail.a_s = (PROM == 2 ? xb_base : xa_base)[ks];
+        tail.b_s = (PROM == 2 ? a.pro.b : xb_base)[ks];
+    }
+    if (PROM == 2) {
+        const uint32_t n_ssq = a.pro.n_ssq;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) {
+            const uint32_t q = lane + 64 * j;
+            const float v = a.pro.ssq[min(q, n_ssq - 1)];
+            tail.pp[j] = q < n_ssq ? v : 0.f;
+        }
+    }
+    QMV_STAMP(1); // loads issued
+    QMV_STAMP(2); // (no separate x phases in this form: same stamp)
+    QMV_STAMP(3);
+    __builtin_amdgcn_sched_barrier(0);
+    uint32_t arg_touch = 0; // (argument-block lines into the scalar cache while the loads fly: see the form above)
+#if defined(__HIP_DEVICE_COMPILE__)
+    {
+        const auto kargs = (const __attribute__((address_space(4))) uint32_t*)__builtin_amdgcn_kernarg_segment_ptr();
+        constexpr uint32_t kArgDwords = (56 + sizeof(QMVArgs)) / 4;
+#pragma unroll
+        for (uint32_t o = 16; o < kArgDwords; o += 16) arg_touch |= kargs[o];
+    }
+#endif
+    float pre0 = 0.f, pre_g = 0.f;
+    bool have_pre0 = false;
+    if (!GROUPED) { // the residual behind the O / down projections, requested under the stream (see the form above)
+        const float* const op0 = a.parts[0].epi[0].operand;
+        have_pre0 = a.parts[0].n_epi != 0 && op0 != nullptr && op0 != out0;
+        pre0 = (have_pre0 ? op0 : xa_base)[have_pre0 ? g * 16 + i : 0];
+        const float* const gp = a.next.xg_out ? a.next.gamma : nullptr;
+        pre_g = (gp ? gp : xa_base)[gp ? g * 16 + i : 0];
+    }
+    f32x2 acc[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++) acc[c] = f32x2{0.f, 0.f};
+    float T = 0.f, SS = 0.f;
+    for (uint32_t gi = 1; gi < n_groups; gi++) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; d++) {
+            it[d].compute(p + d * stride, P, K, acc, T, SS);
+            __builtin_amdgcn_sched_barrier(0); // (hipcc otherwise moves the refills to the end of the body)
+            it[d].load(qs, sc, xa_base, xb_base, p + (DEPTH + d) * stride, p_last, K);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        p += DEPTH * stride;
+    }
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++) it[d].compute(p + d * stride, P, K, acc, T, SS);
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" ::"s"(arg_touch));
+#endif
+    QMV_STAMP(4); // weights streamed
+    // w = q - 8, per lane, before any cross-lane sum: the sums hold t * q / 512, so acc -= T * 8 / 512. With every q = 8 the
+    // chain acc <- fl(acc + t / 64) equals T / 64 term by term (a power of two commutes with rounding): exactly 0 comes out
+    const f32x2 TT = f32x2{T, T}, m64 = f32x2{-0.015625f, -0.015625f};
+#pragma unroll
+    for (int c = 0; c < 8; c++) acc[c] = __builtin_elementwise_fma(TT, m64, acc[c]);
+    // acc[c] = columns (2c, 2c + 1) ... fold the wave: after kon_fold32 over column pairs and kon_fold16 over those, register m
+    // holds, in row r, the partial of column 4m + {0, 2, 1, 3}[r]; one row fold finishes it
+    float a8[8];
+#pragma unroll
+    for (int m2 = 0; m2 < 8; m2++) a8[m2] = kon_fold32(acc[m2].x, acc[m2].y);
+    float a4[4];
+#pragma unroll
+    for (int m4 = 0; m4 < 4; m4++) a4[m4] = row16_sum(kon_fold16(a8[2 * m4], a8[2 * m4 + 1]));
+    const float v = (i & 2) ? ((i & 1) ? a4[3] : a4[2]) : ((i & 1) ? a4[1] : a4[0]);
+    if (i < 4) red[w * 16 + 4 * i + ((r & 1) * 2 + (r >> 1))] = v;
+    if (PRO) {
+        SS = row16_sum(SS);
+        SS = kon_fold32(SS, SS);
+        SS = kon_fold16(SS, SS);
+        if (lane == 0) red[kMaxWaves * 16 + w] = SS;
+    }
+    if (PROM != 0) tail.eps = a.pro.eps;
+    reduce_store<GROUPED, true>(0.f, red, a, pi, out0, g, 0, pre0, have_pre0, n_waves, pub, &tail, pre_g);
+    QMV_STAMP(5);
+#undef QMV_STAMP
+}
+
+template <int DEPTH, int PROM, bool GROUPED, bool XV, bool NT>
+__global__ void __launch_bounds__(1024) qmatvec_kon_kernel(QMV_HEAD_PARAMS, QMVArgs a) {
+    qmatvec_kon_body<DEPTH, PROM, GROUPED, XV, NT>(qs0, sc0, out0, xa_base, xb_base, in_rs, K, nb2_0_flags, nb2_12, a, blockIdx.x, gridDim.x, nullptr);
 }
 
 // The q / k / v projection and the decode attention that consumes it in ONE launch (DESIGN.md section 8.0,
@@ -806,13 +1092,16 @@ struct QkvAttnArgs {
     QmvPublish pub;
     DecodeHandoff ho;
 };
-template <typename ST, bool Q4, int LPK, bool KVQ>
+template <typename ST, bool Q4, int LPK, bool KVQ, bool KON = false, int PROM = 1>
 __global__ void __launch_bounds__(1024) qkv_attn_kernel(QMV_HEAD_PARAMS, QMVArgs a, QkvAttnArgs f) {
     constexpr int DEPTH = 1; // K <= 2048 with up to 16 waves: one load step
     if (blockIdx.x < f.n_mv) {
         const uint32_t n_waves = ((nb2_0_flags >> 20) & 0xFu) + 1;
         if (threadIdx.x >= n_waves * 64) return; // (whole waves: they no longer count at the barriers)
-        qmatvec_body<ST, false, DEPTH, Q4, true, true, true, false>(qs0, sc0, out0, xa_base, xb_base, in_rs, K, nb2_0_flags, nb2_12, a, blockIdx.x, &f.pub);
+        if constexpr (KON) // K-on-lanes weights (QW_Q4K); the launcher checked x alignment
+            qmatvec_kon_body<DEPTH, PROM, true, true, false>(qs0, sc0, out0, xa_base, xb_base, in_rs, K, nb2_0_flags, nb2_12, a, blockIdx.x, f.n_mv, &f.pub);
+        else
+            qmatvec_body<ST, false, DEPTH, Q4, true, true, true, false>(qs0, sc0, out0, xa_base, xb_base, in_rs, K, nb2_0_flags, nb2_12, a, blockIdx.x, &f.pub);
     } else {
         const uint32_t b = blockIdx.x - f.n_mv, n_heads = f.ho.n_heads; // head-major: the always-active split 0 of every head first
         attention_decode_body<LPK, KVQ>(f.params, f.split_buf, f.split_cnt, f.split_min_keys, b % n_heads, b / n_heads, f.n_sp, &f.ho);
@@ -1612,6 +1901,33 @@ __device__ __forceinline__ void write_packed(const QWeightDev& w, const Src& src
     }
 }
 
+// the K-on-lanes layout (QW_Q4K, see qmatvec_kon_body): one thread per 16-byte item (g, p)
+template <typename Src>
+__device__ __forceinline__ void write_packed_kon(const QWeightDev& w, const Src& src) {
+    const uint32_t NB = w.N / 32, NB2 = w.N / 16, P = (w.K + 1) / 2;
+    const uint64_t n_items = (uint64_t)NB2 * P;
+    for (uint64_t it = (uint64_t)blockIdx.x * kBlock + threadIdx.x; it < n_items; it += (uint64_t)gridDim.x * kBlock) {
+        const uint32_t pp = it % P, g = it / P;
+        uint32_t d[4];
+        for (int dd = 0; dd < 4; dd++) {
+            const uint32_t k = 2 * pp + (dd >> 1), c0 = 16 * g + 8 * (dd & 1);
+            uint32_t word = 0;
+            for (int b = 0; b < 4; b++) { // offset-binary; k >= K (odd K): w = 0
+                const uint32_t lo = k < w.K ? (uint32_t)(src.q(k, c0 + b) + 8) & 15u : 8u;
+                const uint32_t hi = k < w.K ? (uint32_t)(src.q(k, c0 + 4 + b) + 8) & 15u : 8u;
+                word |= (lo | (hi << 4)) << (8 * b);
+            }
+            d[dd] = word;
+        }
+        ((uint4*)w.qs)[it] = make_uint4(d[0], d[1], d[2], d[3]);
+        if ((g & 1) == 0) {
+            const uint32_t j = g >> 1, k0 = 2 * pp, k1 = k0 + 1;
+            const __half sa = __float2half_rn(src.scale(k0, j, NB)), sb = __float2half_rn(k1 < w.K ? src.scale(k1, j, NB) : 0.f);
+            ((uint32_t*)w.sc)[(uint64_t)j * P + pp] = (uint32_t)__half_as_ushort(sa) | ((uint32_t)__half_as_ushort(sb) << 16);
+        }
+    }
+}
+
 struct SynthSrc { // SURVEY §8d generator
     uint32_t N, id;
     bool q4;
@@ -1650,18 +1966,27 @@ struct GgufSrc { // GGUF Q4_0 / Q8_0 blocks over the flat [K,N] order (gguf_load
 };
 
 __global__ void __launch_bounds__(kBlock) pack_gguf_kernel(const uint8_t* __restrict__ raw, QWeightDev w) {
-    write_packed<__half>(w, GgufSrc{raw, w.N, w.format == QW_Q4}); // GGUF scales are f16: always exact
+    if (w.format == QW_Q4K)
+        write_packed_kon(w, GgufSrc{raw, w.N, true});
+    else
+        write_packed<__half>(w, GgufSrc{raw, w.N, w.format == QW_Q4}); // GGUF scales are f16: always exact
 }
 
 template <typename ST>
 __global__ void __launch_bounds__(kBlock) synth_packed_kernel(QWeightDev w, uint32_t id) {
-    write_packed<ST>(w, SynthSrc{w.N, id, w.format == QW_Q4});
+    if (w.format == QW_Q4K)
+        write_packed_kon(w, SynthSrc{w.N, id, true});
+    else
+        write_packed<ST>(w, SynthSrc{w.N, id, w.format == QW_Q4});
 }
 
 template <typename ST>
 __global__ void __launch_bounds__(kBlock) pack_kernel(const int8_t* __restrict__ data,
                                                       const float* __restrict__ scales, QWeightDev w) {
-    write_packed<ST>(w, RawSrc{data, scales, w.N});
+    if (w.format == QW_Q4K)
+        write_packed_kon(w, RawSrc{data, scales, w.N});
+    else
+        write_packed<ST>(w, RawSrc{data, scales, w.N});
 }
 
 inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
@@ -1679,6 +2004,12 @@ constexpr size_t kMaxLds = 160 * 1024;
 void packed_bytes(QWFormat format, uint32_t scale_f16, uint64_t K, uint64_t N, uint64_t* qs_bytes,
                   uint64_t* sc_bytes) {
     const uint64_t NB = N / 32, NB2 = N / 16, KC = (K + 31) / 32;
+    if (format == QW_Q4K) { // K on lanes: 16-byte items [NB2][P], f16 scale pairs [NB][P]
+        const uint64_t P = (K + 1) / 2;
+        *qs_bytes = NB2 * P * 16;
+        *sc_bytes = NB * P * 4;
+        return;
+    }
     const uint64_t U = format == QW_Q4 ? KC : 2 * KC;
     *qs_bytes = NB2 * U * 16 * 16;
     const uint64_t n_sc = format == QW_Q4 ? NB * KC * 32 : NB * U * 16;
@@ -1816,8 +2147,101 @@ static bool plain_head_depth1(const QMVArgs& a, const QWeightDev& w0, uint32_t b
     return true;
 }
 
+// ── the K-on-lanes launches (QW_Q4K) ──
+// Waves: 8 for K >= 4096 (4096: one load group of 4 items per lane, every load of the workgroup in flight at once;
+// tools/exp/kon.hip sweep, round 3: 4096^2 chain 4.06 us with 8 waves against 4.9 / 4.5 with 4 / 16); short K: one wave per
+// 64 k-pairs up to the cap (the launch is one latency chain inside the decode stream, as for the form above).
+uint32_t kon_waves(const QWeightDev& w) {
+    const uint32_t wave_steps = cdiv((w.K + 1) / 2, 64);
+    static const int small_cap = getenv("ZGML_QMV_KON_WAVES_SMALLK") ? atoi(getenv("ZGML_QMV_KON_WAVES_SMALLK")) : 16;
+    static const int big_cap = getenv("ZGML_QMV_KON_WAVES") ? atoi(getenv("ZGML_QMV_KON_WAVES")) : 8;
+    const uint32_t cap = (uint32_t)std::max(1, std::min(16, w.K <= 2048 ? small_cap : big_cap));
+    return std::max(1u, std::min(wave_steps, cap));
+}
+
+template <int PROM, bool GRP, bool XV>
+KernelFn pick_kon_depth(int depth_sel, bool nt) {
+    switch (depth_sel) {
+        case 0: return qmatvec_kon_kernel<1, PROM, GRP, XV, false>;
+        case 1: return qmatvec_kon_kernel<2, PROM, GRP, XV, false>;
+        default: return nt ? qmatvec_kon_kernel<4, PROM, GRP, XV, true> : qmatvec_kon_kernel<4, PROM, GRP, XV, false>;
+    }
+}
+template <int PROM>
+KernelFn pick_kon_mode(bool grp, bool xv, int depth_sel, bool nt) {
+    if (xv) return grp ? pick_kon_depth<PROM, true, true>(depth_sel, nt) : pick_kon_depth<PROM, false, true>(depth_sel, nt);
+    return grp ? pick_kon_depth<PROM, true, false>(depth_sel, nt) : pick_kon_depth<PROM, false, false>(depth_sel, nt);
+}
+KernelFn pick_kon(int prom, bool grp, bool xv, int depth_sel, bool nt) {
+    if (prom == 2) return pick_kon_mode<2>(grp, xv, depth_sel, nt);
+    if (prom == 1) return pick_kon_mode<1>(grp, xv, depth_sel, nt);
+    return pick_kon_mode<0>(grp, xv, depth_sel, nt);
+}
+
+bool launch_packed_kon(hipStream_t s, QMVArgs& a, const QWeightDev& w0, uint32_t total_blocks, bool xvec, const QkvAttnArgs* fused, uint32_t extra_blocks,
+                       uint32_t d_head, const FusedO* fo) {
+    if (fo) return false; // (the O projection riding along is only built for the n-on-lanes form; off by default)
+    a.x_vec = xvec ? 1 : 0;
+    const uint32_t P = (a.K + 1) / 2, waves = kon_waves(w0);
+    static const bool contig_ok = !(getenv("ZGML_QMV_CONTIG") && atoi(getenv("ZGML_QMV_CONTIG")) == 0);
+    bool contig = a.n_parts > 1 && a.n_parts <= 3 && contig_ok;
+    for (uint32_t t = 1; t < a.n_parts && contig; t++) {
+        const QMVPartDev &pv = a.parts[t - 1], &pt = a.parts[t];
+        contig = (const char*)pt.qs == (const char*)pv.qs + (size_t)pv.NB2 * P * 16 && (const char*)pt.sc == (const char*)pv.sc + (size_t)(pv.NB2 / 2) * P * 4 &&
+                 pt.block_begin == pv.block_begin + pv.NB2;
+    }
+    if (a.n_parts > 1 && (a.parts[1].NB2 > 0xFFFFu || (a.n_parts > 2 && a.parts[2].NB2 > 0xFFFFu))) contig = false; // 16-bit fields
+    const uint32_t nb2_12 = contig ? (a.parts[1].NB2 | (a.n_parts > 2 ? a.parts[2].NB2 << 16 : 0u)) : 0u;
+    const size_t lds = ((size_t)kMaxWaves * 16 + kMaxWaves) * sizeof(float);
+    const bool pro = a.pro.kind != QMV_PRO_NONE, grp = a.n_parts > 1, nt = w0.stream_nt != 0;
+    const int prom = a.pro.kind == QMV_PRO_PRENORM ? 2 : (pro ? 1 : 0);
+    uint32_t waves_used = waves;
+    // an in-kernel prologue doubles the vector loads of an item: two items per lane in flight with twice the waves
+    // (four items: the compiler runs out of the 128 registers a 1024-thread launch bound leaves)
+    if (prom == 1 && cdiv(P, waves * 64) >= 4) waves_used = std::min<uint32_t>(kMaxWaves, waves * 2);
+    const uint32_t n_steps = cdiv(P, waves_used * 64);
+    int depth_sel = n_steps >= 4 ? 2 : (n_steps >= 2 ? 1 : 0);
+    if (prom == 1 && depth_sel == 2) depth_sel = 1;
+    // the kernel's leading arguments: PRENORM streams the producer's vector and keeps the original one for the side outputs
+    const float* const head_xa = prom == 2 ? a.pro.xg : a.pro.a;
+    const float* const head_xb = prom == 2 ? a.pro.a : a.pro.b;
+    const uint32_t flags = a.parts[0].NB2 | ((waves_used - 1) << 20) | (a.n_parts << 24) | (contig ? 1u << 28 : 0u) | (a.pro.kind == QMV_PRO_RMSNORM_MUL ? 1u << 29 : 0u) |
+                           (a.x_vec ? 1u << 30 : 0u);
+    if (fused) {
+        if (!(pro && grp && !nt && contig && xvec && a.n_parts == 3 && depth_sel == 0 && (d_head == 64 || d_head == 128))) return false;
+        QkvAttnArgs f = *fused;
+        f.n_mv = total_blocks;
+        using FusedFn = void (*)(const uint4*, const void*, float*, const float*, const float*, uint32_t, uint32_t, uint32_t, uint32_t, QMVArgs, QkvAttnArgs);
+        FusedFn ff = nullptr;
+        if (prom == 2) {
+            if (d_head == 64)
+                ff = f.kvq ? qkv_attn_kernel<__half, true, 16, true, true, 2> : qkv_attn_kernel<__half, true, 16, false, true, 2>;
+            else
+                ff = f.kvq ? qkv_attn_kernel<__half, true, 32, true, true, 2> : qkv_attn_kernel<__half, true, 32, false, true, 2>;
+        } else if (d_head == 64) {
+            ff = f.kvq ? qkv_attn_kernel<__half, true, 16, true, true> : qkv_attn_kernel<__half, true, 16, false, true>;
+        } else {
+            ff = f.kvq ? qkv_attn_kernel<__half, true, 32, true, true> : qkv_attn_kernel<__half, true, 32, false, true>;
+        }
+        hipLaunchKernelGGL(ff, dim3(total_blocks + extra_blocks), dim3(1024), lds, s, a.parts[0].qs, a.parts[0].sc, a.parts[0].out, head_xa, head_xb, a.in_rs, a.K, flags,
+                           nb2_12, a, f);
+        return true;
+    }
+    const KernelFn fn = pick_kon(prom, grp, xvec, depth_sel, nt);
+    hipLaunchKernelGGL(fn, dim3(total_blocks), dim3(waves_used * 64), lds, s, a.parts[0].qs, a.parts[0].sc, a.parts[0].out, head_xa, head_xb, a.in_rs, a.K, flags, nb2_12, a);
+    return true;
+}
+
 bool launch_packed(hipStream_t s, QMVArgs& a, const QWeightDev& w0, uint32_t total_blocks, uint32_t M, bool xvec, const QkvAttnArgs* fused,
                    uint32_t extra_blocks, uint32_t d_head, const FusedO* fo) {
+    { // diagnostics: leave out every mat-vec launch of one grid size (wrong results; the token time then drops by that launch's true cost)
+        static const uint32_t skip_blocks = getenv("ZGML_HIP_DEBUG_SKIP_GRID") ? (uint32_t)atoi(getenv("ZGML_HIP_DEBUG_SKIP_GRID")) : 0u;
+        if (skip_blocks && total_blocks == skip_blocks) return true;
+    }
+    if (w0.format == QW_Q4K) { // (only weights whose every use is an M = 1 mat-vec get this layout: compile_program)
+        if (M != 1) return false;
+        return launch_packed_kon(s, a, w0, total_blocks, xvec, fused, extra_blocks, d_head, fo);
+    }
     const bool q4 = w0.format == QW_Q4;
     a.x_vec = xvec ? 1 : 0;
     // x direct (no LDS staging); the rmsnorm prologue reduces the vector while the weights fly
@@ -2014,7 +2438,7 @@ void launch_tile(hipStream_t s, const QWeightDev& w, const QMatmulParams& p, boo
 
 } // namespace
 
-uint32_t qmv_max_prologue_k(const QWeightDev&) { return kMaxWaves * 64 * 4 * kXRegs; } // widest workgroup; launch_packed widens to fit
+uint32_t qmv_max_prologue_k(const QWeightDev& w) { return w.format == QW_Q4K ? UINT32_MAX : kMaxWaves * 64 * 4 * kXRegs; } // widest workgroup; launch_packed widens to fit
 
 bool qmatmul_can_group(const QWeightDev& a, const QMatmulParams& pa, const QWeightDev& b, const QMatmulParams& pb) {
     // one launch computes both: neither output may overlap the other output or the shared input rows
@@ -2040,6 +2464,10 @@ void launch_qmatmul(hipStream_t s, const QWeightDev& w, const QMatmulParams& p, 
     if (w.format == QW_RAW) {
         dim3 grid(cdiv(p.N, kBlock), p.M);
         qmatmul_raw_kernel<<<grid, kBlock, 0, s>>>((const int8_t*)w.qs, (const float*)w.sc, w.bs, p);
+        return;
+    }
+    if (w.format == QW_Q4K && p.M != 1) { // compile_program only gives this layout to weights every use of which has M = 1
+        fprintf(stderr, "[zgml_hip] ERROR: an M = %u matmul over a K-on-lanes (mat-vec only) weight: not launched\n", p.M);
         return;
     }
     const bool xvec = ((uintptr_t)p.input % 16 == 0) && (p.K % 4 == 0) && (p.M == 1 || p.in_rs % 4 == 0);
@@ -2095,12 +2523,14 @@ static void build_qmv_args(const QmvLaunch& L, QMVArgs& a, uint32_t& blocks, boo
         blocks += d.NB2;
     }
     a.pro = L.pro;
+    a.next = L.next;
     if (a.pro.kind == QMV_PRO_NONE) a.pro.b = a.pro.a;
     a.M = 1, a.K = L.K;
     a.U = w0.format == QW_Q4 ? w0.KC : 2 * w0.KC;
     a.in_rs = L.K;
     bool xvec = ((uintptr_t)L.pro.a % 16 == 0) && (L.K % 4 == 0);
     if (L.pro.kind != QMV_PRO_NONE) xvec = xvec && ((uintptr_t)L.pro.b % 16 == 0);
+    if (L.pro.kind == QMV_PRO_PRENORM) xvec = xvec && ((uintptr_t)L.pro.xg % 16 == 0);
     a.trace = L.trace;
     xvec_out = xvec;
 }

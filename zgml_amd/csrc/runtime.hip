@@ -151,6 +151,8 @@ struct zgml_hip_program {
     std::vector<void*> f16_weights; // per buffer: MFMA-packed f16 copy of a promoted matmul B operand (else nullptr)
     std::vector<void*> owned; // other device allocations
     uint32_t* handoff_timeout = nullptr; // fused launches: ONE device word bumped whenever an in-launch wait gave up
+    float* prenorm_buf = nullptr;        // arm_prenorm: [x * gamma | partial sums of squares] handed from a residual epilogue to the next prologue
+    size_t prenorm_bytes = 0;
     float* scratch = nullptr;
     uint64_t scratch_bytes = 0;
     // plan building: the last quantized matmul launch that split its input into the scratch (make_single)
@@ -1005,9 +1007,10 @@ void fuse_qkv_attention(zgml_hip_program* p) {
             if (cut) continue;
         }
         if (L.n_parts != 3 || L.K > 2048 || L.pro.kind == QMV_PRO_NONE || (ad->dh != 64 && ad->dh != 128) || L.trace) continue;
+        if (L.pro.kind == QMV_PRO_PRENORM && L.parts[0].w.format != QW_Q4K) continue;
         const bool kvq = ad->kvq;
         bool ok = true;
-        for (uint32_t t = 0; t < 3; t++) ok = ok && L.parts[t].n_epi == 0 && L.parts[t].w.format == QW_Q4 && L.parts[t].w.scale_f16;
+        for (uint32_t t = 0; t < 3; t++) ok = ok && L.parts[t].n_epi == 0 && (L.parts[t].w.format == QW_Q4 || L.parts[t].w.format == QW_Q4K) && L.parts[t].w.scale_f16;
         const uint32_t nh = ad->nh, dh = ad->dh;
         ok = ok && (uint64_t)nh * dh == L.parts[0].w.N && L.parts[1].w.N == L.parts[2].w.N && L.parts[1].w.N % dh == 0;
         const uint32_t n_kv = ok ? (uint32_t)(L.parts[1].w.N / dh) : 0;
@@ -1072,6 +1075,46 @@ void fuse_qkv_attention(zgml_hip_program* p) {
                  }};
         p->plan[i] = std::move(F);
         p->plan.erase(p->plan.begin() + (ptrdiff_t)i + 1, p->plan.begin() + (ptrdiff_t)i + (o_ok ? 3 : 2));
+    }
+}
+
+// A mat-vec launch with a residual-add epilogue (h = y + r: the O / down projections) that is DIRECTLY followed by the launch
+// whose rmsnorm -> mul(gamma) prologue consumes h prepares that prologue (kernels.h: QmvNextNorm / QMV_PRO_PRENORM): it also
+// stores h * gamma and, per 16 columns, the sum of h^2. The consumer then streams one vector instead of two — x (16 KB at
+// K = 4096) stays in a CU's L1 across the workgroups it hosts, x and gamma together do not (tools/exp/kon.hip: +0.5 us at
+// 4096^2, +0.8 at 4096 x 11008, +1.8 at 4096 x 32000) — and needs no sum over x. Only K-on-lanes consumers (QW_Q4K).
+void arm_prenorm(zgml_hip_program* p) {
+    static const bool on = !(getenv("ZGML_HIP_PRENORM") && atoi(getenv("ZGML_HIP_PRENORM")) == 0);
+    if (!on) return;
+    for (size_t i = 1; i < p->plan.size(); i++) {
+        const auto C = p->plan[i].qmv_desc, P = p->plan[i - 1].qmv_desc;
+        if (!C || !P || C->pro.kind != QMV_PRO_RMSNORM_MUL) continue;
+        bool ok = true;
+        for (uint32_t t = 0; t < C->n_parts; t++) ok = ok && C->parts[t].w.format == QW_Q4K;
+        const QmvPart& pp = P->parts[0];
+        ok = ok && P->n_parts == 1 && pp.w.format != QW_RAW && pp.w.N == C->K && pp.n_epi == 1 && pp.epi[0].op == ZGML_OP_ADD && pp.epi[0].operand &&
+             pp.epi[0].operand != pp.dst && pp.epi[0].store == C->pro.a && C->K % 16 == 0 && !P->next.xg_out;
+        if (!ok) continue;
+        { // a declared barrier between the two launches keeps them independent (zgml_hip_program_set_barriers)
+            const uint64_t lo_b = std::min(p->plan[i - 1].op_lo, p->plan[i].op_lo), hi_b = std::max(p->plan[i - 1].op_hi, p->plan[i].op_hi);
+            bool cut = false;
+            for (uint64_t b : p->barriers) cut = cut || (b > lo_b && b <= hi_b);
+            if (cut) continue;
+        }
+        const size_t need = ((size_t)C->K + C->K / 16) * sizeof(float);
+        if (p->prenorm_bytes < need) { // one block for the whole program: the pairs follow each other in stream order
+            float* blk = nullptr;
+            if (hipMalloc((void**)&blk, need) != hipSuccess || hipMemset(blk, 0, need) != hipSuccess) {
+                if (blk) hipFree(blk);
+                continue;
+            }
+            p->owned.push_back(blk);
+            p->prenorm_buf = blk, p->prenorm_bytes = need;
+        }
+        float *xg = p->prenorm_buf, *ssq = p->prenorm_buf + C->K;
+        P->next = QmvNextNorm{C->pro.b, xg, ssq};
+        C->pro.kind = QMV_PRO_PRENORM;
+        C->pro.xg = xg, C->pro.ssq = ssq, C->pro.n_ssq = C->K / 16;
     }
 }
 
@@ -1885,17 +1928,19 @@ void build_fused_plan(zgml_hip_program* p) {
             static const bool want_qmv_trace = getenv("ZGML_HIP_QMV_TRACE") && atoi(getenv("ZGML_HIP_QMV_TRACE"));
             if (want_qmv_trace) {
                 unsigned long long* t = nullptr;
-                if (hipHostMalloc((void**)&t, 8 * sizeof(unsigned long long), hipHostMallocMapped) == hipSuccess) {
-                    memset(t, 0, 8 * sizeof(unsigned long long));
+                if (hipHostMalloc((void**)&t, 16 * sizeof(unsigned long long), hipHostMallocMapped) == hipSuccess) {
+                    memset(t, 0, 16 * sizeof(unsigned long long));
                     L.trace = t;
                     p->qmv_traces.push_back({t, L.n_parts, L.pro.kind, (uint32_t)w0.K, (uint32_t)w0.N});
                 }
             }
-            Launch QL{ZGML_DOP_QMATMUL, n_ops, lo, hi, [=](hipStream_t s) { launch_qmatvec_fused(s, L); }};
-            QL.qmv_desc = std::make_shared<QmvLaunch>(L);
+            auto desc = std::make_shared<QmvLaunch>(L); // shared with the launch: arm_prenorm may still rewrite it
+            Launch QL{ZGML_DOP_QMATMUL, n_ops, lo, hi, [desc](hipStream_t s) { launch_qmatvec_fused(s, *desc); }};
+            QL.qmv_desc = desc;
             p->plan.push_back(std::move(QL));
         }
     }
+    arm_prenorm(p);
     fuse_qkv_attention(p);
 }
 
@@ -2535,6 +2580,12 @@ zgml_hip_program* zgml_hip_compile_program(zgml_hip_ctx* ctx, const zgml_device_
     };
     std::vector<PendingPack> pending(prog->n_qweights);
     uint64_t qs_total = 0, sc_total = 0;
+    // Q4_0-valued weights with f16 scales that only ever feed M = 1 mat-vecs take the K-on-lanes layout (QW_Q4K, qmatvec.hip);
+    // a weight an M > 1 matmul reads keeps the n-on-lanes layout the tile kernels are built for
+    static const bool kon_on = !(getenv("ZGML_HIP_QMV_KON") && atoi(getenv("ZGML_HIP_QMV_KON")) == 0);
+    std::vector<char> qw_m1(prog->n_qweights, kon_on ? 1 : 0);
+    for (const auto& op : p->ops)
+        if (op.kind == ZGML_DOP_QMATMUL && op.u.qmatmul.M != 1 && op.u.qmatmul.weight_idx < prog->n_qweights) qw_m1[op.u.qmatmul.weight_idx] = 0;
     for (uint64_t i = 0; ok && i < prog->n_qweights; i++) {
         if (!qw_live[i]) continue;
         const zgml_qweight_upload& qw = prog->qweights[i];
@@ -2568,6 +2619,11 @@ zgml_hip_program* zgml_hip_compile_program(zgml_hip_ctx* ctx, const zgml_device_
             w.scale_f16 = (cls & 2) ? 1 : 0;
         }
         if (!ok) break;
+        // (short K stays n-on-lanes: those launches are one latency chain inside the decode stream, where the longer fold of
+        // the K-on-lanes tail and the hand-over of the norm cost more than the cheaper inner loop saves: SmolLM-135M
+        // 1770 tok/s either way without the hand-over, 1680 with it)
+        static const uint32_t kon_min_k = getenv("ZGML_HIP_QMV_KON_MIN_K") ? (uint32_t)atoi(getenv("ZGML_HIP_QMV_KON_MIN_K")) : 2049u;
+        if (w.format == QW_Q4 && w.scale_f16 && qw_m1[i] && w.K >= kon_min_k) w.format = QW_Q4K;
         w.KC = (uint32_t)((qw.rows + 31) / 32);
         packed_bytes(w.format, w.scale_f16, w.K, w.N, &w.qs_bytes, &w.sc_bytes);
         qs_total += w.qs_bytes, sc_total += w.sc_bytes;
@@ -2829,15 +2885,22 @@ void zgml_hip_free_program(zgml_hip_ctx* ctx, zgml_hip_program* p) {
         for (auto* t : p->attn_traces) hipHostFree(t);
     }
     if (!p->qmv_traces.empty()) {
-        fprintf(stderr, "[zgml_hip] mat-vec trace, workgroup 0 (ns: gap since previous mat-vec end | ->loads issued | ->x arrived(+sumsq) | ->x staged | ->streamed | ->reduced+epilogue)\n");
+        fprintf(stderr, "[zgml_hip] mat-vec trace, workgroup 0 (ns: gap since previous mat-vec end | ->loads issued | ->x arrived(+sumsq) | ->x staged | ->streamed | ->reduced+epilogue)"
+                        " || K-on-lanes launches also: LAST workgroup, start after workgroup 0's start | ->loads issued | ->streamed | ->end; launch span = first start -> last end\n");
         unsigned long long prev_end = 0;
-        for (size_t i = 0; i < p->qmv_traces.size() && i < 24; i++) {
+        for (size_t i = 0; i < p->qmv_traces.size() && i < 48; i++) {
             const auto& q = p->qmv_traces[i];
             fprintf(stderr, "  #%02zu K=%5u N0=%5u parts=%u pro=%u gap %6lld |", i, q.K, q.N, q.parts, q.pro,
                     prev_end ? (long long)(q.t[0] - prev_end) * 10 : -1);
             for (int k = 1; k < 6; k++) fprintf(stderr, " %5lld", (long long)(q.t[k] - q.t[k - 1]) * 10);
+            if (q.t[8]) {
+                fprintf(stderr, " || %5lld | %5lld %5lld %5lld | span %5lld", (long long)(q.t[8] - q.t[0]) * 10, (long long)(q.t[9] - q.t[8]) * 10,
+                        (long long)(q.t[12] - q.t[9]) * 10, (long long)(q.t[13] - q.t[12]) * 10, (long long)(std::max(q.t[13], q.t[5]) - q.t[0]) * 10);
+                prev_end = std::max(q.t[13], q.t[5]);
+            } else {
+                prev_end = q.t[5];
+            }
             fprintf(stderr, "\n");
-            prev_end = q.t[5];
         }
         for (auto& q : p->qmv_traces) hipHostFree(q.t);
     }
@@ -2935,8 +2998,9 @@ int64_t zgml_hip_argmax(zgml_hip_ctx* ctx, zgml_hip_program* p, uint16_t buf_idx
     return *ctx->arg_out_host;
 }
 
-static bool make_synth_weight(zgml_hip_ctx* ctx, uint32_t K, uint32_t N, int q4, uint32_t id, QWeightDev* w) {
-    w->format = q4 ? QW_Q4 : QW_Q8;
+static bool make_synth_weight(zgml_hip_ctx* ctx, uint32_t K, uint32_t N, int q4, uint32_t id, QWeightDev* w, uint32_t M = 1) {
+    static const bool kon_on = !(getenv("ZGML_HIP_QMV_KON") && atoi(getenv("ZGML_HIP_QMV_KON")) == 0);
+    w->format = q4 ? (M == 1 && kon_on ? QW_Q4K : QW_Q4) : QW_Q8; // (what compile_program picks for a weight that only feeds mat-vecs)
     w->K = K, w->N = N, w->bs = 32;
     w->KC = (K + 31) / 32;
     w->scale_f16 = 1;
@@ -3024,7 +3088,7 @@ double zgml_hip_qmatmul_bench(zgml_hip_ctx* ctx, uint32_t M, uint32_t K, uint32_
     hipSetDevice(ctx->device);
     std::vector<QWeightDev> ring(n_matrices);
     bool ok = true;
-    for (uint32_t i = 0; ok && i < n_matrices; i++) ok = make_synth_weight(ctx, K, N, q4, i, &ring[i]);
+    for (uint32_t i = 0; ok && i < n_matrices; i++) ok = make_synth_weight(ctx, K, N, q4, i, &ring[i], M);
     if (ok && (ring[0].qs_bytes + ring[0].sc_bytes) * n_matrices >= (192ull << 20)) // the ring stands for a model beyond the cache
         for (auto& w : ring) w.stream_nt = 1;
     float *x = nullptr, *y = nullptr, *scratch = nullptr;
