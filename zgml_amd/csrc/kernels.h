@@ -258,6 +258,9 @@ struct QmvLaunch {
     QmvPart parts[kMaxQmvParts];
     QmvPrologue pro;
     QmvNextNorm next;
+    // gate / up pair (runtime.hip: arm_pair): parts[0] carries the SiLU chain, parts[1] is plain, both K-on-lanes, same shape;
+    // the launch also stores silu(parts[0]) * parts[1] here — the product the NEXT mat-vec's MUL prologue would recompute
+    float* pair_out = nullptr;
     uint32_t K = 0;
     unsigned long long* trace = nullptr; // diagnostics (ZGML_HIP_QMV_TRACE=1): 8 wall-clock stamps of block 0
 };

@@ -141,6 +141,7 @@ struct QMVArgs {
     uint32_t n_parts;
     QmvPrologue pro; // pro.a is the input vector for kind NONE
     QmvNextNorm next; // residual-epilogue launches: side outputs for the next launch's rmsnorm prologue
+    float* pair_out;  // PAIR launches: where silu(part 0) * part 1 goes (nullptr: not a pair launch)
     uint32_t M, K;
     uint32_t U;      // k-units per column group (Q4: KC, Q8: 2*KC)
     uint32_t in_rs;
@@ -363,6 +364,40 @@ struct KonTail {
     bool prenorm;
     float pp[4];
 };
+// wave 0 of a K-on-lanes workgroup, behind the barrier: the deferred rmsnorm factor (1 without a norm) and this workgroup's slice
+// of the prologue's side outputs
+__device__ __forceinline__ float kon_factor_and_slices(const KonTail& kt, const QMVArgs& a, const float* red, uint32_t n_waves, uint32_t lane) {
+    const uint32_t col = lane & 15;
+    float inv = 1.0f;
+    if (kt.prenorm) { // the producer's partials, folded in a fixed order (the same value in every workgroup of the launch)
+        float s4 = (kt.pp[0] + kt.pp[1]) + (kt.pp[2] + kt.pp[3]);
+        for (uint32_t j = lane + 256; j < a.pro.n_ssq; j += 64) s4 += a.pro.ssq[j];
+        const float ss = rows_sum4(row16_sum(s4));
+        inv = 1.0f / sqrtf(ss / (float)kt.K + kt.eps); // reference.zig:365
+    } else if (kt.norm) { // the waves' sums of squares, in wave order (the same value in every workgroup of the launch)
+        const float sv = red[kMaxWaves * 16 + min(col, n_waves - 1)];
+        const float ss = row16_sum(col < n_waves ? sv : 0.f);
+        inv = 1.0f / sqrtf(ss / (float)kt.K + kt.eps); // reference.zig:365
+    }
+    if (kt.has_pro && lane < 16) { // this workgroup's slice of the absorbed ops' outputs (mid = a * inv, x = mid * b: reference order)
+        const QmvPrologue& pr = a.pro;
+        if (kt.slice <= 16) {
+            const uint32_t k = kt.k0 + lane;
+            if (lane < kt.slice && k < kt.K) {
+                const float mid = kt.norm ? kt.a_s * inv : kt.a_s;
+                if (kt.norm && pr.store_mid) pr.store_mid[k] = mid;
+                if (pr.store_x) pr.store_x[k] = mid * kt.b_s;
+            }
+        } else { // few workgroups, long vector: a loop over the slice (not a shape the LLaMA plans produce)
+            for (uint32_t k = kt.k0 + lane; k < min(kt.k0 + kt.slice, kt.K); k += 16) {
+                const float mid = kt.norm ? pr.a[k] * inv : pr.a[k];
+                if (kt.norm && pr.store_mid) pr.store_mid[k] = mid;
+                if (pr.store_x) pr.store_x[k] = mid * pr.b[k];
+            }
+        }
+    }
+    return inv;
+}
 template <bool GROUPED, bool KON = false>
 __device__ __forceinline__ void reduce_store(float acc, float* red, const QMVArgs& a, uint32_t pi, float* out0, uint32_t g, uint32_t m,
                                              float pre0, bool have_pre0, uint32_t n_waves, const QmvPublish* pub = nullptr, const KonTail* kon = nullptr,
@@ -394,39 +429,7 @@ __device__ __forceinline__ void reduce_store(float acc, float* red, const QMVArg
 #pragma unroll
     for (uint32_t j = 0; j < 4; j++) v += r + 4 * j < n_waves ? part[j] : 0.f;
     v = rows_sum4(v);
-    if (KON) {
-        v *= kon->post;
-        float inv = 1.0f;
-        if (kon->prenorm) { // the producer's partials, folded in a fixed order (the same value in every workgroup of the launch)
-            float s4 = (kon->pp[0] + kon->pp[1]) + (kon->pp[2] + kon->pp[3]);
-            for (uint32_t j = lane + 256; j < a.pro.n_ssq; j += 64) s4 += a.pro.ssq[j];
-            const float ss = rows_sum4(row16_sum(s4));
-            inv = 1.0f / sqrtf(ss / (float)kon->K + kon->eps); // reference.zig:365
-            v *= inv;
-        } else if (kon->norm) { // the waves' sums of squares, in wave order (the same value in every workgroup of the launch)
-            const float sv = red[kMaxWaves * 16 + min(col, n_waves - 1)];
-            const float ss = row16_sum(col < n_waves ? sv : 0.f);
-            inv = 1.0f / sqrtf(ss / (float)kon->K + kon->eps); // reference.zig:365
-            v *= inv;
-        }
-        if (kon->has_pro && lane < 16) { // this workgroup's slice of the absorbed ops' outputs (mid = a * inv, x = mid * b: reference order)
-            const QmvPrologue& pr = a.pro;
-            if (kon->slice <= 16) {
-                const uint32_t k = kon->k0 + lane;
-                if (lane < kon->slice && k < kon->K) {
-                    const float mid = kon->norm ? kon->a_s * inv : kon->a_s;
-                    if (kon->norm && pr.store_mid) pr.store_mid[k] = mid;
-                    if (pr.store_x) pr.store_x[k] = mid * kon->b_s;
-                }
-            } else { // few workgroups, long vector: a loop over the slice (not a shape the LLaMA plans produce)
-                for (uint32_t k = kon->k0 + lane; k < min(kon->k0 + kon->slice, kon->K); k += 16) {
-                    const float mid = kon->norm ? pr.a[k] * inv : pr.a[k];
-                    if (kon->norm && pr.store_mid) pr.store_mid[k] = mid;
-                    if (pr.store_x) pr.store_x[k] = mid * pr.b[k];
-                }
-            }
-        }
-    }
+    if (KON) v *= kon->post * kon_factor_and_slices(*kon, a, red, n_waves, lane);
     if (lane < 16) {
         const uint32_t n = g * 16 + threadIdx.x;
         // part 0's output pointer is a preloaded argument; further parts' come from the argument block
@@ -878,13 +881,42 @@ __global__ void __launch_bounds__(1024) qmatvec_kernel(QMV_HEAD_PARAMS, QMVArgs 
 // slices, 1 / workgroups of the vector each, by the lanes that store the results.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <bool NT, bool PRO, bool XV>
+// one dword of an item: 8 nibbles of one k -> four column pairs of the accumulators. ONE asm statement: left to hipcc the
+// converts of all dwords (and items) are hoisted in front of the FMAs, which costs hundreds of live registers (the pair
+// kernel spilled 200 of them); here six temporaries are live and converts and FMAs alternate. `tt.x` = t, broadcast to both
+// halves of the packed FMA by op_sel_hi (tt.y is never read).
+__device__ __forceinline__ void kon_dword(f32x2& a0, f32x2& a1, f32x2& a2, f32x2& a3, uint32_t dw, f32x2 tt) {
+    uint32_t lo, hi;
+    f32x2 c0, c1, c2, c3;
+    asm("v_and_b32_e32 %4, 0xf0f0f0f, %10\n\t"
+        "v_lshrrev_b32_e32 %5, 4, %10\n\t"
+        "v_cvt_pk_f32_fp8_e32 %6, %4\n\t"
+        "v_and_b32_e32 %5, 0xf0f0f0f, %5\n\t"
+        "v_cvt_pk_f32_fp8_sdwa %7, %4 src0_sel:WORD_1\n\t"
+        "v_cvt_pk_f32_fp8_e32 %8, %5\n\t"
+        "v_pk_fma_f32 %0, %6, %11, %0 op_sel_hi:[1,0,1]\n\t"
+        "v_cvt_pk_f32_fp8_sdwa %9, %5 src0_sel:WORD_1\n\t"
+        "v_pk_fma_f32 %1, %7, %11, %1 op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %2, %8, %11, %2 op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %3, %9, %11, %3 op_sel_hi:[1,0,1]"
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "=&v"(lo), "=&v"(hi), "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3)
+        : "v"(dw), "v"(tt));
+}
+__device__ __forceinline__ void kon_dword(f32x2 (&acc)[8], int c, uint32_t dw, float t) {
+    f32x2 tt;
+    tt.x = t, tt.y = t;
+    kon_dword(acc[c], acc[c + 1], acc[c + 2], acc[c + 3], dw, tt);
+}
+// PAIR: the same k-pair and columns of a SECOND matrix (same shape, `pair_off` items / scale pairs further on) ride along: x is
+// loaded once and both column sets are accumulated (gate / up: kon_pair_finish)
+template <bool NT, bool PRO, bool XV, bool PAIR>
 struct KonItem { // one lane's share of a step: k = 2p, 2p + 1 x 16 columns
-    uint4 wq;
-    uint32_t s2;
+    uint4 wq, wq_b;
+    uint32_t s2, s2_b;
     f32x2 xa, xb;
     // unconditional, clamped (counted vmcnt waits need straight-line loads); XV: the vectors are 8-byte aligned and K is even
-    __device__ __forceinline__ void load(const uint4* qs, const uint32_t* sc, const float* a, const float* b, uint32_t p, uint32_t p_last, uint32_t K) {
+    __device__ __forceinline__ void load(const uint4* qs, const uint32_t* sc, const float* a, const float* b, uint32_t p, uint32_t p_last, uint32_t K,
+                                         uint64_t pair_q, uint64_t pair_s) {
         const uint32_t pd = min(p, p_last);
         if (XV) {
             xa = *(const f32x2*)(a + 2 * pd);
@@ -895,9 +927,11 @@ struct KonItem { // one lane's share of a step: k = 2p, 2p + 1 x 16 columns
             if (PRO) xb = f32x2{b[2 * pd], b[k1]};
         }
         s2 = sc[pd];
+        if (PAIR) s2_b = sc[pair_s + pd];
         wq = wload<NT>(qs + pd);
+        if (PAIR) wq_b = wload<NT>(qs + pair_q + pd);
     }
-    __device__ __forceinline__ void compute(uint32_t pd, uint32_t P, uint32_t K, f32x2 (&acc)[8], float& T, float& SS) const {
+    __device__ __forceinline__ void compute(uint32_t pd, uint32_t P, uint32_t K, f32x2 (&acc)[8], f32x2 (&acc_b)[8], float& T, float& T_b, float& SS) const {
         const bool ok0 = pd < P, ok1 = ok0 && (XV || 2 * pd + 1 < K);
         float x0 = ok0 ? xa.x : 0.f, x1 = ok1 ? xa.y : 0.f;
         if (PRO) {
@@ -909,17 +943,19 @@ struct KonItem { // one lane's share of a step: k = 2p, 2p + 1 x 16 columns
         const float t0 = __low2float(h) * x0, t1 = __high2float(h) * x1; // (scale * x as the reference rounds it, reference.zig:552)
         T += t0;
         T += t1;
-        const uint32_t dw[4] = {wq.x, wq.y, wq.z, wq.w};
-#pragma unroll
-        for (int dd = 0; dd < 4; dd++) {
-            const float t = dd < 2 ? t0 : t1;
-            const f32x2 tt = f32x2{t, t};
-            const uint32_t lo = dw[dd] & 0x0F0F0F0Fu, hi = (dw[dd] >> 4) & 0x0F0F0F0Fu;
-            const int c = 4 * (dd & 1);
-            acc[c + 0] = __builtin_elementwise_fma(__builtin_amdgcn_cvt_pk_f32_fp8((int)lo, false), tt, acc[c + 0]);
-            acc[c + 1] = __builtin_elementwise_fma(__builtin_amdgcn_cvt_pk_f32_fp8((int)lo, true), tt, acc[c + 1]);
-            acc[c + 2] = __builtin_elementwise_fma(__builtin_amdgcn_cvt_pk_f32_fp8((int)hi, false), tt, acc[c + 2]);
-            acc[c + 3] = __builtin_elementwise_fma(__builtin_amdgcn_cvt_pk_f32_fp8((int)hi, true), tt, acc[c + 3]);
+        kon_dword(acc, 0, wq.x, t0);
+        kon_dword(acc, 4, wq.y, t0);
+        kon_dword(acc, 0, wq.z, t1);
+        kon_dword(acc, 4, wq.w, t1);
+        if (PAIR) {
+            const __half2 hb = *(const __half2*)&s2_b;
+            const float u0 = __low2float(hb) * x0, u1 = __high2float(hb) * x1;
+            T_b += u0;
+            T_b += u1;
+            kon_dword(acc_b, 0, wq_b.x, u0);
+            kon_dword(acc_b, 4, wq_b.y, u0);
+            kon_dword(acc_b, 0, wq_b.z, u1);
+            kon_dword(acc_b, 4, wq_b.w, u1);
         }
     }
 };
@@ -937,11 +973,59 @@ __device__ __forceinline__ float kon_fold16(float a, float b) {
 
 // PROM: 0 = no prologue, 1 = in-kernel (x = a * b, optionally the deferred rmsnorm), 2 = PRENORM (xa_base is the producer's a * b,
 // the factor comes from its partial sums of squares)
-template <int DEPTH, int PROM, bool GROUPED, bool XV, bool NT>
+// the 16 per-lane column sums of a wave -> red[column] (lanes i < 4 of each row write; see the fold comment in the body)
+__device__ __forceinline__ void kon_fold_wave(f32x2 (&acc)[8], float T, float* red_w, uint32_t r, uint32_t i) {
+    // w = q - 8, per lane, before any cross-lane sum: the sums hold t * q / 512, so acc -= T * 8 / 512. With every q = 8 the
+    // chain acc <- fl(acc + t / 64) equals T / 64 term by term (a power of two commutes with rounding): exactly 0 comes out
+    const f32x2 TT = f32x2{T, T}, m64 = f32x2{-0.015625f, -0.015625f};
+#pragma unroll
+    for (int c = 0; c < 8; c++) acc[c] = __builtin_elementwise_fma(TT, m64, acc[c]);
+    // acc[c] = columns (2c, 2c + 1): after kon_fold32 over column pairs and kon_fold16 over those, register m holds, in row r,
+    // the partial of column 4m + {0, 2, 1, 3}[r]; one row fold finishes it
+    float a8[8];
+#pragma unroll
+    for (int m2 = 0; m2 < 8; m2++) a8[m2] = kon_fold32(acc[m2].x, acc[m2].y);
+    float a4[4];
+#pragma unroll
+    for (int m4 = 0; m4 < 4; m4++) a4[m4] = row16_sum(kon_fold16(a8[2 * m4], a8[2 * m4 + 1]));
+    const float v = (i & 2) ? ((i & 1) ? a4[3] : a4[2]) : ((i & 1) ? a4[1] : a4[0]);
+    if (i < 4) red_w[4 * i + ((r & 1) * 2 + (r >> 1))] = v;
+}
+
+// PAIR launches (gate / up): part 0 carries the SiLU chain, part 1 is plain, and the elementwise product silu(gate) * up that
+// the plan's NEXT mat-vec (the down projection) would recompute as its prologue is stored here, `pair_out` (runtime.hip:
+// arm_pair) — both operands of that product are in this workgroup's registers. Wave 0, behind the barrier.
+__device__ __forceinline__ void kon_pair_finish(const float* red, const QMVArgs& a, float* out0, uint32_t g, uint32_t n_waves, const KonTail& kt, float ones) {
+    const uint32_t lane = threadIdx.x & 63, r = lane >> 4, col = lane & 15;
+    float pa[4], pb[4];
+#pragma unroll
+    for (uint32_t j = 0; j < 4; j++) { // clamped, unconditional
+        const uint32_t ww = min(r + 4 * j, n_waves - 1);
+        pa[j] = red[ww * 16 + col], pb[j] = red[(kMaxWaves + 1 + ww) * 16 + col];
+    }
+    float va = 0.f, vb = 0.f;
+#pragma unroll
+    for (uint32_t j = 0; j < 4; j++) va += r + 4 * j < n_waves ? pa[j] : 0.f, vb += r + 4 * j < n_waves ? pb[j] : 0.f;
+    va = rows_sum4(va), vb = rows_sum4(vb);
+    const float f = kt.post * kon_factor_and_slices(kt, a, red, n_waves, lane);
+    va *= f, vb *= f;
+    if (lane < 16) {
+        const uint32_t n = g * 16 + lane;
+        out0[n] = va;
+        a.parts[1].out[n] = vb;
+        const float e = expf(-va); // NEG, EXP [store], ADD ones, RECIP, MUL by the gate [store]: run_epilogue_silu
+        a.parts[0].epi[1].store[n] = e;
+        const float sl = (1.0f / (e + ones)) * va;
+        a.parts[0].epi[4].store[n] = sl;
+        a.pair_out[n] = sl * vb;
+    }
+}
+
+template <int DEPTH, int PROM, bool GROUPED, bool XV, bool NT, bool PAIR = false>
 __device__ __forceinline__ void qmatvec_kon_body(QMV_HEAD_PARAMS, const QMVArgs& a, const uint32_t bx, const uint32_t n_blocks, const QmvPublish* pub) {
     constexpr bool PRO = PROM == 1;
     extern __shared__ float smem[];
-    float* red = smem; // kMaxWaves * 16 column sums + kMaxWaves sums of squares
+    float* red = smem; // kMaxWaves * 16 column sums + kMaxWaves sums of squares (PAIR: the second matrix's sums from row kMaxWaves + 1)
 #ifdef ZGML_TRACE
 #define QMV_STAMP(i) do { if (a.trace && (bx == 0 || bx == n_blocks - 1) && threadIdx.x == 0) a.trace[(bx ? 8 : 0) + i] = wall_clock64(); } while (0)
 #else
@@ -955,7 +1039,7 @@ __device__ __forceinline__ void qmatvec_kon_body(QMV_HEAD_PARAMS, const QMVArgs&
     const uint32_t n_waves = ((nb2_0_flags >> 20) & 0xFu) + 1, stride = n_waves * 64;
     const uint32_t NB2_0 = nb2_0_flags & 0xFFFFFu, n_parts = (nb2_0_flags >> 24) & 0xF, NB2_1 = nb2_12 & 0xFFFFu, NB2_2 = nb2_12 >> 16;
     uint32_t NB2 = NB2_0, block_begin = 0;
-    if (GROUPED) {
+    if (GROUPED && !PAIR) { // (PAIR: two contiguous parts of equal shape, one workgroup per column group of BOTH)
         if ((nb2_0_flags >> 28) & 1) { // contiguous parts: everything from preloaded scalars (see the form above)
             const uint32_t b1 = NB2_0, b2 = b1 + NB2_1;
             if (n_parts > 1 && bx >= b1) pi = 1, block_begin = b1, NB2 = NB2_1;
@@ -983,9 +1067,10 @@ __device__ __forceinline__ void qmatvec_kon_body(QMV_HEAD_PARAMS, const QMVArgs&
     uint32_t p = threadIdx.x;
     // DEPTH items per lane in flight, refilled one by one: item d of the next group is requested into the registers item d of
     // this group has just left (no second register set, and the stream never drains inside a workgroup)
-    KonItem<NT, PRO, XV> it[DEPTH];
+    const uint64_t pair_q = PAIR ? (uint64_t)NB2_0 * P : 0, pair_s = PAIR ? (uint64_t)(NB2_0 >> 1) * P : 0; // part 1 follows part 0 in the arenas
+    KonItem<NT, PRO, XV, PAIR> it[DEPTH];
 #pragma unroll
-    for (int d = 0; d < DEPTH; d++) it[d].load(qs, sc, xa_base, xb_base, p + d * stride, p_last, K);
+    for (int d = 0; d < DEPTH; d++) it[d].load(qs, sc, xa_base, xb_base, p + d * stride, p_last, K, pair_q, pair_s);
     // this workgroup's slice of the prologue's side outputs: its inputs are requested now, under the weight stream
     KonTail tail{512.0f, norm, 0.f, K, 0.f, 0.f, 0u, 0u, PROM != 0, PROM == 2, {0.f, 0.f, 0.f, 0.f}};
     if (PROM != 0) { // (PRENORM: xb_base carries the ORIGINAL vector a, a.pro.b the gain: the slices are stored from those)
@@ -1026,41 +1111,38 @@ __device__ __forceinline__ void qmatvec_kon_body(QMV_HEAD_PARAMS, const QMVArgs&
         const float* const gp = a.next.xg_out ? a.next.gamma : nullptr;
         pre_g = (gp ? gp : xa_base)[gp ? g * 16 + i : 0];
     }
-    f32x2 acc[8];
+    float ones = 0.f;
+    if (PAIR) ones = a.parts[0].epi[2].operand[g * 16 + i]; // the SiLU chain's constant vector, requested under the stream
+    f32x2 acc[8], acc_b[PAIR ? 8 : 1];
 #pragma unroll
     for (int c = 0; c < 8; c++) acc[c] = f32x2{0.f, 0.f};
-    float T = 0.f, SS = 0.f;
+#pragma unroll
+    for (int c = 0; c < (PAIR ? 8 : 1); c++) acc_b[c] = f32x2{0.f, 0.f};
+    float T = 0.f, T_b = 0.f, SS = 0.f;
+    auto compute = [&](const KonItem<NT, PRO, XV, PAIR>& item, uint32_t pd) {
+        if constexpr (PAIR)
+            item.compute(pd, P, K, acc, acc_b, T, T_b, SS);
+        else
+            item.compute(pd, P, K, acc, acc, T, T_b, SS);
+    };
     for (uint32_t gi = 1; gi < n_groups; gi++) {
 #pragma unroll
         for (int d = 0; d < DEPTH; d++) {
-            it[d].compute(p + d * stride, P, K, acc, T, SS);
+            compute(it[d], p + d * stride);
             __builtin_amdgcn_sched_barrier(0); // (hipcc otherwise moves the refills to the end of the body)
-            it[d].load(qs, sc, xa_base, xb_base, p + (DEPTH + d) * stride, p_last, K);
+            it[d].load(qs, sc, xa_base, xb_base, p + (DEPTH + d) * stride, p_last, K, pair_q, pair_s);
             __builtin_amdgcn_sched_barrier(0);
         }
         p += DEPTH * stride;
     }
 #pragma unroll
-    for (int d = 0; d < DEPTH; d++) it[d].compute(p + d * stride, P, K, acc, T, SS);
+    for (int d = 0; d < DEPTH; d++) compute(it[d], p + d * stride);
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("" ::"s"(arg_touch));
 #endif
     QMV_STAMP(4); // weights streamed
-    // w = q - 8, per lane, before any cross-lane sum: the sums hold t * q / 512, so acc -= T * 8 / 512. With every q = 8 the
-    // chain acc <- fl(acc + t / 64) equals T / 64 term by term (a power of two commutes with rounding): exactly 0 comes out
-    const f32x2 TT = f32x2{T, T}, m64 = f32x2{-0.015625f, -0.015625f};
-#pragma unroll
-    for (int c = 0; c < 8; c++) acc[c] = __builtin_elementwise_fma(TT, m64, acc[c]);
-    // acc[c] = columns (2c, 2c + 1) ... fold the wave: after kon_fold32 over column pairs and kon_fold16 over those, register m
-    // holds, in row r, the partial of column 4m + {0, 2, 1, 3}[r]; one row fold finishes it
-    float a8[8];
-#pragma unroll
-    for (int m2 = 0; m2 < 8; m2++) a8[m2] = kon_fold32(acc[m2].x, acc[m2].y);
-    float a4[4];
-#pragma unroll
-    for (int m4 = 0; m4 < 4; m4++) a4[m4] = row16_sum(kon_fold16(a8[2 * m4], a8[2 * m4 + 1]));
-    const float v = (i & 2) ? ((i & 1) ? a4[3] : a4[2]) : ((i & 1) ? a4[1] : a4[0]);
-    if (i < 4) red[w * 16 + 4 * i + ((r & 1) * 2 + (r >> 1))] = v;
+    kon_fold_wave(acc, T, red + w * 16, r, i);
+    if constexpr (PAIR) kon_fold_wave(acc_b, T_b, red + (kMaxWaves + 1 + w) * 16, r, i);
     if (PRO) {
         SS = row16_sum(SS);
         SS = kon_fold32(SS, SS);
@@ -1068,7 +1150,12 @@ __device__ __forceinline__ void qmatvec_kon_body(QMV_HEAD_PARAMS, const QMVArgs&
         if (lane == 0) red[kMaxWaves * 16 + w] = SS;
     }
     if (PROM != 0) tail.eps = a.pro.eps;
-    reduce_store<GROUPED, true>(0.f, red, a, pi, out0, g, 0, pre0, have_pre0, n_waves, pub, &tail, pre_g);
+    if constexpr (PAIR) {
+        __syncthreads();
+        if (w == 0) kon_pair_finish(red, a, out0, g, n_waves, tail, ones);
+    } else {
+        reduce_store<GROUPED, true>(0.f, red, a, pi, out0, g, 0, pre0, have_pre0, n_waves, pub, &tail, pre_g);
+    }
     QMV_STAMP(5);
 #undef QMV_STAMP
 }
@@ -1076,6 +1163,11 @@ __device__ __forceinline__ void qmatvec_kon_body(QMV_HEAD_PARAMS, const QMVArgs&
 template <int DEPTH, int PROM, bool GROUPED, bool XV, bool NT>
 __global__ void __launch_bounds__(1024) qmatvec_kon_kernel(QMV_HEAD_PARAMS, QMVArgs a) {
     qmatvec_kon_body<DEPTH, PROM, GROUPED, XV, NT>(qs0, sc0, out0, xa_base, xb_base, in_rs, K, nb2_0_flags, nb2_12, a, blockIdx.x, gridDim.x, nullptr);
+}
+// gate / up in pairs (8 waves at most: 512-thread launch bound, the two column sets need the registers)
+template <int DEPTH, int PROM, bool NT>
+__global__ void __launch_bounds__(512, 4) qmatvec_kon_pair_kernel(QMV_HEAD_PARAMS, QMVArgs a) { // (4 waves per SIMD: two workgroups per CU, <= 128 registers)
+    qmatvec_kon_body<DEPTH, PROM, true, true, NT, true>(qs0, sc0, out0, xa_base, xb_base, in_rs, K, nb2_0_flags, nb2_12, a, blockIdx.x, gridDim.x, nullptr);
 }
 
 // The q / k / v projection and the decode attention that consumes it in ONE launch (DESIGN.md section 8.0,
@@ -1092,16 +1184,13 @@ struct QkvAttnArgs {
     QmvPublish pub;
     DecodeHandoff ho;
 };
-template <typename ST, bool Q4, int LPK, bool KVQ, bool KON = false, int PROM = 1>
+template <typename ST, bool Q4, int LPK, bool KVQ>
 __global__ void __launch_bounds__(1024) qkv_attn_kernel(QMV_HEAD_PARAMS, QMVArgs a, QkvAttnArgs f) {
     constexpr int DEPTH = 1; // K <= 2048 with up to 16 waves: one load step
     if (blockIdx.x < f.n_mv) {
         const uint32_t n_waves = ((nb2_0_flags >> 20) & 0xFu) + 1;
         if (threadIdx.x >= n_waves * 64) return; // (whole waves: they no longer count at the barriers)
-        if constexpr (KON) // K-on-lanes weights (QW_Q4K); the launcher checked x alignment
-            qmatvec_kon_body<DEPTH, PROM, true, true, false>(qs0, sc0, out0, xa_base, xb_base, in_rs, K, nb2_0_flags, nb2_12, a, blockIdx.x, f.n_mv, &f.pub);
-        else
-            qmatvec_body<ST, false, DEPTH, Q4, true, true, true, false>(qs0, sc0, out0, xa_base, xb_base, in_rs, K, nb2_0_flags, nb2_12, a, blockIdx.x, &f.pub);
+        qmatvec_body<ST, false, DEPTH, Q4, true, true, true, false>(qs0, sc0, out0, xa_base, xb_base, in_rs, K, nb2_0_flags, nb2_12, a, blockIdx.x, &f.pub);
     } else {
         const uint32_t b = blockIdx.x - f.n_mv, n_heads = f.ho.n_heads; // head-major: the always-active split 0 of every head first
         attention_decode_body<LPK, KVQ>(f.params, f.split_buf, f.split_cnt, f.split_min_keys, b % n_heads, b / n_heads, f.n_sp, &f.ho);
@@ -2164,7 +2253,11 @@ KernelFn pick_kon_depth(int depth_sel, bool nt) {
     switch (depth_sel) {
         case 0: return qmatvec_kon_kernel<1, PROM, GRP, XV, false>;
         case 1: return qmatvec_kon_kernel<2, PROM, GRP, XV, false>;
-        default: return nt ? qmatvec_kon_kernel<4, PROM, GRP, XV, true> : qmatvec_kon_kernel<4, PROM, GRP, XV, false>;
+        default:
+            if constexpr (PROM == 1) // (an in-kernel prologue runs at most two items per lane: launch_packed_kon)
+                return qmatvec_kon_kernel<2, PROM, GRP, XV, false>;
+            else
+                return nt ? qmatvec_kon_kernel<4, PROM, GRP, XV, true> : qmatvec_kon_kernel<4, PROM, GRP, XV, false>;
     }
 }
 template <int PROM>
@@ -2207,24 +2300,22 @@ bool launch_packed_kon(hipStream_t s, QMVArgs& a, const QWeightDev& w0, uint32_t
     const float* const head_xb = prom == 2 ? a.pro.a : a.pro.b;
     const uint32_t flags = a.parts[0].NB2 | ((waves_used - 1) << 20) | (a.n_parts << 24) | (contig ? 1u << 28 : 0u) | (a.pro.kind == QMV_PRO_RMSNORM_MUL ? 1u << 29 : 0u) |
                            (a.x_vec ? 1u << 30 : 0u);
-    if (fused) {
-        if (!(pro && grp && !nt && contig && xvec && a.n_parts == 3 && depth_sel == 0 && (d_head == 64 || d_head == 128))) return false;
-        QkvAttnArgs f = *fused;
-        f.n_mv = total_blocks;
-        using FusedFn = void (*)(const uint4*, const void*, float*, const float*, const float*, uint32_t, uint32_t, uint32_t, uint32_t, QMVArgs, QkvAttnArgs);
-        FusedFn ff = nullptr;
-        if (prom == 2) {
-            if (d_head == 64)
-                ff = f.kvq ? qkv_attn_kernel<__half, true, 16, true, true, 2> : qkv_attn_kernel<__half, true, 16, false, true, 2>;
-            else
-                ff = f.kvq ? qkv_attn_kernel<__half, true, 32, true, true, 2> : qkv_attn_kernel<__half, true, 32, false, true, 2>;
-        } else if (d_head == 64) {
-            ff = f.kvq ? qkv_attn_kernel<__half, true, 16, true, true> : qkv_attn_kernel<__half, true, 16, false, true>;
-        } else {
-            ff = f.kvq ? qkv_attn_kernel<__half, true, 32, true, true> : qkv_attn_kernel<__half, true, 32, false, true>;
+    if (fused) return false; // (the fused q/k/v + attention launch is built for the n-on-lanes form: short K keeps that layout, compile_program)
+    if (a.pair_out) { // gate / up in pairs (arm_pair checked the shapes and the epilogues; the layout conditions are checked here)
+        const bool pair_ok = a.n_parts == 2 && contig && xvec && prom != 1 && a.parts[0].NB2 == a.parts[1].NB2 && a.parts[0].NB2 % 2 == 0 && waves_used <= 8;
+        if (!pair_ok) {
+            fprintf(stderr, "[zgml_hip] ERROR: a gate / up pair launch that does not meet the pair kernel's layout conditions: not launched\n");
+            return false;
         }
-        hipLaunchKernelGGL(ff, dim3(total_blocks + extra_blocks), dim3(1024), lds, s, a.parts[0].qs, a.parts[0].sc, a.parts[0].out, head_xa, head_xb, a.in_rs, a.K, flags,
-                           nb2_12, a, f);
+        using PairFn = void (*)(const uint4*, const void*, float*, const float*, const float*, uint32_t, uint32_t, uint32_t, uint32_t, QMVArgs);
+        PairFn pf = nullptr;
+        // two items per lane in flight = the bytes of four in a single-matrix launch (deeper: the two column sets no longer fit 128 registers)
+        if (prom == 2)
+            pf = depth_sel == 0 ? qmatvec_kon_pair_kernel<1, 2, false> : (nt ? qmatvec_kon_pair_kernel<2, 2, true> : qmatvec_kon_pair_kernel<2, 2, false>);
+        else
+            pf = depth_sel == 0 ? qmatvec_kon_pair_kernel<1, 0, false> : (nt ? qmatvec_kon_pair_kernel<2, 0, true> : qmatvec_kon_pair_kernel<2, 0, false>);
+        const size_t lds2 = ((size_t)(2 * kMaxWaves + 1) * 16) * sizeof(float);
+        hipLaunchKernelGGL(pf, dim3(a.parts[0].NB2), dim3(waves_used * 64), lds2, s, a.parts[0].qs, a.parts[0].sc, a.parts[0].out, head_xa, head_xb, a.in_rs, a.K, flags, nb2_12, a);
         return true;
     }
     const KernelFn fn = pick_kon(prom, grp, xvec, depth_sel, nt);
@@ -2524,6 +2615,7 @@ static void build_qmv_args(const QmvLaunch& L, QMVArgs& a, uint32_t& blocks, boo
     }
     a.pro = L.pro;
     a.next = L.next;
+    a.pair_out = L.pair_out;
     if (a.pro.kind == QMV_PRO_NONE) a.pro.b = a.pro.a;
     a.M = 1, a.K = L.K;
     a.U = w0.format == QW_Q4 ? w0.KC : 2 * w0.KC;

@@ -1118,6 +1118,44 @@ void arm_prenorm(zgml_hip_program* p) {
     }
 }
 
+// gate / up -> down: the grouped launch {gate with the SiLU chain, up} directly followed by the mat-vec whose MUL prologue
+// multiplies exactly silu(gate) and up becomes a PAIR launch (qmatvec.hip: qmatvec_kon_pair_kernel): one workgroup computes
+// the same 16 columns of both matrices (x is loaded once) and stores the product itself; the down projection then streams
+// one vector with no prologue (x = a * b per lane meant two 44 KB vectors per workgroup at Llama-2-7B's d_ff). K-on-lanes
+// weights only.
+void arm_pair(zgml_hip_program* p) {
+    static const bool on = !(getenv("ZGML_HIP_PAIR") && atoi(getenv("ZGML_HIP_PAIR")) == 0);
+    if (!on) return;
+    for (size_t i = 1; i < p->plan.size(); i++) {
+        const auto D = p->plan[i].qmv_desc, G = p->plan[i - 1].qmv_desc;
+        if (!D || !G || D->pro.kind != QMV_PRO_MUL || !D->pro.store_x || G->n_parts != 2 || G->pair_out || G->trace) continue;
+        const QmvPart &ga = G->parts[0], &up = G->parts[1];
+        const QmvEpiStep* st = ga.epi;
+        // the SiLU chain exactly as build_qmv_args recognises it (NEG, EXP [store], ADD vector, RECIP, MUL by the gate [store])
+        bool ok = ga.n_epi == 5 && st[0].op == ZGML_OP_NEG && !st[0].store && st[1].op == ZGML_OP_EXP && st[1].store && st[2].op == ZGML_OP_ADD &&
+                  st[2].operand && st[2].operand != ga.dst && st[2].operand != st[1].store && !st[2].store && st[3].op == ZGML_OP_RECIP && !st[3].store &&
+                  st[4].op == ZGML_OP_MUL && st[4].operand == ga.dst && st[4].store && up.n_epi == 0;
+        ok = ok && ga.w.format == QW_Q4K && up.w.format == QW_Q4K && ga.w.N == up.w.N && ga.w.K == up.w.K && (ga.w.N / 16) % 2 == 0 && ga.w.N == D->K &&
+             (G->pro.kind == QMV_PRO_NONE || G->pro.kind == QMV_PRO_PRENORM) && D->n_parts == 1;
+        // the product's operands: silu(gate) and up, in either order (an f32 product does not depend on it)
+        ok = ok && ((D->pro.a == st[4].store && D->pro.b == up.dst) || (D->pro.b == st[4].store && D->pro.a == up.dst));
+        // the two weights back to back in the arenas (the pair kernel finds part 1 from part 0)
+        ok = ok && (const char*)up.w.qs == (const char*)ga.w.qs + ga.w.qs_bytes && (const char*)up.w.sc == (const char*)ga.w.sc + ga.w.sc_bytes;
+        ok = ok && ((uintptr_t)G->pro.a % 16 == 0) && (G->K % 4 == 0) && (G->pro.kind != QMV_PRO_PRENORM || (uintptr_t)G->pro.xg % 16 == 0);
+        if (!ok) continue;
+        { // a declared barrier between the two launches keeps them independent (zgml_hip_program_set_barriers)
+            const uint64_t lo_b = std::min(p->plan[i - 1].op_lo, p->plan[i].op_lo), hi_b = std::max(p->plan[i - 1].op_hi, p->plan[i].op_hi);
+            bool cut = false;
+            for (uint64_t b : p->barriers) cut = cut || (b > lo_b && b <= hi_b);
+            if (cut) continue;
+        }
+        G->pair_out = D->pro.store_x;
+        QmvPrologue plain;
+        plain.a = D->pro.store_x;
+        D->pro = plain;
+    }
+}
+
 void build_fused_plan(zgml_hip_program* p) {
     const auto& ops = p->ops;
     const size_t n = ops.size();
@@ -1941,6 +1979,7 @@ void build_fused_plan(zgml_hip_program* p) {
         }
     }
     arm_prenorm(p);
+    arm_pair(p);
     fuse_qkv_attention(p);
 }
 
