@@ -380,7 +380,13 @@ enum {
     /* keys per workgroup at which a fused decode attention starts to split one head's context over
      * several workgroups (flash-decoding split; default 128, minimum 32, 0 = never split). A head splits
      * once seq_kv >= 2 * value; below that the launch behaves exactly as without the option. */
-    ZGML_HIP_OPT_ATTN_SPLIT_MIN_KEYS = 7
+    ZGML_HIP_OPT_ATTN_SPLIT_MIN_KEYS = 7,
+    /* workgroups (1024 threads) the device is assumed to keep resident at once, for the launch that carries the q/k/v
+     * projection AND the decode attention that waits for it in one grid (the waiting workgroups spin on workgroups of the
+     * same grid, so the whole grid must be resident): the fusion is only built when projection + attention workgroups fit,
+     * the attention's split count shrinks to fit, otherwise the two launches stay apart. -1 (default): one per compute
+     * unit. 0: never fuse. Takes effect for programs compiled afterwards and at the next plan rebuild of existing ones. */
+    ZGML_HIP_OPT_FUSE_RESIDENT_WGS = 8
 };
 int zgml_hip_set_option(zgml_hip_ctx* ctx, int option, int64_t value);
 /* Drop the cached device copy of host operand `b` (NULL: all of them). */

@@ -337,12 +337,13 @@ __device__ __forceinline__ void attention_decode_body(const AttnDecodeParams* __
                     ok = ok && (int32_t)(__hip_atomic_load((gu32*)ho->cnt + 32 * ci[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target[c]) >= 0;
                 if (ok) break;
                 if (++spins > 400000u) { // bounded: never hang the device; the caller sees the flag
-                    if (tid == 0) atomicAdd(ho->timeout, 1u);
+                    if (tid == 0) __hip_atomic_store(ho->timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); // host-visible word (runtime.hip: handoff_ok)
                     break;
                 }
                 for (uint32_t z = 0; z < ho->poll_sleep; z++) __builtin_amdgcn_s_sleep(1);
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // the agent-scope loads of q / k / v below stay behind the poll (compiler ordering; they bypass L1 themselves)
         if (NW > 1) __syncthreads(); // (waves >= NW have retired and do not count)
         auto ld_agent4 = [](const float* p) { // agent scope: never a stale line of this XCD's L2
             float4 v;

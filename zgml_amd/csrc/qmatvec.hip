@@ -332,6 +332,7 @@ struct QmvPublish {
     uint32_t* cnt;         // [n_heads | n_kv | n_kv]
     uint32_t base[3];      // first counter of part 0 / 1 / 2 (q, k, v)
     uint32_t groups_shift; // log2(d_head / 16): column group -> head slice
+    uint32_t drop;         // diagnostics (ZGML_HIP_DEBUG_DROP_PUBLISH=1): column group 0 of part 0 never signals — its consumers time out
 };
 
 // Fold the 4 rows of each wave, then the waves, in fixed order; 16 outputs per workgroup. The 16
@@ -476,7 +477,7 @@ __device__ __forceinline__ void reduce_store(float acc, float* red, const QMVArg
 #if defined(__HIP_DEVICE_COMPILE__)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the write-through stores of this wave's 16 lanes have left
 #endif
-        if (lane == 0)
+        if (lane == 0 && !(pub->drop && pi == 0 && g == 0))
             __hip_atomic_fetch_add((__attribute__((address_space(1))) uint32_t*)pub->cnt + 32 * (pub->base[pi < 3 ? pi : 2] + (g >> pub->groups_shift)), 1u,
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -771,12 +772,13 @@ __device__ __forceinline__ void qmatvec_body(QMV_HEAD_PARAMS, const QMVArgs& a, 
                 uint32_t spins = 0;
                 while ((int32_t)(__hip_atomic_load((const __attribute__((address_space(1))) uint32_t*)wt->cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
                     if (++spins > 400000u) { // bounded: never hang the device; the caller sees the flag
-                        if (threadIdx.x == 0) atomicAdd(wt->timeout, 1u);
+                        if (threadIdx.x == 0) __hip_atomic_store(wt->timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         break;
                     }
                     __builtin_amdgcn_s_sleep(10); // ~0.3 us between polls (2: 1724, 10: 1741, 40: 1728 tok/s): 36 workgroups polling ONE line back to back starve the line
                 }
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // the agent-scope x loads below stay behind the poll
             if (n_waves > 1) __syncthreads();
             if (threadIdx.x == 0) wt->seen[bx] = target; // (every wave read it before the barrier)
             cur.template load<2, true>(qs, sc, u, stride, u_last, xd, i);
@@ -2243,7 +2245,10 @@ static bool plain_head_depth1(const QMVArgs& a, const QWeightDev& w0, uint32_t b
 uint32_t kon_waves(const QWeightDev& w) {
     const uint32_t wave_steps = cdiv((w.K + 1) / 2, 64);
     static const int small_cap = getenv("ZGML_QMV_KON_WAVES_SMALLK") ? atoi(getenv("ZGML_QMV_KON_WAVES_SMALLK")) : 16;
-    static const int big_cap = getenv("ZGML_QMV_KON_WAVES") ? atoi(getenv("ZGML_QMV_KON_WAVES")) : 8;
+    // (in-decode sweep per launch shape, Llama-2-7B, tools/tune_kon.sh: 4 waves for q/k/v, o, gate/up and the LM head, 8 for
+    // the down projection's K = 11008: 765 tok/s with 8 everywhere, 792 with 4, 807 with this rule)
+    static const int big_env = getenv("ZGML_QMV_KON_WAVES") ? atoi(getenv("ZGML_QMV_KON_WAVES")) : 0;
+    const int big_cap = big_env > 0 ? big_env : (w.K > 6144 ? 8 : 4);
     const uint32_t cap = (uint32_t)std::max(1, std::min(16, w.K <= 2048 ? small_cap : big_cap));
     return std::max(1u, std::min(wave_steps, cap));
 }
@@ -2275,7 +2280,22 @@ bool launch_packed_kon(hipStream_t s, QMVArgs& a, const QWeightDev& w0, uint32_t
                        uint32_t d_head, const FusedO* fo) {
     if (fo) return false; // (the O projection riding along is only built for the n-on-lanes form; off by default)
     a.x_vec = xvec ? 1 : 0;
-    const uint32_t P = (a.K + 1) / 2, waves = kon_waves(w0);
+    const uint32_t P = (a.K + 1) / 2;
+    uint32_t waves = kon_waves(w0);
+    int tune_depth = 0; // 0: by the step count
+    { // experiments: ZGML_QMV_KON_TUNE="<blocks>x<K>:<waves>,..." overrides the wave count of the launches of that grid and K
+        static const char* tune = getenv("ZGML_QMV_KON_TUNE");
+        for (const char* q = tune; q && *q;) {
+            unsigned b = 0, k = 0, wv = 0, dp = 0;
+            const int got = sscanf(q, "%ux%u:%u:%u", &b, &k, &wv, &dp);
+            if (got >= 3 && b == total_blocks && k == a.K && wv >= 1 && wv <= 16) {
+                waves = wv;
+                if (got == 4) tune_depth = (int)dp;
+            }
+            q = strchr(q, ',');
+            if (q) q++;
+        }
+    }
     static const bool contig_ok = !(getenv("ZGML_QMV_CONTIG") && atoi(getenv("ZGML_QMV_CONTIG")) == 0);
     bool contig = a.n_parts > 1 && a.n_parts <= 3 && contig_ok;
     for (uint32_t t = 1; t < a.n_parts && contig; t++) {
@@ -2294,7 +2314,9 @@ bool launch_packed_kon(hipStream_t s, QMVArgs& a, const QWeightDev& w0, uint32_t
     if (prom == 1 && cdiv(P, waves * 64) >= 4) waves_used = std::min<uint32_t>(kMaxWaves, waves * 2);
     const uint32_t n_steps = cdiv(P, waves_used * 64);
     int depth_sel = n_steps >= 4 ? 2 : (n_steps >= 2 ? 1 : 0);
-    if (prom == 1 && depth_sel == 2) depth_sel = 1;
+    if (tune_depth == 4) depth_sel = 2;
+    if (tune_depth == 2) depth_sel = 1;
+    if (prom == 1 && depth_sel >= 2) depth_sel = 1;
     // the kernel's leading arguments: PRENORM streams the producer's vector and keeps the original one for the side outputs
     const float* const head_xa = prom == 2 ? a.pro.xg : a.pro.a;
     const float* const head_xb = prom == 2 ? a.pro.a : a.pro.b;
@@ -2649,7 +2671,8 @@ bool launch_qkv_attention(hipStream_t s, const QmvLaunch& L, const AttnDecodePar
     f.n_sp = sp.splits ? sp.splits : 1;
     uint32_t shift = 0;
     while ((16u << shift) < d_head) shift++;
-    f.pub = QmvPublish{counters, {0, n_heads, n_heads + n_kv}, shift};
+    static const bool drop_publish = getenv("ZGML_HIP_DEBUG_DROP_PUBLISH") && atoi(getenv("ZGML_HIP_DEBUG_DROP_PUBLISH")) != 0;
+    f.pub = QmvPublish{counters, {0, n_heads, n_heads + n_kv}, shift, drop_publish ? 1u : 0u};
     static const uint32_t poll_sleep = getenv("ZGML_HIP_HANDOFF_SLEEP") ? (uint32_t)atoi(getenv("ZGML_HIP_HANDOFF_SLEEP")) : 2u;
     f.ho = DecodeHandoff{counters, seen, idx, n_heads, d_head / 16, timeout, poll_sleep, nullptr};
     if (Lo) { // the O projection rides along

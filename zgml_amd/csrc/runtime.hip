@@ -96,6 +96,7 @@ struct zgml_hip_ctx {
     std::string err;
     bool opt_fusion = true, opt_graph = true, opt_profile = false, opt_skip_dead = true, opt_f16_dense = false;
     int64_t opt_attn_split_min_keys = -1; // -1: environment / default (attn_split_for)
+    int64_t opt_fuse_resident_wgs = -1;   // -1: one 1024-thread workgroup per CU (fuse_qkv_attention)
     // host dense override scratch
     float *mm_a = nullptr, *mm_b = nullptr, *mm_c = nullptr;
     uint64_t mm_a_cap = 0, mm_b_cap = 0, mm_c_cap = 0;
@@ -117,6 +118,23 @@ struct zgml_hip_ctx {
     int64_t* arg_out = nullptr;
     int64_t* arg_out_host = nullptr; // pinned
     struct ShardState* shard = nullptr; // RCCL communicator of the row-shard path (zgml_hip_shard_*), else nullptr
+    // Fused launches (q/k/v projection + decode attention): ONE host-visible word every bounded in-launch wait sets when it
+    // gives up (pinned, device-mapped: the host reads it after any synchronisation without a copy). A set word means the
+    // tokens of that run are wrong: every host sync point reports it (handoff_ok), clears it and switches the fusion off for
+    // the context — plans are rebuilt in the two-launch form (fuse_epoch).
+    uint32_t* handoff_flag = nullptr;     // host pointer
+    uint32_t* handoff_flag_dev = nullptr; // the same word as the kernels see it
+    bool fuse_qkv_off = false;
+    uint64_t fuse_epoch = 0;
+    int n_cu = 0; // compute units (residency guard of the fused launch)
+    bool handoff_ok(const char* where) {
+        if (!handoff_flag || !*(volatile uint32_t*)handoff_flag) return true;
+        *(volatile uint32_t*)handoff_flag = 0;
+        fuse_qkv_off = true, fuse_epoch++;
+        fail(std::string(where) + ": an in-launch hand-off wait of a fused q/k/v + attention launch timed out — the results of this run are wrong; "
+                                  "the fusion is now off for this context (later runs use two launches)");
+        return false;
+    }
 
     void fail(const std::string& what) {
         if (err.empty()) err = what;
@@ -150,7 +168,8 @@ struct zgml_hip_program {
     bool f16_stream_nt = false;     // promoted weights exceed the Infinity Cache: non-temporal loads
     std::vector<void*> f16_weights; // per buffer: MFMA-packed f16 copy of a promoted matmul B operand (else nullptr)
     std::vector<void*> owned; // other device allocations
-    uint32_t* handoff_timeout = nullptr; // fused launches: ONE device word bumped whenever an in-launch wait gave up
+    uint64_t fuse_epoch = 0;             // ctx->fuse_epoch the plan was built at (a time-out rebuilds it without the fusion)
+    std::vector<void*> fuse_owned;       // counters / seen / idx blocks of the fused launches: freed with every plan rebuild
     float* prenorm_buf = nullptr;        // arm_prenorm: [x * gamma | partial sums of squares] handed from a residual epilogue to the next prologue
     size_t prenorm_bytes = 0;
     float* scratch = nullptr;
@@ -994,7 +1013,14 @@ bool anchor_ok(zgml_hip_program* p, uint32_t i) {
 // projection. Only for the shapes that kernel is built for (short K, Q4_0 with f16 scales, d_head 64 / 128, f32 KV).
 void fuse_qkv_attention(zgml_hip_program* p) {
     static const bool on = !(getenv("ZGML_HIP_FUSE_QKV_ATTN") && atoi(getenv("ZGML_HIP_FUSE_QKV_ATTN")) == 0);
-    if (!on) return;
+    if (!on || p->ctx->fuse_qkv_off || !p->ctx->handoff_flag_dev) return; // (off for good once a hand-off wait has timed out in this context)
+    // Residency: the attention's workgroups spin on counters the projection's workgroups of the SAME grid bump, and HIP
+    // promises neither dispatch order nor co-residency. The launch is only built when the whole grid (1024-thread workgroups)
+    // fits the device at ONE workgroup per CU — the occupancy query may say two, but it reads one high near a register-file
+    // edge (guide: residency and cooperative launch) and a stranded producer would mean a time-out, not a slowdown; the
+    // attention's split count shrinks to fit, and if even one split per head does not fit the two launches stay apart.
+    // ZGML_HIP_OPT_FUSE_RESIDENT_WGS overrides the capacity (0 refuses every fusion).
+    const uint64_t resident_cap = p->ctx->opt_fuse_resident_wgs >= 0 ? (uint64_t)p->ctx->opt_fuse_resident_wgs : (uint64_t)std::max(p->ctx->n_cu, 1);
     for (size_t i = 0; i + 1 < p->plan.size(); i++) {
         const auto qd = p->plan[i].qmv_desc;
         const auto ad = p->plan[i + 1].adec_desc;
@@ -1029,7 +1055,11 @@ void fuse_qkv_attention(zgml_hip_program* p) {
             idx[3 * r] = h, idx[3 * r + 1] = nh + kvh, idx[3 * r + 2] = nh + n_kv + kvh;
         }
         if (!ok) continue;
-        const uint32_t n_sp = ad->sp.splits ? ad->sp.splits : 1;
+        uint32_t n_sp = ad->sp.splits ? ad->sp.splits : 1;
+        uint64_t n_mv = 0;
+        for (uint32_t t = 0; t < 3; t++) n_mv += L.parts[t].w.N / 16;
+        if (n_mv + nh > resident_cap) continue; // not even one attention workgroup per head beside the projection's: two launches
+        n_sp = (uint32_t)std::min<uint64_t>(n_sp, (resident_cap - n_mv) / nh);
         // ... and the single-matrix projection that reads exactly the heads' row stores (the O projection) rides along:
         // no prologue, K = n_heads * d_head, every head's rows stored at its static offset h * d_head of that input
         std::shared_ptr<QmvLaunch> od = i + 2 < p->plan.size() ? p->plan[i + 2].qmv_desc : nullptr;
@@ -1046,20 +1076,22 @@ void fuse_qkv_attention(zgml_hip_program* p) {
             const zgml_device_op& so = p->ops[(size_t)(a.att.dyn_dst2_off - p->dyn_dev)];
             o_ok = so.kind == ZGML_DOP_SLICE_ASSIGN && so.u.slice_assign.patch_stride == 0 && so.u.slice_assign.dst_offset == idx[3 * r] * dh;
         }
+        if (o_ok && n_mv + (uint64_t)nh * n_sp + od->parts[0].w.N / 16 > resident_cap) o_ok = false;
         const uint32_t o_blocks = o_ok ? (uint32_t)(od->parts[0].w.N / 16) : 0;
         const size_t n_cnt = 32 * ((size_t)nh + 2 * n_kv + 1); // one counter per 128 bytes (the last: the heads' outputs)
-        if (!p->handoff_timeout) { // one word for the whole program: checked after resident runs and when the program is freed
-            if (hipMalloc((void**)&p->handoff_timeout, 256) != hipSuccess || hipMemset(p->handoff_timeout, 0, 256) != hipSuccess) continue;
-            p->owned.push_back(p->handoff_timeout);
-        }
         const size_t words = n_cnt + (size_t)nh * n_sp * 3 + 1 + 3 * (size_t)nh + o_blocks;
         uint32_t* block = nullptr;
-        if (hipMalloc((void**)&block, words * 4) != hipSuccess || hipMemset(block, 0, words * 4) != hipSuccess) continue;
-        p->owned.push_back(block);
-        uint32_t *counters = block, *seen = block + n_cnt, *timeout = p->handoff_timeout, *idx_dev = seen + (size_t)nh * n_sp * 3 + 1;
+        if (hipMalloc((void**)&block, words * 4) != hipSuccess) continue;
+        if (hipMemset(block, 0, words * 4) != hipSuccess) {
+            hipFree(block);
+            continue;
+        }
+        p->fuse_owned.push_back(block); // (freed by the next build_plan, after its stream sync)
+        uint32_t *counters = block, *seen = block + n_cnt, *timeout = p->ctx->handoff_flag_dev, *idx_dev = seen + (size_t)nh * n_sp * 3 + 1;
         if (hipMemcpy(idx_dev, idx.data(), idx.size() * 4, hipMemcpyHostToDevice) != hipSuccess) continue;
         const AttnDecodeParams* d = ad->dev;
-        const AttnSplit sp = ad->sp;
+        AttnSplit sp = ad->sp;
+        sp.splits = n_sp; // (possibly fewer than the stand-alone launch would use: the residency guard above)
         uint32_t *out_cnt = counters + 32 * ((size_t)nh + 2 * n_kv), *o_seen = idx_dev + 3 * (size_t)nh;
         uint32_t n_ops = p->plan[i].n_ops + p->plan[i + 1].n_ops, lo = std::min(p->plan[i].op_lo, p->plan[i + 1].op_lo),
                  hi = std::max(p->plan[i].op_hi, p->plan[i + 1].op_hi);
@@ -1987,6 +2019,9 @@ void build_plan(zgml_hip_program* p) {
     hipStreamSynchronize(p->ctx->stream); // the previous plan's parameter arrays may still be in use
     p->plan.clear();
     free_param_blobs(p);
+    for (void* d : p->fuse_owned) hipFree(d); // counters / seen / idx of the previous plan's fused launches
+    p->fuse_owned.clear();
+    p->fuse_epoch = p->ctx->fuse_epoch;
     p->split_buf = nullptr, p->split_cnt = nullptr, p->split_buf_floats = 0, p->split_cnt_words = 0; // lived in the blobs
     p->split_pos = UINT64_MAX - 1, p->split_input = nullptr, p->qmm_group = nullptr, p->f16_group = nullptr;
     p->plan_batched = p->ctx->opt_fusion && p->batching_safe;
@@ -2128,7 +2163,7 @@ void flush_dyn(zgml_hip_program* p) {
 // enqueue the whole program on the context stream (graph replay when enabled)
 void enqueue(zgml_hip_program* p) {
     zgml_hip_ctx* ctx = p->ctx;
-    if (p->plan_dirty) {
+    if (p->plan_dirty || p->fuse_epoch != p->ctx->fuse_epoch) {
         free_graph(p);
         build_plan(p);
     }
@@ -2332,6 +2367,12 @@ zgml_hip_ctx* zgml_hip_create(int device_ordinal) {
     hipMalloc((void**)&ctx->arg_idx, 256 * sizeof(int64_t));
     hipMalloc((void**)&ctx->arg_out, sizeof(int64_t));
     hipHostMalloc((void**)&ctx->arg_out_host, sizeof(int64_t), hipHostMallocDefault);
+    ctx->n_cu = prop.multiProcessorCount;
+    // the hand-off flag of the fused launches: pinned + mapped; without it no fusion is built (fuse_qkv_attention)
+    if (hipHostMalloc((void**)&ctx->handoff_flag, 64, hipHostMallocMapped) == hipSuccess) {
+        memset(ctx->handoff_flag, 0, 64);
+        if (hipHostGetDevicePointer((void**)&ctx->handoff_flag_dev, ctx->handoff_flag, 0) != hipSuccess) ctx->handoff_flag_dev = nullptr;
+    }
     return ctx;
 }
 
@@ -2349,6 +2390,7 @@ void zgml_hip_destroy(zgml_hip_ctx* ctx) {
     hipFree(ctx->arg_idx);
     hipFree(ctx->arg_out);
     hipHostFree(ctx->arg_out_host);
+    if (ctx->handoff_flag) hipHostFree(ctx->handoff_flag);
     hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -2374,6 +2416,10 @@ int zgml_hip_set_option(zgml_hip_ctx* ctx, int option, int64_t value) {
         case ZGML_HIP_OPT_SKIP_DEAD_UPLOADS: ctx->opt_skip_dead = value != 0; return 0;
         case ZGML_HIP_OPT_F16_DENSE_WEIGHTS: ctx->opt_f16_dense = value != 0; return 0;
         case ZGML_HIP_OPT_ATTN_SPLIT_MIN_KEYS: ctx->opt_attn_split_min_keys = value < 0 ? -1 : value; return 0;
+        case ZGML_HIP_OPT_FUSE_RESIDENT_WGS:
+            ctx->opt_fuse_resident_wgs = value < 0 ? -1 : value;
+            ctx->fuse_epoch++; // existing programs rebuild their plans under the new capacity
+            return 0;
         case ZGML_HIP_OPT_DENSE_WEIGHT_CACHE:
             ctx->b_cache_cap = value > 0 ? (uint64_t)value : 0;
             if (!ctx->b_cache_cap) ctx->drop_b_cache();
@@ -2812,7 +2858,7 @@ static bool download_outputs(zgml_hip_ctx* ctx, zgml_hip_program* p, const zgml_
         }
     }
     const uint64_t t0 = now_ns();
-    const bool ok = CTX_CHECK(ctx, hipStreamSynchronize(s));
+    const bool ok = CTX_CHECK(ctx, hipStreamSynchronize(s)) && ctx->handoff_ok("execute_program");
     p->profile.sync_time_ns += now_ns() - t0;
     p->profile.sync_count++;
     if (n_outputs && p->out_plan.word_aligned) {
@@ -2906,11 +2952,8 @@ void zgml_hip_free_program(zgml_hip_ctx* ctx, zgml_hip_program* p) {
         hipSetDevice(ctx->device);
         hipStreamSynchronize(ctx->stream);
     }
-    if (p->handoff_timeout) { // a bounded in-launch wait that expired is a bug: say so loudly
-        uint32_t v = 0;
-        if (hipMemcpy(&v, p->handoff_timeout, 4, hipMemcpyDeviceToHost) == hipSuccess && v)
-            fprintf(stderr, "[zgml_hip] ERROR: %u in-launch hand-off wait(s) of a fused q/k/v + attention launch timed out\n", v);
-    }
+    if (ctx && !ctx->handoff_ok("free_program")) fprintf(stderr, "[zgml_hip] ERROR: %s\n", ctx->err.c_str());
+    for (void* d : p->fuse_owned) hipFree(d);
     if (!p->attn_traces.empty()) { // stamps of the last execution, 100 MHz wall clock -> ns
         fprintf(stderr, "[zgml_hip] attention trace (ns since previous launch's end | start->params | ->dyn | ->rope | ->scores | ->max | ->pv | ->end)\n");
         unsigned long long prev_end = 0;
@@ -2998,7 +3041,7 @@ int zgml_hip_copy_program_buffer(zgml_hip_ctx* ctx, zgml_hip_program* dst, uint1
 void zgml_hip_enqueue_ops(zgml_hip_ctx* ctx, zgml_hip_program* p, uint64_t first, uint64_t count) {
     if (!ctx || !p) return;
     hipSetDevice(ctx->device);
-    if (p->plan_dirty) {
+    if (p->plan_dirty || p->fuse_epoch != p->ctx->fuse_epoch) {
         free_graph(p);
         build_plan(p);
     }
@@ -3025,7 +3068,7 @@ int zgml_hip_program_set_barriers(zgml_hip_ctx* ctx, zgml_hip_program* p, const 
 
 void zgml_hip_synchronize(zgml_hip_ctx* ctx) {
     if (!ctx) return;
-    CTX_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (CTX_CHECK(ctx, hipStreamSynchronize(ctx->stream))) ctx->handoff_ok("synchronize");
 }
 
 int64_t zgml_hip_argmax(zgml_hip_ctx* ctx, zgml_hip_program* p, uint16_t buf_idx, uint64_t offset, uint64_t n) {
@@ -3033,7 +3076,7 @@ int64_t zgml_hip_argmax(zgml_hip_ctx* ctx, zgml_hip_program* p, uint16_t buf_idx
     hipSetDevice(ctx->device);
     launch_argmax(ctx->stream, p->bufs[buf_idx] + offset, n, ctx->arg_val, ctx->arg_idx, ctx->arg_out);
     hipMemcpyAsync(ctx->arg_out_host, ctx->arg_out, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream);
-    if (!CTX_CHECK(ctx, hipStreamSynchronize(ctx->stream))) return -1;
+    if (!CTX_CHECK(ctx, hipStreamSynchronize(ctx->stream)) || !ctx->handoff_ok("argmax")) return -1;
     return *ctx->arg_out_host;
 }
 
@@ -3473,7 +3516,7 @@ int zgml_hip_resident_decode(zgml_hip_ctx* ctx, zgml_hip_program* p, uint32_t fi
     }
     hipSetDevice(ctx->device);
     hipStream_t s = ctx->stream;
-    if (p->plan_dirty) {
+    if (p->plan_dirty || p->fuse_epoch != p->ctx->fuse_epoch) {
         free_graph(p);
         build_plan(p);
     }
@@ -3541,13 +3584,7 @@ int zgml_hip_resident_decode(zgml_hip_ctx* ctx, zgml_hip_program* p, uint32_t fi
     }
     hipMemcpyAsync(tokens_out, r->tokens, (size_t)n_steps * 8, hipMemcpyDeviceToHost, s);
     bool ok = CTX_CHECK(ctx, hipStreamSynchronize(s));
-    if (ok && p->handoff_timeout) { // fused launches: a hand-off wait that gave up means wrong tokens — fail loudly
-        uint32_t v = 0;
-        if (hipMemcpy(&v, p->handoff_timeout, 4, hipMemcpyDeviceToHost) == hipSuccess && v) {
-            ctx->fail("resident_decode: an in-launch hand-off wait of a fused q/k/v + attention launch timed out");
-            ok = false;
-        }
-    }
+    ok = ok && ctx->handoff_ok("resident_decode");
     // the device rewrote the dyn block behind the host mirror's back: force a re-upload next time
     memset(p->dyn_host, 0xFF, p->ops.size() * sizeof(uint32_t));
     set_dyn_from_ops(p);
@@ -3574,7 +3611,7 @@ int64_t zgml_hip_resident_prefill(zgml_hip_ctx* ctx, zgml_hip_program* p, const 
         }
     hipSetDevice(ctx->device);
     hipStream_t s = ctx->stream;
-    if (p->plan_dirty) {
+    if (p->plan_dirty || p->fuse_epoch != p->ctx->fuse_epoch) {
         free_graph(p);
         build_plan(p);
     }
@@ -3608,7 +3645,7 @@ int64_t zgml_hip_resident_prefill(zgml_hip_ctx* ctx, zgml_hip_program* p, const 
     // the logits buffer holds one row per token: the greedy token comes from the LAST position's row
     launch_argmax(s, r->logits + (uint64_t)(n_tokens - 1) * r->vocab, r->vocab, ctx->arg_val, ctx->arg_idx, ctx->arg_out);
     hipMemcpyAsync(ctx->arg_out_host, ctx->arg_out, sizeof(int64_t), hipMemcpyDeviceToHost, s);
-    const bool ok = CTX_CHECK(ctx, hipStreamSynchronize(s));
+    const bool ok = CTX_CHECK(ctx, hipStreamSynchronize(s)) && ctx->handoff_ok("resident_prefill");
     // the device rewrote the dyn block behind the host mirror's back: force a re-upload next time
     memset(p->dyn_host, 0xFF, p->ops.size() * sizeof(uint32_t));
     set_dyn_from_ops(p);
@@ -3751,7 +3788,7 @@ int64_t zgml_hip_shard_step(zgml_hip_ctx* ctx, zgml_hip_program* p, const zgml_p
     if (!ctx || !p || !ctx->shard) return -1;
     hipSetDevice(ctx->device);
     hipStream_t s = ctx->stream;
-    if (p->plan_dirty) {
+    if (p->plan_dirty || p->fuse_epoch != p->ctx->fuse_epoch) {
         free_graph(p);
         build_plan(p);
     }
@@ -3787,7 +3824,7 @@ int64_t zgml_hip_shard_step(zgml_hip_ctx* ctx, zgml_hip_program* p, const zgml_p
         launch_argmax(s, p->bufs[p->shard_logits_buf], p->shard_vocab, ctx->arg_val, ctx->arg_idx, ctx->arg_out);
         hipMemcpyAsync(ctx->arg_out_host, ctx->arg_out, sizeof(int64_t), hipMemcpyDeviceToHost, s);
     }
-    if (!CTX_CHECK(ctx, hipStreamSynchronize(s))) return -1;
+    if (!CTX_CHECK(ctx, hipStreamSynchronize(s)) || !ctx->handoff_ok("shard_step")) return -1;
     p->profile.call_count++;
     return *ctx->arg_out_host;
 }
