@@ -560,7 +560,53 @@ def bench_sharded(args):
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     dt = float(dt.item())
     qb, _ = model.quant_bytes()
+    # where a step's device time goes: a few EAGER steps with HIP events around every all-gather (collective: all ranks)
+    prof = {"step_us": [], "gather_us": []}
+    ptok = tok
+    for i in range(4):
+        ptok, su, gu = dec.profile_step(ptok, W + K + i)
+        if i:  # (the first eager step after graph replays pays one-off costs)
+            prof["step_us"].append(su)
+            prof["gather_us"].append(gu)
+    n_gather = max(1, dec.n_points)
+    gather_us = sum(prof["gather_us"]) / max(1, len(prof["gather_us"]))
+    eager_us = sum(prof["step_us"]) / max(1, len(prof["step_us"]))
+    step_mode = dec.mode
+    dec.close()
+    # rank 0: the unsharded model on the same GPU (what the N > 1 value is to be compared with) and the CPU baseline
+    single, cpu = None, None
     if rank == 0:
+        try:
+            m1 = llama.Model(llama.preset("llama2-7b", 2048), llama.Q4_0, threads=16)
+            s1 = llama.Session(m1, llama.hip_backend_fns(be))
+            s1.resident_setup(be)
+            w1 = s1.resident_decode(1, 0, 4)
+            be.synchronize()
+            t1 = time.perf_counter()
+            s1.resident_decode(int(w1[-1]), 4, min(K, 128))
+            be.synchronize()
+            single = round(min(K, 128) / (time.perf_counter() - t1), 1)
+            s1.close()
+            m1.close()
+        except Exception as e:
+            single = str(e)[:200]
+        if not args.skip_cpu:
+            try:
+                cpu = cpu_baseline(llama, llama.preset("smollm-135m"), llama.Q4_0)
+                cpu["note"] = "the N = 1 line's baseline (SmolLM-135M Q4_0 through the C oracle on this host), repeated here so the line stands alone"
+            except Exception as e:
+                cpu = {"error": str(e)[:200]}
+    dist.barrier()
+    if rank == 0:
+        tok_s = K / dt
+        rank_gbps = qb * tok_s / 1e9  # this rank's weight bytes per token x tokens/s
+        roof = {"bound": "hbm", "achieved": round(rank_gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(rank_gbps / HBM_PEAK_GBPS, 4),
+                "traffic": None, "kernel": "per-rank weight stream of one sharded decode token (all quantized mat-vecs of the rank)",
+                "bytes_per_token_per_rank": qb, "all_gathers_per_token": dec.n_points if ws > 1 else 0,
+                "us_per_all_gather": round(gather_us / n_gather, 2), "gather_us_per_token": round(gather_us, 1),
+                "eager_step_us": round(eager_us, 1), "gather_share_of_eager_step": round(gather_us / eager_us, 3) if eager_us else None,
+                "timing": "value: host clock around K graph-replayed steps, max over ranks; gather figures: HIP events around every ncclAllGather "
+                          "of 3 eager steps on rank 0 (zgml_hip_shard_profile_step)"}
         out = {
             "metric": "decode_tokens_per_sec", "value": round(K / dt, 1), "unit": "tokens/s", "n_gpus": ws,
             "steps": K, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / K, 4), "higher_is_better": True,
@@ -569,18 +615,18 @@ def bench_sharded(args):
                                    "(BASELINE configs[3])",
                        "weights": "synthetic Q4_0", "max_seq": cfg.max_seq_len,
                        "parallelism": f"tp{ws} (N-split weights, replicated activations, head-sharded KV)",
-                       "collectives_per_token": dec.n_points if ws > 1 else 0, "rccl_ranks": ws, "step_mode": dec.mode,
+                       "collectives_per_token": dec.n_points if ws > 1 else 0, "rccl_ranks": ws, "step_mode": step_mode,
                        "data_path": "zgml_hip_shard_step (C ABI): op ranges + in-place ncclAllGather + argmax, one graph per token",
                        "verified": f"first {n_chk} greedy tokens equal the oracle's for the unsharded 32-layer program; all ranks agree",
                        "compare_with": "extra.llama2_7b.tok_s of the --gpus 1 line (same model, unsharded)"},
-            "roofline": None, "cpu_baseline": None,
-            "extra": {"q4_0_weight_bytes_per_rank": qb},
+            "roofline": roof, "cpu_baseline": cpu,
+            "extra": {"q4_0_weight_bytes_per_rank": qb, "unsharded_llama2_7b_tok_s_on_rank0_gpu": single,
+                      "speedup_vs_unsharded": round(tok_s / single, 3) if isinstance(single, float) and single else None},
         }
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)
-    dec.close()
     model.close()
     be.close()
     dist.destroy_process_group()

@@ -460,6 +460,10 @@ int zgml_hip_shard_attach(zgml_hip_ctx* ctx, zgml_hip_program* program, const zg
  * rank must call it for every step (the collectives are collective). */
 int64_t zgml_hip_shard_step(zgml_hip_ctx* ctx, zgml_hip_program* program, const zgml_program_io* inputs, uint64_t n_inputs);
 int zgml_hip_shard_step_mode(zgml_hip_program* program); /* 1: steps replay one graph per token, 0: eager */
+/* Diagnostics: one EAGER step with HIP events around every all-gather — device microseconds of the whole step and of the
+ * collectives inside it (launch-bound: eager steps are slower than graph replays; the ratio is what it is for). */
+int64_t zgml_hip_shard_profile_step(zgml_hip_ctx* ctx, zgml_hip_program* program, const zgml_program_io* inputs, uint64_t n_inputs,
+                                    double* step_us, double* gather_us);
 
 /* Device-resident greedy decode for LLaMA-shaped programs (measurement protocol: inputs already
  * in HBM when the timed region starts). The reference's per-token host work — embedding-row

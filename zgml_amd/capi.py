@@ -194,6 +194,7 @@ HIP_SYMBOLS = [
     "zgml_hip_qmatmul_bench", "zgml_hip_qmatvec_overlap_bench", "zgml_hip_qmatvec_chain_bench", "zgml_hip_dense_f16_bench", "zgml_hip_dense_cache_invalidate", "zgml_hip_dense_cache_stats",
     "zgml_hip_qmatvec_synth", "zgml_hip_copy_bench", "zgml_hip_resident_setup", "zgml_hip_resident_decode",
     "zgml_hip_resident_prefill", "zgml_hip_shard_unique_id", "zgml_hip_shard_init", "zgml_hip_shard_destroy", "zgml_hip_shard_attach", "zgml_hip_shard_step", "zgml_hip_shard_step_mode",
+    "zgml_hip_shard_profile_step",
 ]
 
 class ShardPointC(C.Structure):
@@ -275,6 +276,9 @@ def _bind_hip(lib: C.CDLL) -> None:
         lib.zgml_hip_shard_attach.argtypes = [vp, vp, C.POINTER(ShardPointC), u64, C.c_uint16, u64]
         lib.zgml_hip_shard_step.restype, lib.zgml_hip_shard_step.argtypes = C.c_int64, [vp, vp, C.POINTER(ProgramIOC), u64]
         lib.zgml_hip_shard_step_mode.restype, lib.zgml_hip_shard_step_mode.argtypes = i32, [vp]
+    if hasattr(lib, "zgml_hip_shard_profile_step"):
+        lib.zgml_hip_shard_profile_step.restype = C.c_int64
+        lib.zgml_hip_shard_profile_step.argtypes = [vp, vp, C.POINTER(ProgramIOC), u64, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     if hasattr(lib, "zgml_hip_qmatvec_chain_bench"):  # absent from an older build loaded through ZGML_HIP_LIB (diagnostics)
         lib.zgml_hip_qmatvec_chain_bench.restype = C.c_double
         lib.zgml_hip_qmatvec_chain_bench.argtypes = [vp, u32, i32, u32, u32, u32, C.POINTER(u64)]

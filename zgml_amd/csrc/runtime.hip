@@ -3703,13 +3703,17 @@ bool shard_load(zgml_hip_ctx* ctx, ShardState* st) {
 ShardState g_shard_loader; // for zgml_hip_shard_unique_id (no context yet)
 
 // the device side of one sharded step on stream order: op ranges separated by in-place all-gathers
-bool shard_segments(zgml_hip_ctx* ctx, zgml_hip_program* p) {
+bool shard_segments(zgml_hip_ctx* ctx, zgml_hip_program* p, std::vector<hipEvent_t>* ev = nullptr) { // ev: 2 events per gather point (profile_step)
     ShardState* st = ctx->shard;
     uint64_t prev = 0;
+    size_t gi = 0;
     for (const zgml_shard_point& gp : p->shard_points) {
         if (gp.op_end > prev) zgml_hip_enqueue_ops(ctx, p, prev, gp.op_end - prev);
         float* full = p->bufs[gp.buf_idx] + gp.offset;
+        if (ev) hipEventRecord((*ev)[2 * gi], ctx->stream);
         const int rc = st->all_gather(full + (uint64_t)st->rank * gp.len_per_rank, full, gp.len_per_rank, kNcclFloat, st->comm, ctx->stream);
+        if (ev) hipEventRecord((*ev)[2 * gi + 1], ctx->stream);
+        gi++;
         if (rc != 0) {
             ctx->fail(std::string("shard: ncclAllGather: ") + (st->get_error_string ? st->get_error_string(rc) : "error"));
             return false;
@@ -3827,6 +3831,40 @@ int64_t zgml_hip_shard_step(zgml_hip_ctx* ctx, zgml_hip_program* p, const zgml_p
     if (!CTX_CHECK(ctx, hipStreamSynchronize(s)) || !ctx->handoff_ok("shard_step")) return -1;
     p->profile.call_count++;
     return *ctx->arg_out_host;
+}
+
+// One EAGER step with HIP events around every all-gather (diagnostics for bench.py's N > 1 line): the device time of the whole
+// step and the part of it spent inside the collectives. Every rank must call it (the gathers are collective). Returns the
+// greedy token, -1 on error.
+int64_t zgml_hip_shard_profile_step(zgml_hip_ctx* ctx, zgml_hip_program* p, const zgml_program_io* inputs, uint64_t n_inputs, double* step_us,
+                                    double* gather_us) {
+    if (!ctx || !p || !ctx->shard) return -1;
+    hipSetDevice(ctx->device);
+    hipStream_t s = ctx->stream;
+    if (p->plan_dirty || p->fuse_epoch != p->ctx->fuse_epoch) {
+        free_graph(p);
+        build_plan(p);
+    }
+    if (zgml_hip_stage_inputs(ctx, p, inputs, n_inputs) != 0) return -1;
+    std::vector<hipEvent_t> ev(2 * p->shard_points.size() + 2);
+    for (auto& e : ev) hipEventCreate(&e);
+    hipEventRecord(ev[ev.size() - 2], s);
+    zgml_hip_enqueue_staged(ctx, p);
+    bool ok = shard_segments(ctx, p, &ev);
+    launch_argmax(s, p->bufs[p->shard_logits_buf], p->shard_vocab, ctx->arg_val, ctx->arg_idx, ctx->arg_out);
+    hipMemcpyAsync(ctx->arg_out_host, ctx->arg_out, sizeof(int64_t), hipMemcpyDeviceToHost, s);
+    hipEventRecord(ev[ev.size() - 1], s);
+    ok = ok && CTX_CHECK(ctx, hipStreamSynchronize(s)) && ctx->handoff_ok("shard_profile_step");
+    if (ok) {
+        float ms = 0;
+        double g = 0;
+        for (size_t i = 0; i < p->shard_points.size(); i++)
+            if (hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]) == hipSuccess) g += ms * 1e3;
+        if (gather_us) *gather_us = g;
+        if (step_us && hipEventElapsedTime(&ms, ev[ev.size() - 2], ev[ev.size() - 1]) == hipSuccess) *step_us = ms * 1e3;
+    }
+    for (auto& e : ev) hipEventDestroy(e);
+    return ok ? *ctx->arg_out_host : -1;
 }
 
 int zgml_hip_shard_step_mode(zgml_hip_program* p) { return !p ? -1 : (p->shard_graph_exec ? 1 : 0); } // 1 = one graph per token

@@ -61,6 +61,18 @@ class NativeShardedDecoder:
             raise RuntimeError("shard_step: " + self.be.last_error())
         return tok
 
+    def profile_step(self, token: int, pos: int):
+        """One EAGER step with HIP events around every all-gather: (token, device us of the step, us inside the collectives).
+        Collective: every rank calls it."""
+        self.model.patch(token, pos)
+        prog = self.model.program
+        self.lib.zgml_hip_refresh_program(self.be.ctx, self.handle, prog.ops, prog.n_ops)
+        step_us, gather_us = C.c_double(), C.c_double()
+        tok = int(self.lib.zgml_hip_shard_profile_step(self.be.ctx, self.handle, self._in[0], self._in[1], C.byref(step_us), C.byref(gather_us)))
+        if tok < 0:
+            raise RuntimeError("shard_profile_step: " + self.be.last_error())
+        return tok, step_us.value, gather_us.value
+
     @property
     def mode(self) -> str:
         return "graph" if self.lib.zgml_hip_shard_step_mode(self.handle) == 1 else "eager"
