@@ -6,6 +6,7 @@ parity test runs one DeviceProgram through both and compares.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import subprocess
 from pathlib import Path
 from typing import Sequence
@@ -16,7 +17,8 @@ from zgml_amd import capi
 from zgml_amd.program import DeviceOp, DeviceProgram, ProgramIO, ios_to_c, ops_to_c
 
 _DIR = Path(__file__).resolve().parent
-LIB_PATH = _DIR / "_build" / "libzgml_oracle.so"
+# ZGML_ORACLE_LIB: a sanitizer build (oracle/Makefile SAN=asan|tsan, tools/run_sanitizers.sh)
+LIB_PATH = Path(os.environ["ZGML_ORACLE_LIB"]) if os.environ.get("ZGML_ORACLE_LIB") else _DIR / "_build" / "libzgml_oracle.so"
 _lib = None
 
 

@@ -209,7 +209,7 @@ OPT_FUSE_RESIDENT_WGS = 8
 
 _PKG_DIR = Path(__file__).resolve().parent
 HIP_LIB_PATH = _PKG_DIR / "lib" / "libzgml_hip.so"
-HOST_LIB_PATH = _PKG_DIR / "lib" / "libzgml_host.so"
+HOST_LIB_PATH = Path(os.environ["ZGML_HOST_LIB"]) if os.environ.get("ZGML_HOST_LIB") else _PKG_DIR / "lib" / "libzgml_host.so"  # (env: a sanitizer build)
 
 _hip_lib = None
 
