@@ -118,7 +118,8 @@ def cpu_baseline(llama, cfg, kind, budget_s=7.0, max_tokens=64):
     run("B2_exact_all_cores", min(cores, 64), False, "same arithmetic, output columns split over the host cores")
     if cores > 16:  # the pool's per-op wake-up of 63 threads costs more than it buys on 576-wide layers: also the moderate split
         run("B2_exact_16_threads", 16, False, "same arithmetic, output columns split over 16 threads")
-    run("B3_w8a8_gemvpool", min(cores, 16), True, "quantizeInput + gemvRange over GemvPool (<= 16 workers, quant.zig:24-198,320-440)")
+    arm = "AVX-512 VNNI vpdpbusd arm (bit-identical to the scalar loop)" if O.gemv_uses_vnni() else "scalar / auto-vectorised loop (no AVX-512 VNNI on this host)"
+    run("B3_w8a8_gemvpool", min(cores, 16), True, "quantizeInput + gemvRange over GemvPool (<= 16 workers, quant.zig:24-198,320-440); gemvRange: " + arm)
     O.set_threads(1)
     m.close()
     best = max(variants, key=lambda k: variants[k]["value"])
@@ -162,7 +163,7 @@ def cpu_config1_q8_matvec(iters=200):
     nbytes = K * N // 32 * 36 + 4 * K + 4 * N  # int8 [N, K] + one f32 scale per 32 along K, as the transposed copy sits in memory
     return {"workload": "4096x4096 Q8_0 mat-vec, W8A8 (quantizeInput + gemvRange) on the CPU thread pool (BASELINE configs[0])",
             "us_per_matvec": round(us, 1), "GBps": round(nbytes / us / 1e3, 2), "bytes_per_matvec": nbytes, "workers": workers,
-            "iters": iters, "host_cores": cores, "cpu_model": _cpu_model(),
+            "iters": iters, "host_cores": cores, "cpu_model": _cpu_model(), "gemv_arm": "avx512-vnni" if O.gemv_uses_vnni() else "scalar",
             "max_abs_diff_vs_exact_dequant": float(np.abs(dst - exact).max()), "out_abs_max": float(np.abs(exact).max())}
 
 

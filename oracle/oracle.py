@@ -154,6 +154,15 @@ def quantize_input(x, bs=32):
     return q, s
 
 
+def gemv_uses_vnni() -> bool:
+    return bool(load().zo_gemv_uses_vnni())
+
+
+def set_vnni(on: int) -> None:
+    """0: scalar gemvRange loop, 1: the AVX-512 VNNI arm where the host has it, -1: probe again."""
+    load().zo_set_vnni(on)
+
+
 def gemv(t_data, t_scales, x, N, K, bs=32, workers: int = 0):
     q, s = quantize_input(x, bs)
     dst = np.zeros(N, dtype=np.float32)

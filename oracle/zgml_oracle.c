@@ -1101,8 +1101,84 @@ void zo_quantize_input(const float* input, uint64_t K, uint64_t bs, int8_t* inp_
 
 /* The sdot lanes sum exactly in int32, so any summation order gives the same integer; the f32
  * combine order (blocks ascending, acc += f32(int) * (s_x*s_w)) is kept (quant.zig:382-409). */
+static void zo_gemv_range_scalar(const int8_t* t_d, const float* t_s, const int8_t* inp_q, const float* inp_scales,
+                                 float* dst, uint64_t n_start, uint64_t n_end, uint64_t K, uint64_t bs);
+
+/* The reference's kernel is AArch64 `sdot` (16-lane int8 dot into int32, 4 rows unrolled: quant.zig:358-440). The x86 arm of
+ * the same arithmetic: AVX-512 VNNI `vpdpbusd` on one 32-byte block of 8 rows at a time. vpdpbusd
+ * multiplies UNSIGNED by signed bytes, so the sign of x moves to w first (|x| * (w * sgn x) = x * w; quantizeInput clamps to
+ * +-127, so |x| never overflows). The eight 8-lane partial vectors are reduced to one int32 per row by a horizontal-add tree
+ * — the integers are exact, so this is the scalar loop's integer — and the f32 combine (convert, multiply by s_x * s_w, add,
+ * blocks ascending, no FMA) is the scalar loop's, lane by lane: bit-identical results (tests/test_oracle_w8a8.py). */
+#if defined(__x86_64__)
+#include <immintrin.h>
+static int zo_vnni = -1; /* -1: not probed yet; ZGML_ORACLE_VNNI=0 forces the scalar loop */
+static int zo_have_vnni(void) {
+    if (zo_vnni < 0) {
+        const char* e = getenv("ZGML_ORACLE_VNNI");
+        zo_vnni = (e && atoi(e) == 0) ? 0 : (__builtin_cpu_supports("avx512vnni") && __builtin_cpu_supports("avx512vl") && __builtin_cpu_supports("avx2"));
+    }
+    return zo_vnni;
+}
+__attribute__((target("avx2,avx512f,avx512vl,avx512vnni"))) static void zo_gemv_range_vnni(const int8_t* t_d, const float* t_s, const int8_t* inp_q,
+                                                                                          const float* inp_scales, float* dst, uint64_t n_start,
+                                                                                          uint64_t n_end, uint64_t K) {
+    const uint64_t bpr = K / 32; /* caller: bs == 32, K % 32 == 0 */
+    uint64_t n = n_start;
+    for (; n + 8 <= n_end; n += 8) {
+        __m256 acc = _mm256_setzero_ps();
+        for (uint64_t b = 0; b < bpr; b++) {
+            const __m256i x = _mm256_loadu_si256((const __m256i*)(inp_q + 32 * b));
+            const __m256i ax = _mm256_abs_epi8(x);
+            __m256i v[8];
+            for (int r = 0; r < 8; r++) {
+                const __m256i w = _mm256_loadu_si256((const __m256i*)(t_d + (n + r) * K + 32 * b));
+                v[r] = _mm256_dpbusd_epi32(_mm256_setzero_si256(), ax, _mm256_sign_epi8(w, x));
+            }
+            const __m256i h01 = _mm256_hadd_epi32(v[0], v[1]), h23 = _mm256_hadd_epi32(v[2], v[3]);
+            const __m256i h45 = _mm256_hadd_epi32(v[4], v[5]), h67 = _mm256_hadd_epi32(v[6], v[7]);
+            const __m256i q0 = _mm256_hadd_epi32(h01, h23), q1 = _mm256_hadd_epi32(h45, h67); /* rows 0-3 / 4-7, low | high half sums */
+            const __m256i ia = _mm256_add_epi32(_mm256_permute2x128_si256(q0, q1, 0x20), _mm256_permute2x128_si256(q0, q1, 0x31));
+            const float sx = inp_scales[b];
+            const __m256 comb = _mm256_mul_ps(_mm256_set1_ps(sx), _mm256_set_ps(t_s[(n + 7) * bpr + b], t_s[(n + 6) * bpr + b], t_s[(n + 5) * bpr + b],
+                                                                                t_s[(n + 4) * bpr + b], t_s[(n + 3) * bpr + b], t_s[(n + 2) * bpr + b],
+                                                                                t_s[(n + 1) * bpr + b], t_s[(n + 0) * bpr + b]));
+            acc = _mm256_add_ps(acc, _mm256_mul_ps(_mm256_cvtepi32_ps(ia), comb));
+        }
+        _mm256_storeu_ps(dst + n, acc);
+    }
+    if (n < n_end) zo_gemv_range_scalar(t_d, t_s, inp_q, inp_scales, dst, n, n_end, K, 32);
+}
+#endif
+
 void zo_gemv_range(const int8_t* t_d, const float* t_s, const int8_t* inp_q, const float* inp_scales,
                    float* dst, uint64_t n_start, uint64_t n_end, uint64_t K, uint64_t bs) {
+#if defined(__x86_64__)
+    if (bs == 32 && K % 32 == 0 && zo_have_vnni()) {
+        zo_gemv_range_vnni(t_d, t_s, inp_q, inp_scales, dst, n_start, n_end, K);
+        return;
+    }
+#endif
+    zo_gemv_range_scalar(t_d, t_s, inp_q, inp_scales, dst, n_start, n_end, K, bs);
+}
+/* 1: the AVX-512 VNNI arm is in use on this host */
+int zo_gemv_uses_vnni(void) {
+#if defined(__x86_64__)
+    return zo_have_vnni();
+#else
+    return 0;
+#endif
+}
+void zo_set_vnni(int on) { /* tests: 0 = scalar loop, 1 = VNNI if the host has it, -1 = probe again */
+#if defined(__x86_64__)
+    zo_vnni = on < 0 ? -1 : (on && __builtin_cpu_supports("avx512vnni") && __builtin_cpu_supports("avx512vl"));
+#else
+    (void)on;
+#endif
+}
+
+static void zo_gemv_range_scalar(const int8_t* t_d, const float* t_s, const int8_t* inp_q, const float* inp_scales,
+                                 float* dst, uint64_t n_start, uint64_t n_end, uint64_t K, uint64_t bs) {
     uint64_t bpr = (K + bs - 1) / bs;
     for (uint64_t n = n_start; n < n_end; n++) {
         float acc = 0;

@@ -95,6 +95,10 @@ void zo_quantize_input(const float* input, uint64_t K, uint64_t bs, int8_t* inp_
 /* QuantizedWeight.gemvRange, src/quant.zig:358-440 (sdot replaced by an exact int32 dot) */
 void zo_gemv_range(const int8_t* t_d, const float* t_s, const int8_t* inp_q, const float* inp_scales,
                    float* dst, uint64_t n_start, uint64_t n_end, uint64_t K, uint64_t bs);
+/* x86: the AVX-512 VNNI arm of gemvRange (bit-identical to the scalar loop); 1 when it is in use. zo_set_vnni(0) forces the
+ * scalar loop, (1) enables VNNI where the host has it, (-1) probes again (honours ZGML_ORACLE_VNNI). */
+int zo_gemv_uses_vnni(void);
+void zo_set_vnni(int on);
 /* GemvPool.dispatch, src/quant.zig:135-196: N-chunks rounded up to 4, 1 Mi-element threshold,
  * at most 16 workers. Uses the oracle pool; `n_workers` caps the active count. */
 void zo_gemv_pool_dispatch(const int8_t* t_d, const float* t_s, const int8_t* inp_q,

@@ -132,3 +132,33 @@ def test_gemv_pool_small_problem_runs_inline(oracle):
     data, scales = oracle.quantize_from_slice(W, K, N, 32)
     t_data, t_scales = oracle.prepare_transposed(data, scales, K, N, 32)
     assert np.array_equal(oracle.gemv(t_data, t_scales, x, N, K, 32, workers=8), oracle.gemv(t_data, t_scales, x, N, K, 32))
+
+
+@pytest.mark.parametrize("K,N", [(64, 8), (256, 40), (4096, 67), (96, 13)])
+def test_gemv_range_vnni_arm_is_bit_identical_to_the_scalar_loop(oracle, K, N):
+    """The x86 arm of quant.zig:358-440 (AVX-512 VNNI vpdpbusd with the sign moved from x to w, 8 rows per step, horizontal-add
+    tree, the scalar loop's f32 combine): exact int32 dots and the same f32 order -> the same bits, including the row tail
+    (N % 8) and extreme quantised values (+-127 on both sides). Skipped where the host has no AVX-512 VNNI."""
+    from oracle import oracle as O
+    O.set_vnni(1)
+    if not O.gemv_uses_vnni():
+        O.set_vnni(-1)
+        pytest.skip("host has no AVX-512 VNNI")
+    try:
+        rng = np.random.default_rng(K * 7 + N)
+        data = rng.integers(-127, 128, K * N, dtype=np.int8)
+        data[:64] = 127
+        data[64:128] = -127
+        scales = (rng.random(K * N // 32, dtype=np.float32) * 0.01 + 0.001).astype(np.float32)
+        x = rng.standard_normal(K).astype(np.float32) * 3
+        x[:32] = np.abs(x[:32]).max()  # a block whose values all quantise to +127
+        t_data, t_scales = oracle.prepare_transposed(data, scales, K, N, 32)
+        fast = oracle.gemv(t_data, t_scales, x, N, K, 32)
+        O.set_vnni(0)
+        slow = oracle.gemv(t_data, t_scales, x, N, K, 32)
+        assert not O.gemv_uses_vnni()
+        assert np.array_equal(fast, slow)
+        q, s = oracle.quantize_input(x, 32)
+        assert np.array_equal(fast, _gemv_model(t_data, t_scales, q, s, N, K, 32))
+    finally:
+        O.set_vnni(-1)
