@@ -225,16 +225,21 @@ def bench_single(args):
     # the same Q4_0 rings as INDEPENDENT launches (graph forked over 4 branches): what the kernel streams when
     # launches may overlap — not the decode path, where every mat-vec waits for its predecessor (`roofline`)
     indep = {}
-    for (k, n) in ((4096, 4096), (4096, 11008)):
+    for (k, n, ns) in ((4096, 4096, 8), (4096, 11008, 8), (4096, 32000, 2)):
         nb = C.c_uint64()
-        us_ov = be._lib.zgml_hip_qmatvec_overlap_bench(be.ctx, k, n, 1, 64, 4, 1024, C.byref(nb))
-        if us_ov > 0:
-            indep[f"{k}x{n}"] = {"us_per_launch": round(us_ov, 3), "GBps": round(nb.value / us_ov / 1e3, 1),
-                                 "frac": round(nb.value / us_ov / 1e3 / HBM_PEAK_GBPS, 4)}
-    indep["note"] = "64 mat-vecs forked over 4 graph branches; throughput of overlapping launches, not the dependent-launch figure of `roofline`"
+        us_st = be._lib.zgml_hip_qmatvec_streams_bench(be.ctx, k, n, 1, 64, ns, 1024, C.byref(nb))
+        us_br = be._lib.zgml_hip_qmatvec_overlap_bench(be.ctx, k, n, 1, 64, 4, 1024, C.byref(nb))
+        if us_st > 0:
+            indep[f"{k}x{n}"] = {"us_per_launch": round(us_st, 3), "GBps": round(nb.value / us_st / 1e3, 1),
+                                 "frac": round(nb.value / us_st / 1e3 / HBM_PEAK_GBPS, 4), "streams": ns,
+                                 "graph_branches_us_per_launch": round(us_br, 3) if us_br > 0 else None}
+    indep["note"] = ("64 mat-vecs on EXPLICIT streams (one graph per stream, all in flight): what the kernel streams when launch ramps and tails "
+                     "overlap — not the dependent-launch figure of `roofline` (every mat-vec of the decode path waits for its predecessor); "
+                     "graph_branches: the same ring forked over 4 branches of ONE graph (placement is the runtime's: branches on one queue serialise)")
     extra["matvec_q4_0_independent_launches"] = indep
     cp = be._lib.zgml_hip_copy_bench(be.ctx, 1 << 30, 3, 20)
     extra["copy_kernel_GBps_read_plus_write"] = round(2 * (1 << 30) / cp / 1e3, 1)
+    extra["copy_kernel_note"] = "1 GiB device copy, 8 x 16 B in flight per lane, non-temporal; read-only streams reach more (matvec_q4_0_independent_launches)"
 
     # the int8 KV cache variant of the same program (extension ops kvq_store / attention_kvq)
     try:

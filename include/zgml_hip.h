@@ -519,6 +519,10 @@ double zgml_hip_qmatmul_bench(zgml_hip_ctx* ctx, uint32_t M, uint32_t K, uint32_
  * costs. Returns microseconds per launch (< 0 on error). */
 double zgml_hip_qmatvec_overlap_bench(zgml_hip_ctx* ctx, uint32_t K, uint32_t N, int q4, uint32_t n_matrices, uint32_t n_streams,
                                       uint32_t iters, uint64_t* bytes_per_launch);
+/* ... and on EXPLICIT streams: stream t replays its own graph of the matrices i = t (mod n_streams), all n_streams replays
+ * in flight at once on their own queues (n_matrices % n_streams == 0). Microseconds per launch over all streams. */
+double zgml_hip_qmatvec_streams_bench(zgml_hip_ctx* ctx, uint32_t K, uint32_t N, int q4, uint32_t n_matrices, uint32_t n_streams,
+                                      uint32_t iters, uint64_t* bytes_per_launch);
 /* Ring benchmark of the f16-promoted dense matmul (M == 1: f32 x times f16 weights; M > 1: f16
  * MFMA); bytes = 2*K*N + 4*M*K + 4*M*N. N % 16 == 0. */
 double zgml_hip_dense_f16_bench(zgml_hip_ctx* ctx, uint32_t M, uint32_t K, uint32_t N, uint32_t n_matrices,

@@ -1,10 +1,19 @@
-import sys, ctypes as C
-sys.path.insert(0, "/root/repo")
-from zgml_amd import Backend
+"""Independent mat-vec launches: graph branches (one graph forked over n branches) against explicit streams (one graph per
+stream, all in flight), and the copy-kernel calibration variants."""
+import ctypes as C
+import json
+import os
+import sys
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from zgml_amd import Backend  # noqa: E402
+
 be = Backend(0)
-for (K, N) in ((4096, 4096), (4096, 11008)):
+for (k, n) in ((4096, 4096), (4096, 11008), (11008, 4096), (4096, 32000)):
     for ns in (1, 2, 4, 8):
         nb = C.c_uint64()
-        us = be._lib.zgml_hip_qmatvec_overlap_bench(be.ctx, K, N, 1, 64, ns, 1024, C.byref(nb))
-        print(K, N, "streams", ns, "us", round(us, 3), "GB/s", round(nb.value / us / 1e3, 1), be.last_error())
+        a = be._lib.zgml_hip_qmatvec_overlap_bench(be.ctx, k, n, 1, 64, ns, 1024, C.byref(nb))
+        b = be._lib.zgml_hip_qmatvec_streams_bench(be.ctx, k, n, 1, 64, ns, 1024, C.byref(nb))
+        print(json.dumps({"K": k, "N": n, "n": ns, "graph_branches_us": round(a, 3), "explicit_streams_us": round(b, 3),
+                          "streams_GBps": round(nb.value / b / 1e3, 1), "streams_frac": round(nb.value / b / 1e3 / 8000, 4)}), flush=True)
 be.close()

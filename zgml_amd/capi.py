@@ -191,7 +191,7 @@ HIP_SYMBOLS = [
     "zgml_hip_program_buffer_ptr", "zgml_hip_copy_program_buffer", "zgml_hip_stage_inputs", "zgml_hip_enqueue_staged",
     "zgml_hip_enqueue_argmax", "zgml_hip_argmax_result", "zgml_hip_stream", "zgml_hip_enqueue_program",
     "zgml_hip_enqueue_ops", "zgml_hip_program_set_barriers", "zgml_hip_synchronize", "zgml_hip_upload_inputs", "zgml_hip_download_outputs", "zgml_hip_argmax", "zgml_hip_qmatvec_bench",
-    "zgml_hip_qmatmul_bench", "zgml_hip_qmatvec_overlap_bench", "zgml_hip_qmatvec_chain_bench", "zgml_hip_dense_f16_bench", "zgml_hip_dense_cache_invalidate", "zgml_hip_dense_cache_stats",
+    "zgml_hip_qmatmul_bench", "zgml_hip_qmatvec_overlap_bench", "zgml_hip_qmatvec_streams_bench", "zgml_hip_qmatvec_chain_bench", "zgml_hip_dense_f16_bench", "zgml_hip_dense_cache_invalidate", "zgml_hip_dense_cache_stats",
     "zgml_hip_qmatvec_synth", "zgml_hip_copy_bench", "zgml_hip_resident_setup", "zgml_hip_resident_decode",
     "zgml_hip_resident_prefill", "zgml_hip_shard_unique_id", "zgml_hip_shard_init", "zgml_hip_shard_destroy", "zgml_hip_shard_attach", "zgml_hip_shard_step", "zgml_hip_shard_step_mode",
     "zgml_hip_shard_profile_step",
@@ -265,6 +265,9 @@ def _bind_hip(lib: C.CDLL) -> None:
     lib.zgml_hip_qmatmul_bench.argtypes = [vp, u32, u32, u32, i32, u32, u32, u32, C.POINTER(u64)]
     lib.zgml_hip_qmatvec_overlap_bench.restype = C.c_double
     lib.zgml_hip_qmatvec_overlap_bench.argtypes = [vp, u32, u32, i32, u32, u32, u32, C.POINTER(u64)]
+    if hasattr(lib, "zgml_hip_qmatvec_streams_bench"):
+        lib.zgml_hip_qmatvec_streams_bench.restype = C.c_double
+        lib.zgml_hip_qmatvec_streams_bench.argtypes = [vp, u32, u32, i32, u32, u32, u32, C.POINTER(u64)]
     if hasattr(lib, "zgml_hip_resident_prefill"):
         lib.zgml_hip_resident_prefill.restype = C.c_int64
         lib.zgml_hip_resident_prefill.argtypes = [vp, vp, C.POINTER(u32), u32, u32]

@@ -6,6 +6,7 @@
 // are tiny at decode (d_model..d_ff elements): they are latency-bound, so the kernels favour
 // simple full-wave shapes (64-lane shuffles, one workgroup per row) over tiling.
 #include "kernels.h"
+#include <stdlib.h>
 
 #include <hip/hip_fp16.h>
 #include <math.h>
@@ -1086,6 +1087,30 @@ __global__ void __launch_bounds__(kBlock) copy_f4_kernel(float4* __restrict__ ds
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (uint64_t)gridDim.x * kBlock)
         dst[i] = src[i];
 }
+// The HBM calibration copy (bench.py: extra.copy_kernel_*): U 16-byte loads in flight per lane before the first store, each
+// wave-instruction a contiguous 1 KiB, non-temporal on both sides (every byte is touched once). The plain loop above keeps one
+// load in flight per lane: 4.8 TB/s (read + write); this form 5.0-5.1 — a copy tops out near 5 TB/s on the boxes of this pool
+// (the guide quotes 6.3 for its float4 copy), while READ-only streams go higher: the Q4_0 mat-vec at 4096 x 32000 on two
+// streams reads 6.07 TB/s (tools/overlap_bench.py).
+template <int U, bool NT>
+__global__ void __launch_bounds__(kBlock) copy_f4_unrolled_kernel(float4* __restrict__ dst, const float4* __restrict__ src, uint64_t n4) {
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    for (; i + (U - 1) * stride < n4; i += U * stride) {
+        f4v v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) v[u] = NT ? __builtin_nontemporal_load((const f4v*)src + i + u * stride) : *((const f4v*)src + i + u * stride);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (NT)
+                __builtin_nontemporal_store(v[u], (f4v*)dst + i + u * stride);
+            else
+                *((f4v*)dst + i + u * stride) = v[u];
+        }
+    }
+    for (; i < n4; i += stride) dst[i] = src[i];
+}
 
 __global__ void __launch_bounds__(kBlock) f32_to_f16_kernel(__half* __restrict__ dst, const float* __restrict__ src,
                                                             uint64_t n) {
@@ -1285,7 +1310,20 @@ void launch_argmax(hipStream_t s, const float* v, uint64_t n, float* scratch_val
 void launch_copy_f4(hipStream_t s, void* dst, const void* src, uint64_t bytes) {
     uint64_t n4 = bytes / 16;
     if (n4 == 0) return;
-    copy_f4_kernel<<<2048, kBlock, 0, s>>>((float4*)dst, (const float4*)src, n4);
+    // ZGML_COPY_VARIANT: 0 = the plain loop, else U | NT << 8 | blocks-per-CU << 16 (experiments); default: 8 in flight, nt, 32 blocks per CU (sweep: 4.5-5.1 TB/s over all variants on this part)
+    static const int variant = getenv("ZGML_COPY_VARIANT") ? (int)strtol(getenv("ZGML_COPY_VARIANT"), nullptr, 0) : (8 | 1 << 8 | 32 << 16);
+    if (variant == 0) {
+        copy_f4_kernel<<<2048, kBlock, 0, s>>>((float4*)dst, (const float4*)src, n4);
+        return;
+    }
+    const int U = variant & 0xFF, nt = (variant >> 8) & 1, bpc = (variant >> 16) & 0xFF ? (variant >> 16) & 0xFF : 8;
+    const dim3 grid(256 * bpc);
+    if (U >= 8)
+        nt ? copy_f4_unrolled_kernel<8, true><<<grid, kBlock, 0, s>>>((float4*)dst, (const float4*)src, n4) : copy_f4_unrolled_kernel<8, false><<<grid, kBlock, 0, s>>>((float4*)dst, (const float4*)src, n4);
+    else if (U >= 4)
+        nt ? copy_f4_unrolled_kernel<4, true><<<grid, kBlock, 0, s>>>((float4*)dst, (const float4*)src, n4) : copy_f4_unrolled_kernel<4, false><<<grid, kBlock, 0, s>>>((float4*)dst, (const float4*)src, n4);
+    else
+        nt ? copy_f4_unrolled_kernel<2, true><<<grid, kBlock, 0, s>>>((float4*)dst, (const float4*)src, n4) : copy_f4_unrolled_kernel<2, false><<<grid, kBlock, 0, s>>>((float4*)dst, (const float4*)src, n4);
 }
 
 void launch_f32_to_f16(hipStream_t s, void* dst, const float* src, uint64_t n) {

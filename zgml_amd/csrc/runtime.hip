@@ -3383,6 +3383,85 @@ double zgml_hip_qmatvec_overlap_bench(zgml_hip_ctx* ctx, uint32_t K, uint32_t N,
     return us;
 }
 
+// The same ring as INDEPENDENT launches on EXPLICIT streams: stream t replays its own graph of the matrices i = t (mod n_streams),
+// the n_streams replays run concurrently on their own hardware queues (the fork / join form above puts the branches of ONE graph
+// wherever the runtime likes — on one queue they serialise). Throughput of overlapping launches, not the decode path's figure.
+double zgml_hip_qmatvec_streams_bench(zgml_hip_ctx* ctx, uint32_t K, uint32_t N, int q4, uint32_t n_matrices, uint32_t n_streams, uint32_t iters,
+                                      uint64_t* bytes_per_launch) {
+    if (!ctx || N % 32 || !n_matrices || !iters || !n_streams || n_streams > 16 || n_matrices % n_streams) return -1.0;
+    hipSetDevice(ctx->device);
+    std::vector<QWeightDev> ring(n_matrices);
+    bool ok = true;
+    for (uint32_t i = 0; ok && i < n_matrices; i++) ok = make_synth_weight(ctx, K, N, q4, i, &ring[i]);
+    if (ok && (ring[0].qs_bytes + ring[0].sc_bytes) * n_matrices >= (192ull << 20))
+        for (auto& w : ring) w.stream_nt = 1;
+    float *x = nullptr, *y = nullptr;
+    std::vector<float> xh(K);
+    for (size_t i = 0; i < xh.size(); i++) xh[i] = ((int)(i % 17) - 8) * 0.03125f;
+    ok = ok && CTX_CHECK(ctx, hipMalloc((void**)&x, xh.size() * 4)) && CTX_CHECK(ctx, hipMalloc((void**)&y, (size_t)n_streams * N * 4)) &&
+         CTX_CHECK(ctx, hipMemcpy(x, xh.data(), xh.size() * 4, hipMemcpyHostToDevice));
+    std::vector<hipStream_t> st(n_streams, nullptr);
+    std::vector<hipGraph_t> g(n_streams, nullptr);
+    std::vector<hipGraphExec_t> ge(n_streams, nullptr);
+    std::vector<hipEvent_t> done(n_streams, nullptr);
+    for (uint32_t t = 0; ok && t < n_streams; t++)
+        ok = CTX_CHECK(ctx, hipStreamCreateWithFlags(&st[t], hipStreamNonBlocking)) && CTX_CHECK(ctx, hipEventCreateWithFlags(&done[t], hipEventDisableTiming));
+    double us = -1.0;
+    if (ok) {
+        for (uint32_t i = 0; i < n_matrices; i++) { // warm (and resolve the kernels) outside the captures
+            QMatmulParams qp{y + (size_t)(i % n_streams) * N, x, 1, N, K, K, N};
+            launch_qmatmul(ctx->stream, ring[i], qp, nullptr);
+        }
+        hipStreamSynchronize(ctx->stream);
+        for (uint32_t t = 0; ok && t < n_streams; t++) {
+            ok = CTX_CHECK(ctx, hipStreamBeginCapture(st[t], hipStreamCaptureModeThreadLocal));
+            for (uint32_t i = t; ok && i < n_matrices; i += n_streams) {
+                QMatmulParams qp{y + (size_t)t * N, x, 1, N, K, K, N};
+                launch_qmatmul(st[t], ring[i], qp, nullptr);
+            }
+            ok = ok && CTX_CHECK(ctx, hipStreamEndCapture(st[t], &g[t])) && CTX_CHECK(ctx, hipGraphInstantiate(&ge[t], g[t], nullptr, nullptr, 0));
+        }
+    }
+    if (ok) {
+        const uint32_t reps = (iters + n_matrices - 1) / n_matrices;
+        for (uint32_t t = 0; t < n_streams; t++) hipGraphLaunch(ge[t], st[t]);
+        for (uint32_t t = 0; t < n_streams; t++) hipStreamSynchronize(st[t]);
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0);
+        hipEventCreate(&e1);
+        hipEventRecord(e0, ctx->stream); // the timed region starts on the context stream; every side stream waits for it
+        for (uint32_t t = 0; t < n_streams; t++) hipStreamWaitEvent(st[t], e0, 0);
+        for (uint32_t r = 0; r < reps; r++)
+            for (uint32_t t = 0; t < n_streams; t++) hipGraphLaunch(ge[t], st[t]);
+        for (uint32_t t = 0; t < n_streams; t++) {
+            hipEventRecord(done[t], st[t]);
+            hipStreamWaitEvent(ctx->stream, done[t], 0);
+        }
+        hipEventRecord(e1, ctx->stream);
+        if (CTX_CHECK(ctx, hipEventSynchronize(e1))) {
+            float ms = 0;
+            hipEventElapsedTime(&ms, e0, e1);
+            us = (double)ms * 1000.0 / ((double)reps * n_matrices);
+        }
+        hipEventDestroy(e0);
+        hipEventDestroy(e1);
+    }
+    if (bytes_per_launch) *bytes_per_launch = (uint64_t)K * N / 32 * (q4 ? 18 : 34) + 4ull * K + 4ull * N;
+    for (uint32_t t = 0; t < n_streams; t++) {
+        if (ge[t]) hipGraphExecDestroy(ge[t]);
+        if (g[t]) hipGraphDestroy(g[t]);
+        if (st[t]) hipStreamDestroy(st[t]);
+        if (done[t]) hipEventDestroy(done[t]);
+    }
+    for (auto& w : ring) {
+        hipFree(w.qs);
+        hipFree(w.sc);
+    }
+    hipFree(x);
+    hipFree(y);
+    return us;
+}
+
 int zgml_hip_qmatvec_synth(zgml_hip_ctx* ctx, uint32_t K, uint32_t N, int q4, uint32_t matrix_id, const float* x_host,
                            float* y_host) {
     if (!ctx || N % 32 || !x_host || !y_host) return -1;
