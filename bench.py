@@ -48,7 +48,7 @@ def _pmc_traffic(K, N, q4):
     the 1 GiB copy kernel of the same run), newest round first; stamped with the commit the pass was collected at."""
     if (K, N, q4) != (4096, 4096, 1):
         return None, None
-    for name in ("r02_qmatvec_pmc.json", "r01_qmatvec_pmc.json"):
+    for name in ("r03_qmatvec_pmc.json", "r02_qmatvec_pmc.json", "r01_qmatvec_pmc.json"):
         f = ROOT / "profiles" / name
         if f.exists():
             d = json.loads(f.read_text())
@@ -71,7 +71,7 @@ def matvec_roofline(be, K=4096, N=4096, q4=1, ring=64, iters=2048, chain=False):
     traffic, src = _pmc_traffic(K, N, q4)
     return {"bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": src,
-            "kernel": f"qmatvec_kernel<q4_0> {K}x{N} (single launch per mat-vec)",
+            "kernel": f"qmatvec_kon_kernel (K-on-lanes Q4_0 mat-vec) {K}x{N}, single launch per mat-vec" if q4 else f"qmatvec_kernel<q8_0> {K}x{N}",
             "dependency": "data (y_i is x_{i+1}; epilogue multiply by a constant vector)" if chain else "stream order (one x / y)",
             "bytes_per_launch": nbytes.value, "us_per_launch": round(us, 3), "ring_matrices": ring,
             "launches": iters, "timing": "HIP events on the launch stream; ring captured in a hipGraph"}

@@ -32,10 +32,11 @@ if pmc.exists():
         for k, v in agg.items():
             w.writerow([k, int(meta[k][0]), int(meta[k][1]), "FETCH_SIZE", len(v), round(sum(v) / len(v), 3), min(v), max(v)])
     print("wrote", out.name)
-    copy = [v for k, v in agg.items() if "copy_f4_kernel" in k]
-    q4 = [(k, v) for k, v in agg.items() if "qmatvec_kernel" in k and ", true, " in k.split("qmatvec_kernel<")[1][:40]]
-    # Q4 instances have Q4 = true as the 4th template argument
-    q4 = [(k, v) for k, v in agg.items() if "qmatvec_kernel<" in k and k.split("qmatvec_kernel<")[1].split(",")[3].strip() == "true"]
+    copy = [v for k, v in agg.items() if "copy_f4" in k]
+    # round 3: the Q4_0 mat-vec of the roofline shape is the K-on-lanes kernel; before: qmatvec_kernel with Q4 = true (4th template argument)
+    q4 = [(k, v) for k, v in agg.items() if "qmatvec_kon_kernel<" in k]
+    if not q4:
+        q4 = [(k, v) for k, v in agg.items() if "qmatvec_kernel<" in k and k.split("qmatvec_kernel<")[1].split(",")[3].strip() == "true"]
     if q4 and copy:
         k, v = max(q4, key=lambda kv: len(kv[1]))
         kb = sum(v) / len(v)
@@ -46,9 +47,29 @@ if pmc.exists():
               "4096x4096_q4_0": {
             "FETCH_SIZE_KB_avg": round(kb, 3), "traffic_bytes_per_launch": int(round(kb * 1024 * 2)),
             "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request for wide coalesced streams -> x2 "
-                          f"(MI355X_MICROARCH.md, HBM); calibrated in the same run: copy_f4_kernel of 1 GiB reads FETCH_SIZE = {cal:.0f} KB = 0.5 GiB",
+                          f"(MI355X_MICROARCH.md, HBM); calibrated in the same run: the copy kernel of 1 GiB reads FETCH_SIZE = {cal:.0f} KB = 0.5 GiB",
             "write_side": "16 KB per launch (y), not collected (separate --pmc WRITE_SIZE pass)",
             "kernel": k, "source": f"profiles/{out.name}",
             "command": "rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 tools/bench_matvec.py --shapes 4096x4096 --iters 128"}}
         (dst / f"{tag}_qmatvec_pmc.json").write_text(json.dumps(js, indent=1))
         print("traffic bytes/launch", js["4096x4096_q4_0"]["traffic_bytes_per_launch"])
+
+# the SQ counter series of tools/pmc_matvec.sh (one --pmc pass per group): per shape and counter, dispatches and the average
+ser = ROOT / "gpurun_out" / f"pmc_mv_{tag}"
+if ser.exists():
+    rows = []
+    for f in sorted(ser.glob("*_counters.csv")):
+        shape = f.name.split("_p")[0]
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if "qmatvec_kon_kernel" in r["Kernel_Name"] or "qmatvec_kernel" in r["Kernel_Name"]:
+                agg[(r["Kernel_Name"].split("(")[0][-60:], r["Counter_Name"])].append(float(r["Counter_Value"]))
+        for (k, c), v in sorted(agg.items()):
+            rows.append([shape, k, c, len(v), round(sum(v) / len(v), 1)])
+    if rows:
+        out = dst / f"{tag}_qmatvec_pmc_series.csv"
+        with open(out, "w", newline="") as fh:
+            w = csv.writer(fh)
+            w.writerow(["shape", "kernel", "counter", "dispatches", "avg_per_dispatch"])
+            w.writerows(rows)
+        print("wrote", out.name)

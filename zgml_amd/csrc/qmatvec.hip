@@ -135,6 +135,8 @@ constexpr uint32_t kEpiGeneric = 0, kEpiSilu = 1;
 // ADD vector [store]: the residual add behind the O / down projections (single-matrix launches; the vector is the operand
 // the kernel requests at its start, `pre0`)
 constexpr uint32_t kEpiResidual = 2;
+// MUL vector [store]: one multiply by a vector (zgml_hip_qmatvec_chain_bench's bounded-magnitude epilogue), same treatment
+constexpr uint32_t kEpiMulVec = 3;
 
 struct QMVArgs {
     QMVPartDev parts[kMaxQmvParts];
@@ -464,6 +466,8 @@ __device__ __forceinline__ void reduce_store(float acc, float* red, const QMVArg
                 const float sq = row16_sum(h * h);
                 if (lane == 0) a.next.ssq_out[g] = sq;
             }
+        } else if (!GROUPED && have_pre0 && a.parts[0].epi_kind == kEpiMulVec) {
+            a.parts[0].epi[0].store[n] = v * pre0;
         } else if (!GROUPED || pi == 0)
             run_epilogue(a.parts[0], n, v, out_row, pre0, !GROUPED && have_pre0);
         else if (pi == 1)
@@ -2631,7 +2635,8 @@ static void build_qmv_args(const QmvLaunch& L, QMVArgs& a, uint32_t& blocks, boo
                               st[3].op == ZGML_OP_RECIP && !st[3].store && st[4].op == ZGML_OP_MUL && st[4].operand == pt.dst && st[4].store;
             static const bool silu_on = !(getenv("ZGML_QMV_EPI_SILU") && atoi(getenv("ZGML_QMV_EPI_SILU")) == 0);
             const bool residual = pt.n_epi == 1 && st[0].op == ZGML_OP_ADD && st[0].operand && st[0].operand != pt.dst && st[0].store;
-            d.epi_kind = !silu_on ? kEpiGeneric : (silu ? kEpiSilu : (residual ? kEpiResidual : kEpiGeneric));
+            const bool mulvec = pt.n_epi == 1 && st[0].op == ZGML_OP_MUL && st[0].operand && st[0].operand != pt.dst && st[0].store;
+            d.epi_kind = !silu_on ? kEpiGeneric : (silu ? kEpiSilu : (residual ? kEpiResidual : (mulvec ? kEpiMulVec : kEpiGeneric)));
         }
         blocks += d.NB2;
     }

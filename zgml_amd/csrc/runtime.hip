@@ -3251,8 +3251,14 @@ double zgml_hip_qmatvec_chain_bench(zgml_hip_ctx* ctx, uint32_t K, int q4, uint3
          CTX_CHECK(ctx, hipMemcpy(cvec, ch.data(), N * 4, hipMemcpyHostToDevice));
     double us = -1.0;
     if (ok) {
+        // ZGML_HIP_QMV_TRACE=1 (trace build of the library): in-kernel stamps of ONE launch in the middle of the chain, printed below
+        unsigned long long* trace = nullptr;
+        if (getenv("ZGML_HIP_QMV_TRACE") && atoi(getenv("ZGML_HIP_QMV_TRACE")) &&
+            hipHostMalloc((void**)&trace, 16 * sizeof(unsigned long long), hipHostMallocMapped) == hipSuccess)
+            memset(trace, 0, 16 * sizeof(unsigned long long));
         auto one = [&](uint32_t i) { // launch i: x = (i even ? v0 : v1), y = the other (even ring: the wrap keeps the ping-pong)
             QmvLaunch L;
+            L.trace = i == n_matrices / 2 ? trace : nullptr;
             L.n_parts = 1, L.K = K;
             L.parts[0].w = ring[i];
             L.parts[0].dst = (i & 1) ? v0 : v1;
@@ -3288,6 +3294,17 @@ double zgml_hip_qmatvec_chain_bench(zgml_hip_ctx* ctx, uint32_t K, int q4, uint3
         }
         if (ge) hipGraphExecDestroy(ge);
         if (g) hipGraphDestroy(g);
+        if (trace) { // 100 MHz wall clock -> ns; workgroup 0, and (K-on-lanes body) the last workgroup
+            const unsigned long long* t = trace;
+            fprintf(stderr, "[zgml_hip] chain mat-vec stamps, launch %u of the ring (ns): workgroup 0: start->loads issued %lld | ->streamed %lld | ->reduced+epilogue+stored %lld",
+                    n_matrices / 2, (long long)(t[1] - t[0]) * 10, (long long)(t[4] - t[1]) * 10, (long long)(t[5] - t[4]) * 10);
+            if (t[8])
+                fprintf(stderr, " || last workgroup: starts %lld after workgroup 0 | ->loads issued %lld | ->streamed %lld | ->end %lld || first start -> last end %lld",
+                        (long long)(t[8] - t[0]) * 10, (long long)(t[9] - t[8]) * 10, (long long)(t[12] - t[9]) * 10, (long long)(t[13] - t[12]) * 10,
+                        (long long)(std::max(t[13], t[5]) - t[0]) * 10);
+            fprintf(stderr, "\n");
+            hipHostFree(trace);
+        }
     }
     if (bytes_per_launch) *bytes_per_launch = (uint64_t)K * N / 32 * (q4 ? 18 : 34) + 4ull * K + 4ull * N;
     for (auto& w : ring) {
