@@ -1160,7 +1160,7 @@ void arm_pair(zgml_hip_program* p) {
     if (!on) return;
     for (size_t i = 1; i < p->plan.size(); i++) {
         const auto D = p->plan[i].qmv_desc, G = p->plan[i - 1].qmv_desc;
-        if (!D || !G || D->pro.kind != QMV_PRO_MUL || !D->pro.store_x || G->n_parts != 2 || G->pair_out || G->trace) continue;
+        if (!D || !G || D->pro.kind != QMV_PRO_MUL || !D->pro.store_x || G->n_parts != 2 || G->pair_out) continue;
         const QmvPart &ga = G->parts[0], &up = G->parts[1];
         const QmvEpiStep* st = ga.epi;
         // the SiLU chain exactly as build_qmv_args recognises it (NEG, EXP [store], ADD vector, RECIP, MUL by the gate [store])
@@ -2001,7 +2001,7 @@ void build_fused_plan(zgml_hip_program* p) {
                 if (hipHostMalloc((void**)&t, 16 * sizeof(unsigned long long), hipHostMallocMapped) == hipSuccess) {
                     memset(t, 0, 16 * sizeof(unsigned long long));
                     L.trace = t;
-                    p->qmv_traces.push_back({t, L.n_parts, L.pro.kind, (uint32_t)w0.K, (uint32_t)w0.N});
+                    p->qmv_traces.push_back({t, L.n_parts, L.pro.kind, (uint32_t)w0.K, (uint32_t)w0.N}); // (kind as planned: arm_prenorm / arm_pair may still rewrite it)
                 }
             }
             auto desc = std::make_shared<QmvLaunch>(L); // shared with the launch: arm_prenorm may still rewrite it
