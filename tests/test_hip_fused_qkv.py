@@ -131,3 +131,17 @@ def test_handoff_timeout_is_loud_and_falls_back():
     assert not out["second_err"] and not out["third_err"], out
     assert out["launches_after"] == out["plain_launches"], out
     assert out["tokens_equal"] and out["resident_equal"], out
+
+
+@pytest.mark.timeout(600)
+def test_attention_plus_o_projection_launch():
+    """The decode attention + O projection in one launch of 256-thread workgroups (attn_o_kon_kernel; measured slower than two
+    launches and therefore off by default): parity at Llama-2-7B dimensions against the oracle fixtures, short and long context."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    worker = Path(__file__).parent / "attn_o_worker.py"
+    r = subprocess.run([sys.executable, str(worker)], capture_output=True, text=True, timeout=580, env=dict(os.environ, ZGML_HIP_FUSE_ATTN_O="1"))
+    assert r.returncode == 0 and "ATTN_O_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

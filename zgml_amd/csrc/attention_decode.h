@@ -212,7 +212,9 @@ struct DecodeHandoff {
                          // projection's workgroups of the same launch wait for it (qmatvec.hip: QmvWait)
 };
 
-template <int LPK, bool KVQ>
+// BLOCK: threads of the workgroup that runs the body (1024 stand-alone; 256 inside the launch that also carries the O projection,
+// whose workgroups are 4 waves): at most BLOCK / 64 waves work on a chunk of keys, the loop over steps covers the rest
+template <int LPK, bool KVQ, int BLOCK = kAttnBlock>
 __device__ __forceinline__ void attention_decode_body(const AttnDecodeParams* __restrict__ params, float* split_buf, uint32_t* split_cnt,
                                                       uint32_t split_min_keys, const uint32_t hx, const uint32_t sp_in, const uint32_t n_sp,
                                                       const DecodeHandoff* ho) {
@@ -253,8 +255,8 @@ __device__ __forceinline__ void attention_decode_body(const AttnDecodeParams* __
 #define ATTN_STAMP(i) do { } while (0)
 #endif
     ATTN_STAMP(0);
-    __shared__ __attribute__((aligned(8))) float part_ml[2 * (kAttnBlock / 64)];
-    __shared__ float4 part_acc[(kAttnBlock / 64) * LPK];
+    __shared__ __attribute__((aligned(8))) float part_ml[2 * (BLOCK / 64)];
+    __shared__ float4 part_acc[(BLOCK / 64) * LPK];
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t slot = lane / LPK, li = lane % LPK, d0 = 4 * li, pair = d0 & (HALF - 1);
     const bool is_hi = d0 >= (uint32_t)HALF;
@@ -264,8 +266,11 @@ __device__ __forceinline__ void attention_decode_body(const AttnDecodeParams* __
     const uint32_t d2_off = p.dst2 ? ldgu(p.dyn_dst2_off) : 0; // scalar, with the other dynamic words
     // (a fused launch reads the projections' outputs only after the hand-off below; `ho` is a literal nullptr in the
     // stand-alone kernel, so nothing here is a run-time branch there)
+    // (round 3) a hand-off record WITHOUT counters: the projections come from an earlier launch (plain loads, no wait); only its
+    // output side is used — the O projection's workgroups of this launch wait for out_cnt
+    const bool wait_qkv = ho && ho->cnt;
     float4 q_own, q_par, k_own, k_par, v_new;
-    if (!ho) {
+    if (!wait_qkv) {
         q_own = ldg4(P.q_src + d0), q_par = ldg4(P.q_src + (d0 ^ HALF));
         k_own = ldg4(P.k_src + d0), k_par = ldg4(P.k_src + (d0 ^ HALF));
         v_new = ldg4(P.v_src + d0);
@@ -280,7 +285,7 @@ __device__ __forceinline__ void attention_decode_body(const AttnDecodeParams* __
         n_active = seq_kv / split_min_keys;
         n_active = n_active < 1 ? 1 : (n_active > n_sp ? n_sp : n_active);
         if (sp >= n_active) { // (a fused launch: an idle split still moves its private `seen` words with the counters)
-            if (ho && tid == 0) {
+            if (wait_qkv && tid == 0) {
                 uint32_t* const seen = ho->seen + (hx * n_sp + sp) * 3;
                 seen[0] += ho->need, seen[1] += ho->need, seen[2] += ho->need;
             }
@@ -292,7 +297,7 @@ __device__ __forceinline__ void attention_decode_body(const AttnDecodeParams* __
     const uint32_t n_keys = k_end - k_begin;
     // waves the chunk needs: one step of a wave covers KPW * U keys
     uint32_t NW = (n_keys + KPW * U - 1) / (KPW * U);
-    NW = NW < 1 ? 1 : (NW > (uint32_t)(kAttnBlock / 64) ? (uint32_t)(kAttnBlock / 64) : NW);
+    NW = NW < 1 ? 1 : (NW > (uint32_t)(BLOCK / 64) ? (uint32_t)(BLOCK / 64) : NW);
     if (w >= NW) return;
     const uint32_t keys_per_iter = KPW * NW, step_keys = keys_per_iter * U, last = k_end ? k_end - 1 : 0;
     // ---- phase B: first step's K / V / mask rows (clamped to live rows, unconditional)
@@ -323,7 +328,7 @@ __device__ __forceinline__ void attention_decode_body(const AttnDecodeParams* __
         mk[j] = ldg1(p.mask + (uint64_t)s * p.mask_rs); // host passes a zero word with stride 0 when there is no mask
     }
     uint32_t target[3] = {0, 0, 0}; // fused launch: the counter values this execution waits for (written back at the end)
-    if (ho) { // ---- hand-off: the q / k / v column groups of this head have been stored (DecodeHandoff)
+    if (wait_qkv) { // ---- hand-off: the q / k / v column groups of this head have been stored (DecodeHandoff)
         const uint32_t ci[3] = {ho->idx[3 * hx], ho->idx[3 * hx + 1], ho->idx[3 * hx + 2]};
         const uint32_t* const seen = ho->seen + (hx * n_sp + sp) * 3;
 #pragma unroll
@@ -452,8 +457,8 @@ __device__ __forceinline__ void attention_decode_body(const AttnDecodeParams* __
         if (w != 0) return;
         // wave 0, all 64 lanes: lane ww < 16 fetches wave ww's max for the common max (DPP row reduction);
         // slot g folds waves g, g + KPW, ... — every LDS read is issued up front, the exponentials are independent
-        constexpr int MAXW = kAttnBlock / 64, NPS = MAXW / KPW > 0 ? MAXW / KPW : 1;
-        static_assert(MAXW == 16, "lanes 0..15 (one DPP row) hold the waves' maxima");
+        constexpr int MAXW = BLOCK / 64, NPS = MAXW / KPW > 0 ? MAXW / KPW : 1;
+        static_assert(MAXW <= 16, "lanes 0..15 (one DPP row) hold the waves' maxima");
         float M = lane < NW ? part_ml[2 * lane] : -INFINITY;
         float2 ml[NPS];
         float4 pa[NPS];
@@ -482,7 +487,7 @@ __device__ __forceinline__ void attention_decode_body(const AttnDecodeParams* __
         ATTN_STAMP(6);
     }
     { // wave 0 from here on
-        if (ho && lane == 0) { // every wave of this workgroup has passed the hand-off (merge barrier above / single wave)
+        if (wait_qkv && lane == 0) { // every wave of this workgroup has passed the hand-off (merge barrier above / single wave)
             uint32_t* const seen = ho->seen + (hx * n_sp + sp) * 3;
             seen[0] = target[0], seen[1] = target[1], seen[2] = target[2];
         }
@@ -542,10 +547,10 @@ __device__ __forceinline__ void attention_decode_body(const AttnDecodeParams* __
 #undef ATTN_STAMP
 }
 
-template <int LPK, bool KVQ>
-__global__ void __launch_bounds__(kAttnBlock) attention_decode_kernel(const AttnDecodeParams* __restrict__ params, float* split_buf,
-                                                                      uint32_t* split_cnt, uint32_t split_min_keys) {
-    attention_decode_body<LPK, KVQ>(params, split_buf, split_cnt, split_min_keys, blockIdx.x, blockIdx.y, gridDim.y, nullptr);
+template <int LPK, bool KVQ, int BLOCK = kAttnBlock>
+__global__ void __launch_bounds__(BLOCK) attention_decode_kernel(const AttnDecodeParams* __restrict__ params, float* split_buf,
+                                                                 uint32_t* split_cnt, uint32_t split_min_keys) {
+    attention_decode_body<LPK, KVQ, BLOCK>(params, split_buf, split_cnt, split_min_keys, blockIdx.x, blockIdx.y, gridDim.y, nullptr);
 }
 
 } // namespace

@@ -391,6 +391,11 @@ void launch_qmatvec_fused(hipStream_t s, const QmvLaunch& L);
 bool launch_qkv_attention(hipStream_t s, const QmvLaunch& L, const AttnDecodeParams* dev_params, uint32_t n_heads, uint32_t n_kv, uint32_t d_head,
                           const AttnSplit& sp, uint32_t* counters, const uint32_t* idx, uint32_t* seen, uint32_t* timeout,
                           const QmvLaunch* o_proj = nullptr, uint32_t* out_cnt = nullptr, uint32_t* o_seen = nullptr, bool kvq = false);
+// (round 3) decode attention + the K-on-lanes projection that reads the heads' row stores in one launch of 256-thread workgroups
+// (qmatvec.hip: attn_o_kon_kernel); `out_cnt` one zeroed word, `o_seen` one zeroed word per workgroup of the projection
+bool launch_attention_o(hipStream_t s, const AttnDecodeParams* dev_params, uint32_t n_heads, uint32_t d_head, const AttnSplit& sp, const QmvLaunch& o_proj,
+                        uint32_t* out_cnt, uint32_t* o_seen, uint32_t* timeout);
+int attn_o_blocks_per_cu(uint32_t d_head); // occupancy query of that kernel
 // (o_proj: the single-matrix projection that reads the heads' row stores rides in the same launch; out_cnt: one zeroed
 // word, o_seen: one zeroed word per workgroup of that projection)
 // Deterministic synthetic weights for the roofline micro-benchmark, generated on the device

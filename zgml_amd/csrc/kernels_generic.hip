@@ -1223,6 +1223,18 @@ void launch_attention_decode_batch(hipStream_t s, const AttnDecodeParams* dev_pa
         }
         return;
     }
+    // d_head 128 (f32 KV): 4-wave workgroups — at short context the chunk needs few waves anyway and a 256-thread workgroup
+    // dispatches and merges faster, at long context the splits carry the parallelism: Llama-2-7B 802 -> 812 tok/s, position 1900
+    // 605 -> 622 (ZGML_HIP_ATTN_DECODE_BLOCK=1024 / 256 forces either for d_head 64 and 128)
+    static const int block_env = getenv("ZGML_HIP_ATTN_DECODE_BLOCK") ? atoi(getenv("ZGML_HIP_ATTN_DECODE_BLOCK")) : 0;
+    const bool small_block = block_env == 256 || (block_env == 0 && d_head == 128);
+    if (small_block && (d_head == 64 || d_head == 128)) {
+        if (d_head == 64)
+            attention_decode_kernel<16, false, 256><<<grid, 256, 0, s>>>(dev_params, sp.buf, sp.cnt, sp.min_keys);
+        else
+            attention_decode_kernel<32, false, 256><<<grid, 256, 0, s>>>(dev_params, sp.buf, sp.cnt, sp.min_keys);
+        return;
+    }
     switch (d_head) { // all heads of a launch share d_head (checked by the planner)
         case 8: ADEC(2, false); break;
         case 16: ADEC(4, false); break;

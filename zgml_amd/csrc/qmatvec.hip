@@ -701,6 +701,8 @@ struct QmvWait {
     uint32_t* seen;      // [workgroups of this part]
     uint32_t need;
     uint32_t* timeout;
+    uint32_t poll_sleep = 10; // s_sleep units (64 clocks) between two polls
+    uint32_t pre_sleep = 0;   // experiments: s_sleep units before the weights are requested
 };
 
 template <typename ST, bool XVEC, int DEPTH, bool Q4, bool PRO, bool GROUPED, bool XD, bool NT, bool CONSUME = false>
@@ -937,6 +939,18 @@ struct KonItem { // one lane's share of a step: k = 2p, 2p + 1 x 16 columns
         wq = wload<NT>(qs + pd);
         if (PAIR) wq_b = wload<NT>(qs + pair_q + pd);
     }
+    // the consumer side of an in-launch hand-off (the O projection behind the decode attention): weights and scales do not depend on
+    // the producers and are requested first; x is read afterwards with agent-scope loads (never a stale L1 / L2 line). XV only.
+    __device__ __forceinline__ void load_w(const uint4* qs, const uint32_t* sc, uint32_t p, uint32_t p_last) {
+        const uint32_t pd = min(p, p_last);
+        s2 = sc[pd];
+        wq = wload<NT>(qs + pd);
+    }
+    __device__ __forceinline__ void load_x_agent(const float* a, uint32_t p, uint32_t p_last) {
+        const uint32_t pd = min(p, p_last);
+        const unsigned long long v = __hip_atomic_load((const __attribute__((address_space(1))) unsigned long long*)(a + 2 * pd), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        xa = f32x2{__uint_as_float((uint32_t)v), __uint_as_float((uint32_t)(v >> 32))};
+    }
     __device__ __forceinline__ void compute(uint32_t pd, uint32_t P, uint32_t K, f32x2 (&acc)[8], f32x2 (&acc_b)[8], float& T, float& T_b, float& SS) const {
         const bool ok0 = pd < P, ok1 = ok0 && (XV || 2 * pd + 1 < K);
         float x0 = ok0 ? xa.x : 0.f, x1 = ok1 ? xa.y : 0.f;
@@ -1027,9 +1041,11 @@ __device__ __forceinline__ void kon_pair_finish(const float* red, const QMVArgs&
     }
 }
 
-template <int DEPTH, int PROM, bool GROUPED, bool XV, bool NT, bool PAIR = false>
-__device__ __forceinline__ void qmatvec_kon_body(QMV_HEAD_PARAMS, const QMVArgs& a, const uint32_t bx, const uint32_t n_blocks, const QmvPublish* pub) {
+template <int DEPTH, int PROM, bool GROUPED, bool XV, bool NT, bool PAIR = false, bool CONSUME = false>
+__device__ __forceinline__ void qmatvec_kon_body(QMV_HEAD_PARAMS, const QMVArgs& a, const uint32_t bx, const uint32_t n_blocks, const QmvPublish* pub,
+                                                 const QmvWait* wt = nullptr) {
     constexpr bool PRO = PROM == 1;
+    static_assert(!CONSUME || (PROM == 0 && !GROUPED && !PAIR && XV), "the consumer form: one matrix, no prologue, aligned x");
     extern __shared__ float smem[];
     float* red = smem; // kMaxWaves * 16 column sums + kMaxWaves sums of squares (PAIR: the second matrix's sums from row kMaxWaves + 1)
 #ifdef ZGML_TRACE
@@ -1075,8 +1091,30 @@ __device__ __forceinline__ void qmatvec_kon_body(QMV_HEAD_PARAMS, const QMVArgs&
     // this group has just left (no second register set, and the stream never drains inside a workgroup)
     const uint64_t pair_q = PAIR ? (uint64_t)NB2_0 * P : 0, pair_s = PAIR ? (uint64_t)(NB2_0 >> 1) * P : 0; // part 1 follows part 0 in the arenas
     KonItem<NT, PRO, XV, PAIR> it[DEPTH];
+    if constexpr (CONSUME) {
+        for (uint32_t z = 0; z < wt->pre_sleep; z++) __builtin_amdgcn_s_sleep(16);
 #pragma unroll
-    for (int d = 0; d < DEPTH; d++) it[d].load(qs, sc, xa_base, xb_base, p + d * stride, p_last, K, pair_q, pair_s);
+        for (int d = 0; d < DEPTH; d++) it[d].load_w(qs, sc, p + d * stride, p_last);
+        const uint32_t target = wt->seen[bx] + wt->need;
+        if (w == 0) { // one wave polls (bounded: never hang the device; the host sees the flag at its next synchronisation)
+            uint32_t spins = 0;
+            while ((int32_t)(__hip_atomic_load((const __attribute__((address_space(1))) uint32_t*)wt->cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+                if (++spins > 400000u) {
+                    if (threadIdx.x == 0) __hip_atomic_store(wt->timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
+                for (uint32_t z = 0; z < wt->poll_sleep; z++) __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // the agent-scope x loads below stay behind the poll
+        if (n_waves > 1) __syncthreads();
+        if (threadIdx.x == 0) wt->seen[bx] = target; // (every wave read it before the barrier)
+#pragma unroll
+        for (int d = 0; d < DEPTH; d++) it[d].load_x_agent(xa_base, p + d * stride, p_last);
+    } else {
+#pragma unroll
+        for (int d = 0; d < DEPTH; d++) it[d].load(qs, sc, xa_base, xb_base, p + d * stride, p_last, K, pair_q, pair_s);
+    }
     // this workgroup's slice of the prologue's side outputs: its inputs are requested now, under the weight stream
     KonTail tail{512.0f, norm, 0.f, K, 0.f, 0.f, 0u, 0u, PROM != 0, PROM == 2, {0.f, 0.f, 0.f, 0.f}};
     if (PROM != 0) { // (PRENORM: xb_base carries the ORIGINAL vector a, a.pro.b the gain: the slices are stored from those)
@@ -1136,7 +1174,12 @@ __device__ __forceinline__ void qmatvec_kon_body(QMV_HEAD_PARAMS, const QMVArgs&
         for (int d = 0; d < DEPTH; d++) {
             compute(it[d], p + d * stride);
             __builtin_amdgcn_sched_barrier(0); // (hipcc otherwise moves the refills to the end of the body)
-            it[d].load(qs, sc, xa_base, xb_base, p + (DEPTH + d) * stride, p_last, K, pair_q, pair_s);
+            if constexpr (CONSUME) {
+                it[d].load_x_agent(xa_base, p + (DEPTH + d) * stride, p_last);
+                it[d].load_w(qs, sc, p + (DEPTH + d) * stride, p_last);
+            } else {
+                it[d].load(qs, sc, xa_base, xb_base, p + (DEPTH + d) * stride, p_last, K, pair_q, pair_s);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         p += DEPTH * stride;
@@ -1174,6 +1217,33 @@ __global__ void __launch_bounds__(1024) qmatvec_kon_kernel(QMV_HEAD_PARAMS, QMVA
 template <int DEPTH, int PROM, bool NT>
 __global__ void __launch_bounds__(512, 4) qmatvec_kon_pair_kernel(QMV_HEAD_PARAMS, QMVArgs a) { // (4 waves per SIMD: two workgroups per CU, <= 128 registers)
     qmatvec_kon_body<DEPTH, PROM, true, true, NT, true>(qs0, sc0, out0, xa_base, xb_base, in_rs, K, nb2_0_flags, nb2_12, a, blockIdx.x, gridDim.x, nullptr);
+}
+
+// The decode attention and the O projection that consumes it in ONE launch (round 3, Llama-2-7B-class models): workgroups [0, n_attn)
+// run the decode-attention body (4 waves each; head-major, then split), the rest the K-on-lanes mat-vec in its consumer form. The
+// edge is all-to-all (every column group needs every head), so the hand-off is one counter that every head bumps when its output
+// rows are stored write-through — what pays here is not the edge but what overlaps it: the projection's weights (9.4 MB at 4096^2)
+// are requested at once and stream while the attention, a 32-workgroup latency chain (record, dynamic words, rope, scores, merges:
+// 3.5 us), runs; behind the counter the projection has its x loads, 4 x 32 weights of FMAs per lane and the fold left. All
+// workgroups are 256 threads and the kernel is held to 128 registers, so four workgroups per CU are admitted; the launch is only
+// built when the whole grid fits three per CU (runtime.hip: fuse_attention_o).
+struct AttnOArgs {
+    const AttnDecodeParams* params;
+    float* split_buf;
+    uint32_t* split_cnt;
+    uint32_t split_min_keys, n_attn, n_sp;
+    DecodeHandoff ho; // cnt == nullptr: q / k / v come from the previous launch; out_cnt: the counter the projection waits on
+    QmvWait wt;
+};
+template <int LPK, int DEPTH, bool NT>
+__global__ void __launch_bounds__(256, 4) attn_o_kon_kernel(QMV_HEAD_PARAMS, QMVArgs a, AttnOArgs f) {
+    if (blockIdx.x < f.n_attn) {
+        const uint32_t n_heads = f.ho.n_heads;
+        attention_decode_body<LPK, false, 256>(f.params, f.split_buf, f.split_cnt, f.split_min_keys, blockIdx.x % n_heads, blockIdx.x / n_heads, f.n_sp, &f.ho);
+    } else {
+        qmatvec_kon_body<DEPTH, 0, false, true, NT, false, true>(qs0, sc0, out0, xa_base, xb_base, in_rs, K, nb2_0_flags, nb2_12, a, blockIdx.x - f.n_attn,
+                                                                  gridDim.x - f.n_attn, nullptr, &f.wt);
+    }
 }
 
 // The q / k / v projection and the decode attention that consumes it in ONE launch (DESIGN.md section 8.0,
@@ -2691,6 +2761,47 @@ bool launch_qkv_attention(hipStream_t s, const QmvLaunch& L, const AttnDecodePar
         return launch_qmv(s, L, &f, n_heads * f.n_sp, d_head, &fo);
     }
     return launch_qmv(s, L, &f, n_heads * f.n_sp, d_head);
+}
+
+// the decode attention of `n_heads` heads + the single-matrix K-on-lanes projection that reads their row stores, one launch
+// (attn_o_kon_kernel). `out_cnt`: one zeroed word, `o_seen`: one zeroed word per workgroup of the projection. false: not a shape the
+// kernel is built for (nothing launched). attn_o_blocks_per_cu(): what the occupancy query admits per CU (for the planner's guard).
+int attn_o_blocks_per_cu(uint32_t d_head) {
+    int nb = 0;
+    const void* fn = d_head == 64 ? (const void*)attn_o_kon_kernel<16, 4, true> : (const void*)attn_o_kon_kernel<32, 4, true>;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, ((size_t)kMaxWaves * 16 + kMaxWaves) * sizeof(float)) != hipSuccess) return 0;
+    return nb;
+}
+bool launch_attention_o(hipStream_t s, const AttnDecodeParams* dev_params, uint32_t n_heads, uint32_t d_head, const AttnSplit& sp, const QmvLaunch& Lo,
+                        uint32_t* out_cnt, uint32_t* o_seen, uint32_t* timeout) {
+    QMVArgs a;
+    uint32_t blocks = 0;
+    bool xvec = false;
+    build_qmv_args(Lo, a, blocks, xvec);
+    const QWeightDev& w0 = Lo.parts[0].w;
+    if (w0.format != QW_Q4K || a.n_parts != 1 || a.pro.kind != QMV_PRO_NONE || !xvec || (d_head != 64 && d_head != 128)) return false;
+    a.x_vec = 1;
+    const uint32_t P = (a.K + 1) / 2, waves = 4; // (256-thread workgroups: the kernel's launch bound)
+    const uint32_t n_steps = cdiv(P, waves * 64);
+    const int depth = n_steps >= 4 ? 4 : (n_steps >= 2 ? 2 : 1);
+    const bool nt = w0.stream_nt != 0;
+    AttnOArgs f{};
+    f.params = dev_params, f.split_buf = sp.buf, f.split_cnt = sp.cnt, f.split_min_keys = sp.min_keys;
+    f.n_sp = sp.splits ? sp.splits : 1;
+    f.n_attn = n_heads * f.n_sp;
+    f.ho = DecodeHandoff{nullptr, nullptr, nullptr, n_heads, d_head / 16, timeout, 2u, out_cnt};
+    static const uint32_t poll_sleep = getenv("ZGML_HIP_ATTN_O_POLL") ? (uint32_t)atoi(getenv("ZGML_HIP_ATTN_O_POLL")) : 10u;
+    static const uint32_t pre_sleep = getenv("ZGML_HIP_ATTN_O_PRESLEEP") ? (uint32_t)atoi(getenv("ZGML_HIP_ATTN_O_PRESLEEP")) : 0u;
+    f.wt = QmvWait{out_cnt, o_seen, n_heads, timeout, poll_sleep, pre_sleep};
+    const uint32_t flags = a.parts[0].NB2 | ((waves - 1) << 20) | (1u << 24) | (1u << 30);
+    const size_t lds = ((size_t)kMaxWaves * 16 + kMaxWaves) * sizeof(float);
+    using Fn = void (*)(const uint4*, const void*, float*, const float*, const float*, uint32_t, uint32_t, uint32_t, uint32_t, QMVArgs, AttnOArgs);
+    Fn fn = nullptr;
+#define AO(L) (depth == 4 ? (nt ? (Fn)attn_o_kon_kernel<L, 4, true> : (Fn)attn_o_kon_kernel<L, 4, false>) : depth == 2 ? (Fn)attn_o_kon_kernel<L, 2, false> : (Fn)attn_o_kon_kernel<L, 1, false>)
+    fn = d_head == 64 ? AO(16) : AO(32);
+#undef AO
+    hipLaunchKernelGGL(fn, dim3(f.n_attn + blocks), dim3(256), lds, s, a.parts[0].qs, a.parts[0].sc, a.parts[0].out, a.pro.a, a.pro.b, a.in_rs, a.K, flags, 0u, a, f);
+    return true;
 }
 
 void launch_synth_packed(hipStream_t s, const QWeightDev& w, uint32_t matrix_id) {

@@ -1110,6 +1110,78 @@ void fuse_qkv_attention(zgml_hip_program* p) {
     }
 }
 
+// The decode-attention launch directly followed by the single-matrix K-on-lanes projection that reads exactly its heads' row
+// stores (the O projection of a Llama-2-7B-class model) becomes ONE launch of 256-thread workgroups (qmatvec.hip:
+// attn_o_kon_kernel): the projection's weights stream while the attention's latency chain runs, the projection's workgroups wait
+// (bounded) for one counter every head bumps. The waiting workgroups spin on workgroups of the same grid, so — like the q/k/v +
+// attention launch above — it is only built when the WHOLE grid is resident: the occupancy query minus one workgroup per CU
+// (the query reads one high near a register-file edge), the attention's split count shrinks to fit, otherwise two launches.
+void fuse_attention_o(zgml_hip_program* p) {
+    // MEASURED SLOWER, off unless ZGML_HIP_FUSE_ATTN_O=1 (parity green: tests/test_hip_fused_qkv.py): Llama-2-7B 800 -> 749 tok/s
+    // (766 when the projection's weight loads are delayed until the attention is about done; polling interval and split count
+    // make no difference). The projection's stream does hide under the attention, but the attention's dependent round trips run
+    // under 256 workgroups' worth of memory traffic and the all-to-all edge (write-through rows, counter, agent-scope x loads by
+    // 256 workgroups) costs more than the boundary it replaces — the round-2 finding for every all-to-all edge, now also with
+    // 9.4 MB of prefetch credit on the other side of the scale.
+    static const bool on = getenv("ZGML_HIP_FUSE_ATTN_O") && atoi(getenv("ZGML_HIP_FUSE_ATTN_O")) != 0;
+    if (!on || p->ctx->fuse_qkv_off || !p->ctx->handoff_flag_dev || p->ctx->opt_fuse_resident_wgs == 0) return;
+    for (size_t i = 0; i + 1 < p->plan.size(); i++) {
+        const auto ad = p->plan[i].adec_desc;
+        const auto od = p->plan[i + 1].qmv_desc;
+        if (!ad || !od || ad->kvq || (ad->dh != 64 && ad->dh != 128)) continue;
+        { // a declared barrier between the two launches keeps them apart
+            const uint64_t lo_b = std::min(p->plan[i].op_lo, p->plan[i + 1].op_lo), hi_b = std::max(p->plan[i].op_hi, p->plan[i + 1].op_hi);
+            bool cut = false;
+            for (uint64_t b : p->barriers) cut = cut || (b > lo_b && b <= hi_b);
+            if (cut) continue;
+        }
+        const uint32_t nh = ad->nh, dh = ad->dh;
+        bool ok = od->n_parts == 1 && od->pro.kind == QMV_PRO_NONE && od->K == nh * dh && !od->trace && od->parts[0].w.format == QW_Q4K &&
+                  ((uintptr_t)od->pro.a % 16 == 0) && (od->K % 4 == 0);
+        std::vector<char> seen_head(nh, 0);
+        for (uint32_t r = 0; ok && r < nh; r++) { // every head's rows land at a static offset h * d_head of exactly the projection's input
+            const AttnDecodeParams& a = ad->host[r];
+            ok = a.att.dst2 == od->pro.a && a.att.d2_rs == 1 && a.att.dyn_dst2_off >= p->dyn_dev && a.att.dyn_dst2_off < p->dyn_dev + p->ops.size();
+            if (!ok) break;
+            const zgml_device_op& so = p->ops[(size_t)(a.att.dyn_dst2_off - p->dyn_dev)];
+            ok = so.kind == ZGML_DOP_SLICE_ASSIGN && so.u.slice_assign.patch_stride == 0 && so.u.slice_assign.dst_offset % dh == 0 &&
+                 so.u.slice_assign.dst_offset / dh < nh && !seen_head[so.u.slice_assign.dst_offset / dh];
+            if (ok) seen_head[so.u.slice_assign.dst_offset / dh] = 1;
+        }
+        if (!ok) continue;
+        const uint32_t o_blocks = (uint32_t)(od->parts[0].w.N / 16);
+        const int bpc = attn_o_blocks_per_cu(dh);
+        const uint64_t cap = (uint64_t)std::max(bpc - 1, 1) * (uint64_t)std::max(p->ctx->n_cu, 1);
+        if (o_blocks + nh > cap) continue;
+        uint32_t n_sp = ad->sp.splits ? ad->sp.splits : 1;
+        n_sp = (uint32_t)std::min<uint64_t>(n_sp, (cap - o_blocks) / nh);
+        const size_t words = 32 + o_blocks; // the counter on a line of its own, then one `seen` word per projection workgroup
+        uint32_t* block = nullptr;
+        if (hipMalloc((void**)&block, words * 4) != hipSuccess) continue;
+        if (hipMemset(block, 0, words * 4) != hipSuccess) {
+            hipFree(block);
+            continue;
+        }
+        p->fuse_owned.push_back(block);
+        uint32_t *out_cnt = block, *o_seen = block + 32, *timeout = p->ctx->handoff_flag_dev;
+        const AttnDecodeParams* d = ad->dev;
+        AttnSplit sp = ad->sp;
+        sp.splits = n_sp;
+        const AttnSplit sp_plain = ad->sp;
+        const QmvLaunch Lo = *od; // (after arm_prenorm: the residual epilogue's side outputs ride along)
+        const uint32_t n_ops = p->plan[i].n_ops + p->plan[i + 1].n_ops, lo = std::min(p->plan[i].op_lo, p->plan[i + 1].op_lo),
+                       hi = std::max(p->plan[i].op_hi, p->plan[i + 1].op_hi);
+        Launch F{ZGML_DOP_ATTENTION, n_ops, lo, hi, [=](hipStream_t s) {
+                     if (!launch_attention_o(s, d, nh, dh, sp, Lo, out_cnt, o_seen, timeout)) {
+                         launch_attention_decode_batch(s, d, nh, dh, sp_plain, false);
+                         launch_qmatvec_fused(s, Lo);
+                     }
+                 }};
+        p->plan[i] = std::move(F);
+        p->plan.erase(p->plan.begin() + (ptrdiff_t)i + 1);
+    }
+}
+
 // A mat-vec launch with a residual-add epilogue (h = y + r: the O / down projections) that is DIRECTLY followed by the launch
 // whose rmsnorm -> mul(gamma) prologue consumes h prepares that prologue (kernels.h: QmvNextNorm / QMV_PRO_PRENORM): it also
 // stores h * gamma and, per 16 columns, the sum of h^2. The consumer then streams one vector instead of two — x (16 KB at
@@ -2013,6 +2085,7 @@ void build_fused_plan(zgml_hip_program* p) {
     arm_prenorm(p);
     arm_pair(p);
     fuse_qkv_attention(p);
+    fuse_attention_o(p);
 }
 
 void build_plan(zgml_hip_program* p) {
