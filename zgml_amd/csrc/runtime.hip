@@ -170,6 +170,12 @@ struct zgml_hip_program {
     std::vector<void*> owned; // other device allocations
     uint64_t fuse_epoch = 0;             // ctx->fuse_epoch the plan was built at (a time-out rebuilds it without the fusion)
     std::vector<void*> fuse_owned;       // counters / seen / idx blocks of the fused launches: freed with every plan rebuild
+    // repeats of constant data (a weight broadcast to the activation shape: source never written by an op, destination written by
+    // this op only) run ONCE when the plan is built instead of in every execution; a host input that ever targets one of the
+    // buffers involved switches this off for the program (prepare_io)
+    std::vector<char> hoist_op;    // per op: executed at plan-build time, not part of the plan
+    std::vector<char> hoist_guard; // per buffer: read or written by a hoisted repeat
+    bool hoist_ok = true;
     float* prenorm_buf = nullptr;        // arm_prenorm: [x * gamma | partial sums of squares] handed from a residual epilogue to the next prologue
     size_t prenorm_bytes = 0;
     float* scratch = nullptr;
@@ -435,6 +441,13 @@ bool ensure_stage(zgml_hip_program* p, uint64_t bytes) {
 
 // (re)build the cached transfer table when the descriptor list changed
 bool prepare_io(zgml_hip_program* p, IoPlan& plan, const zgml_program_io* ios, uint64_t n) {
+    if (&plan == &p->in_plan && p->hoist_ok)
+        for (uint64_t i = 0; i < n; i++)
+            if (ios[i].buf_idx < p->hoist_guard.size() && p->hoist_guard[ios[i].buf_idx]) { // the host writes what a hoisted repeat read or wrote
+                p->hoist_ok = false;
+                p->plan_dirty = true;
+                break;
+            }
     bool same = plan.entries.size() == n;
     for (uint64_t i = 0; same && i < n; i++)
         same = plan.entries[i] == IoEntry{ios[i].buf_idx, ios[i].offset, ios[i].size};
@@ -774,7 +787,8 @@ struct PlanItem {
 // the batchable kinds of one group of mutually independent items -> one "movement" launch (ropes
 // and slice_assigns together), one attention launch, one repeat launch; the rest one by one
 void emit_batches(zgml_hip_program* p, const std::vector<PlanItem>& group) {
-    std::vector<RepeatParams> reps;
+    std::vector<RepeatParams> reps, hoisted;
+    uint32_t hoisted_max = 0;
     std::vector<MoveParams> moves;
     std::vector<AttentionParams> atts;
     std::vector<int64_t> att_store_off; // per attention: the static offset of its folded row store (else -1)
@@ -792,6 +806,11 @@ void emit_batches(zgml_hip_program* p, const std::vector<PlanItem>& group) {
         const zgml_device_op& op = p->ops[i];
         switch (op.kind) {
             case ZGML_DOP_REPEAT:
+                if (i < p->hoist_op.size() && p->hoist_op[i]) { // constant: runs once, now (below)
+                    hoisted.push_back(make_repeat(p, op.u.repeat));
+                    hoisted_max = std::max(hoisted_max, op.u.repeat.n);
+                    break;
+                }
                 reps.push_back(make_repeat(p, op.u.repeat));
                 rep_max = std::max(rep_max, op.u.repeat.n);
                 n_rep++;
@@ -885,6 +904,10 @@ void emit_batches(zgml_hip_program* p, const std::vector<PlanItem>& group) {
             sp = attn_split_for(p, n, dh, max_kv);
         }
         p->plan.push_back({ZGML_DOP_ATTENTION_KVQ, n, kat_lo, kat_hi, [=](hipStream_t s) { launch_kvq_attention_batch(s, d, n, mq, dh, sp); }});
+    }
+    if (!hoisted.empty()) { // (build_plan runs outside any capture, on the context stream: ordered before the plan's first execution)
+        const RepeatParams* d = upload_params(p, hoisted);
+        launch_repeat_batch(p->ctx->stream, d, (uint32_t)hoisted.size(), hoisted_max);
     }
     if (!reps.empty()) {
         const RepeatParams* d = upload_params(p, reps);
@@ -1264,6 +1287,26 @@ void build_fused_plan(zgml_hip_program* p) {
     const auto& ops = p->ops;
     const size_t n = ops.size();
     const Schedule& s0 = p->sched; // per-op access spans
+    { // constant repeats (see zgml_hip_program::hoist_op)
+        static const bool hoist_on = !(getenv("ZGML_HIP_HOIST_REPEAT") && atoi(getenv("ZGML_HIP_HOIST_REPEAT")) == 0);
+        p->hoist_op.assign(n, 0);
+        p->hoist_guard.assign(p->bufs.size(), 0);
+        if (hoist_on && p->hoist_ok && p->barriers.empty()) {
+            std::vector<uint32_t> writers(p->bufs.size(), 0);
+            for (size_t i = 0; i < n; i++) {
+                std::vector<uint16_t> seen;
+                for (const Span& w : s0.access[i].writes)
+                    if (w.buf < writers.size() && std::find(seen.begin(), seen.end(), w.buf) == seen.end()) writers[w.buf]++, seen.push_back(w.buf);
+            }
+            for (size_t i = 0; i < n; i++) {
+                if (ops[i].kind != ZGML_DOP_REPEAT) continue;
+                const auto& r = ops[i].u.repeat;
+                if (r.src >= writers.size() || r.dst >= writers.size() || r.src == r.dst || writers[r.src] != 0 || writers[r.dst] != 1) continue;
+                p->hoist_op[i] = 1;
+                p->hoist_guard[r.src] = p->hoist_guard[r.dst] = 1;
+            }
+        }
+    }
     std::vector<int> owner(n, -1);  // op -> macro id that absorbed it
     std::vector<Macro> macros;
 
@@ -2105,6 +2148,7 @@ void build_plan(zgml_hip_program* p) {
     if (p->plan_batched) {
         build_fused_plan(p);
     } else {
+        p->hoist_op.clear(); // op by op: every repeat runs
         for (uint32_t i = 0; i < p->ops.size(); i++) emit_batches(p, {PlanItem{i, -1}});
     }
     p->plan_dirty = false;
@@ -3081,7 +3125,13 @@ zgml_runtime_profile* zgml_hip_get_runtime_profile(zgml_hip_ctx*, zgml_hip_progr
 
 // ── extensions ──────────────────────────────────────────────────────────────────────────────
 
+// a caller about to touch a buffer some hoisted (run-once) repeat read or wrote: back to running every repeat in the plan
+void unhoist_if_guarded(zgml_hip_program* p, uint16_t buf_idx) {
+    if (p->hoist_ok && buf_idx < p->hoist_guard.size() && p->hoist_guard[buf_idx]) p->hoist_ok = false, p->plan_dirty = true;
+}
+
 void* zgml_hip_program_buffer_ptr(zgml_hip_program* p, uint16_t buf_idx) {
+    if (p) unhoist_if_guarded(p, buf_idx);
     return (p && buf_idx < p->bufs.size()) ? p->bufs[buf_idx] : nullptr;
 }
 
@@ -3104,6 +3154,7 @@ int zgml_hip_copy_program_buffer(zgml_hip_ctx* ctx, zgml_hip_program* dst, uint1
         ctx->fail("copy_program_buffer: range exceeds a buffer");
         return -1;
     }
+    unhoist_if_guarded(dst, dst_buf);
     hipSetDevice(ctx->device);
     return CTX_CHECK(ctx, hipMemcpyAsync(dst->bufs[dst_buf] + dst_offset, src->bufs[src_buf] + src_offset, n_elems * sizeof(float),
                                          hipMemcpyDeviceToDevice, ctx->stream))
