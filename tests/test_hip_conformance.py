@@ -230,6 +230,28 @@ def test_dead_buffer_elision_and_loud_io_error(hip_backend):
     hip_backend.freeProgram(h)
 
 
+def test_constant_repeat_runs_once_until_the_host_writes_its_source(hip_backend):
+    """A repeat whose source no op writes is executed when the plan is built, not per execution (the γ broadcasts of the
+    LLaMA programs); an execute input on that source puts it back in the plan, with the new values visible."""
+    from zgml_amd import capi
+    prog = DeviceProgram(
+        ops=[DeviceOp.repeat(1, 0, 6, (2, 1, 1, 1), (2, 3, 1, 1), (1, 2, 2, 2), (1, 2, 6, 6)), DeviceOp.elementwise("neg", 2, 1, 1, 6)],
+        buffer_sizes=[2, 6, 6], initial_uploads=[ProgramIO(0, np.array([7, 8], f32))])
+    h = hip_backend.compileProgram(prog)
+    prof = lambda: capi.load_hip().zgml_hip_get_runtime_profile(hip_backend.ctx, h).contents.backend_dispatch_count
+    out = np.zeros(6, f32)
+    for _ in range(2):
+        hip_backend.executeProgram(h, [], [ProgramIO(2, out)])
+        assert out.tolist() == [-7, -8, -7, -8, -7, -8]
+    assert prof() == 2  # one launch per execution: the neg
+    hip_backend.executeProgram(h, [ProgramIO(0, np.array([1, 2], f32))], [ProgramIO(2, out)])
+    assert out.tolist() == [-1, -2, -1, -2, -1, -2]
+    hip_backend.executeProgram(h, [ProgramIO(0, np.array([3, 4], f32))], [ProgramIO(2, out)])
+    assert out.tolist() == [-3, -4, -3, -4, -3, -4]
+    assert prof() == 6  # repeat + neg from then on
+    hip_backend.freeProgram(h)
+
+
 def test_argmax_first_max_wins(hip_backend, oracle):
     rng = np.random.default_rng(5)
     v = rng.standard_normal(49152).astype(f32)

@@ -1979,6 +1979,332 @@ __global__ void __launch_bounds__(512, 2) qmatmul_xdl4_kernel(QMM4Args a) {
     }
 }
 
+// ── XDL tile kernel for M <= 32 with the A pieces SHARED through LDS ──────────────────────────────────────────────────
+// What bounds qmatmul_xdl2_kernel at M = 32 is not the matrix pipe: a workgroup there owns 16 or 32 columns and all of K, so
+// every workgroup pulls the whole A operand (M K 6 B as bf16 pieces, 786 KB at 32 x 4096) out of L2 — 200-540 MB per launch,
+// and the launches run at exactly that traffic over ~16 TB/s (o 12.5 us, q/k/v 32 us, gate/up 52 us, down 30 us). Here
+//   * a workgroup-column is WAVES scale block-columns (32 columns each, one per wave: 256 columns at 8 waves) x RT = 1 or 2
+//     m-tiles (all of M); all waves of a workgroup walk the SAME K steps;
+//   * a step's A pieces (RT x 12 KB) are fetched from L2 ONCE per workgroup into a double-buffered LDS region (one barrier
+//     per step) and every wave reads its MFMA operands from there: A through L2 / (8 x the old form);
+//   * each wave prepares B for its own block-column only (every weight still prepared exactly once per launch) and keeps the
+//     weights of the next two steps in registers; no cross-wave fold — a wave's accumulators ARE its output tile;
+//   * the (workgroup-column, K step) pairs of the launch are ONE list cut into equal runs, one per workgroup (as many
+//     workgroups as the chip holds, whatever N is): a run covers the tail of one column and the head of the next at most.
+//     A run that is not a whole column publishes its partial tile (write-through stores, drain, one agent-scope add on the
+//     column's counter); the LAST arriver sums the column's runs in run order — deterministic — scales and stores.
+struct QMM5Args {
+    QMM2Part parts[kMaxQmmParts]; // NB2 = block-columns (N / 32) of the part, block_begin = its first workgroup-column
+    const uint4* ap;              // split_a_kernel output
+    float* partial;               // [workgroup][segment 0 / 1][wave][2 RT 256] f32
+    uint32_t* counter;            // one word per workgroup-column, zero between launches
+    uint32_t n_parts, M, U, S, run, total; // total = workgroup-columns x S (column, step) pairs, run = pairs per workgroup (<= S)
+    uint32_t dbg;                          // timing experiments only (ZGML_QMM_XDL5_DEBUG): 1 = no fan-in (partial results stored as they are)
+};
+
+// B pieces of one 8-k group: w = (q - 8)/16 * scale (exact in f32: 4 x 11 bits), split into bf16 hi + bf16 lo (exact).
+// Written so that hipcc emits ~4.6 VALU instructions per weight instead of the ~8 of the xdl2 / xdl4 form:
+//   * the scale broadcast rides in the multiply (v_mul_f32_dpp row_newbcast: full masks + bound_ctrl make the DPP move foldable);
+//   * every convert takes its nibble through an SDWA byte select: the high nibbles come from ONE shifted copy of the dword
+//     (kept opaque, or the shifts merge into byte-unaligned ones), and the `& 0xFF` is what lets the peephole pick BYTE_n;
+//   * the residuals w - hi are formed two at a time (v_pk_add_f32 with a negated operand).
+template <int CTRL>
+__device__ __forceinline__ float row_bcast_z(int v) { return __int_as_float(__builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true)); } // (no `old` to initialise)
+typedef float xf32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t xu32x2 __attribute__((ext_vector_type(2)));
+
+template <int J, int C>
+__device__ __forceinline__ void xdl_prep_b(const uint4 (&wq)[C], int sb_lo, int sb_hi, uint4 (&b1)[C], uint4 (&b2)[C]) {
+    const int sbits = J >> 1 ? sb_hi : sb_lo;
+    constexpr int C0 = 0x150 + 8 * (J & 1); // the scale of k_local 8 J + e sits in lane 8 (J & 1) + e of this row
+#pragma unroll
+    for (int g = 0; g < C; g++) {
+        const uint32_t lo = J == 0 ? wq[g].x : J == 1 ? wq[g].y : J == 2 ? wq[g].z : wq[g].w;
+        uint32_t hi = lo >> 4;
+        asm volatile("" : "+v"(hi));
+#define XDL5_W(E, SRC, BYTE) (row_bcast_z<C0 + E>(sbits) * __builtin_amdgcn_cvt_off_f32_i4((int)(((SRC) >> (8 * BYTE)) & 0xFFu))) /* (q - 8)/16 * scale */
+        const xf32x2 w01 = {XDL5_W(0, lo, 0), XDL5_W(1, lo, 1)}, w23 = {XDL5_W(2, lo, 2), XDL5_W(3, lo, 3)};
+        const xf32x2 w45 = {XDL5_W(4, hi, 0), XDL5_W(5, hi, 1)}, w67 = {XDL5_W(6, hi, 2), XDL5_W(7, hi, 3)};
+#undef XDL5_W
+        auto top = [](xf32x2 v) { return __builtin_bit_cast(xf32x2, __builtin_bit_cast(xu32x2, v) & 0xFFFF0000u); };
+        const xf32x2 l01 = w01 - top(w01), l23 = w23 - top(w23), l45 = w45 - top(w45), l67 = w67 - top(w67);
+        b1[g] = make_uint4(pack_hi16(w01.x, w01.y), pack_hi16(w23.x, w23.y), pack_hi16(w45.x, w45.y), pack_hi16(w67.x, w67.y));
+        b2[g] = make_uint4(pack_hi16(l01.x, l01.y), pack_hi16(l23.x, l23.y), pack_hi16(l45.x, l45.y), pack_hi16(l67.x, l67.y));
+    }
+}
+
+// LEAN: no software pipelining inside a wave (one set of B pieces, one accumulator per tile, weights one step ahead) to fit
+// 128 registers — two workgroups per CU, four waves per SIMD, and the overlap of B preparation, MFMAs and LDS reads comes
+// from the other waves instead.
+template <int RT, int WAVES, bool NT, bool LEAN>
+__global__ void __launch_bounds__(WAVES * 64, LEAN ? 4 : 1) qmatmul_xdl5_kernel(QMM5Args a) {
+    constexpr int C = 2;
+    constexpr uint32_t T = WAVES * 64, STEP = RT * 768; // uint4 of one step's A pieces: [tile][J][piece][lane]
+    constexpr uint32_t NA = (STEP + T - 1) / T;
+    constexpr uint32_t WT = C * RT * 256; // floats of one wave's tile
+    extern __shared__ uint4 lds_a[];      // [2][STEP], then one flag word
+    uint32_t* const flag = (uint32_t*)(lds_a + 2 * STEP);
+    const uint32_t lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t row = lane >> 4, i = lane & 15;
+    const uint64_t tile_stride = (uint64_t)a.S * 768;
+    const uint32_t u_begin = blockIdx.x * a.run, u_end = min(u_begin + a.run, a.total);
+
+    for (uint32_t u0 = u_begin, seg = 0; u0 < u_end; seg++) { // at most two segments (run <= S)
+        const uint32_t wgc = u0 / a.S, s_begin = u0 - wgc * a.S, s_end = min(a.S, s_begin + (u_end - u0)), s_last = s_end - 1;
+        u0 += s_end - s_begin;
+        uint32_t pi = 0;
+#pragma unroll
+        for (uint32_t t = 1; t < (uint32_t)kMaxQmmParts; t++)
+            if (t < a.n_parts && wgc >= a.parts[t].block_begin) pi = t;
+        const QMM2Part& P = a.parts[pi];
+        const uint32_t cb_raw = (wgc - P.block_begin) * WAVES + w;
+        const bool live = cb_raw < P.NB2;               // (a part whose block-columns do not fill its last workgroup-column)
+        const uint32_t cb = live ? cb_raw : P.NB2 - 1;  // idle waves shadow the last column: loads stay in bounds
+        const uint4* qs = P.qs + (uint64_t)(cb * C) * a.U * 16 + i;
+        const uint32_t* scd = (const uint32_t*)P.sc + (uint64_t)cb * a.U * 16 + i;
+
+        // two accumulators per (column group, m-tile), one per B piece: with the tiles taken one after the other (their A
+        // registers are refilled in between) that makes FOUR independent MFMA chains, each touched every fourth MFMA — a wave
+        // issues in order, and a dependent 16-cycle MFMA right behind its producer stalls the VALU work queued behind it too
+        // (measured with two chains: MFMA pipe 45 % busy, 41 % of the wave cycles waiting to issue)
+        mfma_f4 acc[C][RT], acc2[C][RT];
+#pragma unroll
+        for (int g = 0; g < C; g++)
+#pragma unroll
+            for (int t = 0; t < RT; t++) acc[g][t] = acc2[g][t] = mfma_f4{0.f, 0.f, 0.f, 0.f};
+
+        struct WStep { // one K step of this lane: its unit's nibbles for the two column groups, its dword of the unit's scales
+            uint4 wq[C];
+            uint32_t sd;
+        };
+        struct BP {
+            uint4 b1[C], b2[C];
+        };
+        auto load_w = [&](WStep& b, uint32_t s) {
+            const uint32_t u = min(4 * s + row, a.U - 1); // units past the end: A is zero there
+#pragma unroll
+            for (int g = 0; g < C; g++) b.wq[g] = wload<NT>(qs + ((uint64_t)g * a.U + u) * 16);
+            b.sd = scd[(uint64_t)u * 16];
+        };
+        // (named registers, not an array: hipcc left a uint4[NA] in scratch memory, whose reloads wait for every older load)
+        uint4 ar0 = {}, ar1 = {}, ar2 = {};
+        static_assert(NA <= 3, "A pieces of a step per thread");
+        auto a_src = [&](uint32_t s, uint32_t q) -> const uint4* {
+            const uint32_t idx = threadIdx.x + q * T;
+            return a.ap + (uint64_t)(idx / 768) * tile_stride + (uint64_t)s * 768 + idx % 768;
+        };
+        auto fetch_a = [&](uint32_t s) {
+            ar0 = *a_src(s, 0);
+            if (NA > 1 && (STEP >= 2 * T || threadIdx.x + T < STEP)) ar1 = *a_src(s, 1);
+            if (NA > 2 && (STEP >= 3 * T || threadIdx.x + 2 * T < STEP)) ar2 = *a_src(s, 2);
+        };
+        auto park_a = [&](uint32_t buf) {
+            lds_a[buf * STEP + threadIdx.x] = ar0;
+            if (NA > 1 && (STEP >= 2 * T || threadIdx.x + T < STEP)) lds_a[buf * STEP + threadIdx.x + T] = ar1;
+            if (NA > 2 && (STEP >= 3 * T || threadIdx.x + 2 * T < STEP)) lds_a[buf * STEP + threadIdx.x + 2 * T] = ar2;
+        };
+        uint4 xa[RT][3]; // the A pieces of the current 8-k group, refilled tile by tile after their last use
+        auto read_a = [&](uint32_t buf, int J, int t) {
+#pragma unroll
+            for (int p = 0; p < 3; p++) xa[t][p] = lds_a[buf * STEP + ((t * 4 + J) * 3 + p) * 64 + lane];
+        };
+        auto mfmas = [&](const BP& o, int t) {
+#pragma unroll
+            for (int p = 0; p < 3; p++) {
+#pragma unroll
+                for (int g = 0; g < C; g++) acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(xa[t][p]), as_bf16x8(o.b1[g]), acc[g][t], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < C; g++) acc2[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(xa[t][p]), as_bf16x8(o.b2[g]), acc2[g][t], 0, 0, 0);
+            }
+        };
+        auto scale_bits = [](const WStep& b, int& lo, int& hi) {
+            const __half2 hh = __builtin_bit_cast(__half2, b.sd);
+            lo = __float_as_int(__half2float(hh.x)), hi = __float_as_int(__half2float(hh.y)); // scales of k_local i, 16 + i
+        };
+
+        if constexpr (LEAN) {
+            WStep wa, wb; // the weights of steps s, s + 1: two names taking turns
+            BP pb;
+            int sl, sh;
+            load_w(wa, s_begin);
+            fetch_a(s_begin);
+            if (seg) __syncthreads(); // the previous segment's last reads of the A buffers
+            park_a(0);
+            __syncthreads();
+            auto group = [&](uint32_t buf, auto jc, const WStep& cur) {
+                constexpr int J = decltype(jc)::value;
+#pragma unroll
+                for (int t = 0; t < RT; t++) read_a(buf, J, t);
+                xdl_prep_b<J, C>(cur.wq, sl, sh, pb.b1, pb.b2);
+#pragma unroll
+                for (int p = 0; p < 3; p++) { // (tile, column group) innermost: four independent chains
+#pragma unroll
+                    for (int t = 0; t < RT; t++)
+#pragma unroll
+                        for (int g = 0; g < C; g++) acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(xa[t][p]), as_bf16x8(pb.b1[g]), acc[g][t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < RT; t++)
+#pragma unroll
+                        for (int g = 0; g < C; g++) acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(xa[t][p]), as_bf16x8(pb.b2[g]), acc[g][t], 0, 0, 0);
+                }
+            };
+#define XDL5_LEAN_STEP(S_, CUR, NXT)                                                   \
+    do {                                                                               \
+        fetch_a(min((S_) + 1, s_last));                                                \
+        load_w(NXT, min((S_) + 1, s_last));                                            \
+        scale_bits(CUR, sl, sh);                                                       \
+        group(buf, std::integral_constant<int, 0>{}, CUR);                             \
+        group(buf, std::integral_constant<int, 1>{}, CUR);                             \
+        group(buf, std::integral_constant<int, 2>{}, CUR);                             \
+        group(buf, std::integral_constant<int, 3>{}, CUR);                             \
+        park_a(buf ^ 1);                                                               \
+        __syncthreads();                                                               \
+        buf ^= 1;                                                                      \
+    } while (0)
+            uint32_t buf = 0;
+            for (uint32_t s = s_begin;; s += 2) {
+                XDL5_LEAN_STEP(s, wa, wb);
+                if (s + 1 >= s_end) break;
+                XDL5_LEAN_STEP(s + 1, wb, wa);
+                if (s + 2 >= s_end) break;
+            }
+#undef XDL5_LEAN_STEP
+        } else {
+        WStep wa, wb, wc; // the weights of steps s, s + 1, s + 2: three names rotating (a register copy would wait for the load)
+        BP p0, p1;
+        int sl, sh;
+        load_w(wa, s_begin);
+        fetch_a(s_begin);
+        load_w(wb, min(s_begin + 1, s_last));
+        if (seg) __syncthreads(); // the previous segment's last reads of the A buffers
+        park_a(0);
+        __syncthreads();
+        scale_bits(wa, sl, sh);
+        read_a(0, 0, 0);
+        if (RT > 1) read_a(0, 0, RT - 1);
+        xdl_prep_b<0, C>(wa.wq, sl, sh, p0.b1, p0.b2);
+        __builtin_amdgcn_sched_barrier(0);
+        // one stage: the MFMAs of group J, tile by tile, each tile's A registers refilled for group JN = J + 1 once its MFMAs
+        // are issued, and the B preparation of group JN spread between the MFMAs
+#define XDL5_STAGE(CUR, NXT, BUF_N, JN, WSRC)                                          \
+    do {                                                                               \
+        xdl_prep_b<JN, C>(WSRC.wq, sl, sh, NXT.b1, NXT.b2);                            \
+        mfmas(CUR, 0);                                                                 \
+        read_a(BUF_N, JN, 0);                                                          \
+        if (RT > 1) {                                                                  \
+            mfmas(CUR, RT - 1);                                                        \
+            read_a(BUF_N, JN, RT - 1);                                                 \
+        }                                                                              \
+        _Pragma("unroll") for (int t_ = 0; t_ < RT; t_++) {                            \
+            _Pragma("unroll") for (int k_ = 0; k_ < 6 * C; k_++) {                     \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); /* 1 MFMA */        \
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0); /* 3 VALU */        \
+            }                                                                          \
+            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0); /* the tile's refill */ \
+        }                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+    } while (0)
+        // one K step: A of step s + 1 and the weights of step s + 2 requested first (in that order: the A pieces are waited
+        // for below with the weight loads still in flight), three stages, the hand-over of the A buffers, the fourth stage
+#define XDL5_STEP(S_, CUR, NXT, LD)                                                                   \
+    do {                                                                                              \
+        fetch_a(min((S_) + 1, s_last)); /* clamped: the last prefetches re-read live lines */          \
+        load_w(LD, min((S_) + 2, s_last));                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        XDL5_STAGE(p0, p1, buf, 1, CUR);                                                              \
+        XDL5_STAGE(p1, p0, buf, 2, CUR);                                                              \
+        XDL5_STAGE(p0, p1, buf, 3, CUR);                                                              \
+        park_a(buf ^ 1); /* every wave is past its last read of that buffer since the previous barrier */ \
+        __syncthreads();                                                                              \
+        scale_bits(NXT, sl, sh);                                                                      \
+        XDL5_STAGE(p1, p0, buf ^ 1, 0, NXT); /* (after the last step: a wasted preparation) */        \
+        buf ^= 1;                                                                                     \
+    } while (0)
+        uint32_t buf = 0;
+        for (uint32_t s = s_begin;; s += 3) {
+            XDL5_STEP(s, wa, wb, wc);
+            if (s + 1 >= s_end) break;
+            XDL5_STEP(s + 1, wb, wc, wa);
+            if (s + 2 >= s_end) break;
+            XDL5_STEP(s + 2, wc, wa, wb);
+            if (s + 3 >= s_end) break;
+        }
+#undef XDL5_STEP
+#undef XDL5_STAGE
+#pragma unroll
+        for (int g = 0; g < C; g++)
+#pragma unroll
+            for (int t = 0; t < RT; t++)
+#pragma unroll
+                for (int v = 0; v < 4; v++) acc[g][t][v] += acc2[g][t][v];
+        }
+        // D[m = 4 * row + v][n = i] in acc[g][t][v]
+        if (s_end - s_begin != a.S && !(a.dbg & 1)) { // part of a column: publish, count, the last arriver sums the column's runs in run order
+            using gf32 = __attribute__((address_space(1))) float;
+            using gu32 = __attribute__((address_space(1))) unsigned int;
+            float* const mine = a.partial + (((uint64_t)blockIdx.x * 2 + seg) * WAVES + w) * WT + lane;
+#pragma unroll
+            for (int g = 0; g < C; g++)
+#pragma unroll
+                for (int t = 0; t < RT; t++)
+#pragma unroll
+                    for (int v = 0; v < 4; v++) __hip_atomic_store((gf32*)(mine + ((g * RT + t) * 4 + v) * 64), acc[g][t][v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains before the count
+            __syncthreads();
+            const uint32_t b_lo = (wgc * a.S) / a.run, b_hi = (wgc * a.S + a.S - 1) / a.run; // the workgroups whose runs touch this column
+            uint32_t* const cnt = a.counter + wgc;
+            if (threadIdx.x == 0) *flag = __hip_atomic_fetch_add((gu32*)cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            const bool last = *flag == b_hi - b_lo;
+            __syncthreads(); // (the flag word is reused by the next segment)
+            if (!last) continue;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // compiler only: the loads below stay below the count
+#pragma unroll
+            for (int g = 0; g < C; g++)
+#pragma unroll
+                for (int t = 0; t < RT; t++)
+#pragma unroll
+                    for (int v = 0; v < 4; v++) acc[g][t][v] = 0.f;
+            // run order, not arrival order; the loads of kBatch runs are in flight together (one run at a time cost a memory
+            // round trip per run: 12 us of a 26 us launch at 16 runs per column)
+            constexpr uint32_t kBatch = 8;
+            for (uint32_t b0 = b_lo; b0 <= b_hi; b0 += kBatch) {
+                float pv[kBatch][C * RT * 4];
+#pragma unroll
+                for (uint32_t q = 0; q < kBatch; q++) {
+                    const uint32_t b = min(b0 + q, b_hi);              // (past the end: a live line again, dropped below)
+                    const uint32_t bseg = (b * a.run) / a.S != wgc;    // the column is that workgroup's second one
+                    const float* const src = a.partial + (((uint64_t)b * 2 + bseg) * WAVES + w) * WT + lane;
+#pragma unroll
+                    for (int e = 0; e < C * RT * 4; e++) pv[q][e] = __hip_atomic_load((gf32*)(src + e * 64), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+                for (uint32_t q = 0; q < kBatch; q++) {
+                    const bool in = b0 + q <= b_hi;
+#pragma unroll
+                    for (int g = 0; g < C; g++)
+#pragma unroll
+                        for (int t = 0; t < RT; t++)
+#pragma unroll
+                            for (int v = 0; v < 4; v++) acc[g][t][v] += in ? pv[q][(g * RT + t) * 4 + v] : 0.f;
+                }
+            }
+            if (threadIdx.x == 0) __hip_atomic_store((gu32*)cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // re-arm
+        }
+        if (live) {
+#pragma unroll
+            for (int g = 0; g < C; g++)
+#pragma unroll
+                for (int t = 0; t < RT; t++)
+#pragma unroll
+                    for (int v = 0; v < 4; v++) {
+                        const uint32_t m = t * 16 + 4 * row + v, n = (cb * C + g) * 16 + i;
+                        if (m < a.M) P.out[(uint64_t)m * P.out_rs + n] = acc[g][t][v] * 16.0f; // the tile carries q/16
+                    }
+        }
+    }
+}
+
 // Raw layout (any block size, any N): one thread per (m, n), k sequential — exactly the
 // reference's loop order, coalesced along n. Used for odd shapes (e.g. the bs=4 conformance case).
 __global__ void __launch_bounds__(kBlock) qmatmul_raw_kernel(const int8_t* __restrict__ data,
@@ -2228,9 +2554,32 @@ static uint64_t xdl4_partial_bytes(const QWeightDev& w, uint32_t M) { // one par
     const uint64_t RT = xdl_tile_pad(M), groups = ((M + 15) / 16 + RT - 1) / RT;
     return groups * (w.N / 32) * 4 * (2 * RT * 256 * 4);
 }
+static uint32_t device_cus() {
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+    }
+    return (uint32_t)n_cu;
+}
+// M <= 32 (qmatmul_xdl5_kernel): workgroups of the launch = CUs x this; two partial tiles of 8 waves each per workgroup
+constexpr uint32_t kX5Waves = 8;
+static uint32_t xdl5_wgs() {
+    static const int per_cu = getenv("ZGML_QMM_XDL5_WGS_PER_CU") ? std::max(1, atoi(getenv("ZGML_QMM_XDL5_WGS_PER_CU"))) : 1;
+    return device_cus() * (uint32_t)per_cu;
+}
+static bool xdl5_enabled() {
+    static const bool on = !(getenv("ZGML_QMM_XDL5") && atoi(getenv("ZGML_QMM_XDL5")) == 0);
+    return on;
+}
+static uint64_t xdl5_partial_bytes(uint32_t M) {
+    if (M > 32 || !xdl5_enabled()) return 0;
+    return (uint64_t)xdl5_wgs() * 2 * kX5Waves * (2 * xdl_tile_pad(M) * 256) * sizeof(float);
+}
 uint64_t qmatmul_scratch_bytes(const QWeightDev& w, uint32_t M) {
     if (!xdl2_applies(w, M)) return 0;
-    return xdl_a_bytes(w, M) + (uint64_t)kMaxQmmParts * xdl4_partial_bytes(w, M);
+    return xdl_a_bytes(w, M) + std::max((uint64_t)kMaxQmmParts * xdl4_partial_bytes(w, M), xdl5_partial_bytes(M));
 }
 
 bool qweight_packable(uint64_t K, uint64_t N, uint64_t bs) {
@@ -2566,6 +2915,42 @@ void launch_xdl4(hipStream_t s, const QWeightDev* w, const QMatmulParams* p, uin
     hipLaunchKernelGGL(fn, grid, dim3(kX4Waves * 64), lds, s, a);
 }
 
+// M <= 32: the shared-A form. false = not applicable (more workgroup-columns than counter words)
+bool launch_xdl5(hipStream_t s, const QWeightDev* w, const QMatmulParams* p, uint32_t n, float* scratch, uint32_t S, uint32_t RT) {
+    QMM5Args a{};
+    uint32_t wg_cols = 0;
+    for (uint32_t t = 0; t < n; t++) {
+        a.parts[t] = {(const uint4*)w[t].qs, (const uint4*)w[t].sc, p[t].dst, p[t].dst_rs, p[t].N / 32, wg_cols};
+        wg_cols += cdiv(p[t].N / 32, kX5Waves);
+    }
+    if ((uint64_t)wg_cols * sizeof(uint32_t) > kQmmScratchHead) return false;
+    // narrow outputs stay with qmatmul_xdl2_kernel: every run of a column costs the column's fan-in one more device-scope
+    // atomic on one word (measured 2.5 + 0.6 us x runs per column: 12.5 us at 4096 x 4096, 16 runs), and below ~40
+    // workgroup-columns (N < 10240) that outweighs the A traffic saved (4096 x 8192: 27.8 against 20.9 us; x 12288: 32.1 against 33.9)
+    static const int min_cols = getenv("ZGML_QMM_XDL5_MIN_COLS") ? atoi(getenv("ZGML_QMM_XDL5_MIN_COLS")) : 40;
+    if ((int)wg_cols < min_cols) return false;
+    static const int min_run = getenv("ZGML_QMM_XDL5_MIN_RUN") ? std::max(1, atoi(getenv("ZGML_QMM_XDL5_MIN_RUN"))) : 2;
+    const uint32_t total = wg_cols * S;
+    const uint32_t run = std::min(S, std::max(cdiv(total, xdl5_wgs()), std::min((uint32_t)min_run, S)));
+    a.ap = (const uint4*)scratch;
+    a.partial = (float*)((char*)scratch + xdl_a_bytes(w[0], p[0].M));
+    a.counter = (uint32_t*)((char*)scratch - kQmmScratchHead);
+    a.n_parts = n, a.M = p[0].M, a.U = w[0].KC, a.S = S, a.run = run, a.total = total;
+    static const int dbg = getenv("ZGML_QMM_XDL5_DEBUG") ? atoi(getenv("ZGML_QMM_XDL5_DEBUG")) : 0;
+    a.dbg = (uint32_t)dbg;
+    const uint32_t grid = cdiv(total, run); // <= xdl5_wgs() unless every run is a whole column (no partial tiles then)
+    const size_t lds = 2 * (size_t)RT * 768 * 16 + 64;
+    const bool nt = w[0].stream_nt != 0;
+    using Fn5 = void (*)(QMM5Args);
+    static const bool lean = getenv("ZGML_QMM_XDL5_LEAN") && atoi(getenv("ZGML_QMM_XDL5_LEAN")) != 0;
+    const Fn5 fn = lean ? (RT == 2 ? (nt ? (Fn5)qmatmul_xdl5_kernel<2, kX5Waves, true, true> : (Fn5)qmatmul_xdl5_kernel<2, kX5Waves, false, true>)
+                                   : (nt ? (Fn5)qmatmul_xdl5_kernel<1, kX5Waves, true, true> : (Fn5)qmatmul_xdl5_kernel<1, kX5Waves, false, true>))
+                        : (RT == 2 ? (nt ? (Fn5)qmatmul_xdl5_kernel<2, kX5Waves, true, false> : (Fn5)qmatmul_xdl5_kernel<2, kX5Waves, false, false>)
+                                   : (nt ? (Fn5)qmatmul_xdl5_kernel<1, kX5Waves, true, false> : (Fn5)qmatmul_xdl5_kernel<1, kX5Waves, false, false>));
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(kX5Waves * 64), lds, s, a);
+    return true;
+}
+
 void launch_xdl2(hipStream_t s, const QWeightDev* w, const QMatmulParams* p, uint32_t n, float* scratch) {
     const uint32_t U = w[0].KC, S = cdiv(U, 4), R = xdl_tile_pad(p[0].M), tiles = cdiv(cdiv(p[0].M, 16), R) * R;
     if (!p[0].reuse_split) hipLaunchKernelGGL(split_a_kernel, dim3(S, tiles), dim3(256), 0, s, p[0].input, p[0].M, p[0].K, p[0].in_rs, (uint4*)scratch, S);
@@ -2574,6 +2959,7 @@ void launch_xdl2(hipStream_t s, const QWeightDev* w, const QMatmulParams* p, uin
         launch_xdl4(s, w, p, n, scratch, S, R, tiles);
         return;
     }
+    if (R <= 2 && tiles == R && xdl5_enabled() && launch_xdl5(s, w, p, n, scratch, S, R)) return;
     const uint32_t R2 = std::min(R, 2u); // (switch off: the M = 32 form over pairs of tiles; the A pieces are laid out per tile)
     static const int env_g = getenv("ZGML_QMM_XDL2_G") ? atoi(getenv("ZGML_QMM_XDL2_G")) : 0;
     uint32_t total_nb2 = 0;
