@@ -91,6 +91,48 @@ def test_matmul_tile_kernel_matches_oracle(hip_backend, oracle, M, K, N, kind):
     assert np.array_equal(got == -7, want == -7)  # sentinels between rows untouched
 
 
+def _q4_case(rng, M, K, N):
+    x = rng.standard_normal(M * K).astype(f32)
+    data = rng.integers(-8, 8, K * N).astype(np.int8)
+    scales = (rng.random((K * N + 31) // 32).astype(np.float16) * 0.05 + 0.001).astype(f32)
+    return x, data, scales
+
+
+@pytest.mark.parametrize("M", [5, 16, 32])
+@pytest.mark.parametrize("K,N", [(576, 12288), (1100, 10240), (4096, 12288)])
+def test_matmul_shared_a_kernel_matches_oracle(hip_backend, oracle, M, K, N):
+    """M <= 32 with a WIDE output (>= 40 workgroup-columns of 256) takes qmatmul_xdl5_kernel: the A pieces staged once per
+    workgroup in LDS, the (column, K step) pairs cut into even runs, partial tiles of a column summed by its last arriver in
+    run order. K = 576: 5 steps and runs of 2 (every column is shared by 3 workgroups, runs straddle columns); K = 1100: the
+    last step is mostly past the end; K = 4096 x 12288: the q/k/v shape of the 7B layer. Same bound as the other forms, and
+    two executions of the same program agree bit for bit (the fan-in is ordered, not first come first served)."""
+    rng = np.random.default_rng(0x5A + M + K + N)
+    x, data, scales = _q4_case(rng, M, K, N)
+    want, got = run_both(hip_backend, oracle, data, scales, x, M, N, K, in_off=4, in_rs=K + 4, dst_off=1, dst_rs=N + 5)
+    b = np.zeros_like(want, dtype=np.float64)
+    bb = bound(data, scales, x, M, N, K, 32)
+    for m in range(M):
+        b[1 + m * (N + 5):][:N] = bb[m]
+    assert np.all(np.abs(got - want) <= TOL * b + 1e-30), np.max(np.abs(got - want) / (b + 1e-30))
+    assert np.array_equal(got == -7, want == -7)
+    _, again = run_both(hip_backend, oracle, data, scales, x, M, N, K, in_off=4, in_rs=K + 4, dst_off=1, dst_rs=N + 5)
+    assert np.array_equal(got, again)
+
+
+@pytest.mark.timeout(900)
+def test_shared_a_kernel_on_narrow_and_ragged_outputs():
+    """The same kernel forced onto every M <= 32 case of this file and of the 7B-dimension file (ZGML_QMM_XDL5_MIN_COLS=1:
+    outputs narrower than one workgroup-column, block-column counts that do not fill the last workgroup, grouped q/k/v and
+    gate/up launches whose parts end mid-workgroup), in a process of its own because the switch is read once."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, ZGML_QMM_XDL5_MIN_COLS="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "tests/test_hip_qmatvec.py", "tests/test_hip_l7dims.py", "tests/test_hip_llama.py",
+                        "-k", "tile_kernel or shared_a_kernel_matches or chunk32 or prefill"], capture_output=True, text=True, timeout=880, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_raw_layout_odd_shapes_bit_exact(hip_backend, oracle):
     """bs != 32 or N % 32 != 0 uses the k-sequential kernel: same loop order as the reference."""
     rng = np.random.default_rng(8)

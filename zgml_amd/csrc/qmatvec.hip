@@ -1632,6 +1632,37 @@ __device__ __forceinline__ bf16x8_t as_bf16x8(uint4 v) { return __builtin_bit_ca
 // (hi16(a), hi16(b)) -> one dword of two bf16 (a in the low half)
 __device__ __forceinline__ uint32_t pack_hi16(float a, float b) { return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u); }
 
+// B pieces of one 8-k group: w = (q - 8)/16 * scale (exact in f32: 4 x 11 bits), split into bf16 hi + bf16 lo (exact).
+// Written so that hipcc emits ~4.6 VALU instructions per weight instead of the ~8 of the xdl2 / xdl4 form:
+//   * the scale broadcast rides in the multiply (v_mul_f32_dpp row_newbcast: full masks + bound_ctrl make the DPP move foldable);
+//   * every convert takes its nibble through an SDWA byte select: the high nibbles come from ONE shifted copy of the dword
+//     (kept opaque, or the shifts merge into byte-unaligned ones), and the `& 0xFF` is what lets the peephole pick BYTE_n;
+//   * the residuals w - hi are formed two at a time (v_pk_add_f32 with a negated operand).
+template <int CTRL>
+__device__ __forceinline__ float row_bcast_z(int v) { return __int_as_float(__builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true)); } // (no `old` to initialise)
+typedef float xf32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t xu32x2 __attribute__((ext_vector_type(2)));
+
+template <int J, int C>
+__device__ __forceinline__ void xdl_prep_b(const uint4 (&wq)[C], int sb_lo, int sb_hi, uint4 (&b1)[C], uint4 (&b2)[C]) {
+    const int sbits = J >> 1 ? sb_hi : sb_lo;
+    constexpr int C0 = 0x150 + 8 * (J & 1); // the scale of k_local 8 J + e sits in lane 8 (J & 1) + e of this row
+#pragma unroll
+    for (int g = 0; g < C; g++) {
+        const uint32_t lo = J == 0 ? wq[g].x : J == 1 ? wq[g].y : J == 2 ? wq[g].z : wq[g].w;
+        uint32_t hi = lo >> 4;
+        asm volatile("" : "+v"(hi));
+#define XDL5_W(E, SRC, BYTE) (row_bcast_z<C0 + E>(sbits) * __builtin_amdgcn_cvt_off_f32_i4((int)(((SRC) >> (8 * BYTE)) & 0xFFu))) /* (q - 8)/16 * scale */
+        const xf32x2 w01 = {XDL5_W(0, lo, 0), XDL5_W(1, lo, 1)}, w23 = {XDL5_W(2, lo, 2), XDL5_W(3, lo, 3)};
+        const xf32x2 w45 = {XDL5_W(4, hi, 0), XDL5_W(5, hi, 1)}, w67 = {XDL5_W(6, hi, 2), XDL5_W(7, hi, 3)};
+#undef XDL5_W
+        auto top = [](xf32x2 v) { return __builtin_bit_cast(xf32x2, __builtin_bit_cast(xu32x2, v) & 0xFFFF0000u); };
+        const xf32x2 l01 = w01 - top(w01), l23 = w23 - top(w23), l45 = w45 - top(w45), l67 = w67 - top(w67);
+        b1[g] = make_uint4(pack_hi16(w01.x, w01.y), pack_hi16(w23.x, w23.y), pack_hi16(w45.x, w45.y), pack_hi16(w67.x, w67.y));
+        b2[g] = make_uint4(pack_hi16(l01.x, l01.y), pack_hi16(l23.x, l23.y), pack_hi16(l45.x, l45.y), pack_hi16(l67.x, l67.y));
+    }
+}
+
 // The K loop is software-pipelined by hand: while the MFMAs of 8-k group J run on the matrix pipe, the VALU
 // prepares the B pieces of group J + 1 (a wave issues in order, so MFMAs and their own operand preparation
 // only overlap if they are interleaved in program order; sched_group_barrier asks hipcc for 1 MFMA : 3 VALU).
@@ -1693,21 +1724,7 @@ __global__ void __launch_bounds__(512) qmatmul_xdl2_kernel(QMM2Args a) {
         constexpr int J = decltype(jc)::value;
         const __half2 hh = __builtin_bit_cast(__half2, b.sd);
         const int sbits = __float_as_int(__half2float(J >> 1 ? hh.y : hh.x)); // this lane's scale of k_local (J >> 1) * 16 + i
-#pragma unroll
-        for (int g = 0; g < G; g++) {
-            const uint32_t lo = J == 0 ? b.wq[g].x : J == 1 ? b.wq[g].y : J == 2 ? b.wq[g].z : b.wq[g].w, hi = lo >> 4;
-            float wv[8];
-            constexpr int C0 = 0x150 + 8 * (J & 1); // DPP row_newbcast:lane — the scale of k_local 8 J + e sits in lane 8 (J & 1) + e of this row
-#define XDL2_W(E, SRC, BYTE) wv[E] = row_bcast<C0 + E>(sbits) * __builtin_amdgcn_cvt_off_f32_i4((int)((SRC) >> (8 * BYTE))) /* (q - 8)/16 * scale */
-            XDL2_W(0, lo, 0), XDL2_W(1, lo, 1), XDL2_W(2, lo, 2), XDL2_W(3, lo, 3);
-            XDL2_W(4, hi, 0), XDL2_W(5, hi, 1), XDL2_W(6, hi, 2), XDL2_W(7, hi, 3);
-#undef XDL2_W
-            float lo2[8];
-#pragma unroll
-            for (int e = 0; e < 8; e++) lo2[e] = wv[e] - __uint_as_float(__float_as_uint(wv[e]) & 0xFFFF0000u);
-            o.b1[g] = make_uint4(pack_hi16(wv[0], wv[1]), pack_hi16(wv[2], wv[3]), pack_hi16(wv[4], wv[5]), pack_hi16(wv[6], wv[7]));
-            o.b2[g] = make_uint4(pack_hi16(lo2[0], lo2[1]), pack_hi16(lo2[2], lo2[3]), pack_hi16(lo2[4], lo2[5]), pack_hi16(lo2[6], lo2[7]));
-        }
+        xdl_prep_b<J, G>(b.wq, sbits, sbits, o.b1, o.b2);
     };
     auto mfmas = [&](const BPieces& o, const AGrp& x) {
 #pragma unroll
@@ -1877,26 +1894,8 @@ __global__ void __launch_bounds__(512, 2) qmatmul_xdl4_kernel(QMM4Args a) {
         __builtin_amdgcn_sched_barrier(0);
         const __half2 hh = __builtin_bit_cast(__half2, sd);
         const int sb_lo = __float_as_int(__half2float(hh.x)), sb_hi = __float_as_int(__half2float(hh.y)); // scales of k_local i, 16 + i
-        bf16x8_t b1[C], b2[C];
-        auto prep = [&](auto jc) {
-            constexpr int J = decltype(jc)::value;
-            const int sbits = J >> 1 ? sb_hi : sb_lo;
-#pragma unroll
-            for (int g = 0; g < C; g++) {
-                const uint32_t lo = J == 0 ? wq[g].x : J == 1 ? wq[g].y : J == 2 ? wq[g].z : wq[g].w, hi = lo >> 4;
-                float wv[8];
-                constexpr int C0 = 0x150 + 8 * (J & 1); // the scale of k_local 8 J + e sits in lane 8 (J & 1) + e of this row
-#define XDL4_W(E, SRC, BYTE) wv[E] = row_bcast<C0 + E>(sbits) * __builtin_amdgcn_cvt_off_f32_i4((int)((SRC) >> (8 * BYTE)))
-                XDL4_W(0, lo, 0), XDL4_W(1, lo, 1), XDL4_W(2, lo, 2), XDL4_W(3, lo, 3);
-                XDL4_W(4, hi, 0), XDL4_W(5, hi, 1), XDL4_W(6, hi, 2), XDL4_W(7, hi, 3);
-#undef XDL4_W
-                float lo2[8];
-#pragma unroll
-                for (int e = 0; e < 8; e++) lo2[e] = wv[e] - __uint_as_float(__float_as_uint(wv[e]) & 0xFFFF0000u);
-                b1[g] = as_bf16x8(make_uint4(pack_hi16(wv[0], wv[1]), pack_hi16(wv[2], wv[3]), pack_hi16(wv[4], wv[5]), pack_hi16(wv[6], wv[7])));
-                b2[g] = as_bf16x8(make_uint4(pack_hi16(lo2[0], lo2[1]), pack_hi16(lo2[2], lo2[3]), pack_hi16(lo2[4], lo2[5]), pack_hi16(lo2[6], lo2[7])));
-            }
-        };
+        uint4 b1[C], b2[C];
+        auto prep = [&](auto jc) { xdl_prep_b<decltype(jc)::value, C>(wq, sb_lo, sb_hi, b1, b2); };
         auto mfmas = [&](const AHalf& x, int half) {
 #pragma unroll
             for (int g = 0; g < C; g++)
@@ -1904,8 +1903,8 @@ __global__ void __launch_bounds__(512, 2) qmatmul_xdl4_kernel(QMM4Args a) {
                 for (int t = 0; t < H; t++)
 #pragma unroll
                     for (int p = 0; p < 3; p++) {
-                        acc[g][half * H + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(x.v[t][p]), b1[g], acc[g][half * H + t], 0, 0, 0);
-                        acc[g][half * H + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(x.v[t][p]), b2[g], acc[g][half * H + t], 0, 0, 0);
+                        acc[g][half * H + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(x.v[t][p]), as_bf16x8(b1[g]), acc[g][half * H + t], 0, 0, 0);
+                        acc[g][half * H + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(x.v[t][p]), as_bf16x8(b2[g]), acc[g][half * H + t], 0, 0, 0);
                     }
         };
         // eight half-groups: the A pieces of the next half are requested before the MFMAs of the current one
@@ -1999,45 +1998,10 @@ struct QMM5Args {
     float* partial;               // [workgroup][segment 0 / 1][wave][2 RT 256] f32
     uint32_t* counter;            // one word per workgroup-column, zero between launches
     uint32_t n_parts, M, U, S, run, total; // total = workgroup-columns x S (column, step) pairs, run = pairs per workgroup (<= S)
-    uint32_t dbg;                          // timing experiments only (ZGML_QMM_XDL5_DEBUG): 1 = no fan-in (partial results stored as they are)
 };
 
-// B pieces of one 8-k group: w = (q - 8)/16 * scale (exact in f32: 4 x 11 bits), split into bf16 hi + bf16 lo (exact).
-// Written so that hipcc emits ~4.6 VALU instructions per weight instead of the ~8 of the xdl2 / xdl4 form:
-//   * the scale broadcast rides in the multiply (v_mul_f32_dpp row_newbcast: full masks + bound_ctrl make the DPP move foldable);
-//   * every convert takes its nibble through an SDWA byte select: the high nibbles come from ONE shifted copy of the dword
-//     (kept opaque, or the shifts merge into byte-unaligned ones), and the `& 0xFF` is what lets the peephole pick BYTE_n;
-//   * the residuals w - hi are formed two at a time (v_pk_add_f32 with a negated operand).
-template <int CTRL>
-__device__ __forceinline__ float row_bcast_z(int v) { return __int_as_float(__builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true)); } // (no `old` to initialise)
-typedef float xf32x2 __attribute__((ext_vector_type(2)));
-typedef uint32_t xu32x2 __attribute__((ext_vector_type(2)));
-
-template <int J, int C>
-__device__ __forceinline__ void xdl_prep_b(const uint4 (&wq)[C], int sb_lo, int sb_hi, uint4 (&b1)[C], uint4 (&b2)[C]) {
-    const int sbits = J >> 1 ? sb_hi : sb_lo;
-    constexpr int C0 = 0x150 + 8 * (J & 1); // the scale of k_local 8 J + e sits in lane 8 (J & 1) + e of this row
-#pragma unroll
-    for (int g = 0; g < C; g++) {
-        const uint32_t lo = J == 0 ? wq[g].x : J == 1 ? wq[g].y : J == 2 ? wq[g].z : wq[g].w;
-        uint32_t hi = lo >> 4;
-        asm volatile("" : "+v"(hi));
-#define XDL5_W(E, SRC, BYTE) (row_bcast_z<C0 + E>(sbits) * __builtin_amdgcn_cvt_off_f32_i4((int)(((SRC) >> (8 * BYTE)) & 0xFFu))) /* (q - 8)/16 * scale */
-        const xf32x2 w01 = {XDL5_W(0, lo, 0), XDL5_W(1, lo, 1)}, w23 = {XDL5_W(2, lo, 2), XDL5_W(3, lo, 3)};
-        const xf32x2 w45 = {XDL5_W(4, hi, 0), XDL5_W(5, hi, 1)}, w67 = {XDL5_W(6, hi, 2), XDL5_W(7, hi, 3)};
-#undef XDL5_W
-        auto top = [](xf32x2 v) { return __builtin_bit_cast(xf32x2, __builtin_bit_cast(xu32x2, v) & 0xFFFF0000u); };
-        const xf32x2 l01 = w01 - top(w01), l23 = w23 - top(w23), l45 = w45 - top(w45), l67 = w67 - top(w67);
-        b1[g] = make_uint4(pack_hi16(w01.x, w01.y), pack_hi16(w23.x, w23.y), pack_hi16(w45.x, w45.y), pack_hi16(w67.x, w67.y));
-        b2[g] = make_uint4(pack_hi16(l01.x, l01.y), pack_hi16(l23.x, l23.y), pack_hi16(l45.x, l45.y), pack_hi16(l67.x, l67.y));
-    }
-}
-
-// LEAN: no software pipelining inside a wave (one set of B pieces, one accumulator per tile, weights one step ahead) to fit
-// 128 registers — two workgroups per CU, four waves per SIMD, and the overlap of B preparation, MFMAs and LDS reads comes
-// from the other waves instead.
-template <int RT, int WAVES, bool NT, bool LEAN>
-__global__ void __launch_bounds__(WAVES * 64, LEAN ? 4 : 1) qmatmul_xdl5_kernel(QMM5Args a) {
+template <int RT, int WAVES, bool NT>
+__global__ void __launch_bounds__(WAVES * 64) qmatmul_xdl5_kernel(QMM5Args a) {
     constexpr int C = 2;
     constexpr uint32_t T = WAVES * 64, STEP = RT * 768; // uint4 of one step's A pieces: [tile][J][piece][lane]
     constexpr uint32_t NA = (STEP + T - 1) / T;
@@ -2122,54 +2086,6 @@ __global__ void __launch_bounds__(WAVES * 64, LEAN ? 4 : 1) qmatmul_xdl5_kernel(
             lo = __float_as_int(__half2float(hh.x)), hi = __float_as_int(__half2float(hh.y)); // scales of k_local i, 16 + i
         };
 
-        if constexpr (LEAN) {
-            WStep wa, wb; // the weights of steps s, s + 1: two names taking turns
-            BP pb;
-            int sl, sh;
-            load_w(wa, s_begin);
-            fetch_a(s_begin);
-            if (seg) __syncthreads(); // the previous segment's last reads of the A buffers
-            park_a(0);
-            __syncthreads();
-            auto group = [&](uint32_t buf, auto jc, const WStep& cur) {
-                constexpr int J = decltype(jc)::value;
-#pragma unroll
-                for (int t = 0; t < RT; t++) read_a(buf, J, t);
-                xdl_prep_b<J, C>(cur.wq, sl, sh, pb.b1, pb.b2);
-#pragma unroll
-                for (int p = 0; p < 3; p++) { // (tile, column group) innermost: four independent chains
-#pragma unroll
-                    for (int t = 0; t < RT; t++)
-#pragma unroll
-                        for (int g = 0; g < C; g++) acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(xa[t][p]), as_bf16x8(pb.b1[g]), acc[g][t], 0, 0, 0);
-#pragma unroll
-                    for (int t = 0; t < RT; t++)
-#pragma unroll
-                        for (int g = 0; g < C; g++) acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(xa[t][p]), as_bf16x8(pb.b2[g]), acc[g][t], 0, 0, 0);
-                }
-            };
-#define XDL5_LEAN_STEP(S_, CUR, NXT)                                                   \
-    do {                                                                               \
-        fetch_a(min((S_) + 1, s_last));                                                \
-        load_w(NXT, min((S_) + 1, s_last));                                            \
-        scale_bits(CUR, sl, sh);                                                       \
-        group(buf, std::integral_constant<int, 0>{}, CUR);                             \
-        group(buf, std::integral_constant<int, 1>{}, CUR);                             \
-        group(buf, std::integral_constant<int, 2>{}, CUR);                             \
-        group(buf, std::integral_constant<int, 3>{}, CUR);                             \
-        park_a(buf ^ 1);                                                               \
-        __syncthreads();                                                               \
-        buf ^= 1;                                                                      \
-    } while (0)
-            uint32_t buf = 0;
-            for (uint32_t s = s_begin;; s += 2) {
-                XDL5_LEAN_STEP(s, wa, wb);
-                if (s + 1 >= s_end) break;
-                XDL5_LEAN_STEP(s + 1, wb, wa);
-                if (s + 2 >= s_end) break;
-            }
-#undef XDL5_LEAN_STEP
-        } else {
         WStep wa, wb, wc; // the weights of steps s, s + 1, s + 2: three names rotating (a register copy would wait for the load)
         BP p0, p1;
         int sl, sh;
@@ -2237,9 +2153,8 @@ __global__ void __launch_bounds__(WAVES * 64, LEAN ? 4 : 1) qmatmul_xdl5_kernel(
             for (int t = 0; t < RT; t++)
 #pragma unroll
                 for (int v = 0; v < 4; v++) acc[g][t][v] += acc2[g][t][v];
-        }
         // D[m = 4 * row + v][n = i] in acc[g][t][v]
-        if (s_end - s_begin != a.S && !(a.dbg & 1)) { // part of a column: publish, count, the last arriver sums the column's runs in run order
+        if (s_end - s_begin != a.S) { // part of a column: publish, count, the last arriver sums the column's runs in run order
             using gf32 = __attribute__((address_space(1))) float;
             using gu32 = __attribute__((address_space(1))) unsigned int;
             float* const mine = a.partial + (((uint64_t)blockIdx.x * 2 + seg) * WAVES + w) * WT + lane;
@@ -2936,17 +2851,12 @@ bool launch_xdl5(hipStream_t s, const QWeightDev* w, const QMatmulParams* p, uin
     a.partial = (float*)((char*)scratch + xdl_a_bytes(w[0], p[0].M));
     a.counter = (uint32_t*)((char*)scratch - kQmmScratchHead);
     a.n_parts = n, a.M = p[0].M, a.U = w[0].KC, a.S = S, a.run = run, a.total = total;
-    static const int dbg = getenv("ZGML_QMM_XDL5_DEBUG") ? atoi(getenv("ZGML_QMM_XDL5_DEBUG")) : 0;
-    a.dbg = (uint32_t)dbg;
     const uint32_t grid = cdiv(total, run); // <= xdl5_wgs() unless every run is a whole column (no partial tiles then)
     const size_t lds = 2 * (size_t)RT * 768 * 16 + 64;
     const bool nt = w[0].stream_nt != 0;
     using Fn5 = void (*)(QMM5Args);
-    static const bool lean = getenv("ZGML_QMM_XDL5_LEAN") && atoi(getenv("ZGML_QMM_XDL5_LEAN")) != 0;
-    const Fn5 fn = lean ? (RT == 2 ? (nt ? (Fn5)qmatmul_xdl5_kernel<2, kX5Waves, true, true> : (Fn5)qmatmul_xdl5_kernel<2, kX5Waves, false, true>)
-                                   : (nt ? (Fn5)qmatmul_xdl5_kernel<1, kX5Waves, true, true> : (Fn5)qmatmul_xdl5_kernel<1, kX5Waves, false, true>))
-                        : (RT == 2 ? (nt ? (Fn5)qmatmul_xdl5_kernel<2, kX5Waves, true, false> : (Fn5)qmatmul_xdl5_kernel<2, kX5Waves, false, false>)
-                                   : (nt ? (Fn5)qmatmul_xdl5_kernel<1, kX5Waves, true, false> : (Fn5)qmatmul_xdl5_kernel<1, kX5Waves, false, false>));
+    const Fn5 fn = RT == 2 ? (nt ? (Fn5)qmatmul_xdl5_kernel<2, kX5Waves, true> : (Fn5)qmatmul_xdl5_kernel<2, kX5Waves, false>)
+                           : (nt ? (Fn5)qmatmul_xdl5_kernel<1, kX5Waves, true> : (Fn5)qmatmul_xdl5_kernel<1, kX5Waves, false>);
     hipLaunchKernelGGL(fn, dim3(grid), dim3(kX5Waves * 64), lds, s, a);
     return true;
 }
