@@ -168,6 +168,76 @@ __global__ void __launch_bounds__(kBlock) softmax_kernel(float* __restrict__ dst
     for (uint32_t j = threadIdx.x; j < cols; j += kBlock) d[j] *= inv;
 }
 
+// The same chain with every step's second operand requested UP FRONT: the form above reads a step's operand only when the
+// chain reaches it, one memory round trip per binary step (silu(gate) * up over 32 x 11008: 2 round trips for 1.4 MB, 5.9 us).
+// V = 4: four consecutive elements per thread (16-byte loads and stores, 8-byte piece stores) — only for long chains, a short
+// one is latency bound and wants the threads (32 x 11008: 4.68 ms per prefill chunk with V = 4 against 4.62 with V = 1).
+// Per element the operations and their order are the scalar kernel's: bit-identical outputs. The launcher takes this form
+// only when no operand is an EARLIER step's output (the chain's own stores would have to land first); V = 4 also needs
+// n % 4 == 0 and 16-byte aligned pointers.
+template <int V>
+__global__ void __launch_bounds__(kBlock) eltwise_chain_pre_kernel(EltChainParams p) {
+    const uint32_t q = blockIdx.x * kBlock + threadIdx.x;
+    if (q * V >= p.n) return;
+    float v[V], sec[kMaxChainSteps][V];
+    auto load = [&](float (&d)[V], const float* src) {
+        if (V == 4) {
+            const float4 t = ((const float4*)src)[q];
+            d[0] = t.x, d[V > 1 ? 1 : 0] = t.y, d[V > 2 ? 2 : 0] = t.z, d[V > 3 ? 3 : 0] = t.w;
+        } else {
+            d[0] = src[q];
+        }
+    };
+    load(v, p.src);
+#pragma unroll
+    for (int s = 0; s < kMaxChainSteps; s++)
+        if ((uint32_t)s < p.n_steps && p.steps[s].secondary) load(sec[s], p.steps[s].secondary);
+#pragma unroll
+    for (int s = 0; s < kMaxChainSteps; s++) {
+        if ((uint32_t)s >= p.n_steps) break;
+        const uint32_t op = p.steps[s].op;
+#pragma unroll
+        for (int e = 0; e < V; e++) {
+            if (op == ZGML_OP_ADD)
+                v[e] = p.steps[s].swapped ? sec[s][e] + v[e] : v[e] + sec[s][e];
+            else if (op == ZGML_OP_MUL)
+                v[e] = p.steps[s].swapped ? sec[s][e] * v[e] : v[e] * sec[s][e];
+            else
+                v[e] = apply_unary(op, v[e]);
+        }
+        if (p.steps[s].store) {
+            if (V == 4)
+                ((float4*)p.steps[s].store)[q] = make_float4(v[0], v[V > 1 ? 1 : 0], v[V > 2 ? 2 : 0], v[V > 3 ? 3 : 0]);
+            else
+                p.steps[s].store[q] = v[0];
+        }
+    }
+    if (!p.ap) return;
+    const uint32_t i = q * V, m = i / p.ap_cols, j = i - m * p.ap_cols;
+    if (V == 1) {
+        store_a_pieces(p.ap, p.ap_S, m, j, v[0]);
+    } else if (p.ap_S & kApF16) { // ap_cols % 4 == 0: four consecutive k of one row, inside one 8-k group
+        uint16_t h[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) h[e] = __half_as_ushort(__float2half_rn(v[e % V]));
+        *(uint2*)(p.ap + a_f16_index(p.ap_S & ~kApF16, m, j)) = make_uint2(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16));
+    } else {
+        uint32_t h1[4], h2[4], h3[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) { // store_a_pieces' arithmetic
+            const float x = v[e % V];
+            h1[e] = __float_as_uint(x) & 0xFFFF0000u;
+            const float r1 = x - __uint_as_float(h1[e]);
+            h2[e] = __float_as_uint(r1) & 0xFFFF0000u;
+            h3[e] = __float_as_uint(r1 - __uint_as_float(h2[e]));
+        }
+        uint16_t* const d = p.ap + a_piece_index(p.ap_S, m, j);
+        *(uint2*)d = make_uint2((h1[0] >> 16) | (h1[1] & 0xFFFF0000u), (h1[2] >> 16) | (h1[3] & 0xFFFF0000u));
+        *(uint2*)(d + 512) = make_uint2((h2[0] >> 16) | (h2[1] & 0xFFFF0000u), (h2[2] >> 16) | (h2[3] & 0xFFFF0000u));
+        *(uint2*)(d + 1024) = make_uint2((h3[0] >> 16) | (h3[1] & 0xFFFF0000u), (h3[2] >> 16) | (h3[3] & 0xFFFF0000u));
+    }
+}
+
 // reference.zig:329-347
 __global__ void __launch_bounds__(kBlock) layernorm_kernel(float* __restrict__ dst, const float* __restrict__ src,
                                                            uint32_t cols, float eps) {
@@ -1134,7 +1204,23 @@ void launch_fused_elementwise(hipStream_t s, const FusedParams& p) {
 
 void launch_eltwise_chain(hipStream_t s, const EltChainParams& p) {
     if (p.n == 0) return;
-    eltwise_chain_kernel<<<cdiv(p.n, kBlock), kBlock, 0, s>>>(p);
+    // ZGML_HIP_ELT_PRELOAD=0: the step-by-step form always
+    static const bool pre_on = !(getenv("ZGML_HIP_ELT_PRELOAD") && atoi(getenv("ZGML_HIP_ELT_PRELOAD")) == 0);
+    static const uint32_t vec_min = getenv("ZGML_HIP_ELT_VEC4_MIN") ? (uint32_t)atol(getenv("ZGML_HIP_ELT_VEC4_MIN")) : (1u << 20);
+    auto a16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+    bool pre = pre_on;
+    bool vec = p.n >= vec_min && p.n % 4 == 0 && a16(p.src) && (!p.ap || (p.ap_cols % 4 == 0 && a16(p.ap)));
+    for (uint32_t t = 0; pre && t < p.n_steps; t++) {
+        vec = vec && a16(p.steps[t].secondary) && a16(p.steps[t].store);
+        for (uint32_t e = 0; pre && p.steps[t].secondary && e < t; e++) // an operand written by an earlier step of this chain: keep the step-by-step reads
+            if (p.steps[e].store && p.steps[t].secondary < p.steps[e].store + p.n && p.steps[e].store < p.steps[t].secondary + p.n) pre = false;
+    }
+    if (pre && vec)
+        eltwise_chain_pre_kernel<4><<<cdiv(p.n / 4, kBlock), kBlock, 0, s>>>(p);
+    else if (pre)
+        eltwise_chain_pre_kernel<1><<<cdiv(p.n, kBlock), kBlock, 0, s>>>(p);
+    else
+        eltwise_chain_kernel<<<cdiv(p.n, kBlock), kBlock, 0, s>>>(p);
 }
 
 void launch_softmax(hipStream_t s, float* dst, const float* src, uint32_t rows, uint32_t cols) {
