@@ -1998,7 +1998,14 @@ struct QMM5Args {
     float* partial;               // [workgroup][segment 0 / 1][wave][2 RT 256] f32
     uint32_t* counter;            // one word per workgroup-column, zero between launches
     uint32_t n_parts, M, U, S, run, total; // total = workgroup-columns x S (column, step) pairs, run = pairs per workgroup (<= S)
+    uint64_t* trace;                       // trace builds (ZGML_QMM_XDL5_TRACE=1): 8 wall-clock stamps per workgroup and segment
 };
+#ifdef ZGML_TRACE // (never in product builds: the stamps serialise)
+#define X5_STAMP(K) \
+    if (a.trace && threadIdx.x == 0) a.trace[(blockIdx.x * 2 + seg) * 8 + (K)] = wall_clock64()
+#else
+#define X5_STAMP(K) (void)0
+#endif
 
 template <int RT, int WAVES, bool NT>
 __global__ void __launch_bounds__(WAVES * 64) qmatmul_xdl5_kernel(QMM5Args a) {
@@ -2089,6 +2096,7 @@ __global__ void __launch_bounds__(WAVES * 64) qmatmul_xdl5_kernel(QMM5Args a) {
         WStep wa, wb, wc; // the weights of steps s, s + 1, s + 2: three names rotating (a register copy would wait for the load)
         BP p0, p1;
         int sl, sh;
+        X5_STAMP(0);
         load_w(wa, s_begin);
         fetch_a(s_begin);
         load_w(wb, min(s_begin + 1, s_last));
@@ -2099,6 +2107,7 @@ __global__ void __launch_bounds__(WAVES * 64) qmatmul_xdl5_kernel(QMM5Args a) {
         read_a(0, 0, 0);
         if (RT > 1) read_a(0, 0, RT - 1);
         xdl_prep_b<0, C>(wa.wq, sl, sh, p0.b1, p0.b2);
+        X5_STAMP(1);
         __builtin_amdgcn_sched_barrier(0);
         // one stage: the MFMAs of group J, tile by tile, each tile's A registers refilled for group JN = J + 1 once its MFMAs
         // are issued, and the B preparation of group JN spread between the MFMAs
@@ -2147,6 +2156,7 @@ __global__ void __launch_bounds__(WAVES * 64) qmatmul_xdl5_kernel(QMM5Args a) {
         }
 #undef XDL5_STEP
 #undef XDL5_STAGE
+        X5_STAMP(2);
 #pragma unroll
         for (int g = 0; g < C; g++)
 #pragma unroll
@@ -2165,6 +2175,7 @@ __global__ void __launch_bounds__(WAVES * 64) qmatmul_xdl5_kernel(QMM5Args a) {
 #pragma unroll
                     for (int v = 0; v < 4; v++) __hip_atomic_store((gf32*)(mine + ((g * RT + t) * 4 + v) * 64), acc[g][t][v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains before the count
+            X5_STAMP(3);
             __syncthreads();
             const uint32_t b_lo = (wgc * a.S) / a.run, b_hi = (wgc * a.S + a.S - 1) / a.run; // the workgroups whose runs touch this column
             uint32_t* const cnt = a.counter + wgc;
@@ -2172,6 +2183,7 @@ __global__ void __launch_bounds__(WAVES * 64) qmatmul_xdl5_kernel(QMM5Args a) {
             __syncthreads();
             const bool last = *flag == b_hi - b_lo;
             __syncthreads(); // (the flag word is reused by the next segment)
+            X5_STAMP(4);
             if (!last) continue;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // compiler only: the loads below stay below the count
 #pragma unroll
@@ -2217,6 +2229,10 @@ __global__ void __launch_bounds__(WAVES * 64) qmatmul_xdl5_kernel(QMM5Args a) {
                         if (m < a.M) P.out[(uint64_t)m * P.out_rs + n] = acc[g][t][v] * 16.0f; // the tile carries q/16
                     }
         }
+#ifdef ZGML_TRACE
+        if (a.trace) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        X5_STAMP(5);
+#endif
     }
 }
 
@@ -2857,6 +2873,39 @@ bool launch_xdl5(hipStream_t s, const QWeightDev* w, const QMatmulParams* p, uin
     using Fn5 = void (*)(QMM5Args);
     const Fn5 fn = RT == 2 ? (nt ? (Fn5)qmatmul_xdl5_kernel<2, kX5Waves, true> : (Fn5)qmatmul_xdl5_kernel<2, kX5Waves, false>)
                            : (nt ? (Fn5)qmatmul_xdl5_kernel<1, kX5Waves, true> : (Fn5)qmatmul_xdl5_kernel<1, kX5Waves, false>);
+#ifdef ZGML_TRACE
+    static const bool tr = getenv("ZGML_QMM_XDL5_TRACE") && atoi(getenv("ZGML_QMM_XDL5_TRACE")) != 0;
+    static uint64_t* tbuf = nullptr;
+    static uint32_t t_grid, t_cols, t_run, t_units;
+    if (tr) { // every launch stamps into one buffer (graph replays included); the LAST launch's stamps are printed at exit
+        if (!tbuf) {
+            hipHostMalloc((void**)&tbuf, 4096 * 16 * sizeof(uint64_t));
+            memset(tbuf, 0, 4096 * 16 * sizeof(uint64_t));
+            atexit([] {
+                hipDeviceSynchronize();
+                uint64_t t0 = UINT64_MAX, t_end = 0;
+                for (uint32_t b = 0; b < t_grid; b++) {
+                    t0 = std::min(t0, tbuf[b * 16]);
+                    for (int k = 0; k < 16; k++) t_end = std::max(t_end, tbuf[b * 16 + k]);
+                }
+                fprintf(stderr, "[x5 trace] K units %u, %u workgroup-columns, grid %u, run %u: span %.2f us (100 MHz clock; thread 0 of each workgroup)\n", t_units, t_cols,
+                        t_grid, t_run, (t_end - t0) * 0.01);
+                const char* names[6] = {"start", "prologue done", "K loop done", "partial drained", "counted", "output stored"};
+                for (int seg = 0; seg < 2; seg++)
+                    for (int k = 0; k < 6; k++) {
+                        double mn = 1e30, mx = 0, sum = 0;
+                        uint32_t n = 0;
+                        for (uint32_t b = 0; b < t_grid; b++) {
+                            const uint64_t v = tbuf[(b * 2 + seg) * 8 + k];
+                            if (v >= t0 && v) mn = std::min(mn, (v - t0) * 0.01), mx = std::max(mx, (v - t0) * 0.01), sum += (v - t0) * 0.01, n++;
+                        }
+                        if (n) fprintf(stderr, "[x5 trace]   segment %d %-16s n %4u  min %7.2f  avg %7.2f  max %7.2f us\n", seg, names[k], n, mn, sum / n, mx);
+                    }
+            });
+        }
+        a.trace = tbuf, t_grid = grid, t_cols = wg_cols, t_run = run, t_units = a.U;
+    }
+#endif
     hipLaunchKernelGGL(fn, dim3(grid), dim3(kX5Waves * 64), lds, s, a);
     return true;
 }
