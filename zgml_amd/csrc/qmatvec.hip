@@ -2481,7 +2481,6 @@ static uint64_t xdl_a_bytes(const QWeightDev& w, uint32_t M) {
     return (tiles + R - 1) / R * R * S * 12 * 1024;
 }
 static uint64_t xdl4_partial_bytes(const QWeightDev& w, uint32_t M) { // one part, at most 4 K slices
-    if (M <= 32) return 0;
     const uint64_t RT = xdl_tile_pad(M), groups = ((M + 15) / 16 + RT - 1) / RT;
     return groups * (w.N / 32) * 4 * (2 * RT * 256 * 4);
 }
@@ -2840,8 +2839,9 @@ void launch_xdl4(hipStream_t s, const QWeightDev* w, const QMatmulParams* p, uin
     const size_t lds = (size_t)kX4Waves * 2 * RT * 256 * sizeof(float) + 64;
     const bool nt = w[0].stream_nt != 0 && groups == 1;
     using Fn4 = void (*)(QMM4Args);
-    const Fn4 fn = RT == 8 ? (nt ? (Fn4)qmatmul_xdl4_kernel<8, 1, true> : (Fn4)qmatmul_xdl4_kernel<8, 1, false>)
-                           : (nt ? (Fn4)qmatmul_xdl4_kernel<4, 1, true> : (Fn4)qmatmul_xdl4_kernel<4, 1, false>);
+    const Fn4 fn = RT == 8   ? (nt ? (Fn4)qmatmul_xdl4_kernel<8, 1, true> : (Fn4)qmatmul_xdl4_kernel<8, 1, false>)
+                   : RT == 4 ? (nt ? (Fn4)qmatmul_xdl4_kernel<4, 1, true> : (Fn4)qmatmul_xdl4_kernel<4, 1, false>)
+                             : (nt ? (Fn4)qmatmul_xdl4_kernel<2, 1, true> : (Fn4)qmatmul_xdl4_kernel<2, 1, false>);
     if (lds > 64 * 1024) hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(fn, grid, dim3(kX4Waves * 64), lds, s, a);
 }
@@ -2919,6 +2919,19 @@ void launch_xdl2(hipStream_t s, const QWeightDev* w, const QMatmulParams* p, uin
         return;
     }
     if (R <= 2 && tiles == R && xdl5_enabled() && launch_xdl5(s, w, p, n, scratch, S, R)) return;
+    // narrow outputs at 17-32 rows: the K-split kernel of the M > 32 form at two m-tiles when it splits K at least two ways with
+    // >= 16 steps per slice — a workgroup then pulls half (a quarter) of A instead of all of it and the fan-in has 2-4 arrivals
+    // (4096 x 4096: 15.6 -> 14.5 us, 11008 x 4096: 31.8 -> 26.5; 2048 x 2048, one step per wave: 9.9 -> 10.3, hence the floor)
+    static const bool x4_m32 = !(getenv("ZGML_QMM_XDL4_M32") && atoi(getenv("ZGML_QMM_XDL4_M32")) == 0);
+    if (R == 2 && tiles == R && x4_m32 && xdl4_on) {
+        uint32_t bcs = 0;
+        for (uint32_t t = 0; t < n; t++) bcs += p[t].N / 32;
+        const uint32_t sk = std::min({cdiv(device_cus(), bcs), 4u, cdiv(S, (uint32_t)kX4Waves)});
+        if (sk >= 2 && S / sk >= 16 && (uint64_t)bcs * sizeof(uint32_t) <= kQmmScratchHead) {
+            launch_xdl4(s, w, p, n, scratch, S, R, tiles);
+            return;
+        }
+    }
     const uint32_t R2 = std::min(R, 2u); // (switch off: the M = 32 form over pairs of tiles; the A pieces are laid out per tile)
     static const int env_g = getenv("ZGML_QMM_XDL2_G") ? atoi(getenv("ZGML_QMM_XDL2_G")) : 0;
     uint32_t total_nb2 = 0;
