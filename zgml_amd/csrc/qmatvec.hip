@@ -2110,7 +2110,10 @@ __global__ void __launch_bounds__(WAVES * 64) qmatmul_xdl5_kernel(QMM5Args a) {
         X5_STAMP(1);
         __builtin_amdgcn_sched_barrier(0);
         // one stage: the MFMAs of group J, tile by tile, each tile's A registers refilled for group JN = J + 1 once its MFMAs
-        // are issued, and the B preparation of group JN spread between the MFMAs
+        // are issued, and the B preparation of group JN. The order inside a stage is the compiler's: matrix and vector
+        // instructions of a SIMD do not overlap (tools/exp/stage_parts.hip: 24 MFMAs + their B preparation cost the SUM, 32.0
+        // cycles per MFMA on a busy chip; forcing 1 MFMA : 3 VALU with sched_group_barrier: 34.9)
+        constexpr bool kX5Interleave = false;
 #define XDL5_STAGE(CUR, NXT, BUF_N, JN, WSRC)                                          \
     do {                                                                               \
         xdl_prep_b<JN, C>(WSRC.wq, sl, sh, NXT.b1, NXT.b2);                            \
@@ -2120,12 +2123,14 @@ __global__ void __launch_bounds__(WAVES * 64) qmatmul_xdl5_kernel(QMM5Args a) {
             mfmas(CUR, RT - 1);                                                        \
             read_a(BUF_N, JN, RT - 1);                                                 \
         }                                                                              \
-        _Pragma("unroll") for (int t_ = 0; t_ < RT; t_++) {                            \
-            _Pragma("unroll") for (int k_ = 0; k_ < 6 * C; k_++) {                     \
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); /* 1 MFMA */        \
-                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0); /* 3 VALU */        \
+        if (kX5Interleave) {                                                           \
+            _Pragma("unroll") for (int t_ = 0; t_ < RT; t_++) {                        \
+                _Pragma("unroll") for (int k_ = 0; k_ < 6 * C; k_++) {                 \
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); /* 1 MFMA */    \
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0); /* 3 VALU */    \
+                }                                                                      \
+                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0); /* tile refill */   \
             }                                                                          \
-            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0); /* the tile's refill */ \
         }                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                             \
     } while (0)
