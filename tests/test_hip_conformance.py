@@ -233,7 +233,10 @@ def test_dead_buffer_elision_and_loud_io_error(hip_backend):
 def test_constant_repeat_runs_once_until_the_host_writes_its_source(hip_backend):
     """A repeat whose source no op writes is executed when the plan is built, not per execution (the γ broadcasts of the
     LLaMA programs); an execute input on that source puts it back in the plan, with the new values visible."""
+    import os
     from zgml_amd import capi
+    if os.environ.get("ZGML_HIP_HOIST_REPEAT") == "0":
+        pytest.skip("the diagnostic switch under test turns the hoisting off")
     prog = DeviceProgram(
         ops=[DeviceOp.repeat(1, 0, 6, (2, 1, 1, 1), (2, 3, 1, 1), (1, 2, 2, 2), (1, 2, 6, 6)), DeviceOp.elementwise("neg", 2, 1, 1, 6)],
         buffer_sizes=[2, 6, 6], initial_uploads=[ProgramIO(0, np.array([7, 8], f32))])

@@ -11,7 +11,8 @@ import pytest
 
 from zgml_amd import capi, llama
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(__import__("os").environ.get("ZGML_HIP_FUSE_QKV_ATTN") == "0",
+                                                  reason="the diagnostic switch under test turns the fused launch off")]
 
 
 def _cfg(name, max_seq, kvq):
@@ -142,6 +143,8 @@ def test_attention_plus_o_projection_launch():
     import sys
     from pathlib import Path
 
+    if os.environ.get("ZGML_HIP_QMV_KON") == "0":
+        pytest.skip("the launch is built from the K-on-lanes mat-vec, which the diagnostic switch under test turns off")
     worker = Path(__file__).parent / "attn_o_worker.py"
     r = subprocess.run([sys.executable, str(worker)], capture_output=True, text=True, timeout=580, env=dict(os.environ, ZGML_HIP_FUSE_ATTN_O="1"))
     assert r.returncode == 0 and "ATTN_O_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

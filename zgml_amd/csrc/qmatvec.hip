@@ -3069,7 +3069,8 @@ static void build_qmv_args(const QmvLaunch& L, QMVArgs& a, uint32_t& blocks, boo
             static const bool silu_on = !(getenv("ZGML_QMV_EPI_SILU") && atoi(getenv("ZGML_QMV_EPI_SILU")) == 0);
             const bool residual = pt.n_epi == 1 && st[0].op == ZGML_OP_ADD && st[0].operand && st[0].operand != pt.dst && st[0].store;
             const bool mulvec = pt.n_epi == 1 && st[0].op == ZGML_OP_MUL && st[0].operand && st[0].operand != pt.dst && st[0].store;
-            d.epi_kind = !silu_on ? kEpiGeneric : (silu ? kEpiSilu : (residual ? kEpiResidual : (mulvec ? kEpiMulVec : kEpiGeneric)));
+            // (the switch is about the SiLU chain only: the residual form also carries the next launch's rmsnorm, arm_prenorm)
+            d.epi_kind = silu ? (silu_on ? kEpiSilu : kEpiGeneric) : (residual ? kEpiResidual : (mulvec ? kEpiMulVec : kEpiGeneric));
         }
         blocks += d.NB2;
     }

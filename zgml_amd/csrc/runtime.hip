@@ -1251,7 +1251,8 @@ void arm_prenorm(zgml_hip_program* p) {
 // one vector with no prologue (x = a * b per lane meant two 44 KB vectors per workgroup at Llama-2-7B's d_ff). K-on-lanes
 // weights only.
 void arm_pair(zgml_hip_program* p) {
-    static const bool on = !(getenv("ZGML_HIP_PAIR") && atoi(getenv("ZGML_HIP_PAIR")) == 0);
+    // (ZGML_QMV_EPI_SILU=0 asks for the SiLU chain through the generic step interpreter: the pair launch IS a fused SiLU epilogue)
+    static const bool on = !(getenv("ZGML_HIP_PAIR") && atoi(getenv("ZGML_HIP_PAIR")) == 0) && !(getenv("ZGML_QMV_EPI_SILU") && atoi(getenv("ZGML_QMV_EPI_SILU")) == 0);
     if (!on) return;
     for (size_t i = 1; i < p->plan.size(); i++) {
         const auto D = p->plan[i].qmv_desc, G = p->plan[i - 1].qmv_desc;
