@@ -1638,6 +1638,10 @@ __device__ __forceinline__ uint32_t pack_hi16(float a, float b) { return __built
 //   * every convert takes its nibble through an SDWA byte select: the high nibbles come from ONE shifted copy of the dword
 //     (kept opaque, or the shifts merge into byte-unaligned ones), and the `& 0xFF` is what lets the peephole pick BYTE_n;
 //   * the residuals w - hi are formed two at a time (v_pk_add_f32 with a negated operand).
+// x w = (a1 + a2 + a3)(b1 + b2) exactly (bf16 pieces, 8 bits each; b2 holds the <= 7 bits b1 leaves of the 15-bit weight). Five of the
+// six piece products are computed: a3 b2 is <= 2^-16 x 2^-8 of |x w| — measured 2.9e-9 of sum |x w| at K = 4096 against 4.8e-8
+// for a plain f32 matmul's own rounding and the tests' 2e-5 — and costs one MFMA in six. (3 = all six.)
+constexpr int kXdlLoPieces = 2;
 template <int CTRL>
 __device__ __forceinline__ float row_bcast_z(int v) { return __int_as_float(__builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true)); } // (no `old` to initialise)
 typedef float xf32x2 __attribute__((ext_vector_type(2)));
@@ -1735,7 +1739,7 @@ __global__ void __launch_bounds__(512) qmatmul_xdl2_kernel(QMM2Args a) {
 #pragma unroll
                 for (int t = 0; t < R; t++) acc[g][t][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(x.v[t][p]), b1, acc[g][t][p], 0, 0, 0);
 #pragma unroll
-            for (int p = 0; p < 3; p++)
+            for (int p = 0; p < kXdlLoPieces; p++) // (the third A piece x the low B piece is not computed: kXdlLoPieces)
 #pragma unroll
                 for (int t = 0; t < R; t++) acc[g][t][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(x.v[t][p]), b2, acc[g][t][p], 0, 0, 0);
         }
@@ -1747,7 +1751,7 @@ __global__ void __launch_bounds__(512) qmatmul_xdl2_kernel(QMM2Args a) {
         PREP;                                                                          \
         MFMA;                                                                          \
         __builtin_amdgcn_sched_group_barrier(0x020, 3 * R, 0); /* the A loads first */ \
-        _Pragma("unroll") for (int k_ = 0; k_ < 6 * R * G; k_++) {                     \
+        _Pragma("unroll") for (int k_ = 0; k_ < (3 + kXdlLoPieces) * R * G; k_++) {    \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); /* 1 MFMA */            \
             __builtin_amdgcn_sched_group_barrier(0x002, 4, 0); /* 4 VALU */            \
         }                                                                              \
@@ -1904,7 +1908,7 @@ __global__ void __launch_bounds__(512, 2) qmatmul_xdl4_kernel(QMM4Args a) {
 #pragma unroll
                     for (int p = 0; p < 3; p++) {
                         acc[g][half * H + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(x.v[t][p]), as_bf16x8(b1[g]), acc[g][half * H + t], 0, 0, 0);
-                        acc[g][half * H + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(x.v[t][p]), as_bf16x8(b2[g]), acc[g][half * H + t], 0, 0, 0);
+                        if (p < kXdlLoPieces) acc[g][half * H + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(x.v[t][p]), as_bf16x8(b2[g]), acc[g][half * H + t], 0, 0, 0);
                     }
         };
         // eight half-groups: the A pieces of the next half are requested before the MFMAs of the current one
@@ -2085,7 +2089,8 @@ __global__ void __launch_bounds__(WAVES * 64) qmatmul_xdl5_kernel(QMM5Args a) {
 #pragma unroll
                 for (int g = 0; g < C; g++) acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(xa[t][p]), as_bf16x8(o.b1[g]), acc[g][t], 0, 0, 0);
 #pragma unroll
-                for (int g = 0; g < C; g++) acc2[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(xa[t][p]), as_bf16x8(o.b2[g]), acc2[g][t], 0, 0, 0);
+                for (int g = 0; g < C; g++)
+                    if (p < kXdlLoPieces) acc2[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(xa[t][p]), as_bf16x8(o.b2[g]), acc2[g][t], 0, 0, 0);
             }
         };
         auto scale_bits = [](const WStep& b, int& lo, int& hi) {
@@ -2125,7 +2130,7 @@ __global__ void __launch_bounds__(WAVES * 64) qmatmul_xdl5_kernel(QMM5Args a) {
         }                                                                              \
         if (kX5Interleave) {                                                           \
             _Pragma("unroll") for (int t_ = 0; t_ < RT; t_++) {                        \
-                _Pragma("unroll") for (int k_ = 0; k_ < 6 * C; k_++) {                 \
+                _Pragma("unroll") for (int k_ = 0; k_ < (3 + kXdlLoPieces) * C; k_++) { \
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); /* 1 MFMA */    \
                     __builtin_amdgcn_sched_group_barrier(0x002, 3, 0); /* 3 VALU */    \
                 }                                                                      \
