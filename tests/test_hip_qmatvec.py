@@ -133,6 +133,23 @@ def test_shared_a_kernel_on_narrow_and_ragged_outputs():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("knobs", [{"ZGML_QMM_XDL5_MIN_RUN": "1", "ZGML_QMM_XDL5_WGS_PER_CU": "4"}, {"ZGML_QMM_XDL5_MIN_RUN": "3"},
+                                   {"ZGML_QMM_XDL5_MIN_RUN": "7"}, {"ZGML_QMM_XDL5_MIN_RUN": "1000"}])
+def test_shared_a_kernel_other_cuts_of_the_work_list(knobs):
+    """The cut of the (column, K step) list into runs decides which workgroups share a column, where a run straddles two columns
+    and how many partial tiles a column's last arriver sums: runs of one step (four workgroups per CU queued), of 3 and of 7 steps
+    (boundaries that divide neither S = 5, 35 nor 128), and whole columns only (no fan-in at all) — every M <= 32 tile test of
+    this file on the shared-A kernel, a process per cut because the switches are read once."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, ZGML_QMM_XDL5_MIN_COLS="1", **knobs)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "tests/test_hip_qmatvec.py", "-k", "tile_kernel or shared_a_kernel_matches"],
+                       capture_output=True, text=True, timeout=880, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_raw_layout_odd_shapes_bit_exact(hip_backend, oracle):
     """bs != 32 or N % 32 != 0 uses the k-sequential kernel: same loop order as the reference."""
     rng = np.random.default_rng(8)
