@@ -19,6 +19,8 @@ def _cfg(name, max_seq, kvq):
     """2 layers of a model that really takes the fused launch; a small vocabulary keeps the CPU oracle quick."""
     if name == "smollm":  # SmolLM-135M's layer: d 576, 9 heads x 64, 3 kv heads, d_ff 1536 -> qkv_attn_kernel<..., 16, ...>
         cfg = llama.preset("smollm-135m", max_seq)
+    elif name == "l7":  # Llama-2-7B's layer: d 4096, 32 x 128, K-on-lanes weights -> qkv_attn_kon_kernel<32, ...> (256-thread workgroups)
+        cfg = llama.preset("llama2-7b", max_seq)
     else:  # d_head 128 with d_model <= 2048: 2048 wide, 16 x 128, 4 kv heads -> qkv_attn_kernel<..., 32, ...>
         cfg = llama.preset("smollm-135m", max_seq)
         cfg.d_model, cfg.n_heads, cfg.n_kv_heads, cfg.d_ff = 2048, 16, 4, 2048
@@ -31,7 +33,7 @@ def _dispatches(hip_backend, s):
 
 
 @pytest.mark.parametrize("kvq", [0, 32])
-@pytest.mark.parametrize("name", ["smollm", "dh128"])
+@pytest.mark.parametrize("name", ["smollm", "dh128", "l7"])
 def test_fused_qkv_attention_with_the_split_active(hip_backend, oracle, name, kvq):
     """148 positions with the split threshold at 32 keys: from position 63 on every head's context is spread over several
     consumer workgroups INSIDE the fused launch. Logits within 2e-4 of the oracle's range (1e-3 with int8 KV: a 1-ulp
@@ -48,7 +50,10 @@ def test_fused_qkv_attention_with_the_split_active(hip_backend, oracle, name, kv
     try:
         s_f = llama.Session(m, llama.hip_backend_fns(hip_backend))
         tok, toks, logits = 3, [], []
-        tol = 1e-3 if kvq else 2e-4
+        # (int8 KV at 7B dimensions: the synthetic projections sit on storeColumn's truncation boundaries, a 1-ulp difference flips
+        # 5-24 cache units per head — up to 4.2e-3 of the range over these positions, bit for bit the same with the fusion on
+        # and off: the launch form is not what is being bounded there; tests/test_hip_longctx.py documents the effect)
+        tol = (6e-3 if name == "l7" else 1e-3) if kvq else 2e-4
         for pos in range(n):
             t_ref, l_ref = s_ref.step(tok, pos)
             t_f, l_f = s_f.step(tok, pos)
@@ -78,7 +83,8 @@ def test_fused_qkv_attention_with_the_split_active(hip_backend, oracle, name, kv
                 scale = np.abs(logits[pos]).max()
                 assert np.abs(l_u - logits[pos]).max() / scale < (tol if kvq else 2e-5), pos
                 tok = toks[pos]
-            assert _dispatches(hip_backend, s_u) // n == fused_launches + cfg.n_layers
+            # (K-on-lanes models: the first layer's q / k / v launch computes its rmsnorm itself and stays apart)
+            assert _dispatches(hip_backend, s_u) // n == fused_launches + (cfg.n_layers - 1 if name == "l7" else cfg.n_layers)
             s_u.close()
         finally:
             hip_backend.set_option(capi.OPT_FUSE_RESIDENT_WGS, -1)

@@ -395,7 +395,8 @@ bool launch_qkv_attention(hipStream_t s, const QmvLaunch& L, const AttnDecodePar
 // (qmatvec.hip: attn_o_kon_kernel); `out_cnt` one zeroed word, `o_seen` one zeroed word per workgroup of the projection
 bool launch_attention_o(hipStream_t s, const AttnDecodeParams* dev_params, uint32_t n_heads, uint32_t d_head, const AttnSplit& sp, const QmvLaunch& o_proj,
                         uint32_t* out_cnt, uint32_t* o_seen, uint32_t* timeout);
-int attn_o_blocks_per_cu(uint32_t d_head); // occupancy query of that kernel
+int attn_o_blocks_per_cu(uint32_t d_head);
+int qkv_attn_kon_blocks_per_cu(uint32_t d_head, bool kvq); // fused q / k / v + attention launch of K-on-lanes weights (256-thread workgroups) // occupancy query of that kernel
 // (o_proj: the single-matrix projection that reads the heads' row stores rides in the same launch; out_cnt: one zeroed
 // word, o_seen: one zeroed word per workgroup of that projection)
 // Deterministic synthetic weights for the roofline micro-benchmark, generated on the device

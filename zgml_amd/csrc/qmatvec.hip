@@ -1273,6 +1273,19 @@ __global__ void __launch_bounds__(1024) qkv_attn_kernel(QMV_HEAD_PARAMS, QMVArgs
     }
 }
 
+// The same for K-on-lanes weights (K > 2048: Llama-2-7B's 768 projection workgroups + one or more per head): 256-thread
+// workgroups, both bodies at four waves and within 128 registers, so four workgroups per CU are resident and the whole grid is
+// co-resident (fuse_qkv_attention checks it against the occupancy query minus one workgroup per CU).
+template <int LPK, int DEPTH, int PROM, bool NT, bool KVQ>
+__global__ void __launch_bounds__(256, 4) qkv_attn_kon_kernel(QMV_HEAD_PARAMS, QMVArgs a, QkvAttnArgs f) {
+    if (blockIdx.x < f.n_mv) {
+        qmatvec_kon_body<DEPTH, PROM, true, true, NT>(qs0, sc0, out0, xa_base, xb_base, in_rs, K, nb2_0_flags, nb2_12, a, blockIdx.x, f.n_mv, &f.pub);
+    } else {
+        const uint32_t b = blockIdx.x - f.n_mv, n_heads = f.ho.n_heads; // head-major: the always-active split 0 of every head first
+        attention_decode_body<LPK, KVQ, 256>(f.params, f.split_buf, f.split_cnt, f.split_min_keys, b % n_heads, b / n_heads, f.n_sp, &f.ho);
+    }
+}
+
 // ... and the O projection behind the attention in the same launch (third range of workgroups): its weights are requested
 // at once, its x (the heads' row stores) is taken over through one counter that every head bumps when its rows are stored.
 struct QmvHead { // the leading arguments of a mat-vec launch (QMV_HEAD_PARAMS) as a value
@@ -2685,7 +2698,28 @@ bool launch_packed_kon(hipStream_t s, QMVArgs& a, const QWeightDev& w0, uint32_t
     const float* const head_xb = prom == 2 ? a.pro.a : a.pro.b;
     const uint32_t flags = a.parts[0].NB2 | ((waves_used - 1) << 20) | (a.n_parts << 24) | (contig ? 1u << 28 : 0u) | (a.pro.kind == QMV_PRO_RMSNORM_MUL ? 1u << 29 : 0u) |
                            (a.x_vec ? 1u << 30 : 0u);
-    if (fused) return false; // (the fused q/k/v + attention launch is built for the n-on-lanes form: short K keeps that layout, compile_program)
+    if (fused) { // q / k / v + decode attention in one launch of 256-thread workgroups (qkv_attn_kon_kernel)
+        using FusedFn = void (*)(const uint4*, const void*, float*, const float*, const float*, uint32_t, uint32_t, uint32_t, uint32_t, QMVArgs, QkvAttnArgs);
+        if (!grp || !contig || !xvec || prom == 1 || (d_head != 64 && d_head != 128)) return false;
+        const uint32_t steps4 = cdiv(P, 4 * 64);
+        const bool deep = steps4 >= 4; // four items per lane in flight (K >= 2048 with four waves), else two
+        const uint32_t flags4 = (flags & ~(0xFu << 20)) | (3u << 20);
+        FusedFn ff = nullptr;
+#define ZGML_QKV_KON(LPK_, KVQ_)                                                                                                                   \
+    ff = prom == 2 ? (deep ? (nt ? qkv_attn_kon_kernel<LPK_, 4, 2, true, KVQ_> : qkv_attn_kon_kernel<LPK_, 4, 2, false, KVQ_>) : qkv_attn_kon_kernel<LPK_, 2, 2, false, KVQ_>) \
+                   : (deep ? (nt ? qkv_attn_kon_kernel<LPK_, 4, 0, true, KVQ_> : qkv_attn_kon_kernel<LPK_, 4, 0, false, KVQ_>) : qkv_attn_kon_kernel<LPK_, 2, 0, false, KVQ_>)
+        if (d_head == 64) {
+            if (fused->kvq) ZGML_QKV_KON(16, true); else ZGML_QKV_KON(16, false);
+        } else {
+            if (fused->kvq) ZGML_QKV_KON(32, true); else ZGML_QKV_KON(32, false);
+        }
+#undef ZGML_QKV_KON
+        QkvAttnArgs f = *fused;
+        f.n_mv = total_blocks;
+        hipLaunchKernelGGL(ff, dim3(total_blocks + extra_blocks), dim3(256), lds, s, a.parts[0].qs, a.parts[0].sc, a.parts[0].out, head_xa, head_xb, a.in_rs, a.K, flags4, nb2_12,
+                           a, f);
+        return true;
+    }
     if (a.pair_out) { // gate / up in pairs (arm_pair checked the shapes and the epilogues; the layout conditions are checked here)
         const bool pair_ok = a.n_parts == 2 && contig && xvec && prom != 1 && a.parts[0].NB2 == a.parts[1].NB2 && a.parts[0].NB2 % 2 == 0 && waves_used <= 8;
         if (!pair_ok) {
@@ -3135,6 +3169,13 @@ bool launch_qkv_attention(hipStream_t s, const QmvLaunch& L, const AttnDecodePar
 // the decode attention of `n_heads` heads + the single-matrix K-on-lanes projection that reads their row stores, one launch
 // (attn_o_kon_kernel). `out_cnt`: one zeroed word, `o_seen`: one zeroed word per workgroup of the projection. false: not a shape the
 // kernel is built for (nothing launched). attn_o_blocks_per_cu(): what the occupancy query admits per CU (for the planner's guard).
+int qkv_attn_kon_blocks_per_cu(uint32_t d_head, bool kvq) { // what the occupancy query admits per CU for the fused K-on-lanes launch (the deepest variant)
+    int nb = 0;
+    const void* fn = d_head == 64 ? (kvq ? (const void*)qkv_attn_kon_kernel<16, 4, 2, true, true> : (const void*)qkv_attn_kon_kernel<16, 4, 2, true, false>)
+                                  : (kvq ? (const void*)qkv_attn_kon_kernel<32, 4, 2, true, true> : (const void*)qkv_attn_kon_kernel<32, 4, 2, true, false>);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, ((size_t)kMaxWaves * 16 + kMaxWaves) * sizeof(float)) != hipSuccess) return 0;
+    return nb;
+}
 int attn_o_blocks_per_cu(uint32_t d_head) {
     int nb = 0;
     const void* fn = d_head == 64 ? (const void*)attn_o_kon_kernel<16, 4, true> : (const void*)attn_o_kon_kernel<32, 4, true>;

@@ -1055,8 +1055,11 @@ void fuse_qkv_attention(zgml_hip_program* p) {
             for (uint64_t b : p->barriers) cut = cut || (b > lo_b && b <= hi_b);
             if (cut) continue;
         }
-        if (L.n_parts != 3 || L.K > 2048 || L.pro.kind == QMV_PRO_NONE || (ad->dh != 64 && ad->dh != 128) || L.trace) continue;
+        const bool kon = L.parts[0].w.format == QW_Q4K && L.K > 2048; // the 256-thread form of the launch (qkv_attn_kon_kernel)
+        static const bool kon_on = !(getenv("ZGML_HIP_FUSE_QKV_ATTN_KON") && atoi(getenv("ZGML_HIP_FUSE_QKV_ATTN_KON")) == 0);
+        if (L.n_parts != 3 || (L.K > 2048 && !(kon && kon_on)) || L.pro.kind == QMV_PRO_NONE || (ad->dh != 64 && ad->dh != 128) || L.trace) continue;
         if (L.pro.kind == QMV_PRO_PRENORM && L.parts[0].w.format != QW_Q4K) continue;
+        if (kon && L.pro.kind != QMV_PRO_PRENORM) continue; // (an in-kernel rmsnorm prologue runs eight waves: launch_packed_kon)
         const bool kvq = ad->kvq;
         bool ok = true;
         for (uint32_t t = 0; t < 3; t++) ok = ok && L.parts[t].n_epi == 0 && (L.parts[t].w.format == QW_Q4 || L.parts[t].w.format == QW_Q4K) && L.parts[t].w.scale_f16;
@@ -1081,8 +1084,21 @@ void fuse_qkv_attention(zgml_hip_program* p) {
         uint32_t n_sp = ad->sp.splits ? ad->sp.splits : 1;
         uint64_t n_mv = 0;
         for (uint32_t t = 0; t < 3; t++) n_mv += L.parts[t].w.N / 16;
-        if (n_mv + nh > resident_cap) continue; // not even one attention workgroup per head beside the projection's: two launches
-        n_sp = (uint32_t)std::min<uint64_t>(n_sp, (resident_cap - n_mv) / nh);
+        uint64_t cap = resident_cap;
+        if (kon && p->ctx->opt_fuse_resident_wgs < 0) {
+            // 256-thread workgroups: what the occupancy query admits (four per CU at 127 registers: 1024; the 7B launch is 768 projection
+            // workgroups + 32 heads x up to 8 splits = 1024). No margin here, unlike the 1024-thread form: with 4 instead of 8 splits
+            // the launch LOSES at long contexts (position 1900: 590 against 632 tok/s unfused; with 8: 644), and the projection's
+            // workgroups have the lower ids — should fewer be resident than the query says, the attention's workgroups queue behind
+            // them instead of spinning beside them (no overlap then, nothing worse); a stranded wait is still bounded and loud.
+            const int per_cu = qkv_attn_kon_blocks_per_cu(ad->dh, kvq);
+            static const int eighths = getenv("ZGML_HIP_FUSE_KON_CAP_EIGHTHS") ? atoi(getenv("ZGML_HIP_FUSE_KON_CAP_EIGHTHS")) : 8; // (experiments)
+            cap = per_cu > 0 ? (uint64_t)per_cu * (uint64_t)std::max(p->ctx->n_cu, 1) * (uint64_t)eighths / 8 : 0;
+        }
+        if (n_mv + nh > cap) continue; // not even one attention workgroup per head beside the projection's: two launches
+        n_sp = (uint32_t)std::min<uint64_t>(n_sp, (cap - n_mv) / nh);
+        for (uint32_t t = 0; kon && t < 3; t++) ok = ok && L.parts[t].w.format == QW_Q4K;
+        if (!ok) continue;
         // ... and the single-matrix projection that reads exactly the heads' row stores (the O projection) rides along:
         // no prologue, K = n_heads * d_head, every head's rows stored at its static offset h * d_head of that input
         std::shared_ptr<QmvLaunch> od = i + 2 < p->plan.size() ? p->plan[i + 2].qmv_desc : nullptr;
@@ -1099,6 +1115,7 @@ void fuse_qkv_attention(zgml_hip_program* p) {
             const zgml_device_op& so = p->ops[(size_t)(a.att.dyn_dst2_off - p->dyn_dev)];
             o_ok = so.kind == ZGML_DOP_SLICE_ASSIGN && so.u.slice_assign.patch_stride == 0 && so.u.slice_assign.dst_offset == idx[3 * r] * dh;
         }
+        if (kon) o_ok = false;
         if (o_ok && n_mv + (uint64_t)nh * n_sp + od->parts[0].w.N / 16 > resident_cap) o_ok = false;
         const uint32_t o_blocks = o_ok ? (uint32_t)(od->parts[0].w.N / 16) : 0;
         const size_t n_cnt = 32 * ((size_t)nh + 2 * n_kv + 1); // one counter per 128 bytes (the last: the heads' outputs)
