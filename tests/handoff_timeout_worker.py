@@ -14,8 +14,13 @@ from zgml_amd import Backend, capi, llama  # noqa: E402
 def main():
     be = Backend(0)
     hip = capi.load_hip()
-    cfg = llama.preset("smollm-135m", 64)
-    cfg.n_layers, cfg.vocab_size = 1, 1024
+    import os
+    if os.environ.get("ZGML_TEST_HANDOFF_MODEL") == "l7":  # the 256-thread form of the launch (K-on-lanes weights): layer 1 of a 7B-dimension model
+        cfg = llama.preset("llama2-7b", 64)
+        cfg.n_layers, cfg.vocab_size = 2, 1024
+    else:
+        cfg = llama.preset("smollm-135m", 64)
+        cfg.n_layers, cfg.vocab_size = 1, 1024
     m = llama.Model(cfg, llama.Q4_0, threads=4)
     out = {}
     # reference tokens: the fusion refused from the start (the dropped publish only exists inside the fused launch)
