@@ -1096,6 +1096,9 @@ void fuse_qkv_attention(zgml_hip_program* p) {
             cap = per_cu > 0 ? (uint64_t)per_cu * (uint64_t)std::max(p->ctx->n_cu, 1) * (uint64_t)eighths / 8 : 0;
         }
         if (n_mv + nh > cap) continue; // not even one attention workgroup per head beside the projection's: two launches
+        // (the 256-thread form only with ALL the splits the stand-alone attention would use: with fewer it loses at long contexts —
+        // 7B dimensions with 4 of 8: 590 against 632 tok/s at position 1900 — so a wider model keeps its two launches)
+        if (kon && p->ctx->opt_fuse_resident_wgs < 0 && (cap - n_mv) / nh < n_sp) continue;
         n_sp = (uint32_t)std::min<uint64_t>(n_sp, (cap - n_mv) / nh);
         for (uint32_t t = 0; kon && t < 3; t++) ok = ok && L.parts[t].w.format == QW_Q4K;
         if (!ok) continue;
