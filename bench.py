@@ -453,6 +453,68 @@ def verify_longctx(be, llama, case):
     return f"tests/golden/longctx.json {case} (oracle; vtable logits probes + resident tokens at positions {pos0}..{pos0 + 3})"
 
 
+def verify_longctx_filled(be, llama, case, fused_attention=True):
+    """The HIP path against a `*_filled` case of tests/golden/longctx.json (tools/gen_golden_longctx.py --filled; the ORACLE): the
+    reference's flow — prefill in chunks of 128 (src/llama_inference.zig:474) over 1920 real tokens, so every cache column the
+    decode attention reads holds a key / value, then 4 greedy decode steps. HIP: the chunks through zgml_hip_resident_prefill
+    (greedy token of every chunk against the fixture; the last chunk through the vtable for its logits probe), the caches handed
+    to the decode plan on the device (zgml_hip_copy_program_buffer), the decode steps through the vtable with logits probes, then
+    the same positions again through the device-resident loop (tokens). f32 KV: 2e-4 of the logit range; int8 KV: 1e-3 (single
+    cache units on the truncation boundary of storeColumn, tests/test_hip_longctx_filled.py). fused_attention=False refuses the
+    q/k/v + attention fusion, so the stand-alone decode attention (and its context split) is what runs. Raises ParityError."""
+    import ctypes as C
+    from zgml_amd import capi
+    g = json.loads((ROOT / "tests" / "golden" / "longctx.json").read_text())[case]
+    cfg = llama.preset("smollm-135m" if case.startswith("smollm") else "llama2-7b", 2048)
+    cfg.n_layers, cfg.kv_quant_block = g["n_layers"], g["kv_quant_block"]
+    tol = 1e-3 if g["kv_quant_block"] else 2e-4
+    T, n_chunks = g["chunk"], g["n_chunks"]
+    m_pre, m_dec = llama.Model(cfg, llama.Q4_0, threads=16, token_len=T), llama.Model(cfg, llama.Q4_0, threads=16)
+    s_pre = s_dec = None
+    try:
+        s_pre = llama.Session(m_pre, llama.hip_backend_fns(be))
+        be.set_option(capi.OPT_FUSE_RESIDENT_WGS, -1 if fused_attention else 0)
+        try:
+            s_dec = llama.Session(m_dec, llama.hip_backend_fns(be))
+        finally:
+            be.set_option(capi.OPT_FUSE_RESIDENT_WGS, -1)
+        s_pre.resident_setup(be)
+        for c in range(n_chunks):
+            toks = [(7 * (c * T + i) + 3) % cfg.vocab_size for i in range(T)]
+            if c < n_chunks - 1:
+                tok = s_pre.resident_prefill(toks, c * T)
+            else:
+                tok, logits = s_pre.prefill(toks, c * T)
+                _check_probe(logits, g["prefill_probe"], tol, f"{case}: last prefill chunk")
+            if tok != g["chunk_tokens"][c]:
+                raise ParityError(f"{case}: prefill chunk {c} gives token {tok}, oracle {g['chunk_tokens'][c]}")
+        hip = capi.load_hip()
+
+        def hand_over():
+            for (bp, n), (bd, n2) in zip(m_pre.kv_buffers(), m_dec.kv_buffers()):
+                if n != n2 or hip.zgml_hip_copy_program_buffer(be.ctx, s_dec.handle, bd, 0, s_pre.handle, bp, 0, n) != 0:
+                    raise ParityError(f"{case}: KV hand-off failed: " + be.last_error())
+        hand_over()
+        first = tok
+        for i, pos in enumerate(g["positions"]):
+            tok, logits = s_dec.step(tok, pos)
+            _check_probe(logits, g["probes"][i], tol, f"{case}: position {pos}")
+            if tok != g["tokens"][i]:
+                raise ParityError(f"{case}: token {tok} != oracle {g['tokens'][i]} at position {pos}")
+        hand_over()  # the prefilled image again (the steps above appended their own columns), now the resident loop
+        s_dec.resident_setup(be)
+        got = s_dec.resident_decode(first, g["positions"][0], len(g["positions"])).tolist()
+        if got != g["tokens"]:
+            raise ParityError(f"{case}: resident tokens {got} != oracle {g['tokens']}")
+    finally:
+        for x in (s_pre, s_dec, m_pre, m_dec):
+            if x is not None:
+                x.close()
+    return (f"tests/golden/longctx.json {case} (oracle; 1920-token prefilled cache, prefill tokens + last-chunk probe, vtable logits "
+            f"probes + resident tokens at positions {g['positions'][0]}..{g['positions'][-1]}, "
+            f"{'fused q/k/v + attention launch' if fused_attention else 'stand-alone decode attention'})")
+
+
 def verify_l7_shapes(be, llama):
     """Before any Llama-2-7B number is reported: the HIP path at 7B shapes against the oracle's committed fixture
     (tests/golden/l7dims.json: 2 layers, d 4096 / 32 x 128 heads / d_ff 11008 / vocab 32000) — vtable steps with

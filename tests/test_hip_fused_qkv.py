@@ -135,7 +135,10 @@ def test_handoff_timeout_is_loud_and_falls_back(model):
     worker = Path(__file__).parent / "handoff_timeout_worker.py"
     if model == "l7" and any(os.environ.get(v) == "0" for v in ("ZGML_HIP_FUSE_QKV_ATTN_KON", "ZGML_HIP_QMV_KON", "ZGML_HIP_PRENORM")):
         pytest.skip("the diagnostic switch under test turns the fused K-on-lanes launch off")
-    env = dict(os.environ, ZGML_HIP_DEBUG_DROP_PUBLISH="1", ZGML_TEST_HANDOFF_MODEL=model)
+    # the switch that suppresses one publish exists only in the diagnostics library (-DZGML_TRACE): the product build cannot drop it
+    trace_lib = Path(__file__).resolve().parent.parent / "zgml_amd" / "lib" / "libzgml_hip_trace.so"
+    assert trace_lib.exists(), "run __graft_entry__.build(): it builds the diagnostics library too"
+    env = dict(os.environ, ZGML_HIP_DEBUG_DROP_PUBLISH="1", ZGML_TEST_HANDOFF_MODEL=model, ZGML_HIP_LIB=str(trace_lib))
     r = subprocess.run([sys.executable, str(worker)], capture_output=True, text=True, timeout=580, env=env)
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("HANDOFF_RESULT ")]
     assert r.returncode == 0 and line, r.stdout[-2000:] + r.stderr[-4000:]
@@ -159,5 +162,8 @@ def test_attention_plus_o_projection_launch():
     if os.environ.get("ZGML_HIP_QMV_KON") == "0":
         pytest.skip("the launch is built from the K-on-lanes mat-vec, which the diagnostic switch under test turns off")
     worker = Path(__file__).parent / "attn_o_worker.py"
-    r = subprocess.run([sys.executable, str(worker)], capture_output=True, text=True, timeout=580, env=dict(os.environ, ZGML_HIP_FUSE_ATTN_O="1"))
+    trace_lib = Path(__file__).resolve().parent.parent / "zgml_amd" / "lib" / "libzgml_hip_trace.so"  # (the kernel is not in the product library)
+    assert trace_lib.exists(), "run __graft_entry__.build(): it builds the diagnostics library too"
+    r = subprocess.run([sys.executable, str(worker)], capture_output=True, text=True, timeout=580,
+                       env=dict(os.environ, ZGML_HIP_FUSE_ATTN_O="1", ZGML_HIP_LIB=str(trace_lib)))
     assert r.returncode == 0 and "ATTN_O_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -1227,6 +1227,7 @@ __global__ void __launch_bounds__(512, 4) qmatvec_kon_pair_kernel(QMV_HEAD_PARAM
 // 3.5 us), runs; behind the counter the projection has its x loads, 4 x 32 weights of FMAs per lane and the fold left. All
 // workgroups are 256 threads and the kernel is held to 128 registers, so four workgroups per CU are admitted; the launch is only
 // built when the whole grid fits three per CU (runtime.hip: fuse_attention_o).
+#ifdef ZGML_TRACE // (diagnostics build only: measured slower than two launches; tests load libzgml_hip_trace.so)
 struct AttnOArgs {
     const AttnDecodeParams* params;
     float* split_buf;
@@ -1245,6 +1246,7 @@ __global__ void __launch_bounds__(256, 4) attn_o_kon_kernel(QMV_HEAD_PARAMS, QMV
                                                                   gridDim.x - f.n_attn, nullptr, &f.wt);
     }
 }
+#endif
 
 // The q / k / v projection and the decode attention that consumes it in ONE launch (DESIGN.md section 8.0,
 // tools/exp/localdep.hip): workgroups [0, n_mv) are the grouped mat-vec's, the rest the attention's (head-major, then
@@ -1296,6 +1298,7 @@ struct QmvHead { // the leading arguments of a mat-vec launch (QMV_HEAD_PARAMS) 
     const float* xb_base;
     uint32_t in_rs, K, nb2_0_flags, nb2_12;
 };
+#ifdef ZGML_TRACE // (diagnostics build only: measured slower)
 struct QkvAttnOArgs {
     QkvAttnArgs f;
     QmvHead h2;
@@ -1320,6 +1323,7 @@ __global__ void __launch_bounds__(1024) qkv_attn_o_kernel(QMV_HEAD_PARAMS, QMVAr
                                                                        blockIdx.x - f.n_mv - fo.n_attn, nullptr, &fo.wt);
     }
 }
+#endif
 
 // ── M > 1 (prefill): tile kernel on the f32 matrix cores ─────────────────────────────────────
 // With M rows of x the same weight stream feeds M dot products, so the op is a real contraction
@@ -2744,10 +2748,12 @@ bool launch_packed_kon(hipStream_t s, QMVArgs& a, const QWeightDev& w0, uint32_t
 
 bool launch_packed(hipStream_t s, QMVArgs& a, const QWeightDev& w0, uint32_t total_blocks, uint32_t M, bool xvec, const QkvAttnArgs* fused,
                    uint32_t extra_blocks, uint32_t d_head, const FusedO* fo) {
-    { // diagnostics: leave out every mat-vec launch of one grid size (wrong results; the token time then drops by that launch's true cost)
+#ifdef ZGML_TRACE
+    { // diagnostics build only: leave out every mat-vec launch of one grid size (wrong results; the token time then drops by that launch's true cost)
         static const uint32_t skip_blocks = getenv("ZGML_HIP_DEBUG_SKIP_GRID") ? (uint32_t)atoi(getenv("ZGML_HIP_DEBUG_SKIP_GRID")) : 0u;
         if (skip_blocks && total_blocks == skip_blocks) return true;
     }
+#endif
     if (w0.format == QW_Q4K) { // (only weights whose every use is an M = 1 mat-vec get this layout: compile_program)
         if (M != 1) return false;
         return launch_packed_kon(s, a, w0, total_blocks, xvec, fused, extra_blocks, d_head, fo);
@@ -2791,7 +2797,8 @@ bool launch_packed(hipStream_t s, QMVArgs& a, const QWeightDev& w0, uint32_t tot
         QkvAttnArgs f = *fused;
         f.n_mv = total_blocks;
         const bool fused_kvq = f.kvq != 0;
-        if (fo && depth_sel == 0 && !fused_kvq) { // ... and the O projection behind the attention
+#ifdef ZGML_TRACE
+        if (fo && depth_sel == 0 && !fused_kvq) { // ... and the O projection behind the attention (diagnostics build only)
             QkvAttnOArgs g{f, fo->h2, fo->wt, extra_blocks};
             const dim3 grid3(total_blocks + extra_blocks + fo->blocks2);
             if (d_head == 64)
@@ -2804,6 +2811,7 @@ bool launch_packed(hipStream_t s, QMVArgs& a, const QWeightDev& w0, uint32_t tot
                                    nb2_12, a, g, fo->a2);
             return true;
         }
+#endif
         if (fo) return false; // (the caller asked for the triple: let it fall back as a whole)
         if (depth_sel != 0) return false; // (one load step: K <= 2048)
         using FusedFn = void (*)(const uint4*, const void*, float*, const float*, const float*, uint32_t, uint32_t, uint32_t, uint32_t, QMVArgs, QkvAttnArgs);
@@ -2833,10 +2841,11 @@ TileFn pick_tile_nt(bool two, bool xvec) {
 }
 template <typename ST, bool Q4>
 TileFn pick_tile(bool two, bool xvec, bool nt) {
-    // ZGML_QMM_XDL=0 keeps the contraction on the f32 MFMA (same results up to rounding order)
+#ifdef ZGML_TRACE // diagnostics build only: ZGML_QMM_XDL=0 keeps the contraction on the f32 MFMA (same results up to rounding order; slower)
     static const bool xdl = !(getenv("ZGML_QMM_XDL") && atoi(getenv("ZGML_QMM_XDL")) == 0);
-    if (xdl) return nt ? pick_tile_nt<ST, Q4, true, true>(two, xvec) : pick_tile_nt<ST, Q4, false, true>(two, xvec);
-    return nt ? pick_tile_nt<ST, Q4, true, false>(two, xvec) : pick_tile_nt<ST, Q4, false, false>(two, xvec);
+    if (!xdl) return nt ? pick_tile_nt<ST, Q4, true, false>(two, xvec) : pick_tile_nt<ST, Q4, false, false>(two, xvec);
+#endif
+    return nt ? pick_tile_nt<ST, Q4, true, true>(two, xvec) : pick_tile_nt<ST, Q4, false, true>(two, xvec);
 }
 
 template <int R, bool NT>
@@ -3149,11 +3158,16 @@ bool launch_qkv_attention(hipStream_t s, const QmvLaunch& L, const AttnDecodePar
     f.n_sp = sp.splits ? sp.splits : 1;
     uint32_t shift = 0;
     while ((16u << shift) < d_head) shift++;
+#ifdef ZGML_TRACE // diagnostics build only (tests/handoff_timeout_worker.py loads libzgml_hip_trace.so): one column group never signals
     static const bool drop_publish = getenv("ZGML_HIP_DEBUG_DROP_PUBLISH") && atoi(getenv("ZGML_HIP_DEBUG_DROP_PUBLISH")) != 0;
+#else
+    constexpr bool drop_publish = false;
+#endif
     f.pub = QmvPublish{counters, {0, n_heads, n_heads + n_kv}, shift, drop_publish ? 1u : 0u};
     static const uint32_t poll_sleep = getenv("ZGML_HIP_HANDOFF_SLEEP") ? (uint32_t)atoi(getenv("ZGML_HIP_HANDOFF_SLEEP")) : 2u;
     f.ho = DecodeHandoff{counters, seen, idx, n_heads, d_head / 16, timeout, poll_sleep, nullptr};
-    if (Lo) { // the O projection rides along
+#ifdef ZGML_TRACE
+    if (Lo) { // the O projection rides along (diagnostics build only)
         FusedO fo;
         bool xvec2 = false;
         build_qmv_args(*Lo, fo.a2, fo.blocks2, xvec2);
@@ -3163,6 +3177,9 @@ bool launch_qkv_attention(hipStream_t s, const QmvLaunch& L, const AttnDecodePar
         f.ho.out_cnt = out_cnt;
         return launch_qmv(s, L, &f, n_heads * f.n_sp, d_head, &fo);
     }
+#else
+    if (Lo) return false;
+#endif
     return launch_qmv(s, L, &f, n_heads * f.n_sp, d_head);
 }
 
@@ -3176,6 +3193,7 @@ int qkv_attn_kon_blocks_per_cu(uint32_t d_head, bool kvq) { // what the occupanc
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, ((size_t)kMaxWaves * 16 + kMaxWaves) * sizeof(float)) != hipSuccess) return 0;
     return nb;
 }
+#ifdef ZGML_TRACE // the attention + O projection launch: diagnostics build only (measured slower)
 int attn_o_blocks_per_cu(uint32_t d_head) {
     int nb = 0;
     const void* fn = d_head == 64 ? (const void*)attn_o_kon_kernel<16, 4, true> : (const void*)attn_o_kon_kernel<32, 4, true>;
@@ -3213,6 +3231,7 @@ bool launch_attention_o(hipStream_t s, const AttnDecodeParams* dev_params, uint3
     hipLaunchKernelGGL(fn, dim3(f.n_attn + blocks), dim3(256), lds, s, a.parts[0].qs, a.parts[0].sc, a.parts[0].out, a.pro.a, a.pro.b, a.in_rs, a.K, flags, 0u, a, f);
     return true;
 }
+#endif
 
 void launch_synth_packed(hipStream_t s, const QWeightDev& w, uint32_t matrix_id) {
     if (w.scale_f16)

@@ -1108,7 +1108,11 @@ void fuse_qkv_attention(zgml_hip_program* p) {
         // (measured: 93 launches per SmolLM-135M token instead of 123, parity green, and SLOWER — 1714-1734 against 1772 tok/s:
         // this edge is all-to-all (every column group of the projection needs every head), its hand-off costs more than the
         // boundary it replaces. Off unless ZGML_HIP_FUSE_QKV_ATTN_O=1.)
+#ifdef ZGML_TRACE // (diagnostics build only)
         static const bool with_o = getenv("ZGML_HIP_FUSE_QKV_ATTN_O") && atoi(getenv("ZGML_HIP_FUSE_QKV_ATTN_O")) != 0;
+#else
+        constexpr bool with_o = false;
+#endif
         bool o_ok = with_o && !kvq && od && od->n_parts == 1 && od->pro.kind == QMV_PRO_NONE && od->K == nh * dh && od->K <= 2048 && !od->trace &&
                     od->parts[0].w.format == QW_Q4 && od->parts[0].w.scale_f16;
         for (uint32_t r = 0; o_ok && r < nh; r++) {
@@ -1159,6 +1163,7 @@ void fuse_qkv_attention(zgml_hip_program* p) {
 // (bounded) for one counter every head bumps. The waiting workgroups spin on workgroups of the same grid, so — like the q/k/v +
 // attention launch above — it is only built when the WHOLE grid is resident: the occupancy query minus one workgroup per CU
 // (the query reads one high near a register-file edge), the attention's split count shrinks to fit, otherwise two launches.
+#ifdef ZGML_TRACE // diagnostics build only: the kernel is not in the product library
 void fuse_attention_o(zgml_hip_program* p) {
     // MEASURED SLOWER, off unless ZGML_HIP_FUSE_ATTN_O=1 (parity green: tests/test_hip_fused_qkv.py): Llama-2-7B 800 -> 749 tok/s
     // (766 when the projection's weight loads are delayed until the attention is about done; polling interval and split count
@@ -1224,6 +1229,7 @@ void fuse_attention_o(zgml_hip_program* p) {
         p->plan.erase(p->plan.begin() + (ptrdiff_t)i + 1);
     }
 }
+#endif
 
 // A mat-vec launch with a residual-add epilogue (h = y + r: the O / down projections) that is DIRECTLY followed by the launch
 // whose rmsnorm -> mul(gamma) prologue consumes h prepares that prologue (kernels.h: QmvNextNorm / QMV_PRO_PRENORM): it also
@@ -2149,12 +2155,20 @@ void build_fused_plan(zgml_hip_program* p) {
     arm_prenorm(p);
     arm_pair(p);
     fuse_qkv_attention(p);
+#ifdef ZGML_TRACE
     fuse_attention_o(p);
+#endif
 }
 
 void build_plan(zgml_hip_program* p) {
     hipStreamSynchronize(p->ctx->stream); // the previous plan's parameter arrays may still be in use
     p->plan.clear();
+    for (size_t i = 0; i < p->ops.size(); i++) { // (refresh_program refuses this already; a launch must never be skipped silently)
+        const zgml_device_op& op = p->ops[i];
+        if (op.kind == ZGML_DOP_QMATMUL && op.u.qmatmul.M != 1 && op.u.qmatmul.weight_idx < p->qweights.size() &&
+            p->qweights[op.u.qmatmul.weight_idx].format == QW_Q4K)
+            p->ctx->fail("build_plan: op " + std::to_string(i) + " is an M > 1 qmatmul over a weight packed for M = 1 mat-vecs (K-on-lanes layout)");
+    }
     free_param_blobs(p);
     for (void* d : p->fuse_owned) hipFree(d); // counters / seen / idx of the previous plan's fused launches
     p->fuse_owned.clear();
@@ -2275,7 +2289,8 @@ bool same_static(const zgml_device_op& a, const zgml_device_op& b) {
 }
 
 void run_plan(zgml_hip_program* p, hipStream_t s, size_t first, size_t count) {
-    // diagnostics: ZGML_HIP_SKIP_KINDS=<bitmask of DeviceOp tags> drops those launches (timing ablation
+#ifdef ZGML_TRACE
+    // diagnostics build only: ZGML_HIP_SKIP_KINDS=<bitmask of DeviceOp tags> drops those launches (timing ablation
     // only; results are garbage)
     static const unsigned skip = getenv("ZGML_HIP_SKIP_KINDS") ? (unsigned)strtoul(getenv("ZGML_HIP_SKIP_KINDS"), nullptr, 0) : 0u;
     // ZGML_HIP_SKIP_MOD="<period>:<bitmask>" drops launch i >= 1 when bit ((i-1) % period) is set
@@ -2290,6 +2305,9 @@ void run_plan(zgml_hip_program* p, hipStream_t s, size_t first, size_t count) {
         if (mod_period && i >= 1 && (mod_mask & (1u << ((i - 1) % mod_period)))) continue;
         p->plan[i].run(s);
     }
+#else
+    for (size_t i = first; i < first + count && i < p->plan.size(); i++) p->plan[i].run(s);
+#endif
 }
 
 void flush_dyn(zgml_hip_program* p) {
@@ -2953,6 +2971,19 @@ void zgml_hip_refresh_program(zgml_hip_ctx* ctx, zgml_hip_program* p, const zgml
     }
     // a static field changed: legal for the reference's CPU backend (it re-reads ops every
     // execute, src/backend/cpu.zig:128-131), so honour it by rebuilding the launch list
+    for (uint64_t i = 0; i < n_ops; i++) {
+        // ... except where compile_program specialised a weight's layout on the op list it was given: a Q4_0 weight that only
+        // fed M = 1 mat-vecs was packed K-on-lanes (QW_Q4K), which the M > 1 tile kernels cannot read. Refuse the refresh (the
+        // program keeps its previous ops) instead of skipping the launch later: a stale destination must never look like success.
+        const zgml_device_op& op = ops[i];
+        if (op.kind == ZGML_DOP_QMATMUL && op.u.qmatmul.M != 1 && op.u.qmatmul.weight_idx < p->qweights.size() &&
+            p->qweights[op.u.qmatmul.weight_idx].format == QW_Q4K) {
+            ctx->fail("refresh_program: op " + std::to_string(i) + " turns weight " + std::to_string(op.u.qmatmul.weight_idx) +
+                      " into the operand of an M = " + std::to_string(op.u.qmatmul.M) +
+                      " qmatmul, but the weight was packed for M = 1 mat-vecs at compile time (K-on-lanes layout): recompile the program");
+            return;
+        }
+    }
     hipStreamSynchronize(ctx->stream);
     own_ops(p, ops, n_ops);
     set_dyn_from_ops(p);

@@ -123,6 +123,12 @@ uint16_t zh_model_buf(zh_model* m, int which, uint32_t layer) {
         default: return 0;
     }
 }
+// KV-cache buffers of the plan in builder order (DecodeProgram::kv_buffers): ids into `bufs`, f32-element counts into `elems`.
+uint64_t zh_model_kv_buffers(zh_model* m, uint16_t* bufs, uint64_t* elems, uint64_t cap) {
+    const auto& k = m->dp->kv_buffers;
+    for (uint64_t i = 0; i < k.size() && i < cap; i++) bufs[i] = k[i].buf, elems[i] = k[i].elems;
+    return k.size();
+}
 uint64_t zh_model_gather_points(zh_model* m, zh_gather_point* out, uint64_t cap) {
     const auto& g = m->dp->gather_points;
     for (uint64_t i = 0; i < g.size() && i < cap; i++) out[i] = {g[i].op_end, g[i].buf, 0, g[i].offset, g[i].len_per_rank};

@@ -328,6 +328,10 @@ std::unique_ptr<DecodeProgram> build_decode_program(const LlamaModel& model, boo
         const uint16_t k_cache = b.buffer((uint64_t)dh * S * KV_loc), v_cache = b.buffer((uint64_t)dh * S * KV_loc);
         dp.buf_k_cache.push_back(k_cache);
         dp.buf_v_cache.push_back(v_cache);
+        if (!c.kv_quant_block) {
+            dp.kv_buffers.push_back({k_cache, (uint64_t)dh * S * KV_loc});
+            dp.kv_buffers.push_back({v_cache, (uint64_t)dh * S * KV_loc});
+        }
         if (include_dead_f32 && model.kind != WeightKind::f32_dense) { // f32 master copies: buffers + uploads, never referenced by an op (F8)
             for (int j = 0; j < 7; j++) {
                 const auto& qw = model.qweights[l * 7 + j];
@@ -355,6 +359,8 @@ std::unique_ptr<DecodeProgram> build_decode_program(const LlamaModel& model, boo
             for (uint32_t j = 0; j < KV_loc; j++) {
                 const uint64_t elems = (uint64_t)S * dh / 4 + (uint64_t)S * (dh / kvq);
                 kq_cache[j] = b.buffer(elems), vq_cache[j] = b.buffer(elems);
+                dp.kv_buffers.push_back({kq_cache[j], elems});
+                dp.kv_buffers.push_back({vq_cache[j], elems});
             }
         for (int hl = (int)H_loc - 1; hl >= 0; hl--) {
             const uint32_t h = h0 + hl, kvh = h / n_rep, kvl = kvh - kv0;

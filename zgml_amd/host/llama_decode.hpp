@@ -83,6 +83,15 @@ struct DecodeProgram {
     uint32_t token_len = 1; // tokens per execution (1 = decode plan, N = prefill plan)
     uint16_t buf_token_input = 0, buf_attn_mask = 0, buf_logits = 0;
     std::vector<uint16_t> buf_rope, buf_k_cache, buf_v_cache;
+    // every KV-cache buffer of the plan, in builder order, with its f32-element count: the consolidated f32 caches
+    // (K, V per layer) or, with kv_quant_block, the per-kv-head int8 caches (K, V per head per layer). A prefill plan
+    // and the decode plan of the same model list them in the same order, so the hand-off (llama_inference.prefill, then
+    // step) is a pairwise copy.
+    struct KvBuffer {
+        uint16_t buf;
+        uint64_t elems;
+    };
+    std::vector<KvBuffer> kv_buffers;
     std::vector<uint32_t> slice_assign_op_indices, attention_op_indices;
     std::vector<backend::ProgramIO> step_inputs, step_outputs;
     std::vector<float> logits_host;

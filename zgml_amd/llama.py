@@ -62,6 +62,8 @@ def load_host() -> C.CDLL:
         lib.zh_model_rope_table.argtypes, lib.zh_model_rope_table.restype = [vp, C.c_int], C.POINTER(C.c_float)
         lib.zh_model_buf.argtypes, lib.zh_model_buf.restype = [vp, C.c_int, u32], C.c_uint16
         lib.zh_model_gather_points.argtypes, lib.zh_model_gather_points.restype = [vp, C.POINTER(GatherPoint), u64], u64
+        lib.zh_model_kv_buffers.argtypes = [vp, C.POINTER(C.c_uint16), C.POINTER(u64), u64]
+        lib.zh_model_kv_buffers.restype = u64
         lib.zh_model_quant_bytes.argtypes, lib.zh_model_quant_bytes.restype = [vp, C.POINTER(u64)], u64
         lib.zh_session_create.argtypes, lib.zh_session_create.restype = [vp, C.POINTER(BackendFns)], vp
         lib.zh_session_free.argtypes, lib.zh_session_free.restype = [vp], None
@@ -132,6 +134,14 @@ class Model:
         arr = (GatherPoint * max(1, n))()
         self.lib.zh_model_gather_points(self.ptr, arr, n)
         return list(arr[:n])
+
+    def kv_buffers(self):
+        """[(buffer id, f32 elements)] of every KV-cache buffer, in builder order (same order in a prefill plan and the
+        decode plan of one config: the hand-off of llama_inference.prefill -> step is a pairwise copy)."""
+        n = self.lib.zh_model_kv_buffers(self.ptr, None, None, 0)
+        bufs, elems = (C.c_uint16 * max(1, n))(), (C.c_uint64 * max(1, n))()
+        self.lib.zh_model_kv_buffers(self.ptr, bufs, elems, n)
+        return [(int(bufs[i]), int(elems[i])) for i in range(n)]
 
     def quant_bytes(self):
         n = C.c_uint64()
