@@ -50,6 +50,22 @@ def test_ctypes_layout_matches_c(tmp_path):
     assert out == py
 
 
+def test_zig_abi_asserts_are_current():
+    """zig/abi_asserts.zig (the `comptime` size / offset asserts of the Zig adapter, zig/backend_hip.zig) is what
+    tools/gen_zig_abi_asserts.py generates from include/zgml_hip.h TODAY: header, ctypes mirror and Zig adapter share one table."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_zig_abi_asserts", ROOT / "tools" / "gen_zig_abi_asserts.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert (ROOT / "zig" / "abi_asserts.zig").read_text() == mod.render()
+    adapter = (ROOT / "zig" / "backend_hip.zig").read_text()
+    for entry in ("zgml_hip_create", "zgml_hip_destroy", "zgml_hip_dense_matmul_f32", "zgml_hip_compile_program", "zgml_hip_refresh_program",
+                  "zgml_hip_execute_program", "zgml_hip_free_program", "zgml_hip_get_runtime_profile", "zgml_hip_last_error"):
+        assert "c." + entry + "(" in adapter, entry  # every vtable entry of src/backend.zig:338-352 forwards to its C entry point
+    for tag in capi.DOP_KINDS:
+        assert f".{tag} => |" in adapter, tag  # every DeviceOp arm is flattened
+
+
 def test_capabilities_hip(lib):
     c = capi.CapabilitiesC()
     lib.zgml_hip_capabilities(C.byref(c))

@@ -283,3 +283,47 @@ def test_matvec_prologues_and_epilogue_chains_store_every_intermediate(hip_backe
         # f32 products sequentially) into a relative one, hence 1e-3 here: the test is about structure, not the last bit
         scale = max(1.0, float(np.abs(want).max()))
         np.testing.assert_allclose(got, want, rtol=1e-3, atol=1e-4 * scale, err_msg=name)
+
+
+def test_refresh_to_a_matmul_over_a_matvec_only_weight_fails_loudly(hip_backend, oracle):
+    """compile_program packs a Q4_0 weight K-on-lanes when every op that uses it has M == 1
+    (K >= 2048). A later refresh_program that changes static fields is legal for the reference's CPU backend
+    (src/backend/cpu.zig:128-131) — but an M > 1 qmatmul over that weight has no kernel for the layout. It used to print to
+    stderr and skip the launch (stale destination, no error). Now the refresh is REFUSED with an error on the context and the
+    program keeps its previous ops: the next execute still computes the M = 1 product."""
+    K, N = 4096, 64
+    data, scales = synth_weight(K, N, True)
+    x = synth_x(2 * K)
+    dst_len = 2 * N
+    ops1 = [DeviceOp.qmatmul(1, 0, 0, 1, N, K)]
+    prog = DeviceProgram(ops=ops1, buffer_sizes=[2 * K, dst_len], initial_uploads=[ProgramIO(0, x), ProgramIO(1, np.zeros(dst_len, f32))],
+                         qweights=[QuantizedWeightUpload(data, scales, K, N, 32)])
+    want = oracle.run_program(prog, 1, dst_len)
+    h = hip_backend.compileProgram(prog)
+    try:
+        out = np.zeros(dst_len, f32)
+        hip_backend.executeProgram(h, [], [ProgramIO(1, out)])
+        assert not hip_backend.last_error(), hip_backend.last_error()
+        b = bound(data, scales, x[:K], 1, N, K, 32)
+        assert np.all(np.abs(out[:N] - want[:N]) <= TOL * b.ravel() + 1e-30)
+        hip_backend.refreshProgram(h, [DeviceOp.qmatmul(1, 0, 0, 2, N, K)])
+        err = hip_backend.last_error()
+        if "K-on-lanes" not in err:  # (the weight kept the tile-kernel layout, e.g. ZGML_HIP_QMV_KON=0: the refresh is simply honoured)
+            assert not err, err
+            out2 = np.zeros(dst_len, f32)
+            hip_backend.executeProgram(h, [], [ProgramIO(1, out2)])
+            want2 = oracle.run_program(DeviceProgram(ops=[DeviceOp.qmatmul(1, 0, 0, 2, N, K)], buffer_sizes=prog.buffer_sizes,
+                                                     initial_uploads=prog.initial_uploads, qweights=prog.qweights), 1, dst_len)
+            b2 = bound(data, scales, x, 2, N, K, 32)
+            assert np.all(np.abs(out2 - want2) <= TOL * b2.ravel() + 1e-30)
+            return
+        assert "refresh_program" in err and "recompile" in err, err
+        import ctypes as C
+        from zgml_amd import capi
+        capi.load_hip().zgml_hip_clear_error(hip_backend.ctx)
+        out3 = np.full(dst_len, 5, f32)
+        hip_backend.executeProgram(h, [], [ProgramIO(1, out3)])  # the previous (M = 1) ops are still in force
+        assert not hip_backend.last_error(), hip_backend.last_error()
+        assert np.array_equal(out3[:N], out[:N]) and np.all(out3[N:] == 0)
+    finally:
+        hip_backend.freeProgram(h)

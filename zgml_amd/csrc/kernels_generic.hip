@@ -1182,6 +1182,30 @@ __global__ void __launch_bounds__(kBlock) copy_f4_unrolled_kernel(float4* __rest
     for (; i < n4; i += stride) dst[i] = src[i];
 }
 
+// Two more calibration forms (ZGML_COPY_VARIANT=1 / 2): ONE float4 per thread on a grid of n4 / 256 workgroups (the textbook copy:
+// the dispatcher, not a loop, walks the buffer), and a READ-ONLY stream (U loads in flight per lane, a sum per lane kept alive by
+// one conditional store) — the mat-vec is a read stream, so this is the ceiling it is to be held against.
+__global__ void __launch_bounds__(kBlock) copy_f4_one_kernel(float4* __restrict__ dst, const float4* __restrict__ src, uint64_t n4) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n4) dst[i] = src[i];
+}
+template <int U>
+__global__ void __launch_bounds__(kBlock) read_f4_kernel(float* __restrict__ sink, const float4* __restrict__ src, uint64_t n4) {
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    f4v acc = {0.f, 0.f, 0.f, 0.f};
+    for (; i + (U - 1) * stride < n4; i += U * stride) {
+        f4v v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) v[u] = __builtin_nontemporal_load((const f4v*)src + i + u * stride);
+#pragma unroll
+        for (int u = 0; u < U; u++) acc += v[u];
+    }
+    const float t = acc.x + acc.y + acc.z + acc.w;
+    if (t == 123456.789f) sink[blockIdx.x] = t; // (never true for the benchmark's data: keeps the loads alive)
+}
+
 __global__ void __launch_bounds__(kBlock) f32_to_f16_kernel(__half* __restrict__ dst, const float* __restrict__ src,
                                                             uint64_t n) {
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock)
@@ -1412,6 +1436,14 @@ void launch_copy_f4(hipStream_t s, void* dst, const void* src, uint64_t bytes) {
     static const int variant = getenv("ZGML_COPY_VARIANT") ? (int)strtol(getenv("ZGML_COPY_VARIANT"), nullptr, 0) : (8 | 1 << 8 | 32 << 16);
     if (variant == 0) {
         copy_f4_kernel<<<2048, kBlock, 0, s>>>((float4*)dst, (const float4*)src, n4);
+        return;
+    }
+    if (variant == 1) { // one float4 per thread
+        copy_f4_one_kernel<<<(unsigned)((n4 + kBlock - 1) / kBlock), kBlock, 0, s>>>((float4*)dst, (const float4*)src, n4);
+        return;
+    }
+    if (variant == 2) { // read-only stream (dst is only the never-written sink)
+        read_f4_kernel<8><<<256 * 16, kBlock, 0, s>>>((float*)dst, (const float4*)src, n4);
         return;
     }
     const int U = variant & 0xFF, nt = (variant >> 8) & 1, bpc = (variant >> 16) & 0xFF ? (variant >> 16) & 0xFF : 8;
