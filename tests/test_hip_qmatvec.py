@@ -327,3 +327,43 @@ def test_refresh_to_a_matmul_over_a_matvec_only_weight_fails_loudly(hip_backend,
         assert np.array_equal(out3[:N], out[:N]) and np.all(out3[N:] == 0)
     finally:
         hip_backend.freeProgram(h)
+
+
+def _bf16_rne(v):
+    u = v.astype(np.float32).view(np.uint32).astype(np.uint64)
+    return (((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32)).view(np.float32)
+
+
+@pytest.mark.parametrize("pattern", ["same_sign", "alternating"])
+@pytest.mark.parametrize("M,K,N", [(32, 4096, 512), (32, 4096, 12288), (128, 4096, 512)])
+def test_matmul_two_piece_operand_bound_is_exercised_by_a_worst_case_vector(hip_backend, oracle, M, K, N, pattern):
+    """the M > 1 Q4_0 tile kernels carry x as TWO bf16 pieces by round-to-nearest-even (kernels.h: split_a_pieces),
+    |x - (a1 + a2)| <= 2^-17 |x| per element, and compute all four piece products with the weight's exact two pieces, so
+    |delta| <= 2^-17 sum|x w| ~ 7.6e-6 sum|x w| — inside the contract's 2e-5. Random data meets that bound
+    with room to spare because the per-element residuals cancel; here they do NOT: every |x_k| is the SAME value, chosen
+    (numpy model of the split) as the float whose two-piece residual is the largest of 2^16 candidates, against weights of one
+    sign in every column (`same_sign`: the residuals of a column add up coherently) and with alternating signs of x
+    (`alternating`: the sum cancels, the bound's right-hand side does not). Asserted: the contract, and that the measured error
+    is what the model predicts — at least a quarter of the coherent residual sum in the same-sign case, i.e. the test really
+    sits on the operand split and would see a third dropped piece product or a truncating split."""
+    rng = np.random.default_rng(11)
+    cand = (1.0 + rng.random(1 << 16)).astype(f32)
+    a1 = _bf16_rne(cand)
+    a2 = _bf16_rne(cand - a1)
+    res = np.abs(cand.astype(np.float64) - a1.astype(np.float64) - a2.astype(np.float64))
+    c = cand[int(np.argmax(res))]
+    rel = float(res.max() / c)
+    assert 2.0 ** -19 < rel <= 2.0 ** -17
+    sign = np.where(np.arange(K) % 2 == 0, 1.0, -1.0) if pattern == "alternating" else np.ones(K)
+    x = np.tile((c * sign).astype(f32), M)
+    data = rng.integers(1, 8, K * N).astype(np.int8)  # one sign per column (all positive)
+    scales = (rng.random((K * N + 31) // 32).astype(np.float16) * 0.05 + 0.001).astype(f32)
+    want, got = run_both(hip_backend, oracle, data, scales, x, M, N, K)
+    b = bound(data, scales, x, M, N, K, 32).ravel()
+    err = np.abs(got.astype(np.float64)[:M * N] - want.astype(np.float64)[:M * N])
+    assert np.all(err <= TOL * b + 1e-30), float(np.max(err / b))
+    worst = float(np.max(err / b))
+    print(f"{pattern} M={M} K={K} N={N}: worst |delta| / sum|x w| = {worst:.3e} (per-element residual {rel:.3e}, contract {TOL:.0e})")
+    if pattern == "same_sign":
+        assert worst >= 0.25 * rel, (worst, rel)  # the coherent residual really shows: the split is what is being measured
+        assert worst <= 2.0 ** -17 + 3e-7, worst   # ... and nothing beyond it (+ f32 summation rounding over K terms)

@@ -215,17 +215,13 @@ __global__ void __launch_bounds__(kTileWavesMax * 64) attention_tiles_kernel(con
         const float il = linv[qq];
         const uint32_t qo = q0 + qq, d0 = 64 * h + 16 * gg + 4 * v;
         if (qo >= p.seq_q) continue;
-        uint32_t h1[4], h2[4], h3[4];
+        uint32_t hp[4][kAPieces]; // the bf16 pieces of the four values (kernels.h: split_a_pieces) for the piece sink below
 #pragma unroll
         for (int c = 0; c < 4; c++) {
             const float val = o[c] * il;
             p.dst[(uint64_t)qo * p.dst_cs + (uint64_t)(d0 + c) * p.dst_rs] = val;
             if (p.dst2) p.dst2[(uint64_t)d2_off + (uint64_t)(d0 + c) * p.d2_rs + (uint64_t)qo * p.d2_cs] = val;
-            // exact three-way bf16 split (split_a_kernel's arithmetic) for the piece sink below
-            h1[c] = __float_as_uint(val) & 0xFFFF0000u;
-            const float r1 = val - __uint_as_float(h1[c]);
-            h2[c] = __float_as_uint(r1) & 0xFFFF0000u;
-            h3[c] = __float_as_uint(r1 - __uint_as_float(h2[c]));
+            split_a_pieces(val, hp[c]);
         }
         if (sink.ap && p.dst2 && (sink.S & kApF16)) { // ... of an f16-promoted matmul: four halves, round to nearest even
             uint16_t* const dp = sink.ap + a_f16_index(sink.S & ~kApF16, qo, d2_off + d0);
@@ -233,9 +229,9 @@ __global__ void __launch_bounds__(kTileWavesMax * 64) attention_tiles_kernel(con
                                      (uint32_t)__half_as_ushort(__float2half_rn(o[2] * il)) | ((uint32_t)__half_as_ushort(__float2half_rn(o[3] * il)) << 16));
         } else if (sink.ap && p.dst2) { // the row store fills row qo, columns d2_off + d0 .. + 3 of the next matmul's input (planner-checked)
             uint16_t* const dp = sink.ap + a_piece_index(sink.S, qo, d2_off + d0);
-            *(uint2*)dp = make_uint2((h1[0] >> 16) | h1[1], (h1[2] >> 16) | h1[3]);
-            *(uint2*)(dp + 512) = make_uint2((h2[0] >> 16) | h2[1], (h2[2] >> 16) | h2[3]);
-            *(uint2*)(dp + 1024) = make_uint2((h3[0] >> 16) | (h3[1] & 0xFFFF0000u), (h3[2] >> 16) | (h3[3] & 0xFFFF0000u));
+#pragma unroll
+            for (int pc = 0; pc < kAPieces; pc++)
+                *(uint2*)(dp + 512 * pc) = make_uint2((hp[0][pc] >> 16) | hp[1][pc], (hp[2][pc] >> 16) | hp[3][pc]);
         }
     }
 }

@@ -256,13 +256,17 @@ __global__ void __launch_bounds__(kBlock) pack_a_f16_kernel(const float* __restr
     }
 }
 
-template <int R, bool NT>
+template <int R, bool NT, int CG = 1>
 __global__ void __launch_bounds__(512) dense_f16_tile2_kernel(F16Args2 a) {
-    // chunks in flight per wave, (1 + R) x 16 B per lane each (8 measured no faster at R = 2). R = 4 / 8 (prefill chunks of
+    // chunks in flight per wave, (CG + R) x 16 B per lane each (8 measured no faster at R = 2). R = 4 / 8 (prefill chunks of
     // 64 / 128 tokens): all m-tiles in one workgroup, so the weights are read ONCE per matmul instead of once per tile pair
     // (Llama-2-7B at 128 tokens: 13.5 GB of f16 weights per chunk instead of 54 GB); 3 / 2 chunks in flight keep the ring
-    // within the register budget of two waves per SIMD
-    constexpr int DEPTH = R >= 8 ? 2 : (R >= 4 ? 3 : 4);
+    // within the register budget of two waves per SIMD.
+    // CG (round 4): column groups per workgroup. Every workgroup re-reads the whole pre-laid-out A operand from L2 (R x 1 KiB per
+    // 32-k chunk) next to ONE KiB of weights per column group: at CG = 1 and R = 2 two of every three bytes a CU's vector-memory
+    // path returns are A, and that path (64 B / clk per CU whatever the hit level), not HBM, paces the launch (3.6 TB/s at
+    // 32 x 4096 x 22016). With CG column groups per workgroup one A chunk feeds CG x R MFMAs: A : B = R : CG.
+    constexpr int DEPTH = R >= 8 ? 2 : (R >= 4 ? 3 : (CG >= 4 ? 3 : 4));
     extern __shared__ float smem[];
     // w in an SGPR: the chunk guard below must be a scalar branch — a v_mfma ignores EXEC, so a predicated
     // (if-converted) guard would still accumulate the clamped duplicate chunks
@@ -272,29 +276,34 @@ __global__ void __launch_bounds__(512) dense_f16_tile2_kernel(F16Args2 a) {
     for (uint32_t t = 1; t < (uint32_t)kMaxF16Parts; t++)
         if (t < a.n_parts && blockIdx.x >= a.parts[t].block_begin) pi = t;
     const F16Part2& P = a.parts[pi];
-    const uint32_t g = blockIdx.x - P.block_begin, t0 = blockIdx.y * R;
+    const uint32_t g = (blockIdx.x - P.block_begin) * CG, t0 = blockIdx.y * R; // first column group of this workgroup
     const uint4* bp = P.bp + (uint64_t)g * a.KC * 64 + lane;
     const uint4* ap = a.ap + (uint64_t)t0 * a.KC * 64 + lane;
     const uint64_t tile_stride = (uint64_t)a.KC * 64;
     struct Chunk {
-        uint4 b;
+        uint4 b[CG];
         uint4 av[R];
     };
     auto load = [&](Chunk& x, uint32_t c) { // clamped, unconditional: a repeated chunk is never used twice (the loop bounds decide)
         const uint32_t cc = min(c, a.KC - 1);
-        if (NT) {
-            typedef unsigned int u4v __attribute__((ext_vector_type(4)));
-            const u4v v = __builtin_nontemporal_load((const u4v*)(bp + (uint64_t)cc * 64));
-            x.b = make_uint4(v.x, v.y, v.z, v.w);
-        } else {
-            x.b = bp[(uint64_t)cc * 64];
+#pragma unroll
+        for (int j = 0; j < CG; j++) {
+            if (NT) {
+                typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+                const u4v v = __builtin_nontemporal_load((const u4v*)(bp + j * tile_stride + (uint64_t)cc * 64));
+                x.b[j] = make_uint4(v.x, v.y, v.z, v.w);
+            } else {
+                x.b[j] = bp[j * tile_stride + (uint64_t)cc * 64];
+            }
         }
 #pragma unroll
         for (int t = 0; t < R; t++) x.av[t] = ap[t * tile_stride + (uint64_t)cc * 64];
     };
-    mfma_f4 acc[R];
+    mfma_f4 acc[R][CG];
 #pragma unroll
-    for (int t = 0; t < R; t++) acc[t] = mfma_f4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < R; t++)
+#pragma unroll
+        for (int j = 0; j < CG; j++) acc[t][j] = mfma_f4{0.f, 0.f, 0.f, 0.f};
     // wave w takes chunks w, w + n_waves, ...; ring of DEPTH chunks
     Chunk ring[DEPTH];
 #pragma unroll
@@ -306,9 +315,12 @@ __global__ void __launch_bounds__(512) dense_f16_tile2_kernel(F16Args2 a) {
             load(ring[d], c + (d + DEPTH) * n_waves);
             __builtin_amdgcn_sched_barrier(0); // the refill is issued before the MFMAs of this chunk
             if (c + d * n_waves < a.KC) { // (wave-uniform)
-                const half8 bv = __builtin_bit_cast(half8, cur.b);
 #pragma unroll
-                for (int t = 0; t < R; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, cur.av[t]), bv, acc[t], 0, 0, 0);
+                for (int j = 0; j < CG; j++) {
+                    const half8 bv = __builtin_bit_cast(half8, cur.b[j]);
+#pragma unroll
+                    for (int t = 0; t < R; t++) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, cur.av[t]), bv, acc[t][j], 0, 0, 0);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -316,13 +328,15 @@ __global__ void __launch_bounds__(512) dense_f16_tile2_kernel(F16Args2 a) {
 #pragma unroll
     for (int t = 0; t < R; t++)
 #pragma unroll
-        for (int v = 0; v < 4; v++) smem[((w * R + t) * 4 + v) * 64 + lane] = acc[t][v];
+        for (int j = 0; j < CG; j++)
+#pragma unroll
+            for (int v = 0; v < 4; v++) smem[(((w * R + t) * CG + j) * 4 + v) * 64 + lane] = acc[t][j][v];
     __syncthreads();
-    for (uint32_t idx = threadIdx.x; idx < (uint32_t)R * 256; idx += blockDim.x) {
-        const uint32_t t = idx >> 8, v = (idx >> 6) & 3, l = idx & 63;
-        float sum = smem[(t * 4 + v) * 64 + l];
-        for (uint32_t ww = 1; ww < n_waves; ww++) sum += smem[((ww * R + t) * 4 + v) * 64 + l];
-        const uint32_t m = (t0 + t) * 16 + 4 * (l >> 4) + v, n = g * 16 + (l & 15);
+    for (uint32_t idx = threadIdx.x; idx < (uint32_t)R * CG * 256; idx += blockDim.x) {
+        const uint32_t t = idx / (CG * 256), j = (idx >> 8) % CG, v = (idx >> 6) & 3, l = idx & 63;
+        float sum = smem[((t * CG + j) * 4 + v) * 64 + l];
+        for (uint32_t ww = 1; ww < n_waves; ww++) sum += smem[(((ww * R + t) * CG + j) * 4 + v) * 64 + l]; // waves in order: deterministic
+        const uint32_t m = (t0 + t) * 16 + 4 * (l >> 4) + v, n = (g + j) * 16 + (l & 15);
         if (m < a.M) P.out[(uint64_t)m * P.out_rs + n] = sum;
     }
 }
@@ -382,21 +396,46 @@ static void launch_dense_f16_tile2(hipStream_t s, const DenseF16Params* p, uint3
     }
     static const int env_w = getenv("ZGML_F16_TILE2_WAVES") ? atoi(getenv("ZGML_F16_TILE2_WAVES")) : 8;
     const uint32_t waves = std::max(1u, std::min<uint32_t>(KC, (uint32_t)env_w));
+    // column groups per workgroup (R <= 2 only: the wide-M forms already amortise A over 4 / 8 m-tiles): as many as keep the grid
+    // at >= ~1.3 workgroups per CU, every part a whole number of workgroups
+    uint32_t total_groups = 0;
+    for (uint32_t t = 0; t < n; t++) total_groups += p[t].N / 16;
+    static const int env_cg = getenv("ZGML_F16_TILE2_CG") ? atoi(getenv("ZGML_F16_TILE2_CG")) : 0;
+    uint32_t CG = 1;
+    if (R <= 2) {
+        // measured at M = 32, K = 4096 (tools/f16_m32_sweep.sh, us per launch incl. the A pack; CG = 1 / 2 / 4): N = 4096 13.6 / 16.8 / 22.9,
+        // N = 12288 29.9 / 30.0 / 28.5, N = 22016 51.3 / 44.0 / 48.4, N = 32000 68.5 / 55.4 / 56.1; K = 11008, N = 4096 27.8 / 35.3 / 47.2:
+        // two groups per workgroup once that still leaves >= 2.5 workgroups per CU (CG = 4 runs one workgroup per CU: 142 registers)
+        {
+            bool fits = total_groups / 2 >= 640;
+            for (uint32_t t = 0; t < n; t++) fits = fits && (p[t].N / 16) % 2 == 0;
+            if (fits) CG = 2;
+        }
+        if (env_cg == 1 || env_cg == 2 || env_cg == 4) {
+            bool fits = true;
+            for (uint32_t t = 0; t < n; t++) fits = fits && (p[t].N / 16) % (uint32_t)env_cg == 0;
+            if (fits) CG = (uint32_t)env_cg;
+        }
+    }
     F16Args2 a{};
     uint32_t blocks = 0;
     for (uint32_t t = 0; t < n; t++) {
         a.parts[t] = {(const uint4*)p[t].bp, p[t].dst, p[t].dst_rs, blocks};
-        blocks += p[t].N / 16;
+        blocks += p[t].N / 16 / CG;
     }
     a.ap = (const uint4*)p[0].scratch, a.n_parts = n, a.M = p[0].M, a.KC = KC;
     const dim3 grid(blocks, tiles / R);
-    const size_t lds = (size_t)waves * R * 256 * sizeof(float);
+    const size_t lds = (size_t)waves * R * CG * 256 * sizeof(float);
     const bool nt = p[0].stream_nt != 0 && tiles / R == 1;
     using Fn2 = void (*)(F16Args2);
+#define ZGML_T2(RV) (CG == 4 ? (nt ? (Fn2)dense_f16_tile2_kernel<RV, true, 4> : (Fn2)dense_f16_tile2_kernel<RV, false, 4>)                    \
+                     : CG == 2 ? (nt ? (Fn2)dense_f16_tile2_kernel<RV, true, 2> : (Fn2)dense_f16_tile2_kernel<RV, false, 2>)                 \
+                               : (nt ? (Fn2)dense_f16_tile2_kernel<RV, true, 1> : (Fn2)dense_f16_tile2_kernel<RV, false, 1>))
     const Fn2 fn = R == 8   ? (nt ? (Fn2)dense_f16_tile2_kernel<8, true> : (Fn2)dense_f16_tile2_kernel<8, false>)
                    : R == 4 ? (nt ? (Fn2)dense_f16_tile2_kernel<4, true> : (Fn2)dense_f16_tile2_kernel<4, false>)
-                   : R == 2 ? (nt ? (Fn2)dense_f16_tile2_kernel<2, true> : (Fn2)dense_f16_tile2_kernel<2, false>)
-                            : (nt ? (Fn2)dense_f16_tile2_kernel<1, true> : (Fn2)dense_f16_tile2_kernel<1, false>);
+                   : R == 2 ? ZGML_T2(2)
+                            : ZGML_T2(1);
+#undef ZGML_T2
     if (lds > 64 * 1024) hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(fn, grid, dim3(waves * 64), lds, s, a);
 }

@@ -297,11 +297,33 @@ struct RowChainParams {
     uint16_t* ap = nullptr;
     uint32_t ap_S = 0;
 };
+// The A operand of the Q4_0 XDL tile kernels (M > 1 qmatmul): x as kAPieces bf16 pieces, x ~ a1 + a2.
+// Round 4: TWO pieces by round-to-nearest-even — a1 = bf16(x), a2 = bf16(x - a1) (the difference is exact in
+// f32; |x - a1| <= 2^-8 of x's binade, and rounding that 16-bit residual to 8 bits leaves <= 2^-17) — so |x - (a1 + a2)| <=
+// 2^-17 |x| PER ELEMENT (bf16 keeps f32's exponent range: no dependence on the row's largest element), and with the weight's
+// exact two-piece split all four piece products are computed: |delta| <= 2^-17 sum|x w| = 7.6e-6 sum|x w| against the
+// contract's 2e-5 (tests/test_hip_qmatvec.py exercises it with a worst-case vector: measured 4.3e-6). Rounds 2-3 carried three truncation pieces (exact, five of
+// six products): one MFMA in five and a third of the A bytes more for accuracy the contract does not ask for.
+constexpr int kAPieces = 2;
+#if defined(__HIPCC__)
+__device__ __forceinline__ void split_a_pieces(float v, uint32_t (&h)[kAPieces]) { // h[p] = piece p as a bf16 in the HIGH half of a dword
+    auto rne = [](float f) { // f32 -> bf16 (round to nearest even), as the high half
+        const uint32_t u = __float_as_uint(f);
+        return (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u; // (finite activations: the NaN caveat of the integer form does not arise on this path's inputs being finite)
+    };
+    float r = v;
+#pragma unroll
+    for (int p = 0; p < kAPieces; p++) {
+        h[p] = rne(r);
+        r = r - __uint_as_float(h[p]); // exact
+    }
+}
+#endif
 // element (row m, column j) of an activation matrix in the A-operand layout of the XDL tile kernels: index of its bf16 in
-// units of 2 bytes for piece 0; pieces 1 and 2 follow at + 512 and + 1024 (64 lanes x 8 bf16 each)
+// units of 2 bytes for piece 0; piece p follows at + 512 p (64 lanes x 8 bf16 each)
 __host__ __device__ inline uint64_t a_piece_index(uint32_t S, uint32_t m, uint32_t j) {
     const uint64_t t = m >> 4, i = m & 15, s = j >> 7, r = (j >> 5) & 3, jj = (j >> 3) & 3, e = j & 7;
-    return ((((t * S + s) * 4 + jj) * 3) * 64 + (i + 16 * r)) * 8 + e;
+    return ((((t * S + s) * 4 + jj) * kAPieces) * 64 + (i + 16 * r)) * 8 + e;
 }
 // the same for the f16-promoted matmuls' A operand (dense_f16.hip: pack_a_f16_kernel): index of the element's half. A
 // producer is told the format by the top bit of its ap_S field: kApF16 | KC (32-k chunks) instead of the 128-k step count.

@@ -109,18 +109,17 @@ __global__ void __launch_bounds__(kBlock) fused_elementwise_kernel(FusedParams p
 }
 
 // several elementwise / fused_elementwise ops in a row (same arithmetic, same order, per element)
-// x = h1 + h2 + h3 exactly, each piece a bf16 (truncation split, 8 + 8 + 8 significant bits: split_a_kernel's arithmetic)
+// the bf16 pieces of x in the A-operand layout of the XDL tile kernels (kernels.h: split_a_pieces — split_a_kernel's arithmetic)
 __device__ __forceinline__ void store_a_pieces(uint16_t* ap, uint32_t S, uint32_t m, uint32_t j, float v) {
     if (S & kApF16) { // f16-promoted matmul: one half, round to nearest even (pack_a_f16_kernel's rounding)
         ap[a_f16_index(S & ~kApF16, m, j)] = __half_as_ushort(__float2half_rn(v));
         return;
     }
-    const uint32_t h1 = __float_as_uint(v) & 0xFFFF0000u;
-    const float r1 = v - __uint_as_float(h1);
-    const uint32_t h2 = __float_as_uint(r1) & 0xFFFF0000u;
-    const float r2 = r1 - __uint_as_float(h2);
+    uint32_t h[kAPieces];
+    split_a_pieces(v, h);
     uint16_t* const d = ap + a_piece_index(S, m, j);
-    d[0] = (uint16_t)(h1 >> 16), d[512] = (uint16_t)(h2 >> 16), d[1024] = (uint16_t)(__float_as_uint(r2) >> 16);
+#pragma unroll
+    for (int p = 0; p < kAPieces; p++) d[512 * p] = (uint16_t)(h[p] >> 16);
 }
 
 __global__ void __launch_bounds__(kBlock) eltwise_chain_kernel(EltChainParams p) {
@@ -222,19 +221,13 @@ __global__ void __launch_bounds__(kBlock) eltwise_chain_pre_kernel(EltChainParam
         for (int e = 0; e < 4; e++) h[e] = __half_as_ushort(__float2half_rn(v[e % V]));
         *(uint2*)(p.ap + a_f16_index(p.ap_S & ~kApF16, m, j)) = make_uint2(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16));
     } else {
-        uint32_t h1[4], h2[4], h3[4];
+        uint32_t hp[4][kAPieces];
 #pragma unroll
-        for (int e = 0; e < 4; e++) { // store_a_pieces' arithmetic
-            const float x = v[e % V];
-            h1[e] = __float_as_uint(x) & 0xFFFF0000u;
-            const float r1 = x - __uint_as_float(h1[e]);
-            h2[e] = __float_as_uint(r1) & 0xFFFF0000u;
-            h3[e] = __float_as_uint(r1 - __uint_as_float(h2[e]));
-        }
+        for (int e = 0; e < 4; e++) split_a_pieces(v[e % V], hp[e]); // store_a_pieces' arithmetic
         uint16_t* const d = p.ap + a_piece_index(p.ap_S, m, j);
-        *(uint2*)d = make_uint2((h1[0] >> 16) | (h1[1] & 0xFFFF0000u), (h1[2] >> 16) | (h1[3] & 0xFFFF0000u));
-        *(uint2*)(d + 512) = make_uint2((h2[0] >> 16) | (h2[1] & 0xFFFF0000u), (h2[2] >> 16) | (h2[3] & 0xFFFF0000u));
-        *(uint2*)(d + 1024) = make_uint2((h3[0] >> 16) | (h3[1] & 0xFFFF0000u), (h3[2] >> 16) | (h3[3] & 0xFFFF0000u));
+#pragma unroll
+        for (int pc = 0; pc < kAPieces; pc++)
+            *(uint2*)(d + 512 * pc) = make_uint2((hp[0][pc] >> 16) | (hp[1][pc] & 0xFFFF0000u), (hp[2][pc] >> 16) | (hp[3][pc] & 0xFFFF0000u));
     }
 }
 
@@ -284,7 +277,7 @@ __global__ void __launch_bounds__(kBlock) row_chain_kernel(RowChainParams p) {
     float ss = 0;
     if (NPT > 0) {
         constexpr int N = NPT > 0 ? NPT : 1;
-        __shared__ __attribute__((aligned(16))) uint16_t pl[3 * N * kBlock]; // A pieces of the row (RowChainParams::ap)
+        __shared__ __attribute__((aligned(16))) uint16_t pl[kAPieces * N * kBlock]; // A pieces of the row (RowChainParams::ap)
         float v[N], mo[N];
         const uint32_t last = p.cols - 1;
         if (p.add_dst) {
@@ -324,12 +317,11 @@ __global__ void __launch_bounds__(kBlock) row_chain_kernel(RowChainParams p) {
                 if (p.mul_dst) p.mul_dst[base + j] = xv;
                 if (p.ap && (p.ap_S & kApF16)) { // f16 A operand: one half per element
                     pl[j] = __half_as_ushort(__float2half_rn(xv));
-                } else if (p.ap) { // the three bf16 pieces, transposed through LDS so that they leave as 16-byte stores
-                    const uint32_t h1 = __float_as_uint(xv) & 0xFFFF0000u;
-                    const float r1 = xv - __uint_as_float(h1);
-                    const uint32_t h2 = __float_as_uint(r1) & 0xFFFF0000u;
-                    const float r2 = r1 - __uint_as_float(h2);
-                    pl[j] = (uint16_t)(h1 >> 16), pl[N * kBlock + j] = (uint16_t)(h2 >> 16), pl[2 * N * kBlock + j] = (uint16_t)(__float_as_uint(r2) >> 16);
+                } else if (p.ap) { // the bf16 pieces (kernels.h: split_a_pieces), transposed through LDS so that they leave as 16-byte stores
+                    uint32_t hp[kAPieces];
+                    split_a_pieces(xv, hp);
+#pragma unroll
+                    for (int pc = 0; pc < kAPieces; pc++) pl[pc * N * kBlock + j] = (uint16_t)(hp[pc] >> 16);
                 }
             }
         }
@@ -337,7 +329,7 @@ __global__ void __launch_bounds__(kBlock) row_chain_kernel(RowChainParams p) {
             __syncthreads();
             const uint32_t groups = p.cols / 8;
             const bool f16 = (p.ap_S & kApF16) != 0;
-            for (uint32_t u = threadIdx.x; u < (f16 ? 1u : 3u) * groups; u += kBlock) {
+            for (uint32_t u = threadIdx.x; u < (f16 ? 1u : (uint32_t)kAPieces) * groups; u += kBlock) {
                 const uint32_t piece = u / groups, j0 = (u - piece * groups) * 8;
                 const uint4 val = *(const uint4*)(pl + piece * (N * kBlock) + j0);
                 uint16_t* const d = f16 ? p.ap + a_f16_index(p.ap_S & ~kApF16, blockIdx.x, j0) : p.ap + a_piece_index(p.ap_S, blockIdx.x, j0) + piece * 512;

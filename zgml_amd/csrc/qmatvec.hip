@@ -1619,25 +1619,24 @@ struct QMM2Args {
     uint32_t spw_max;          // ceil(S / waves) <= kMaxSpw: sizes the weights' LDS region
 };
 
-// A pieces: ap[(((t * S + s) * 4 + j) * 3 + p) * 64 + lane] = the 8 bf16 of piece p that lane (i = lane % 16:
+// A pieces: ap[(((t * S + s) * 4 + j) * kAPieces + p) * 64 + lane] = the 8 bf16 of piece p that lane (i = lane % 16:
 // row 16 t + i, r = lane / 16: unit 4 s + r) feeds to the MFMA of k_local 8 j .. 8 j + 7. Rows >= M and k >= K are zero.
 __global__ void __launch_bounds__(256) split_a_kernel(const float* __restrict__ x, uint32_t M, uint32_t K, uint32_t in_rs, uint4* __restrict__ ap,
                                                       uint32_t S) {
     const uint32_t s = blockIdx.x, t = blockIdx.y, j = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, r = lane >> 4;
     const uint32_t m = 16 * t + i, k0 = (4 * s + r) * 32 + 8 * j;
-    uint32_t h[3][8];
+    uint32_t h[kAPieces][8];
 #pragma unroll
     for (int e = 0; e < 8; e++) {
         const float v = (m < M && k0 + e < K) ? x[(uint64_t)m * in_rs + k0 + e] : 0.0f;
-        const uint32_t h1 = __float_as_uint(v) & 0xFFFF0000u;
-        const float r1 = v - __uint_as_float(h1);
-        const uint32_t h2 = __float_as_uint(r1) & 0xFFFF0000u;
-        const float r2 = r1 - __uint_as_float(h2); // <= 8 significant bits: a bf16
-        h[0][e] = h1, h[1][e] = h2, h[2][e] = __float_as_uint(r2);
-    }
-    uint4* dst = ap + ((((uint64_t)t * S + s) * 4 + j) * 3) * 64 + lane;
+        uint32_t hp[kAPieces];
+        split_a_pieces(v, hp); // kernels.h: bf16 pieces by round-to-nearest-even, each in the high half of its dword
 #pragma unroll
-    for (int p = 0; p < 3; p++)
+        for (int p = 0; p < kAPieces; p++) h[p][e] = hp[p];
+    }
+    uint4* dst = ap + ((((uint64_t)t * S + s) * 4 + j) * kAPieces) * 64 + lane;
+#pragma unroll
+    for (int p = 0; p < kAPieces; p++)
         dst[p * 64] = make_uint4((h[p][0] >> 16) | (h[p][1] & 0xFFFF0000u), (h[p][2] >> 16) | (h[p][3] & 0xFFFF0000u),
                                  (h[p][4] >> 16) | (h[p][5] & 0xFFFF0000u), (h[p][6] >> 16) | (h[p][7] & 0xFFFF0000u));
 }
@@ -1658,7 +1657,7 @@ __device__ __forceinline__ uint32_t pack_hi16(float a, float b) { return __built
 // x w = (a1 + a2 + a3)(b1 + b2) exactly (bf16 pieces, 8 bits each; b2 holds the <= 7 bits b1 leaves of the 15-bit weight). Five of the
 // six piece products are computed: a3 b2 is <= 2^-16 x 2^-8 of |x w| — measured 2.9e-9 of sum |x w| at K = 4096 against 4.8e-8
 // for a plain f32 matmul's own rounding and the tests' 2e-5 — and costs one MFMA in six. (3 = all six.)
-constexpr int kXdlLoPieces = 2;
+constexpr int kXdlLoPieces = kAPieces < 2 ? kAPieces : 2; // A pieces that also meet the weight's LOW piece (round 4: both of the two)
 template <int CTRL>
 __device__ __forceinline__ float row_bcast_z(int v) { return __int_as_float(__builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true)); } // (no `old` to initialise)
 typedef float xf32x2 __attribute__((ext_vector_type(2)));
@@ -1707,24 +1706,24 @@ __global__ void __launch_bounds__(512) qmatmul_xdl2_kernel(QMM2Args a) {
     const uint4* qs = P.qs + (uint64_t)g0 * a.U * 16 + i;
     // 32 f16 scales per unit = 16 dwords; dword d = {k_local d, k_local 16 + d}
     const uint32_t* scd = (const uint32_t*)P.sc + (uint64_t)(g0 >> 1) * a.U * 16 + i;
-    const uint4* ap = a.ap + (uint64_t)t0 * a.S * 12 * 64 + lane;
-    const uint64_t tile_stride = (uint64_t)a.S * 12 * 64; // uint4 between m-tiles
+    const uint4* ap = a.ap + (uint64_t)t0 * a.S * (4 * kAPieces) * 64 + lane;
+    const uint64_t tile_stride = (uint64_t)a.S * (4 * kAPieces) * 64; // uint4 between m-tiles
 
     // one accumulator per (column group, m-tile, A piece): consecutive MFMAs never chain through the same registers
-    mfma_f4 acc[G][R][3];
+    mfma_f4 acc[G][R][kAPieces];
 #pragma unroll
     for (int g = 0; g < G; g++)
 #pragma unroll
         for (int t = 0; t < R; t++)
 #pragma unroll
-            for (int p = 0; p < 3; p++) acc[g][t][p] = mfma_f4{0.f, 0.f, 0.f, 0.f};
+            for (int p = 0; p < kAPieces; p++) acc[g][t][p] = mfma_f4{0.f, 0.f, 0.f, 0.f};
 
     struct BStep { // one K step of this lane: its unit's nibbles per column group, its dword of the unit's scales
         uint4 wq[G];
         uint32_t sd;
     };
     struct AGrp { // the A pieces of one 8-k group
-        uint4 v[R][3];
+        uint4 v[R][kAPieces];
     };
     struct BPieces { // w = (q - 8)/16 * scale of one 8-k group, as two bf16x8 operands per column group
         uint4 b1[G], b2[G];
@@ -1739,7 +1738,7 @@ __global__ void __launch_bounds__(512) qmatmul_xdl2_kernel(QMM2Args a) {
 #pragma unroll
         for (int t = 0; t < R; t++)
 #pragma unroll
-            for (int p = 0; p < 3; p++) x.v[t][p] = ap[t * tile_stride + (((uint64_t)s * 4 + j) * 3 + p) * 64];
+            for (int p = 0; p < kAPieces; p++) x.v[t][p] = ap[t * tile_stride + (((uint64_t)s * 4 + j) * kAPieces + p) * 64];
     };
     auto prep = [&](BPieces& o, const BStep& b, auto jc) {
         constexpr int J = decltype(jc)::value;
@@ -1752,7 +1751,7 @@ __global__ void __launch_bounds__(512) qmatmul_xdl2_kernel(QMM2Args a) {
         for (int g = 0; g < G; g++) {
             const bf16x8_t b1 = as_bf16x8(o.b1[g]), b2 = as_bf16x8(o.b2[g]);
 #pragma unroll
-            for (int p = 0; p < 3; p++)
+            for (int p = 0; p < kAPieces; p++)
 #pragma unroll
                 for (int t = 0; t < R; t++) acc[g][t][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(x.v[t][p]), b1, acc[g][t][p], 0, 0, 0);
 #pragma unroll
@@ -1767,8 +1766,8 @@ __global__ void __launch_bounds__(512) qmatmul_xdl2_kernel(QMM2Args a) {
         LOAD_A;                                                                        \
         PREP;                                                                          \
         MFMA;                                                                          \
-        __builtin_amdgcn_sched_group_barrier(0x020, 3 * R, 0); /* the A loads first */ \
-        _Pragma("unroll") for (int k_ = 0; k_ < (3 + kXdlLoPieces) * R * G; k_++) {    \
+        __builtin_amdgcn_sched_group_barrier(0x020, kAPieces * R, 0); /* the A loads first */ \
+        _Pragma("unroll") for (int k_ = 0; k_ < (kAPieces + kXdlLoPieces) * R * G; k_++) {    \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); /* 1 MFMA */            \
             __builtin_amdgcn_sched_group_barrier(0x002, 4, 0); /* 4 VALU */            \
         }                                                                              \
@@ -1831,7 +1830,7 @@ __global__ void __launch_bounds__(512) qmatmul_xdl2_kernel(QMM2Args a) {
 #pragma unroll
         for (int t = 0; t < R; t++)
 #pragma unroll
-            for (int v = 0; v < 4; v++) smem[((w * (G * R) + g * R + t) * 4 + v) * 64 + lane] = (acc[g][t][0][v] + acc[g][t][1][v]) + acc[g][t][2][v];
+            for (int v = 0; v < 4; v++) smem[((w * (G * R) + g * R + t) * 4 + v) * 64 + lane] = kAPieces == 2 ? acc[g][t][0][v] + acc[g][t][kAPieces - 1][v] : (acc[g][t][0][v] + acc[g][t][1][v]) + acc[g][t][kAPieces - 1][v];
     __syncthreads();
     for (uint32_t idx = threadIdx.x; idx < (uint32_t)(G * R) * 256; idx += blockDim.x) {
         const uint32_t gt = idx >> 8, v = (idx >> 6) & 3, l = idx & 63;
@@ -1885,8 +1884,8 @@ __global__ void __launch_bounds__(512, 2) qmatmul_xdl4_kernel(QMM4Args a) {
     const uint32_t row = lane >> 4, i = lane & 15;
     const uint4* qs = P.qs + (uint64_t)g0 * a.U * 16 + i;
     const uint32_t* scd = (const uint32_t*)P.sc + (uint64_t)cb * a.U * 16 + i;
-    const uint4* ap = a.ap + (uint64_t)t0 * a.S * 12 * 64 + lane;
-    const uint64_t tile_stride = (uint64_t)a.S * 12 * 64;
+    const uint4* ap = a.ap + (uint64_t)t0 * a.S * (4 * kAPieces) * 64 + lane;
+    const uint64_t tile_stride = (uint64_t)a.S * (4 * kAPieces) * 64;
     const uint32_t s_begin = slice * a.steps_per_slice, s_end = min(s_begin + a.steps_per_slice, a.S);
 
     mfma_f4 acc[C][RT];
@@ -1896,13 +1895,13 @@ __global__ void __launch_bounds__(512, 2) qmatmul_xdl4_kernel(QMM4Args a) {
         for (int t = 0; t < RT; t++) acc[g][t] = mfma_f4{0.f, 0.f, 0.f, 0.f};
 
     struct AHalf {
-        uint4 v[H][3];
+        uint4 v[H][kAPieces];
     };
     auto load_a = [&](AHalf& x, uint32_t s, int J, int half) {
 #pragma unroll
         for (int t = 0; t < H; t++)
 #pragma unroll
-            for (int p = 0; p < 3; p++) x.v[t][p] = ap[(uint64_t)(half * H + t) * tile_stride + (((uint64_t)s * 4 + J) * 3 + p) * 64];
+            for (int p = 0; p < kAPieces; p++) x.v[t][p] = ap[(uint64_t)(half * H + t) * tile_stride + (((uint64_t)s * 4 + J) * kAPieces + p) * 64];
     };
     for (uint32_t s = s_begin + kw; s < s_end; s += KW) { // (scalar loop: kw, s are in SGPRs)
         const uint32_t u = min(4 * s + row, a.U - 1); // units past the end: A is zero there
@@ -1923,7 +1922,7 @@ __global__ void __launch_bounds__(512, 2) qmatmul_xdl4_kernel(QMM4Args a) {
 #pragma unroll
                 for (int t = 0; t < H; t++)
 #pragma unroll
-                    for (int p = 0; p < 3; p++) {
+                    for (int p = 0; p < kAPieces; p++) {
                         acc[g][half * H + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(x.v[t][p]), as_bf16x8(b1[g]), acc[g][half * H + t], 0, 0, 0);
                         if (p < kXdlLoPieces) acc[g][half * H + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(x.v[t][p]), as_bf16x8(b2[g]), acc[g][half * H + t], 0, 0, 0);
                     }
@@ -2005,7 +2004,7 @@ __global__ void __launch_bounds__(512, 2) qmatmul_xdl4_kernel(QMM4Args a) {
 // and the launches run at exactly that traffic over ~16 TB/s (o 12.5 us, q/k/v 32 us, gate/up 52 us, down 30 us). Here
 //   * a workgroup-column is WAVES scale block-columns (32 columns each, one per wave: 256 columns at 8 waves) x RT = 1 or 2
 //     m-tiles (all of M); all waves of a workgroup walk the SAME K steps;
-//   * a step's A pieces (RT x 12 KB) are fetched from L2 ONCE per workgroup into a double-buffered LDS region (one barrier
+//   * a step's A pieces (RT x 4 kAPieces KB) are fetched from L2 ONCE per workgroup into a double-buffered LDS region (one barrier
 //     per step) and every wave reads its MFMA operands from there: A through L2 / (8 x the old form);
 //   * each wave prepares B for its own block-column only (every weight still prepared exactly once per launch) and keeps the
 //     weights of the next two steps in registers; no cross-wave fold — a wave's accumulators ARE its output tile;
@@ -2031,14 +2030,15 @@ struct QMM5Args {
 template <int RT, int WAVES, bool NT>
 __global__ void __launch_bounds__(WAVES * 64) qmatmul_xdl5_kernel(QMM5Args a) {
     constexpr int C = 2;
-    constexpr uint32_t T = WAVES * 64, STEP = RT * 768; // uint4 of one step's A pieces: [tile][J][piece][lane]
+    constexpr uint32_t APS = 4 * kAPieces * 64; // uint4 of one m-tile's A pieces per 128-k step: [J][piece][lane]
+    constexpr uint32_t T = WAVES * 64, STEP = RT * APS; // uint4 of one step's A pieces: [tile][J][piece][lane]
     constexpr uint32_t NA = (STEP + T - 1) / T;
     constexpr uint32_t WT = C * RT * 256; // floats of one wave's tile
     extern __shared__ uint4 lds_a[];      // [2][STEP], then one flag word
     uint32_t* const flag = (uint32_t*)(lds_a + 2 * STEP);
     const uint32_t lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t row = lane >> 4, i = lane & 15;
-    const uint64_t tile_stride = (uint64_t)a.S * 768;
+    const uint64_t tile_stride = (uint64_t)a.S * APS;
     const uint32_t u_begin = blockIdx.x * a.run, u_end = min(u_begin + a.run, a.total);
 
     for (uint32_t u0 = u_begin, seg = 0; u0 < u_end; seg++) { // at most two segments (run <= S)
@@ -2083,7 +2083,7 @@ __global__ void __launch_bounds__(WAVES * 64) qmatmul_xdl5_kernel(QMM5Args a) {
         static_assert(NA <= 3, "A pieces of a step per thread");
         auto a_src = [&](uint32_t s, uint32_t q) -> const uint4* {
             const uint32_t idx = threadIdx.x + q * T;
-            return a.ap + (uint64_t)(idx / 768) * tile_stride + (uint64_t)s * 768 + idx % 768;
+            return a.ap + (uint64_t)(idx / APS) * tile_stride + (uint64_t)s * APS + idx % APS;
         };
         auto fetch_a = [&](uint32_t s) {
             ar0 = *a_src(s, 0);
@@ -2095,14 +2095,14 @@ __global__ void __launch_bounds__(WAVES * 64) qmatmul_xdl5_kernel(QMM5Args a) {
             if (NA > 1 && (STEP >= 2 * T || threadIdx.x + T < STEP)) lds_a[buf * STEP + threadIdx.x + T] = ar1;
             if (NA > 2 && (STEP >= 3 * T || threadIdx.x + 2 * T < STEP)) lds_a[buf * STEP + threadIdx.x + 2 * T] = ar2;
         };
-        uint4 xa[RT][3]; // the A pieces of the current 8-k group, refilled tile by tile after their last use
+        uint4 xa[RT][kAPieces]; // the A pieces of the current 8-k group, refilled tile by tile after their last use
         auto read_a = [&](uint32_t buf, int J, int t) {
 #pragma unroll
-            for (int p = 0; p < 3; p++) xa[t][p] = lds_a[buf * STEP + ((t * 4 + J) * 3 + p) * 64 + lane];
+            for (int p = 0; p < kAPieces; p++) xa[t][p] = lds_a[buf * STEP + ((t * 4 + J) * kAPieces + p) * 64 + lane];
         };
         auto mfmas = [&](const BP& o, int t) {
 #pragma unroll
-            for (int p = 0; p < 3; p++) {
+            for (int p = 0; p < kAPieces; p++) {
 #pragma unroll
                 for (int g = 0; g < C; g++) acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(xa[t][p]), as_bf16x8(o.b1[g]), acc[g][t], 0, 0, 0);
 #pragma unroll
@@ -2147,11 +2147,11 @@ __global__ void __launch_bounds__(WAVES * 64) qmatmul_xdl5_kernel(QMM5Args a) {
         }                                                                              \
         if (kX5Interleave) {                                                           \
             _Pragma("unroll") for (int t_ = 0; t_ < RT; t_++) {                        \
-                _Pragma("unroll") for (int k_ = 0; k_ < (3 + kXdlLoPieces) * C; k_++) { \
+                _Pragma("unroll") for (int k_ = 0; k_ < (kAPieces + kXdlLoPieces) * C; k_++) { \
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); /* 1 MFMA */    \
                     __builtin_amdgcn_sched_group_barrier(0x002, 3, 0); /* 3 VALU */    \
                 }                                                                      \
-                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0); /* tile refill */   \
+                __builtin_amdgcn_sched_group_barrier(0x100, kAPieces, 0); /* tile refill */   \
             }                                                                          \
         }                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                             \
@@ -2487,7 +2487,7 @@ void launch_pack_gguf(hipStream_t s, const uint8_t* raw_blocks, const QWeightDev
 }
 
 // Scratch of one M > 1 launch: the pre-split A operand of the second XDL form (split_a_kernel): per
-// 16-row tile and 128-k step 12 KB (4 groups x 3 pieces x 64 lanes x 16 B). Launches are serialised on one
+// 16-row tile and 128-k step 4 * kAPieces KB (4 groups x kAPieces pieces x 64 lanes x 16 B). Launches are serialised on one
 // stream, so one block serves all of a program's quantized matmuls.
 static bool xdl2_enabled() {
     static const bool on = !(getenv("ZGML_QMM_XDL2") && atoi(getenv("ZGML_QMM_XDL2")) == 0);
@@ -2505,7 +2505,7 @@ static bool xdl2_applies(const QWeightDev& w, uint32_t M) { // K <= 12288: a wav
 static uint32_t xdl_tile_pad(uint32_t M) { return M > 64 ? 8 : (M > 32 ? 4 : (M > 16 ? 2 : 1)); } // m-tiles per workgroup
 static uint64_t xdl_a_bytes(const QWeightDev& w, uint32_t M) {
     const uint64_t S = (w.KC + 3) / 4, tiles = (M + 15) / 16, R = xdl_tile_pad(M);
-    return (tiles + R - 1) / R * R * S * 12 * 1024;
+    return (tiles + R - 1) / R * R * S * (4 * kAPieces) * 1024;
 }
 static uint64_t xdl4_partial_bytes(const QWeightDev& w, uint32_t M) { // one part, at most 4 K slices
     const uint64_t RT = xdl_tile_pad(M), groups = ((M + 15) / 16 + RT - 1) / RT;
@@ -2921,7 +2921,7 @@ bool launch_xdl5(hipStream_t s, const QWeightDev* w, const QMatmulParams* p, uin
     a.counter = (uint32_t*)((char*)scratch - kQmmScratchHead);
     a.n_parts = n, a.M = p[0].M, a.U = w[0].KC, a.S = S, a.run = run, a.total = total;
     const uint32_t grid = cdiv(total, run); // <= xdl5_wgs() unless every run is a whole column (no partial tiles then)
-    const size_t lds = 2 * (size_t)RT * 768 * 16 + 64;
+    const size_t lds = 2 * (size_t)RT * (4 * kAPieces * 64) * 16 + 64;
     const bool nt = w[0].stream_nt != 0;
     using Fn5 = void (*)(QMM5Args);
     const Fn5 fn = RT == 2 ? (nt ? (Fn5)qmatmul_xdl5_kernel<2, kX5Waves, true> : (Fn5)qmatmul_xdl5_kernel<2, kX5Waves, false>)
