@@ -1198,6 +1198,30 @@ __global__ void __launch_bounds__(kBlock) read_f4_kernel(float* __restrict__ sin
     if (t == 123456.789f) sink[blockIdx.x] = t; // (never true for the benchmark's data: keeps the loads alive)
 }
 
+// Access-pattern calibration for the mat-vec (ZGML_COPY_VARIANT=3 / 4, read-only, 4 x 16 B in flight per lane, 256-thread workgroups,
+// `grid` workgroups of one wave-set each): 3 = every workgroup streams its OWN contiguous region of n4 / grid items (the packed
+// weight layout: column-group-major), 4 = the workgroups' 4 KiB chunks interleaved (chunk c of workgroup b at (c * grid + b)): the
+// resident workgroups together sweep ONE window of the buffer, as the hardware-dispatched one-float4-per-thread copy does.
+template <bool INTERLEAVED>
+__global__ void __launch_bounds__(kBlock) read_regions_kernel(float* __restrict__ sink, const float4* __restrict__ src, uint64_t n4) {
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const uint64_t per = n4 / gridDim.x / kBlock * kBlock; // items of one workgroup (a multiple of 256)
+    const uint64_t chunks = per / kBlock;                  // 4 KiB chunks (one item per lane)
+    f4v acc = {0.f, 0.f, 0.f, 0.f};
+    for (uint64_t c = 0; c + 3 < chunks; c += 4) {
+        f4v v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint64_t idx = INTERLEAVED ? ((c + u) * gridDim.x + blockIdx.x) * kBlock + threadIdx.x : (uint64_t)blockIdx.x * per + (c + u) * kBlock + threadIdx.x;
+            v[u] = __builtin_nontemporal_load((const f4v*)src + idx);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) acc += v[u];
+    }
+    const float t = acc.x + acc.y + acc.z + acc.w;
+    if (t == 123456.789f) sink[blockIdx.x] = t;
+}
+
 __global__ void __launch_bounds__(kBlock) f32_to_f16_kernel(__half* __restrict__ dst, const float* __restrict__ src,
                                                             uint64_t n) {
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock)
@@ -1432,6 +1456,14 @@ void launch_copy_f4(hipStream_t s, void* dst, const void* src, uint64_t bytes) {
     }
     if (variant == 1) { // one float4 per thread
         copy_f4_one_kernel<<<(unsigned)((n4 + kBlock - 1) / kBlock), kBlock, 0, s>>>((float4*)dst, (const float4*)src, n4);
+        return;
+    }
+    if ((variant & 0xFF) == 3 || (variant & 0xFF) == 4) { // regions / interleaved regions; workgroups = variant >> 8 (default 688)
+        const unsigned grid = (unsigned)(variant >> 8) ? (unsigned)(variant >> 8) : 688u;
+        if ((variant & 0xFF) == 3)
+            read_regions_kernel<false><<<grid, kBlock, 0, s>>>((float*)dst, (const float4*)src, n4);
+        else
+            read_regions_kernel<true><<<grid, kBlock, 0, s>>>((float*)dst, (const float4*)src, n4);
         return;
     }
     if (variant == 2) { // read-only stream (dst is only the never-written sink)
