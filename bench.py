@@ -636,6 +636,8 @@ def bench_sharded(args):
     os.dup2(2, 1)
     rank, ws = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", rank))
+    if os.environ.get("ZGML_BENCH_ONE_GPU"):  # rehearsal on a one-GPU box: every rank on device 0 (only the peer gather can run there: RCCL refuses two ranks on one device)
+        local = 0
     if ws != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={ws}")
     if "MASTER_ADDR" not in os.environ:  # single-process rehearsal (ZGML_BENCH_FORCE_SHARDED)
@@ -648,28 +650,77 @@ def bench_sharded(args):
         dist.broadcast(t, 0)
         return bytes(t.tolist())
 
+    def exchange_handles(mine: bytes):
+        out = [None] * ws
+        dist.all_gather_object(out, mine)
+        return out
+
     cfg = llama.preset("llama2-7b", 2048)
     cfg.shard_rank, cfg.shard_world = rank, ws
     model = llama.Model(cfg, llama.Q4_0, threads=max(2, 16 // max(1, ws // 2)))
-    dec = NativeShardedDecoder(be, model, rank, ws, exchange_id if ws > 1 else None)
     K = min(args.steps, 256)
     W = max(2, args.warmup)
-    tok = 1
-    toks = []
-    for pos in range(W):
-        tok = dec.step(tok, pos)
-        toks.append(tok)
-    # every rank must have produced the same greedy tokens (replicated logits), and with the whole model on the ranks
-    # they are the oracle's (tests/golden/l7full.json: the unsharded 32-layer program)
-    t = torch.tensor(toks, dtype=torch.int64)
-    gathered = [torch.empty_like(t) for _ in range(ws)]
-    dist.all_gather(gathered, t)
-    if not all(torch.equal(g, gathered[0]) for g in gathered):
-        raise SystemExit("sharded decode: ranks disagree on the greedy tokens")
     gold = json.loads((ROOT / "tests" / "golden" / "l7full.json").read_text())["tokens"]
+
+    def all_ok(flag: bool) -> bool:
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
+    def bring_up(backend, gather):
+        """A decoder in gather mode `gather`, warmed up over W greedy steps; (decoder, tokens, last token) when EVERY rank produced
+        the oracle's tokens (tests/golden/l7full.json: the unsharded 32-layer program) and the ranks agree, else (None, why, None) on
+        every rank alike (the decision is an all-reduce over the control plane)."""
+        dec, why, toks, tok = None, "", [], 1
+        try:
+            dec = NativeShardedDecoder(backend, model, rank, ws, exchange_id if ws > 1 else None, gather=gather,
+                                       exchange_handles=exchange_handles if gather == "peer" else None)
+        except Exception as e:  # noqa: BLE001
+            why = f"rank {rank}: {type(e).__name__}: {str(e)[:200]}"
+        if not all_ok(dec is not None):
+            if dec is not None:
+                dec.close()
+            return None, why or "another rank failed to set the gather up", None
+        try:
+            for pos in range(W):
+                tok = dec.step(tok, pos)
+                toks.append(tok)
+        except Exception as e:  # noqa: BLE001
+            why = f"rank {rank}: {type(e).__name__}: {str(e)[:200]}"
+        n_chk = min(len(gold), len(toks))
+        good = not why and len(toks) == W and toks[:n_chk] == gold[:n_chk]
+        if not why and not good:
+            why = f"rank {rank}: tokens {toks[:n_chk]} != oracle {gold[:n_chk]}"
+        if not all_ok(good):
+            dec.close()
+            return None, why or "another rank failed the token check", None
+        t = torch.tensor(toks, dtype=torch.int64)
+        gathered = [torch.empty_like(t) for _ in range(ws)]
+        dist.all_gather(gathered, t)
+        if not all(torch.equal(g, gathered[0]) for g in gathered):
+            dec.close()
+            return None, "ranks disagree on the greedy tokens", None
+        return dec, toks, tok
+
+    # Gather mode: peer stores first (zgml_amd/csrc/shard_peer.hip: one small kernel per gather point instead of an ncclAllGather),
+    # RCCL when that cannot be set up or does not reproduce the oracle's tokens on every rank — each attempt on a context of its own.
+    # ZGML_SHARD_GATHER=rccl / peer pins one of them.
+    want = os.environ.get("ZGML_SHARD_GATHER", "auto")
+    modes = ["rccl"] if want == "rccl" or ws == 1 else (["peer"] if want == "peer" else ["peer", "rccl"])
+    dec, gather_mode, fallback_reason = None, None, None
+    for mode in modes:
+        if dec is None and mode != modes[0]:
+            be.close()
+            be = Backend(local)  # a fresh context: the failed attempt may have left an error (or a timed-out step) on the old one
+        dec, toks, tok = bring_up(be, mode)
+        if dec is not None:
+            gather_mode = mode
+            break
+        fallback_reason = f"{mode}: {toks}"
+        log(f"[bench] rank {rank}: gather mode {mode} not usable ({toks})")
+    if dec is None:
+        raise SystemExit(f"PARITY / SETUP FAILURE: no gather mode produced the oracle's tokens ({fallback_reason})")
     n_chk = min(len(gold), len(toks))
-    if toks[:n_chk] != gold[:n_chk]:
-        raise SystemExit(f"PARITY FAILURE: sharded decode tokens {toks[:n_chk]} != oracle {gold[:n_chk]}")
     dist.barrier()
     be.synchronize()
     t0 = time.perf_counter()
@@ -726,7 +777,7 @@ def bench_sharded(args):
                 "bytes_per_token_per_rank": qb, "all_gathers_per_token": dec.n_points if ws > 1 else 0,
                 "us_per_all_gather": round(gather_us / n_gather, 2), "gather_us_per_token": round(gather_us, 1),
                 "eager_step_us": round(eager_us, 1), "gather_share_of_eager_step": round(gather_us / eager_us, 3) if eager_us else None,
-                "timing": "value: host clock around K graph-replayed steps, max over ranks; gather figures: HIP events around every ncclAllGather "
+                "timing": "value: host clock around K graph-replayed steps, max over ranks; gather figures: HIP events around every gather point "
                           "of 3 eager steps on rank 0 (zgml_hip_shard_profile_step)"}
         out = {
             "metric": "decode_tokens_per_sec", "value": round(K / dt, 1), "unit": "tokens/s", "n_gpus": ws,
@@ -737,7 +788,10 @@ def bench_sharded(args):
                        "weights": "synthetic Q4_0", "max_seq": cfg.max_seq_len,
                        "parallelism": f"tp{ws} (N-split weights, replicated activations, head-sharded KV)",
                        "collectives_per_token": dec.n_points if ws > 1 else 0, "rccl_ranks": ws, "step_mode": step_mode,
-                       "data_path": "zgml_hip_shard_step (C ABI): op ranges + in-place ncclAllGather + argmax, one graph per token",
+                       "gather": gather_mode + (" (fallback: " + fallback_reason + ")" if fallback_reason else ""),
+                       "data_path": "zgml_hip_shard_step (C ABI): op ranges + " + ("peer-store gather kernels (xGMI stores into the peers' fine-grained staging, "
+                                    "arrival counters, bounded waits)" if gather_mode == "peer" else "in-place ncclAllGather") +
+                                    " + (max, index) pair gather of the greedy token, one graph per token",
                        "verified": f"first {n_chk} greedy tokens equal the oracle's for the unsharded 32-layer program; all ranks agree",
                        "compare_with": "extra.llama2_7b.tok_s of the --gpus 1 line (same model, unsharded)"},
             "roofline": roof, "cpu_baseline": cpu,

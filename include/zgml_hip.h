@@ -460,6 +460,26 @@ int zgml_hip_shard_attach(zgml_hip_ctx* ctx, zgml_hip_program* program, const zg
  * rank must call it for every step (the collectives are collective). */
 int64_t zgml_hip_shard_step(zgml_hip_ctx* ctx, zgml_hip_program* program, const zgml_program_io* inputs, uint64_t n_inputs);
 int zgml_hip_shard_step_mode(zgml_hip_program* program); /* 1: steps replay one graph per token, 0: eager */
+/* The greedy token of the N-sharded LM head: when the LAST gather point covers the logits buffer, that gather is replaced by
+ * one (max, index) pair per rank (8 bytes instead of 4 * vocab / world; first maximum wins, src/nn.zig:122-138) in BOTH gather
+ * modes; the logits buffer then holds only the rank's own slice after a step.
+ *
+ * PEER gather mode (no RCCL; zgml_amd/csrc/shard_peer.hip): every gather point is one small kernel per rank that stores the
+ * rank's slice into a staging area in every peer's fine-grained block (xGMI peer stores), counts an arrival on every peer,
+ * waits (bounded) for its own arrivals and lands the peers' slices in its program buffer. Use: every rank calls
+ * shard_init_peer instead of shard_unique_id / shard_init, then compile_program + shard_attach as before, then exports its
+ * block's handle, hands it to every other rank by any channel (64 + 24 bytes), imports the others', and steps as before.
+ * Ranks may be processes (hipIpc handles) or contexts of ONE process (raw pointers: how the single-GPU tests run two ranks).
+ * A wait that gives up (ZGML_SHARD_PEER_WAIT_MS, default 5000) makes shard_step return -1 with an error on the context. */
+typedef struct zgml_shard_peer_handle {
+    unsigned char ipc[64]; /* hipIpcMemHandle_t of the block */
+    uint64_t pid;          /* exporting process: an importer in the same process uses `raw` */
+    uint64_t raw;          /* the block's device pointer in the exporting process */
+    uint64_t bytes;
+} zgml_shard_peer_handle;
+int zgml_hip_shard_init_peer(zgml_hip_ctx* ctx, int rank, int world);
+int zgml_hip_shard_peer_export(zgml_hip_ctx* ctx, zgml_hip_program* program, zgml_shard_peer_handle* out);
+int zgml_hip_shard_peer_import(zgml_hip_ctx* ctx, zgml_hip_program* program, int peer_rank, const zgml_shard_peer_handle* handle);
 /* Diagnostics: one EAGER step with HIP events around every all-gather — device microseconds of the whole step and of the
  * collectives inside it (launch-bound: eager steps are slower than graph replays; the ratio is what it is for). */
 int64_t zgml_hip_shard_profile_step(zgml_hip_ctx* ctx, zgml_hip_program* program, const zgml_program_io* inputs, uint64_t n_inputs,

@@ -194,13 +194,18 @@ HIP_SYMBOLS = [
     "zgml_hip_qmatmul_bench", "zgml_hip_qmatvec_overlap_bench", "zgml_hip_qmatvec_streams_bench", "zgml_hip_qmatvec_chain_bench", "zgml_hip_dense_f16_bench", "zgml_hip_dense_cache_invalidate", "zgml_hip_dense_cache_stats",
     "zgml_hip_qmatvec_synth", "zgml_hip_copy_bench", "zgml_hip_resident_setup", "zgml_hip_resident_decode",
     "zgml_hip_resident_prefill", "zgml_hip_shard_unique_id", "zgml_hip_shard_init", "zgml_hip_shard_destroy", "zgml_hip_shard_attach", "zgml_hip_shard_step", "zgml_hip_shard_step_mode",
-    "zgml_hip_shard_profile_step",
+    "zgml_hip_shard_profile_step", "zgml_hip_shard_init_peer", "zgml_hip_shard_peer_export", "zgml_hip_shard_peer_import",
 ]
 
 class ShardPointC(C.Structure):
     """zgml_shard_point (include/zgml_hip.h)."""
     _fields_ = [("op_end", C.c_uint64), ("buf_idx", C.c_uint16), ("_pad", C.c_uint16), ("offset", C.c_uint32),
                 ("len_per_rank", C.c_uint32)]
+
+
+class ShardPeerHandleC(C.Structure):
+    """zgml_shard_peer_handle (include/zgml_hip.h): what a rank hands to its peers in the peer gather mode."""
+    _fields_ = [("ipc", C.c_ubyte * 64), ("pid", C.c_uint64), ("raw", C.c_uint64), ("bytes", C.c_uint64)]
 
 
 OPT_FUSION, OPT_GRAPH, OPT_PROFILE, OPT_SKIP_DEAD_UPLOADS, OPT_F16_DENSE_WEIGHTS, OPT_DENSE_WEIGHT_CACHE = 1, 2, 3, 4, 5, 6
@@ -279,6 +284,10 @@ def _bind_hip(lib: C.CDLL) -> None:
         lib.zgml_hip_shard_attach.argtypes = [vp, vp, C.POINTER(ShardPointC), u64, C.c_uint16, u64]
         lib.zgml_hip_shard_step.restype, lib.zgml_hip_shard_step.argtypes = C.c_int64, [vp, vp, C.POINTER(ProgramIOC), u64]
         lib.zgml_hip_shard_step_mode.restype, lib.zgml_hip_shard_step_mode.argtypes = i32, [vp]
+    if hasattr(lib, "zgml_hip_shard_init_peer"):
+        lib.zgml_hip_shard_init_peer.restype, lib.zgml_hip_shard_init_peer.argtypes = i32, [vp, i32, i32]
+        lib.zgml_hip_shard_peer_export.restype, lib.zgml_hip_shard_peer_export.argtypes = i32, [vp, vp, C.POINTER(ShardPeerHandleC)]
+        lib.zgml_hip_shard_peer_import.restype, lib.zgml_hip_shard_peer_import.argtypes = i32, [vp, vp, i32, C.POINTER(ShardPeerHandleC)]
     if hasattr(lib, "zgml_hip_shard_profile_step"):
         lib.zgml_hip_shard_profile_step.restype = C.c_int64
         lib.zgml_hip_shard_profile_step.argtypes = [vp, vp, C.POINTER(ProgramIOC), u64, C.POINTER(C.c_double), C.POINTER(C.c_double)]

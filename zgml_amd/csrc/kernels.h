@@ -425,4 +425,28 @@ int qkv_attn_kon_blocks_per_cu(uint32_t d_head, bool kvq); // fused q / k / v + 
 // directly in the packed layout (SURVEY §8d generator).
 void launch_synth_packed(hipStream_t s, const QWeightDev& w, uint32_t matrix_id);
 
+// ── shard_peer.hip: the row-shard all-gather as peer stores (ZGML_SHARD_GATHER=peer) and the (max, index) gather of the greedy token ──
+struct PeerGatherArgs {
+    char* const* blocks; // device array [world]: every rank's fine-grained block (own included) as THIS process maps them
+    float* local;        // the point's region of this rank's program buffer: world * len floats, own slice already computed
+    uint32_t* seen;      // this rank's private count of arrivals already consumed at this point
+    uint32_t* timeout;   // the context's host-visible hand-off word
+    uint64_t ctr_off, stage_off; // byte offsets of the point's arrival counter / staging area inside a block
+    uint64_t wait_ticks;         // give-up bound of the wait, 100 MHz ticks
+    uint32_t len, rank, world;
+};
+struct PeerArgmaxArgs {
+    char* const* blocks;
+    const float* slice; // this rank's logits slice, len floats
+    uint32_t* seen;
+    uint32_t* timeout;
+    int64_t* out;       // the greedy token (-1 after a give-up)
+    uint64_t ctr_off, pairs_off, wait_ticks;
+    uint32_t len, rank, world;
+};
+void launch_peer_gather(hipStream_t s, const PeerGatherArgs& a);
+void launch_peer_argmax(hipStream_t s, const PeerArgmaxArgs& a);
+void launch_local_argmax_pair(hipStream_t s, const float* slice, uint32_t len, uint32_t rank, unsigned long long* pairs);
+void launch_reduce_pairs(hipStream_t s, const unsigned long long* pairs, uint32_t world, int64_t* out);
+
 } // namespace zgml

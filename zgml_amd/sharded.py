@@ -28,16 +28,25 @@ class NativeShardedDecoder:
     LlamaDeviceSession) and hands the 128-byte communicator id around — `exchange_id` is any callable that returns
     rank 0's bytes on every rank (bench.py broadcasts it over a gloo control plane; world size 1 needs none)."""
 
-    def __init__(self, backend, model: Model, rank: int, world: int, exchange_id=None):
+    def __init__(self, backend, model: Model, rank: int, world: int, exchange_id=None, gather: str = "rccl", exchange_handles=None):
+        """gather = "rccl": in-place ncclAllGather per gather point (`exchange_id` hands rank 0's 128-byte id to every rank);
+        gather = "peer": the peer-store gather of zgml_amd/csrc/shard_peer.hip, no RCCL — `exchange_handles` is a callable that
+        takes this rank's handle bytes and returns every rank's, in rank order (bench.py: all_gather_object over gloo), or None
+        when the caller wires the ranks itself (`export_handle` / `import_handle`: ranks as contexts of one process)."""
         self.be, self.model, self.lib = backend, model, capi.load_hip()
-        uid = (C.c_ubyte * 128)()
-        if rank == 0 and self.lib.zgml_hip_shard_unique_id(uid) != 0:
-            raise RuntimeError("shard_unique_id failed (librccl.so?)")
-        if exchange_id is not None:
-            raw = exchange_id(bytes(uid))
-            uid = (C.c_ubyte * 128)(*raw)
-        if self.lib.zgml_hip_shard_init(backend.ctx, uid, rank, world) != 0:
-            raise RuntimeError("shard_init: " + backend.last_error())
+        self.rank, self.world, self.gather = rank, world, gather
+        if gather == "peer":
+            if self.lib.zgml_hip_shard_init_peer(backend.ctx, rank, world) != 0:
+                raise RuntimeError("shard_init_peer: " + backend.last_error())
+        else:
+            uid = (C.c_ubyte * 128)()
+            if rank == 0 and self.lib.zgml_hip_shard_unique_id(uid) != 0:
+                raise RuntimeError("shard_unique_id failed (librccl.so?)")
+            if exchange_id is not None:
+                raw = exchange_id(bytes(uid))
+                uid = (C.c_ubyte * 128)(*raw)
+            if self.lib.zgml_hip_shard_init(backend.ctx, uid, rank, world) != 0:
+                raise RuntimeError("shard_init: " + backend.last_error())
         prog = model.program
         self.handle = self.lib.zgml_hip_compile_program(backend.ctx, C.byref(prog))
         if not self.handle:
@@ -51,6 +60,20 @@ class NativeShardedDecoder:
         self.n_points = len(pts)
         n = C.c_uint64()
         self._in = model.lib.zh_model_step_inputs(model.ptr, C.byref(n)), n.value
+        if gather == "peer" and exchange_handles is not None:
+            for r, raw in enumerate(exchange_handles(self.export_handle())):
+                self.import_handle(r, raw)
+
+    def export_handle(self) -> bytes:
+        h = capi.ShardPeerHandleC()
+        if self.lib.zgml_hip_shard_peer_export(self.be.ctx, self.handle, C.byref(h)) != 0:
+            raise RuntimeError("shard_peer_export: " + self.be.last_error())
+        return bytes(h)
+
+    def import_handle(self, peer_rank: int, raw: bytes) -> None:
+        h = capi.ShardPeerHandleC.from_buffer_copy(raw)
+        if self.lib.zgml_hip_shard_peer_import(self.be.ctx, self.handle, peer_rank, C.byref(h)) != 0:
+            raise RuntimeError("shard_peer_import: " + self.be.last_error())
 
     def step(self, token: int, pos: int) -> int:
         self.model.patch(token, pos)
