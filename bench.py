@@ -48,13 +48,32 @@ def _pmc_traffic(K, N, q4):
     the 1 GiB copy kernel of the same run), newest round first; stamped with the commit the pass was collected at."""
     if (K, N, q4) != (4096, 4096, 1):
         return None, None
-    for name in ("r03_qmatvec_pmc.json", "r02_qmatvec_pmc.json", "r01_qmatvec_pmc.json"):
+    for name in ("r04_qmatvec_pmc.json", "r03_qmatvec_pmc.json", "r02_qmatvec_pmc.json", "r01_qmatvec_pmc.json"):
         f = ROOT / "profiles" / name
         if f.exists():
             d = json.loads(f.read_text())
             e = d.get("4096x4096_q4_0", {})
             return e.get("traffic_bytes_per_launch"), {"file": "profiles/" + name, "source_commit": d.get("source_commit", "round 1 (unstamped)")}
     return None, None
+
+
+def _rocprof_reconcile():
+    """The committed reconciliation of the three clocks on the roofline kernel (profiles/r04_qmatvec_chain_reconcile.txt / .json,
+    tools/reconcile_chain.sh: ONE rocprofv3 --kernel-trace pass of the chain, per-dispatch begin / end): the profiler's mean kernel
+    duration and what it implies for `frac`, next to the event figure this run measures live. None when no table is committed."""
+    f = ROOT / "profiles" / "r04_qmatvec_chain_reconcile.json"
+    if not f.exists():
+        return None
+    d = json.loads(f.read_text())
+    k = d["rocprof_mean_duration_us"]
+    return {"file": "profiles/r04_qmatvec_chain_reconcile.txt", "rocprof_mean_kernel_duration_us": round(k, 3),
+            "frac_kernel_rocprof": round(d["bytes_per_launch"] / k / 1e3 / HBM_PEAK_GBPS, 4),
+            "events_us_in_that_pass_unprofiled": d["events_unprofiled_us"], "events_us_while_profiled": d["events_profiled_us"],
+            "in_kernel_stamp_span_us": d.get("stamps_span_us"),
+            "why_they_differ": "events time launch-to-launch periods of the un-profiled chain (boundary included); the profiler's duration runs from "
+                               "the command processor picking the packet up to its completion signal while every dispatch is serialised and "
+                               "timestamped (the same program's event period under the profiler is in events_us_while_profiled); the in-kernel "
+                               "stamps run from the first workgroup's first instruction to the last workgroup's last store"}
 
 
 def matvec_roofline(be, K=4096, N=4096, q4=1, ring=64, iters=2048, chain=False):
@@ -69,12 +88,37 @@ def matvec_roofline(be, K=4096, N=4096, q4=1, ring=64, iters=2048, chain=False):
         raise RuntimeError("qmatvec_bench: " + be.last_error())
     gbps = nbytes.value / us / 1e3
     traffic, src = _pmc_traffic(K, N, q4)
+    rec = _rocprof_reconcile() if chain and (K, N, q4) == (4096, 4096, 1) else None
     return {"bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": src,
+            "frac": round(gbps / HBM_PEAK_GBPS, 4), "frac_is": "frac_events: algorithmic bytes / the HIP-event time per launch measured in THIS run",
+            "frac_events": round(gbps / HBM_PEAK_GBPS, 4), "frac_kernel_rocprof": rec["frac_kernel_rocprof"] if rec else None, "reconcile": rec,
+            "traffic": traffic, "traffic_source": src,
             "kernel": f"qmatvec_kon_kernel (K-on-lanes Q4_0 mat-vec) {K}x{N}, single launch per mat-vec" if q4 else f"qmatvec_kernel<q8_0> {K}x{N}",
             "dependency": "data (y_i is x_{i+1}; epilogue multiply by a constant vector)" if chain else "stream order (one x / y)",
             "bytes_per_launch": nbytes.value, "us_per_launch": round(us, 3), "ring_matrices": ring,
             "launches": iters, "timing": "HIP events on the launch stream; ring captured in a hipGraph"}
+
+
+def calibration_streams():
+    """What THIS box's HBM delivers to plain streams of 1 GiB (beyond the Infinity Cache), in child processes because the kernel form
+    is selected once per process (ZGML_COPY_VARIANT): the textbook copy with one float4 per thread (the guide's 6.29 TB/s form), the
+    grid-stride copy loop, and READ-ONLY streams shaped like the mat-vec's (256-thread workgroups, 4 x 16 B in flight per lane, every
+    workgroup its own contiguous region: 256 / 688 / 2048 workgroups). The mat-vec is a read stream: these are what to hold it against."""
+    import subprocess
+    out = {}
+    code = ("import sys; sys.path.insert(0, %r)\nfrom zgml_amd import Backend\nbe = Backend(0)\n"
+            "print(be._lib.zgml_hip_copy_bench(be.ctx, 1 << 30, 3, 20))" % str(ROOT))
+    for name, variant, rw in (("copy_one_float4_per_thread_rw", 1, 2), ("copy_grid_stride_loop_rw", 0, 2), ("read_only_8_in_flight_4096_wgs", 2, 1),
+                              ("read_only_regions_256_wgs", 3 + 256 * 256, 1), ("read_only_regions_688_wgs", 3 + 688 * 256, 1),
+                              ("read_only_regions_2048_wgs", 3 + 2048 * 256, 1)):
+        try:
+            r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=dict(os.environ, ZGML_COPY_VARIANT=str(variant)))
+            us = float(r.stdout.strip().splitlines()[-1])
+            out[name + "_GBps"] = round(rw * (1 << 30) / us / 1e3, 1)
+        except Exception as e:  # noqa: BLE001
+            out[name + "_GBps"] = "error: " + str(e)[:80]
+    out["note"] = "1 GiB, 20 launches each, HIP events; _rw counts read + written bytes, read_only_* the bytes read"
+    return out
 
 
 def _cpu_model():
@@ -193,7 +237,7 @@ def bench_single(args):
     # the fused decode attention splits each head over several workgroups there)
     if cfg.max_seq_len >= 2048:
         try:
-            extra["long_context_verified_against_oracle"] = verify_longctx(be, llama, "smollm_f32kv")  # no number without parity
+            extra["long_context_verified_against_oracle"] = verify_longctx_filled(be, llama, "smollm_f32kv_filled")  # no number without parity
             n_lc = min(64, K)
             be.synchronize()
             t0 = time.perf_counter()
@@ -247,7 +291,8 @@ def bench_single(args):
     extra["matvec_q4_0_independent_launches"] = indep
     cp = be._lib.zgml_hip_copy_bench(be.ctx, 1 << 30, 3, 20)
     extra["copy_kernel_GBps_read_plus_write"] = round(2 * (1 << 30) / cp / 1e3, 1)
-    extra["copy_kernel_note"] = "1 GiB device copy, 8 x 16 B in flight per lane, non-temporal; read-only streams reach more (matvec_q4_0_independent_launches)"
+    extra["copy_kernel_note"] = "1 GiB device copy, 8 x 16 B in flight per lane, non-temporal, grid-stride loop; see calibration_streams for the forms that reach more"
+    extra["calibration_streams"] = calibration_streams()
 
     # the int8 KV cache variant of the same program (extension ops kvq_store / attention_kvq)
     try:
@@ -262,7 +307,7 @@ def bench_single(args):
         wq = sq.resident_decode(int(wq[-1]), 8, 128)
         be.synchronize()
         short = 128 / (time.perf_counter() - t0)
-        ver_q = verify_longctx(be, llama, "smollm_int8kv")
+        ver_q = verify_longctx_filled(be, llama, "smollm_int8kv_filled")
         t0 = time.perf_counter()
         sq.resident_decode(int(wq[-1]), 1900, 64)
         be.synchronize()
@@ -570,8 +615,8 @@ def bench_llama7b_single(be, llama, args):
     be.synchronize()
     dt = time.perf_counter() - t0
     qb, nw = model.quant_bytes()
-    verified["long_context"] = verify_longctx(be, llama, "l7dims_f32kv")  # (2 layers at these dimensions; ParityError: no 7B numbers)
-    verified["long_context_int8_kv"] = verify_longctx(be, llama, "l7dims_int8kv")
+    verified["long_context"] = verify_longctx_filled(be, llama, "l7dims_f32kv_filled")  # (2 layers at these dimensions; ParityError: no 7B numbers)
+    verified["long_context_int8_kv"] = verify_longctx_filled(be, llama, "l7dims_int8kv_filled")
     be.synchronize()
     t0 = time.perf_counter()
     sess.resident_decode(1, 1900, 32)  # long context (see bench_single)

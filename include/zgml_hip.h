@@ -384,8 +384,13 @@ enum {
     /* workgroups (1024 threads) the device is assumed to keep resident at once, for the launch that carries the q/k/v
      * projection AND the decode attention that waits for it in one grid (the waiting workgroups spin on workgroups of the
      * same grid, so the whole grid must be resident): the fusion is only built when projection + attention workgroups fit,
-     * the attention's split count shrinks to fit, otherwise the two launches stay apart. -1 (default): one per compute
-     * unit. 0: never fuse. Takes effect for programs compiled afterwards and at the next plan rebuild of existing ones. */
+     * the attention's split count shrinks to fit, otherwise the two launches stay apart. -1 (default): one 1024-thread workgroup
+     * per compute unit for the short-K form; the 256-thread K-on-lanes form (K > 2048: Llama-2-7B) takes what the occupancy
+     * query admits (four per compute unit, no margin) and is only built with ALL the splits the stand-alone attention would
+     * use. 0: never fuse. Takes effect for programs compiled afterwards and at the next plan rebuild of existing ones.
+     * A hand-off wait that gives up is bounded and reported at the next host synchronisation (sticky error on the context): the
+     * results of THAT execution are wrong, including the KV-cache column it wrote — re-run the step at the same position (the
+     * context has switched the fusion off and rebuilt the plan, the re-run rewrites the column); nothing older is affected. */
     ZGML_HIP_OPT_FUSE_RESIDENT_WGS = 8
 };
 int zgml_hip_set_option(zgml_hip_ctx* ctx, int option, int64_t value);

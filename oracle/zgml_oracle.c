@@ -1106,8 +1106,11 @@ static void zo_gemv_range_scalar(const int8_t* t_d, const float* t_s, const int8
 
 /* The reference's kernel is AArch64 `sdot` (16-lane int8 dot into int32, 4 rows unrolled: quant.zig:358-440). The x86 arm of
  * the same arithmetic: AVX-512 VNNI `vpdpbusd` on one 32-byte block of 8 rows at a time. vpdpbusd
- * multiplies UNSIGNED by signed bytes, so the sign of x moves to w first (|x| * (w * sgn x) = x * w; quantizeInput clamps to
- * +-127, so |x| never overflows). The eight 8-lane partial vectors are reduced to one int32 per row by a horizontal-add tree
+ * multiplies UNSIGNED by signed bytes, so the sign of w moves to x first: |w| * (x * sgn w) = w * x. |w| is taken as an
+ * UNSIGNED byte, so w = -128 (raw GGUF Q8_0 bytes may hold it; prepareTransposed's own output is clamped to +-127) is 128,
+ * not a wrapped -128 (with the roles the other way round, _mm256_sign_epi8(w, x) kept w = -128 at -128 for
+ * x < 0 and the product's sign flipped). x * sgn w only wraps for x = -128 with w < 0; quantizeInput clamps x to +-127, and
+ * a block of an arbitrary caller that does hold -128 takes the scalar loop. The eight 8-lane partial vectors are reduced to one int32 per row by a horizontal-add tree
  * — the integers are exact, so this is the scalar loop's integer — and the f32 combine (convert, multiply by s_x * s_w, add,
  * blocks ascending, no FMA) is the scalar loop's, lane by lane: bit-identical results (tests/test_oracle_w8a8.py). */
 #if defined(__x86_64__)
@@ -1129,16 +1132,27 @@ __attribute__((target("avx2,avx512f,avx512vl,avx512vnni"))) static void zo_gemv_
         __m256 acc = _mm256_setzero_ps();
         for (uint64_t b = 0; b < bpr; b++) {
             const __m256i x = _mm256_loadu_si256((const __m256i*)(inp_q + 32 * b));
-            const __m256i ax = _mm256_abs_epi8(x);
-            __m256i v[8];
-            for (int r = 0; r < 8; r++) {
-                const __m256i w = _mm256_loadu_si256((const __m256i*)(t_d + (n + r) * K + 32 * b));
-                v[r] = _mm256_dpbusd_epi32(_mm256_setzero_si256(), ax, _mm256_sign_epi8(w, x));
+            __m256i ia;
+            if (_mm256_movemask_epi8(_mm256_cmpeq_epi8(x, _mm256_set1_epi8((char)-128))) != 0) { /* x = -128 somewhere: the scalar integers */
+                int32_t iv[8];
+                for (int r = 0; r < 8; r++) {
+                    const int8_t* w = t_d + (n + r) * K + 32 * b;
+                    int32_t t = 0;
+                    for (int k = 0; k < 32; k++) t += (int32_t)inp_q[32 * b + k] * (int32_t)w[k];
+                    iv[r] = t;
+                }
+                ia = _mm256_loadu_si256((const __m256i*)iv);
+            } else {
+                __m256i v[8];
+                for (int r = 0; r < 8; r++) {
+                    const __m256i w = _mm256_loadu_si256((const __m256i*)(t_d + (n + r) * K + 32 * b));
+                    v[r] = _mm256_dpbusd_epi32(_mm256_setzero_si256(), _mm256_abs_epi8(w), _mm256_sign_epi8(x, w)); /* |w| (u8: -128 -> 128) x (x sgn w) */
+                }
+                const __m256i h01 = _mm256_hadd_epi32(v[0], v[1]), h23 = _mm256_hadd_epi32(v[2], v[3]);
+                const __m256i h45 = _mm256_hadd_epi32(v[4], v[5]), h67 = _mm256_hadd_epi32(v[6], v[7]);
+                const __m256i q0 = _mm256_hadd_epi32(h01, h23), q1 = _mm256_hadd_epi32(h45, h67); /* rows 0-3 / 4-7, low | high half sums */
+                ia = _mm256_add_epi32(_mm256_permute2x128_si256(q0, q1, 0x20), _mm256_permute2x128_si256(q0, q1, 0x31));
             }
-            const __m256i h01 = _mm256_hadd_epi32(v[0], v[1]), h23 = _mm256_hadd_epi32(v[2], v[3]);
-            const __m256i h45 = _mm256_hadd_epi32(v[4], v[5]), h67 = _mm256_hadd_epi32(v[6], v[7]);
-            const __m256i q0 = _mm256_hadd_epi32(h01, h23), q1 = _mm256_hadd_epi32(h45, h67); /* rows 0-3 / 4-7, low | high half sums */
-            const __m256i ia = _mm256_add_epi32(_mm256_permute2x128_si256(q0, q1, 0x20), _mm256_permute2x128_si256(q0, q1, 0x31));
             const float sx = inp_scales[b];
             const __m256 comb = _mm256_mul_ps(_mm256_set1_ps(sx), _mm256_set_ps(t_s[(n + 7) * bpr + b], t_s[(n + 6) * bpr + b], t_s[(n + 5) * bpr + b],
                                                                                 t_s[(n + 4) * bpr + b], t_s[(n + 3) * bpr + b], t_s[(n + 2) * bpr + b],

@@ -11,6 +11,14 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from zgml_amd import Backend, capi, llama  # noqa: E402
 
 
+def _download(be, hip, handle, buf, n):
+    import numpy as np
+    out = np.zeros(n, np.float32)
+    io = (capi.ProgramIOC * 1)(capi.ProgramIOC(buf, 0, 0, out.ctypes.data, 4 * n, 0))
+    hip.zgml_hip_download_outputs(be.ctx, handle, io, 1)
+    return out
+
+
 def main():
     be = Backend(0)
     hip = capi.load_hip()
@@ -28,6 +36,7 @@ def main():
     s = llama.Session(m, llama.hip_backend_fns(be))
     want, _ = s.decode(3, 0, 6)
     out["plain_err"] = be.last_error()
+    kv_want = [_download(be, hip, s.handle, buf, n) for buf, n in m.kv_buffers()]
     plain_launches = hip.zgml_hip_get_runtime_profile(be.ctx, s.handle).contents.backend_dispatch_count // 6
     s.close()
     be.set_option(capi.OPT_FUSE_RESIDENT_WGS, -1)
@@ -42,6 +51,10 @@ def main():
     out["launches_after"] = (hip.zgml_hip_get_runtime_profile(be.ctx, s.handle).contents.backend_dispatch_count - before) // 6
     out["plain_launches"] = plain_launches
     out["tokens_equal"] = got.tolist() == want.tolist()
+    # the contract of include/zgml_hip.h (ZGML_HIP_OPT_FUSE_RESIDENT_WGS): the failed execution's KV column is wrong, re-running the
+    # step at the same position rewrites it — after the re-run above the caches hold exactly what the two-launch plan writes
+    kv_got = [_download(be, hip, s.handle, buf, n) for buf, n in m.kv_buffers()]
+    out["kv_equal_after_rerun"] = all((a.view("uint32") == b.view("uint32")).all() for a, b in zip(kv_got, kv_want))
     s.close()
     # a program compiled afterwards in the same context never fuses again
     s = llama.Session(m, llama.hip_backend_fns(be))

@@ -162,3 +162,41 @@ def test_gemv_range_vnni_arm_is_bit_identical_to_the_scalar_loop(oracle, K, N):
         assert np.array_equal(fast, _gemv_model(t_data, t_scales, q, s, N, K, 32))
     finally:
         O.set_vnni(-1)
+
+
+def test_gemv_range_vnni_arm_with_minus_128_bytes(oracle):
+    """zo_gemv_range is exported and takes arbitrary int8 bytes — raw GGUF Q8_0 blocks can hold w = -128, a caller's
+    own quantiser x = -128. vpdpbusd multiplies unsigned by signed bytes: the arm now takes |w| as the UNSIGNED operand (128 fits)
+    and x * sgn(w) as the signed one, and a block whose x holds -128 takes the scalar integers. Every combination of extreme
+    bytes gives the scalar loop's bits (before the fix _mm256_sign_epi8(w, x) kept w = -128 at -128 for x < 0: sign flipped)."""
+    import ctypes as C
+    from oracle import oracle as O
+    O.set_vnni(1)
+    if not O.gemv_uses_vnni():
+        O.set_vnni(-1)
+        pytest.skip("host has no AVX-512 VNNI")
+    try:
+        K, N = 128, 16
+        rng = np.random.default_rng(128)
+        t_d = rng.integers(-128, 128, N * K, dtype=np.int8)
+        t_d[:K] = -128                      # a whole row of -128
+        t_d[K:K + 32] = 127
+        q = rng.integers(-127, 128, K, dtype=np.int8)
+        q[:16] = -127                       # x < 0 against w = -128: the case that flipped
+        q[40] = -128                        # block 1 holds x = -128: scalar integers for that block
+        t_s = (rng.random(N * (K // 32), dtype=np.float32) * 0.01 + 0.001).astype(np.float32)
+        s = (rng.random(K // 32, dtype=np.float32) + 0.5).astype(np.float32)
+        lib = O.load()
+
+        def run():
+            dst = np.zeros(N, np.float32)
+            lib.zo_gemv_range(t_d.ctypes.data, t_s.ctypes.data, q.ctypes.data, s.ctypes.data, dst.ctypes.data, 0, N, K, 32)
+            return dst
+        fast = run()
+        O.set_vnni(0)
+        slow = run()
+        assert np.array_equal(fast, slow)
+        assert np.array_equal(fast, _gemv_model(t_d, t_s, q, s, N, K, 32))
+        assert fast[0] > 0 or True  # (row 0: -128 x mostly negative x: the sign the old arm got wrong is pinned by the equality above)
+    finally:
+        O.set_vnni(-1)

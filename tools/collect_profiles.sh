@@ -4,7 +4,7 @@
 #   --pmc FETCH_SIZE pass of the mat-vec ring. Summaries land under gpurun_out/prof_<tag>/ ; copy the
 #   ones to be judged into profiles/ (tools/summarise_profiles.py does that).
 set -e -o pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"

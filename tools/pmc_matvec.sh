@@ -3,7 +3,7 @@
 # activity, issue stalls, busy cycles, waves — one counter group per pass (separate runs, as the guide prescribes;
 # the program sits directly after `--`). SHAPES: comma list, default the roofline shape and the gate/up-sized one.
 set -e -o pipefail
-TAG=${TAG:-r03}
+TAG=${TAG:-r04}
 OUT=gpurun_out/pmc_mv_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"

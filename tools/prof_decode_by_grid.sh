@@ -2,7 +2,7 @@
 # rocprofv3 kernel trace of a resident decode run, aggregated per (kernel, grid): tools/prof_decode_by_grid.sh <model> <steps> <outname> [env...]
 set -o pipefail
 MODEL=$1; STEPS=$2; NAME=$3
-OUT=gpurun_out/r3/$NAME
+OUT=gpurun_out/${ROUND_DIR:-r4}/$NAME
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 tools/decode_run.py $MODEL $STEPS > $OUT.log 2>&1

@@ -341,6 +341,141 @@ __global__ void __launch_bounds__(512) dense_f16_tile2_kernel(F16Args2 a) {
     }
 }
 
+constexpr int kT3Chunks = 4; // (the experiment below) 32-k chunks per stage: 512 threads x 16 B = 4 chunks x R = 2 tiles x 1 KiB
+constexpr int kT3Waves = 8;
+#ifdef ZGML_TRACE // diagnostics build only: MEASURED NO FASTER than the form above (tools/f16_m32_sweep.sh)
+// ── M <= 32, third form (round 4 experiment): A SHARED through LDS, K split over workgroups ─────────────────────────────
+// Result: 32 x 4096 x 22016 46.2 us against 42.6 (two column groups per workgroup above), 4096^2 15.5 against 13.2, K = 11008
+// 25.3 against 27.4 at 8 slices: taking seven eighths of the A traffic out of the vector-memory path did NOT raise the stream
+// (4.0-4.5 TB/s either way, a read-only stream of the same access shape does 6.5) — the A re-read is not what paces the launch.
+// The hypothesis it was built on: what paces the form above (3.6 TB/s at 32 x 4096 x 22016) is the A operand:
+// every workgroup (16 columns) re-reads the whole pre-laid-out A from L2 — R KiB per 1 KiB of weights — through the CU's one
+// vector-memory return path. Here a workgroup owns 8 column groups (128 columns: one per wave) and a SLICE of K:
+//   * all eight waves work on the SAME 32-k chunks, so a chunk's A operand (R KiB) is fetched from L2 ONCE per workgroup, by
+//     one 16-byte load per thread for a stage of kT3Chunks chunks, parked in LDS (two stages: one barrier per stage) and read
+//     back by every wave with ds_read_b128: A : B through the vector-memory path drops from R : 1 to R : 8;
+//   * a wave streams only its own column group's weights (1 KiB per chunk, two stages in flight) and owns its 16 x 16R output
+//     tile: no cross-wave fold;
+//   * the grid is (column tiles, K slices): enough workgroups for every CU although a tile is 128 columns wide. A K split
+//     publishes partial tiles (write-through stores, drained, one agent-scope add on the tile's counter); the LAST arriver
+//     sums the slices IN SLICE ORDER (deterministic: two executions agree bit for bit) and stores.
+struct F16Args3 {
+    F16Part2 parts[kMaxF16Parts]; // block_begin in COLUMN TILES (8 column groups)
+    const uint4* ap;              // pack_a_f16_kernel output: [tile][KC][64] uint4
+    float* partial;               // [column tile][slice][wave][R][4][64] floats
+    uint32_t* counter;            // one word per column tile, zero between launches
+    uint32_t n_parts, M, KC, SK, chunks_per_slice;
+};
+template <int R, bool NT>
+__global__ void __launch_bounds__(kT3Waves * 64) dense_f16_tile3_kernel(F16Args3 a) {
+    static_assert(R * kT3Chunks * 64 == kT3Waves * 64, "one 16-byte A load per thread and stage");
+    __shared__ uint4 lds_a[2][kT3Chunks * R * 64];
+    __shared__ uint32_t flag;
+    const uint32_t lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t pi = 0;
+#pragma unroll
+    for (uint32_t t = 1; t < (uint32_t)kMaxF16Parts; t++)
+        if (t < a.n_parts && blockIdx.x >= a.parts[t].block_begin) pi = t;
+    const F16Part2& P = a.parts[pi];
+    const uint32_t tile = blockIdx.x - P.block_begin, g = tile * kT3Waves + w, slice = blockIdx.y;
+    const uint32_t c_begin = slice * a.chunks_per_slice, c_end = min(c_begin + a.chunks_per_slice, a.KC), c_last = a.KC - 1;
+    const uint4* const bp = P.bp + (uint64_t)g * a.KC * 64 + lane;
+    // this thread's share of a stage's A: chunk (tid / (R * 64)), tile ((tid / 64) % R), lane
+    const uint32_t a_cc = threadIdx.x / (R * 64), a_t = (threadIdx.x >> 6) % R;
+    const uint4* const ap = a.ap + (uint64_t)a_t * a.KC * 64 + lane;
+    auto load_a = [&](uint32_t c0) { return ap[(uint64_t)min(c0 + a_cc, c_last) * 64]; };
+    struct BStage {
+        uint4 b[kT3Chunks];
+    };
+    auto load_b = [&](BStage& x, uint32_t c0) { // clamped, unconditional; chunks past the slice's end are never multiplied
+#pragma unroll
+        for (int j = 0; j < kT3Chunks; j++) {
+            const uint4* const src = bp + (uint64_t)min(c0 + j, c_last) * 64;
+            if (NT) {
+                typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+                const u4v v = __builtin_nontemporal_load((const u4v*)src);
+                x.b[j] = make_uint4(v.x, v.y, v.z, v.w);
+            } else {
+                x.b[j] = *src;
+            }
+        }
+    };
+    mfma_f4 acc[R];
+#pragma unroll
+    for (int t = 0; t < R; t++) acc[t] = mfma_f4{0.f, 0.f, 0.f, 0.f};
+    BStage cur, nxt;
+    uint4 a_reg = load_a(c_begin);
+    load_b(cur, c_begin);
+    lds_a[0][threadIdx.x] = a_reg;
+    __syncthreads();
+    uint32_t buf = 0;
+    for (uint32_t c0 = c_begin; c0 < c_end; c0 += kT3Chunks) {
+        a_reg = load_a(c0 + kT3Chunks);
+        load_b(nxt, c0 + kT3Chunks);
+        __builtin_amdgcn_sched_barrier(0); // the next stage is requested before this one is multiplied
+#pragma unroll
+        for (int j = 0; j < kT3Chunks; j++) {
+            if (c0 + j < c_end) { // (scalar: c0, c_end are wave-uniform)
+                const half8 bv = __builtin_bit_cast(half8, cur.b[j]);
+#pragma unroll
+                for (int t = 0; t < R; t++)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, lds_a[buf][(j * R + t) * 64 + lane]), bv, acc[t], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        lds_a[buf ^ 1][threadIdx.x] = a_reg; // (every wave left that buffer at the previous barrier)
+        __syncthreads();
+        cur = nxt;
+        buf ^= 1;
+    }
+    // D[m = 16 t + 4 (lane / 16) + v][n = 16 g + lane % 16] in acc[t][v]
+    if (a.SK > 1) {
+        using gf32 = __attribute__((address_space(1))) float;
+        using gu32 = __attribute__((address_space(1))) unsigned int;
+        constexpr uint32_t WT = R * 256; // floats of one wave's tile
+        float* const mine = a.partial + (((uint64_t)blockIdx.x * a.SK + slice) * kT3Waves + w) * WT + lane;
+#pragma unroll
+        for (int t = 0; t < R; t++)
+#pragma unroll
+            for (int v = 0; v < 4; v++) __hip_atomic_store((gf32*)(mine + (t * 4 + v) * 64), acc[t][v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains before the count
+        __syncthreads();
+        if (threadIdx.x == 0) flag = __hip_atomic_fetch_add((gu32*)(a.counter + blockIdx.x), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (flag != a.SK - 1) return; // not the last slice of this column tile
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // compiler only: the loads below stay below the count
+#pragma unroll
+        for (int t = 0; t < R; t++) acc[t] = mfma_f4{0.f, 0.f, 0.f, 0.f};
+        const float* const base = a.partial + (((uint64_t)blockIdx.x * a.SK) * kT3Waves + w) * WT + lane;
+        for (uint32_t s0 = 0; s0 < a.SK; s0 += 4) { // slice order, four slices' loads in flight together
+            float pv[4][R * 4];
+#pragma unroll
+            for (uint32_t q = 0; q < 4; q++) {
+                const uint32_t sl = min(s0 + q, a.SK - 1);
+#pragma unroll
+                for (int e = 0; e < R * 4; e++)
+                    pv[q][e] = __hip_atomic_load((gf32*)(base + (uint64_t)sl * kT3Waves * WT + e * 64), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (uint32_t q = 0; q < 4; q++)
+#pragma unroll
+                for (int t = 0; t < R; t++)
+#pragma unroll
+                    for (int v = 0; v < 4; v++) acc[t][v] += s0 + q < a.SK ? pv[q][t * 4 + v] : 0.f;
+        }
+        if (threadIdx.x == 0) __hip_atomic_store((gu32*)(a.counter + blockIdx.x), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // re-arm
+    }
+#pragma unroll
+    for (int t = 0; t < R; t++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            const uint32_t m = t * 16 + 4 * (lane >> 4) + v, n = g * 16 + (lane & 15);
+            if (m < a.M) P.out[(uint64_t)m * P.out_rs + n] = acc[t][v];
+        }
+}
+
+#endif // ZGML_TRACE
+
 // f32 B (any strides, device memory) -> MFMA-packed f16. One thread per 16-byte item.
 __global__ void __launch_bounds__(kBlock) pack_f16_kernel(const float* __restrict__ b, uint32_t b_rs, uint32_t b_cs,
                                                           uint32_t K, uint32_t N, uint32_t KC, uint4* __restrict__ out) {
@@ -380,11 +515,55 @@ static uint32_t f16_tiles_per_wg(uint32_t M) { // m-tiles a workgroup of the A-p
 bool dense_f16_a_unpadded(uint32_t M, uint32_t K) {
     return M > 1 && M % 16 == 0 && K % 32 == 0 && (M / 16) % f16_tiles_per_wg(M) == 0 && dense_f16_scratch_bytes(M, K) != 0;
 }
+static uint64_t f16_a_bytes(uint32_t M, uint32_t K) { // the pre-laid-out A operand (rounded up to 256 B)
+    const uint64_t tiles = (M + 15) / 16, R = f16_tiles_per_wg(M);
+    return ((tiles + R - 1) / R * R * ((K + 31) / 32) * 1024 + 255) / 256 * 256;
+}
+// the shared-A form's K split: at most kT3MaxWgs workgroups per launch, one partial tile (8 waves x R x 1 KiB) each
+constexpr uint64_t kT3MaxWgs = 1024;
+static bool f16_tile3_on() { // the shared-A K-split experiment: diagnostics build only, and only on request
+#ifdef ZGML_TRACE
+    static const bool on = getenv("ZGML_F16_TILE3") && atoi(getenv("ZGML_F16_TILE3")) != 0;
+    return on;
+#else
+    return false;
+#endif
+}
 uint64_t dense_f16_scratch_bytes(uint32_t M, uint32_t K) {
     static const bool on = !(getenv("ZGML_F16_TILE2") && atoi(getenv("ZGML_F16_TILE2")) == 0);
     if (!on || M <= 1) return 0;
-    const uint64_t tiles = (M + 15) / 16, R = f16_tiles_per_wg(M);
-    return (tiles + R - 1) / R * R * ((K + 31) / 32) * 1024;
+    return f16_a_bytes(M, K) + (M <= 32 && M > 16 && f16_tile3_on() ? kT3MaxWgs * kT3Waves * 2 * 1024 : 0);
+}
+
+// M in (16, 32], every part a whole number of 128-column tiles: the shared-A form with a K split. false: not applicable.
+static bool launch_dense_f16_tile3(hipStream_t s, const DenseF16Params* p, uint32_t n, uint32_t KC) {
+#ifndef ZGML_TRACE
+    (void)s, (void)p, (void)n, (void)KC;
+    return false;
+#else
+    if (!f16_tile3_on() || p[0].M <= 16 || p[0].M > 32) return false;
+    F16Args3 a{};
+    uint32_t tiles = 0;
+    for (uint32_t t = 0; t < n; t++) {
+        if ((p[t].N / 16) % kT3Waves != 0) return false;
+        a.parts[t] = {(const uint4*)p[t].bp, p[t].dst, p[t].dst_rs, tiles};
+        tiles += p[t].N / 16 / kT3Waves;
+    }
+    if ((uint64_t)tiles * sizeof(uint32_t) > kQmmScratchHead) return false; // one counter word per column tile
+    // K slices: ~2.5 workgroups per CU, whole stages per slice, at least 4 stages each, no more partial tiles than the scratch holds
+    static const int env_sk = getenv("ZGML_F16_TILE3_SK") ? atoi(getenv("ZGML_F16_TILE3_SK")) : 0;
+    const uint32_t stages = cdiv(KC, kT3Chunks);
+    uint32_t SK = env_sk > 0 ? (uint32_t)env_sk : std::max(1u, std::min(cdiv(640u, tiles), stages / 4));
+    SK = std::max(1u, std::min<uint32_t>(SK, (uint32_t)(kT3MaxWgs / tiles)));
+    uint32_t cps = cdiv(stages, SK) * kT3Chunks; // chunks per slice
+    SK = cdiv(KC, cps);
+    a.ap = (const uint4*)p[0].scratch, a.n_parts = n, a.M = p[0].M, a.KC = KC, a.SK = SK, a.chunks_per_slice = cps;
+    a.partial = (float*)((char*)p[0].scratch + f16_a_bytes(p[0].M, p[0].K));
+    a.counter = (uint32_t*)((char*)p[0].scratch - kQmmScratchHead);
+    const bool nt = p[0].stream_nt != 0;
+    hipLaunchKernelGGL((nt ? dense_f16_tile3_kernel<2, true> : dense_f16_tile3_kernel<2, false>), dim3(tiles, SK), dim3(kT3Waves * 64), 0, s, a);
+    return true;
+#endif
 }
 
 static void launch_dense_f16_tile2(hipStream_t s, const DenseF16Params* p, uint32_t n) {
@@ -394,6 +573,7 @@ static void launch_dense_f16_tile2(hipStream_t s, const DenseF16Params* p, uint3
         pack_a_f16_kernel<<<(uint32_t)std::min<uint64_t>(2048, (items + kBlock - 1) / kBlock), kBlock, 0, s>>>(p[0].a, p[0].M, p[0].K, p[0].a_rs, KC,
                                                                                                              tiles, (uint4*)p[0].scratch);
     }
+    if (R == 2 && tiles == 2 && launch_dense_f16_tile3(s, p, n, KC)) return;
     static const int env_w = getenv("ZGML_F16_TILE2_WAVES") ? atoi(getenv("ZGML_F16_TILE2_WAVES")) : 8;
     const uint32_t waves = std::max(1u, std::min<uint32_t>(KC, (uint32_t)env_w));
     // column groups per workgroup (R <= 2 only: the wide-M forms already amortise A over 4 / 8 m-tiles): as many as keep the grid

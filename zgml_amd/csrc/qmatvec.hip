@@ -1277,7 +1277,10 @@ __global__ void __launch_bounds__(1024) qkv_attn_kernel(QMV_HEAD_PARAMS, QMVArgs
 
 // The same for K-on-lanes weights (K > 2048: Llama-2-7B's 768 projection workgroups + one or more per head): 256-thread
 // workgroups, both bodies at four waves and within 128 registers, so four workgroups per CU are resident and the whole grid is
-// co-resident (fuse_qkv_attention checks it against the occupancy query minus one workgroup per CU).
+// co-resident (fuse_qkv_attention builds the launch only when projection + attention workgroups fit what the occupancy query admits:
+// four per CU at <= 128 registers and 96-100 SGPRs, which both the register file and the guide's SGPR admission rule confirm — NO
+// margin: the 7B grid is exactly 1024 = 4 x 256; the projection's workgroups carry the lower ids, so should fewer be resident than
+// counted the attention's workgroups queue behind them instead of spinning beside them; a wait that gives up is bounded and loud).
 template <int LPK, int DEPTH, int PROM, bool NT, bool KVQ>
 __global__ void __launch_bounds__(256, 4) qkv_attn_kon_kernel(QMV_HEAD_PARAMS, QMVArgs a, QkvAttnArgs f) {
     if (blockIdx.x < f.n_mv) {

@@ -2166,6 +2166,14 @@ void build_fused_plan(zgml_hip_program* p) {
 }
 
 void build_plan(zgml_hip_program* p) {
+    { // a rebuild synchronises the stream and may launch (hoisted repeats): never inside a caller's stream capture (ADVICE r03 — a
+      // first upload to a hoist-guarded buffer, or a fusion time-out, can mark the plan dirty between two enqueue calls)
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(p->ctx->stream, &st) == hipSuccess && st != hipStreamCaptureStatusNone) {
+            p->ctx->fail("build_plan: the plan has to be rebuilt, but the context's stream is being captured — run one step outside the capture first");
+            return;
+        }
+    }
     hipStreamSynchronize(p->ctx->stream); // the previous plan's parameter arrays may still be in use
     p->plan.clear();
     for (size_t i = 0; i < p->ops.size(); i++) { // (refresh_program refuses this already; a launch must never be skipped silently)
@@ -3296,8 +3304,10 @@ double zgml_hip_dense_f16_bench(zgml_hip_ctx* ctx, uint32_t M, uint32_t K, uint3
     double us = -1.0;
     if (ok) {
         DenseF16Params fp{y, x, nullptr, M, N, K, K, N, f16_packed_bytes(K, N) * n_matrices >= (192ull << 20) ? 1u : 0u};
-        if (const uint64_t sb = dense_f16_scratch_bytes(M, K)) ok = CTX_CHECK(ctx, hipMalloc(&a_scratch, sb));
-        fp.scratch = a_scratch;
+        if (const uint64_t sb = dense_f16_scratch_bytes(M, K)) { // (kernels.h: the head in front of the block holds the K-split counters)
+            ok = CTX_CHECK(ctx, hipMalloc(&a_scratch, kQmmScratchHead + sb)) && CTX_CHECK(ctx, hipMemsetAsync(a_scratch, 0, kQmmScratchHead, ctx->stream));
+        }
+        fp.scratch = a_scratch ? (char*)a_scratch + kQmmScratchHead : nullptr;
         for (uint32_t i = 0; ok && i < warmup; i++) {
             fp.bp = ring[i % n_matrices];
             launch_dense_f16(ctx->stream, fp);
@@ -3778,6 +3788,13 @@ int zgml_hip_resident_setup(zgml_hip_ctx* ctx, zgml_hip_program* p, const zgml_r
         free_resident(p);
         return -1;
     }
+    // The resident kernels write token_input, attn_mask and the rope buffers from the device, outside the op list: to the hoist
+    // analysis those buffers look like constants (never written by an op), so a `repeat` that broadcasts one of them would have
+    // been run once at plan build and its stale copy read ever after. Today's LLaMA stream only repeats gamma and the
+    // scalar 1, but the guard must not depend on that: every buffer handed over here leaves the hoisted set.
+    unhoist_if_guarded(p, d->buf_token_input);
+    unhoist_if_guarded(p, d->buf_attn_mask);
+    for (uint32_t l = 0; l < d->n_rope; l++) unhoist_if_guarded(p, d->buf_rope[l]);
     return 0;
 }
 
