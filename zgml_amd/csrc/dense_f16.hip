@@ -256,7 +256,10 @@ __global__ void __launch_bounds__(kBlock) pack_a_f16_kernel(const float* __restr
     }
 }
 
-template <int R, bool NT, int CG = 1>
+// SINK (diagnostics build, ZGML_F16_SINK=1 / 2): the same kernel with its MFMAs replaced by a vector-ALU sink of the operands
+// (1: xor of every loaded dword into the accumulators) or with the A loads gone as well (2) — WRONG results by construction;
+// separates what the matrix instructions cost the stream from what the memory path costs.
+template <int R, bool NT, int CG = 1, int SINK = 0>
 __global__ void __launch_bounds__(512) dense_f16_tile2_kernel(F16Args2 a) {
     // chunks in flight per wave, (CG + R) x 16 B per lane each (8 measured no faster at R = 2). R = 4 / 8 (prefill chunks of
     // 64 / 128 tokens): all m-tiles in one workgroup, so the weights are read ONCE per matmul instead of once per tile pair
@@ -297,7 +300,7 @@ __global__ void __launch_bounds__(512) dense_f16_tile2_kernel(F16Args2 a) {
             }
         }
 #pragma unroll
-        for (int t = 0; t < R; t++) x.av[t] = ap[t * tile_stride + (uint64_t)cc * 64];
+        for (int t = 0; t < R; t++) x.av[t] = SINK == 2 ? make_uint4(cc, 1u, 2u, 3u) : ap[t * tile_stride + (uint64_t)cc * 64];
     };
     mfma_f4 acc[R][CG];
 #pragma unroll
@@ -319,7 +322,15 @@ __global__ void __launch_bounds__(512) dense_f16_tile2_kernel(F16Args2 a) {
                 for (int j = 0; j < CG; j++) {
                     const half8 bv = __builtin_bit_cast(half8, cur.b[j]);
 #pragma unroll
-                    for (int t = 0; t < R; t++) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, cur.av[t]), bv, acc[t][j], 0, 0, 0);
+                    for (int t = 0; t < R; t++) {
+                        if (SINK) { // four vector-ALU instructions per (tile, column group) instead of one MFMA
+                            const uint4 bq = cur.b[j], aq = cur.av[t];
+                            acc[t][j][0] = __uint_as_float(__float_as_uint(acc[t][j][0]) ^ bq.x ^ aq.x), acc[t][j][1] = __uint_as_float(__float_as_uint(acc[t][j][1]) ^ bq.y ^ aq.y);
+                            acc[t][j][2] = __uint_as_float(__float_as_uint(acc[t][j][2]) ^ bq.z ^ aq.z), acc[t][j][3] = __uint_as_float(__float_as_uint(acc[t][j][3]) ^ bq.w ^ aq.w);
+                        } else {
+                            acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, cur.av[t]), bv, acc[t][j], 0, 0, 0);
+                        }
+                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -369,7 +380,7 @@ struct F16Args3 {
 template <int R, bool NT>
 __global__ void __launch_bounds__(kT3Waves * 64) dense_f16_tile3_kernel(F16Args3 a) {
     static_assert(R * kT3Chunks * 64 == kT3Waves * 64, "one 16-byte A load per thread and stage");
-    __shared__ uint4 lds_a[2][kT3Chunks * R * 64];
+    __shared__ uint4 lds_a[3][kT3Chunks * R * 64]; // three stages: the one being multiplied, the next (already parked), the one after (in flight)
     __shared__ uint32_t flag;
     const uint32_t lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t pi = 0;
@@ -403,16 +414,20 @@ __global__ void __launch_bounds__(kT3Waves * 64) dense_f16_tile3_kernel(F16Args3
     mfma_f4 acc[R];
 #pragma unroll
     for (int t = 0; t < R; t++) acc[t] = mfma_f4{0.f, 0.f, 0.f, 0.f};
-    BStage cur, nxt;
-    uint4 a_reg = load_a(c_begin);
+    // two stages of weights in flight per wave beside the one being multiplied (with one, a workgroup keeps 4 KiB per wave in
+    // flight and the stream starves: Little's law)
+    BStage cur, n1, n2;
+    uint4 a0 = load_a(c_begin);
     load_b(cur, c_begin);
-    lds_a[0][threadIdx.x] = a_reg;
+    uint4 a1 = load_a(c_begin + kT3Chunks);
+    load_b(n1, c_begin + kT3Chunks);
+    lds_a[0][threadIdx.x] = a0;
     __syncthreads();
     uint32_t buf = 0;
     for (uint32_t c0 = c_begin; c0 < c_end; c0 += kT3Chunks) {
-        a_reg = load_a(c0 + kT3Chunks);
-        load_b(nxt, c0 + kT3Chunks);
-        __builtin_amdgcn_sched_barrier(0); // the next stage is requested before this one is multiplied
+        const uint4 a2 = load_a(c0 + 2 * kT3Chunks);
+        load_b(n2, c0 + 2 * kT3Chunks);
+        __builtin_amdgcn_sched_barrier(0); // the stage after next is requested before this one is multiplied
 #pragma unroll
         for (int j = 0; j < kT3Chunks; j++) {
             if (c0 + j < c_end) { // (scalar: c0, c_end are wave-uniform)
@@ -423,10 +438,11 @@ __global__ void __launch_bounds__(kT3Waves * 64) dense_f16_tile3_kernel(F16Args3
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        lds_a[buf ^ 1][threadIdx.x] = a_reg; // (every wave left that buffer at the previous barrier)
+        const uint32_t nb = buf == 2 ? 0 : buf + 1;
+        lds_a[nb][threadIdx.x] = a1; // (that buffer was last read two stages ago: every wave has passed a barrier since)
         __syncthreads();
-        cur = nxt;
-        buf ^= 1;
+        cur = n1, n1 = n2, a1 = a2;
+        buf = nb;
     }
     // D[m = 16 t + 4 (lane / 16) + v][n = 16 g + lane % 16] in acc[t][v]
     if (a.SK > 1) {
@@ -611,11 +627,20 @@ static void launch_dense_f16_tile2(hipStream_t s, const DenseF16Params* p, uint3
 #define ZGML_T2(RV) (CG == 4 ? (nt ? (Fn2)dense_f16_tile2_kernel<RV, true, 4> : (Fn2)dense_f16_tile2_kernel<RV, false, 4>)                    \
                      : CG == 2 ? (nt ? (Fn2)dense_f16_tile2_kernel<RV, true, 2> : (Fn2)dense_f16_tile2_kernel<RV, false, 2>)                 \
                                : (nt ? (Fn2)dense_f16_tile2_kernel<RV, true, 1> : (Fn2)dense_f16_tile2_kernel<RV, false, 1>))
-    const Fn2 fn = R == 8   ? (nt ? (Fn2)dense_f16_tile2_kernel<8, true> : (Fn2)dense_f16_tile2_kernel<8, false>)
-                   : R == 4 ? (nt ? (Fn2)dense_f16_tile2_kernel<4, true> : (Fn2)dense_f16_tile2_kernel<4, false>)
-                   : R == 2 ? ZGML_T2(2)
-                            : ZGML_T2(1);
+    Fn2 fn = R == 8   ? (nt ? (Fn2)dense_f16_tile2_kernel<8, true> : (Fn2)dense_f16_tile2_kernel<8, false>)
+             : R == 4 ? (nt ? (Fn2)dense_f16_tile2_kernel<4, true> : (Fn2)dense_f16_tile2_kernel<4, false>)
+             : R == 2 ? ZGML_T2(2)
+                      : ZGML_T2(1);
 #undef ZGML_T2
+#ifdef ZGML_TRACE // the MFMA-sink experiment (wrong results): diagnostics build only
+    static const int sink = getenv("ZGML_F16_SINK") ? atoi(getenv("ZGML_F16_SINK")) : 0;
+    if (sink && R == 2 && nt) {
+        if (CG == 2)
+            fn = sink == 2 ? (Fn2)dense_f16_tile2_kernel<2, true, 2, 2> : (Fn2)dense_f16_tile2_kernel<2, true, 2, 1>;
+        else if (CG == 1)
+            fn = sink == 2 ? (Fn2)dense_f16_tile2_kernel<2, true, 1, 2> : (Fn2)dense_f16_tile2_kernel<2, true, 1, 1>;
+    }
+#endif
     if (lds > 64 * 1024) hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(fn, grid, dim3(waves * 64), lds, s, a);
 }
