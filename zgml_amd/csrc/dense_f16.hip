@@ -492,6 +492,160 @@ __global__ void __launch_bounds__(kT3Waves * 64) dense_f16_tile3_kernel(F16Args3
 
 #endif // ZGML_TRACE
 
+#ifdef ZGML_TRACE // diagnostics build only (ZGML_F16_TILE4=1): parity green, MEASURED within +-5 % of the shipped form on wide outputs and
+                  // 28 % slower at 4096 x 4096 (profiles/r04_f16_m32_tile4.txt) — the A loads it removes are not all that paces the stream
+// ── M <= 32, fourth form (round 4 experiment): A STATIONARY in LDS ──────────────────────────────────────────────────────
+// The sink experiment (tools/f16_sink.sh) says what paces the forms above: not the MFMAs (replaced by a VALU sink: unchanged),
+// the A operand's GLOBAL loads (gone as well: 5.6 TB/s instead of 3.6-4.4) — R KiB of L2 hits per KiB of weights through the CU's
+// one vector-memory path. Here that path carries weights only:
+//   * one workgroup per CU (16 waves; its dynamic LDS is sized to keep a second one out) owns a K SLICE of <= 64 chunks and
+//     loads that slice of the pre-laid-out A (<= 128 KiB) into LDS ONCE; one barrier, then no A load and no barrier again;
+//   * a wave's work is a list of TASKS = (column group, this slice): the column groups cb, cb + n_cwg, ... of the workgroup's
+//     column class are dealt to its waves round-robin; per 32-k chunk a wave issues one 16-byte weight load per lane (1 KiB per
+//     wave-instruction, DEPTH in flight, the ring runs on across task boundaries), reads its two A operands from LDS
+//     (ds_read_b128, lane-contiguous: conflict-free) and issues two MFMAs; it owns its 16 x 32 output tile: no cross-wave fold;
+//   * K slices: as many as give every CU ~10 tasks (the tasks, not the workgroups, carry the parallelism). A split K publishes
+//     each task's partial tile (write-through stores, drained by the storing wave, one agent-scope add on the column group's
+//     counter); the LAST arriver of a column group sums ALL slices in slice order — its own included — so two executions agree
+//     bit for bit, stores, and re-arms the counter.
+#endif
+constexpr int kT4Waves = 16, kT4MaxSliceChunks = 64, kT4Depth = 4;
+#ifdef ZGML_TRACE
+struct F16Args4 {
+    F16Part2 parts[kMaxF16Parts]; // block_begin in COLUMN GROUPS
+    const uint4* ap;              // pack_a_f16_kernel output: [tile][KC][64] uint4
+    float* partial;               // [column group][slice][2][4][64] floats
+    uint32_t* counter;            // one word per column group, zero between launches
+    uint32_t n_parts, M, KC, SK, chunks_per_slice, n_cwg, total_groups;
+};
+template <bool NT>
+__global__ void __launch_bounds__(kT4Waves * 64) dense_f16_tile4_kernel(F16Args4 a) {
+    constexpr int R = 2;
+    extern __shared__ uint4 lds_a4[]; // [chunk of the slice][R][64]
+    const uint32_t lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t slice = blockIdx.x % a.SK, cb = blockIdx.x / a.SK;
+    const uint32_t c_begin = slice * a.chunks_per_slice, c_end = min(c_begin + a.chunks_per_slice, a.KC), S = c_end - c_begin;
+    // this wave's tasks: column groups cb + (w + kT4Waves * r) * n_cwg, r = 0, 1, ... (< total_groups)
+    const uint32_t g_first = cb + w * a.n_cwg, g_step = kT4Waves * a.n_cwg;
+    const uint32_t n_tasks = g_first < a.total_groups ? (a.total_groups - 1 - g_first) / g_step + 1 : 0;
+    auto part_of = [&](uint32_t g, uint32_t& gl) -> const F16Part2& { // (<= 3 parts: selects, no loop-carried lookups)
+        uint32_t pi = 0;
+#pragma unroll
+        for (uint32_t t = 1; t < (uint32_t)kMaxF16Parts; t++)
+            if (t < a.n_parts && g >= a.parts[t].block_begin) pi = t;
+        gl = g - a.parts[pi].block_begin;
+        return a.parts[pi];
+    };
+    auto b_src = [&](uint32_t task, uint32_t c) -> const uint4* { // weights of chunk c_begin + c of task `task` (clamped: in bounds)
+        const uint32_t g = min(g_first + task * g_step, a.total_groups - 1);
+        uint32_t gl;
+        const F16Part2& P = part_of(g, gl);
+        return P.bp + ((uint64_t)gl * a.KC + min(c_begin + c, a.KC - 1)) * 64 + lane;
+    };
+    auto wl = [&](const uint4* src) {
+        if (NT) {
+            typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+            const u4v v = __builtin_nontemporal_load((const u4v*)src);
+            return make_uint4(v.x, v.y, v.z, v.w);
+        }
+        return *src;
+    };
+    // the weight ring starts before the A slice is in LDS (its first loads fly while A is fetched)
+    uint4 ring[kT4Depth];
+    uint32_t lt = 0, lc = 0; // (task, chunk) of the next load
+    auto advance = [&](uint32_t& t, uint32_t& c) {
+        if (++c == S) c = 0, t++;
+    };
+    if (n_tasks) {
+#pragma unroll
+        for (int d = 0; d < kT4Depth; d++) {
+            ring[d] = wl(b_src(min(lt, n_tasks - 1), lc));
+            advance(lt, lc);
+        }
+    }
+    // A slice -> LDS: item (c, t, lane) of the slice from ap[t][c_begin + c][lane]
+    for (uint32_t i = threadIdx.x; i < S * R * 64; i += kT4Waves * 64) {
+        const uint32_t l = i & 63, t = (i >> 6) % R, c = i / (R * 64);
+        lds_a4[i] = a.ap[((uint64_t)t * a.KC + c_begin + c) * 64 + l];
+    }
+    __syncthreads();
+    if (!n_tasks) return;
+    using gf32 = __attribute__((address_space(1))) float;
+    using gu32 = __attribute__((address_space(1))) unsigned int;
+    for (uint32_t task = 0; task < n_tasks; task++) {
+        mfma_f4 acc[R] = {mfma_f4{0.f, 0.f, 0.f, 0.f}, mfma_f4{0.f, 0.f, 0.f, 0.f}};
+        for (uint32_t c0 = 0; c0 < S; c0 += kT4Depth) {
+#pragma unroll
+            for (int d = 0; d < kT4Depth; d++) {
+                const uint4 bq = ring[d];
+                ring[d] = wl(b_src(min(lt, n_tasks - 1), lc)); // refill the slot just read (runs on into the next task; clamped past the end)
+                advance(lt, lc);
+                __builtin_amdgcn_sched_barrier(0);
+                if (c0 + d < S) { // (scalar)
+                    const half8 bv = __builtin_bit_cast(half8, bq);
+#pragma unroll
+                    for (int t = 0; t < R; t++)
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, lds_a4[((c0 + d) * R + t) * 64 + lane]), bv, acc[t], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // (S need not be a multiple of the depth: the ring slots consumed past S belong to the next task's first chunks — realign)
+        if (S % kT4Depth) { // rare (K / 32 not a multiple of 4 per slice): restart the ring at the next task's first chunk
+            lt = task + 1, lc = 0;
+#pragma unroll
+            for (int d = 0; d < kT4Depth; d++) {
+                ring[d] = wl(b_src(min(lt, n_tasks - 1), lc));
+                advance(lt, lc);
+            }
+        }
+        const uint32_t g = g_first + task * g_step;
+        uint32_t gl;
+        const F16Part2& P = part_of(g, gl);
+        if (a.SK > 1) {
+            constexpr uint32_t WT = R * 256;
+            float* const mine = a.partial + ((uint64_t)g * a.SK + slice) * WT + lane;
+#pragma unroll
+            for (int t = 0; t < R; t++)
+#pragma unroll
+                for (int v = 0; v < 4; v++) __hip_atomic_store((gf32*)(mine + (t * 4 + v) * 64), acc[t][v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's stores have left before it counts itself in
+            uint32_t old = 0;
+            if (lane == 0) old = __hip_atomic_fetch_add((gu32*)(a.counter + g), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            old = __builtin_amdgcn_readfirstlane(old);
+            if (old != a.SK - 1) continue; // not the last slice of this column group
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // compiler only: the loads below stay below the count
+            acc[0] = acc[1] = mfma_f4{0.f, 0.f, 0.f, 0.f};
+            const float* const base = a.partial + (uint64_t)g * a.SK * WT + lane;
+            for (uint32_t s0 = 0; s0 < a.SK; s0 += 4) { // slice order; four slices' loads in flight together
+                float pv[4][R * 4];
+#pragma unroll
+                for (uint32_t q = 0; q < 4; q++) {
+                    const uint32_t sl = min(s0 + q, a.SK - 1);
+#pragma unroll
+                    for (int e = 0; e < R * 4; e++) pv[q][e] = __hip_atomic_load((gf32*)(base + (uint64_t)sl * WT + e * 64), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+                for (uint32_t q = 0; q < 4; q++)
+#pragma unroll
+                    for (int t = 0; t < R; t++)
+#pragma unroll
+                        for (int v = 0; v < 4; v++) acc[t][v] += s0 + q < a.SK ? pv[q][t * 4 + v] : 0.f;
+            }
+            if (lane == 0) __hip_atomic_store((gu32*)(a.counter + g), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // re-arm
+        }
+#pragma unroll
+        for (int t = 0; t < R; t++)
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                const uint32_t m = t * 16 + 4 * (lane >> 4) + v, n = gl * 16 + (lane & 15);
+                if (m < a.M) P.out[(uint64_t)m * P.out_rs + n] = acc[t][v];
+            }
+    }
+}
+
+#endif // ZGML_TRACE (tile4)
+
 // f32 B (any strides, device memory) -> MFMA-packed f16. One thread per 16-byte item.
 __global__ void __launch_bounds__(kBlock) pack_f16_kernel(const float* __restrict__ b, uint32_t b_rs, uint32_t b_cs,
                                                           uint32_t K, uint32_t N, uint32_t KC, uint4* __restrict__ out) {
@@ -545,10 +699,11 @@ static bool f16_tile3_on() { // the shared-A K-split experiment: diagnostics bui
     return false;
 #endif
 }
+static bool f16_tile4_on();
 uint64_t dense_f16_scratch_bytes(uint32_t M, uint32_t K) {
     static const bool on = !(getenv("ZGML_F16_TILE2") && atoi(getenv("ZGML_F16_TILE2")) == 0);
     if (!on || M <= 1) return 0;
-    return f16_a_bytes(M, K) + (M <= 32 && M > 16 && f16_tile3_on() ? kT3MaxWgs * kT3Waves * 2 * 1024 : 0);
+    return f16_a_bytes(M, K) + (M <= 32 && M > 16 && (f16_tile3_on() || f16_tile4_on()) ? kT3MaxWgs * kT3Waves * 2 * 1024 : 0);
 }
 
 // M in (16, 32], every part a whole number of 128-column tiles: the shared-A form with a K split. false: not applicable.
@@ -582,6 +737,63 @@ static bool launch_dense_f16_tile3(hipStream_t s, const DenseF16Params* p, uint3
 #endif
 }
 
+static bool f16_tile4_on() { // the A-stationary experiment: diagnostics build only, and only on request
+#ifdef ZGML_TRACE
+    static const bool on = getenv("ZGML_F16_TILE4") && atoi(getenv("ZGML_F16_TILE4")) != 0;
+    return on;
+#else
+    return false;
+#endif
+}
+static uint32_t f16_device_cus() {
+    static const uint32_t n = [] {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        return (uint32_t)cus;
+    }();
+    return n;
+}
+// M in (16, 32]: the A-stationary form. false: not applicable (launch nothing).
+static bool launch_dense_f16_tile4(hipStream_t s, const DenseF16Params* p, uint32_t n, uint32_t KC) {
+#ifndef ZGML_TRACE
+    (void)s, (void)p, (void)n, (void)KC;
+    return false;
+#else
+    if (!f16_tile4_on() || p[0].M <= 16 || p[0].M > 32) return false;
+    F16Args4 a{};
+    uint32_t groups = 0;
+    for (uint32_t t = 0; t < n; t++) {
+        a.parts[t] = {(const uint4*)p[t].bp, p[t].dst, p[t].dst_rs, groups};
+        groups += p[t].N / 16;
+    }
+    if ((uint64_t)groups * sizeof(uint32_t) > kQmmScratchHead || groups == 0) return false; // one counter word per column group
+    const uint32_t cus = f16_device_cus();
+    // K slices: every CU ~10 tasks (column group x slice), a slice of at most 64 chunks (its A: 128 KiB of LDS) and at least 8
+    static const int env_sk = getenv("ZGML_F16_TILE4_SK") ? atoi(getenv("ZGML_F16_TILE4_SK")) : 0;
+    const uint32_t sk_min = cdiv(KC, (uint32_t)kT4MaxSliceChunks), sk_max = std::max(sk_min, KC / 8);
+    uint32_t SK = env_sk > 0 ? (uint32_t)env_sk : (10u * cus + groups / 2) / groups;
+    SK = std::max(sk_min, std::min(SK, sk_max));
+    SK = std::min(SK, cus);
+    uint32_t cps = cdiv(KC, SK);
+    cps = cdiv(cps, (uint32_t)kT4Depth) * kT4Depth; // whole ring rounds per slice (the last slice may be shorter)
+    if (cps > (uint32_t)kT4MaxSliceChunks) cps = kT4MaxSliceChunks;
+    SK = cdiv(KC, cps);
+    if ((uint64_t)groups * SK * 2 * 1024 > kT3MaxWgs * kT3Waves * 2 * 1024) return false; // partial tiles must fit the scratch's partial region
+    a.ap = (const uint4*)p[0].scratch, a.n_parts = n, a.M = p[0].M, a.KC = KC, a.SK = SK, a.chunks_per_slice = cps;
+    a.n_cwg = std::max(1u, cus / SK), a.total_groups = groups;
+    a.partial = (float*)((char*)p[0].scratch + f16_a_bytes(p[0].M, p[0].K));
+    a.counter = (uint32_t*)((char*)p[0].scratch - kQmmScratchHead);
+    const bool nt = p[0].stream_nt != 0;
+    const size_t lds = std::max<size_t>((size_t)cps * 2 * 1024, 96 * 1024); // >= 96 KiB: never two workgroups on one CU
+    using Fn4 = void (*)(F16Args4);
+    const Fn4 fn = nt ? (Fn4)dense_f16_tile4_kernel<true> : (Fn4)dense_f16_tile4_kernel<false>;
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[nt]) attr_set[nt] = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+    hipLaunchKernelGGL(fn, dim3(a.n_cwg * SK), dim3(kT4Waves * 64), lds, s, a);
+    return true;
+#endif
+}
+
 static void launch_dense_f16_tile2(hipStream_t s, const DenseF16Params* p, uint32_t n) {
     const uint32_t KC = (p[0].K + 31) / 32, R = f16_tiles_per_wg(p[0].M), tiles = cdiv(cdiv(p[0].M, 16), R) * R;
     if (!p[0].reuse_a) {
@@ -590,6 +802,7 @@ static void launch_dense_f16_tile2(hipStream_t s, const DenseF16Params* p, uint3
                                                                                                              tiles, (uint4*)p[0].scratch);
     }
     if (R == 2 && tiles == 2 && launch_dense_f16_tile3(s, p, n, KC)) return;
+    if (R == 2 && tiles == 2 && launch_dense_f16_tile4(s, p, n, KC)) return;
     static const int env_w = getenv("ZGML_F16_TILE2_WAVES") ? atoi(getenv("ZGML_F16_TILE2_WAVES")) : 8;
     const uint32_t waves = std::max(1u, std::min<uint32_t>(KC, (uint32_t)env_w));
     // column groups per workgroup (R <= 2 only: the wide-M forms already amortise A over 4 / 8 m-tiles): as many as keep the grid

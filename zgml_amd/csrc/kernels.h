@@ -394,7 +394,8 @@ void launch_pack_qweight(hipStream_t s, const int8_t* raw_data, const float* raw
 // the kQmmScratchHead bytes IN FRONT of that pointer belong to the launchers: fan-in counters of the K-split tile kernel,
 // zero at allocation and re-armed by every launch. Whoever allocates the block allocates kQmmScratchHead + bytes,
 // zeroes the head and passes base + kQmmScratchHead.
-constexpr uint64_t kQmmScratchHead = 4096;
+constexpr uint64_t kQmmScratchHead = 16384;  // (round 4: 4096 counter words — the A-stationary f16 kernel keeps one per column group)
+constexpr uint64_t kQmmCounterBytes = 4096; // what the Q4_0 tile launchers size their K splits by (unchanged from round 3)
 uint64_t qmatmul_scratch_bytes(const QWeightDev& w, uint32_t M);
 void launch_qmatmul(hipStream_t s, const QWeightDev& w, const QMatmulParams& p, float* scratch);
 // M > 1: up to qmatmul_max_group() quantized matmuls over the same rows in one launch (qmatmul_can_group pairwise)

@@ -2883,7 +2883,7 @@ void launch_xdl4(hipStream_t s, const QWeightDev* w, const QMatmulParams* p, uin
     static const int env_sk = getenv("ZGML_QMM_XDL4_SK") ? atoi(getenv("ZGML_QMM_XDL4_SK")) : 0;
     uint32_t SK = env_sk > 0 ? (uint32_t)env_sk : cdiv((uint32_t)n_cu, blocks * groups);
     SK = std::max(1u, std::min({SK, 4u, cdiv(S, KW)}));
-    if ((uint64_t)blocks * groups * sizeof(uint32_t) > kQmmScratchHead) SK = 1; // one counter word per (tile group, block-column)
+    if ((uint64_t)blocks * groups * sizeof(uint32_t) > kQmmCounterBytes) SK = 1; // one counter word per (tile group, block-column)
     const uint32_t steps_per_slice = cdiv(S, SK);
     SK = cdiv(S, steps_per_slice);
     const uint64_t a_bytes = xdl_a_bytes(w[0], p[0].M);
@@ -2910,7 +2910,7 @@ bool launch_xdl5(hipStream_t s, const QWeightDev* w, const QMatmulParams* p, uin
         a.parts[t] = {(const uint4*)w[t].qs, (const uint4*)w[t].sc, p[t].dst, p[t].dst_rs, p[t].N / 32, wg_cols};
         wg_cols += cdiv(p[t].N / 32, kX5Waves);
     }
-    if ((uint64_t)wg_cols * sizeof(uint32_t) > kQmmScratchHead) return false;
+    if ((uint64_t)wg_cols * sizeof(uint32_t) > kQmmCounterBytes) return false;
     // narrow outputs stay with qmatmul_xdl2_kernel: every run of a column costs the column's fan-in one more device-scope
     // atomic on one word (measured 2.5 + 0.6 us x runs per column: 12.5 us at 4096 x 4096, 16 runs), and below ~40
     // workgroup-columns (N < 10240) that outweighs the A traffic saved (4096 x 8192: 27.8 against 20.9 us; x 12288: 32.1 against 33.9)
@@ -2983,7 +2983,7 @@ void launch_xdl2(hipStream_t s, const QWeightDev* w, const QMatmulParams* p, uin
         uint32_t bcs = 0;
         for (uint32_t t = 0; t < n; t++) bcs += p[t].N / 32;
         const uint32_t sk = std::min({cdiv(device_cus(), bcs), 4u, cdiv(S, (uint32_t)kX4Waves)});
-        if (sk >= 2 && S / sk >= 16 && (uint64_t)bcs * sizeof(uint32_t) <= kQmmScratchHead) {
+        if (sk >= 2 && S / sk >= 16 && (uint64_t)bcs * sizeof(uint32_t) <= kQmmCounterBytes) {
             launch_xdl4(s, w, p, n, scratch, S, R, tiles);
             return;
         }
