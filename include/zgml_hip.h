@@ -366,6 +366,12 @@ zgml_runtime_profile* zgml_hip_get_runtime_profile(zgml_hip_ctx* ctx, zgml_hip_p
 
 /* ── Extensions (no reference counterpart) ──────────────────────────────────────────────── */
 
+/* The launch plan of a program as text, one line per launch, for diagnostics and tests (which ops a launch covers, and for
+ * a quantized mat-vec launch its parts, K, prologue form — none | mul | rmsnorm | prenorm —, whether it prepares the NEXT
+ * launch's norm, carries the gate / up pair product or the decode attention of its heads). Builds the plan if it is not
+ * built yet. Writes at most cap - 1 bytes + NUL; returns the bytes the whole text needs (without the NUL). */
+uint64_t zgml_hip_program_plan_text(zgml_hip_ctx* ctx, zgml_hip_program* handle, char* out, uint64_t cap);
+
 /* Program options, set before compile on the context. */
 enum {
     ZGML_HIP_OPT_FUSION = 1,         /* 0/1: pattern-fuse the op stream (default 1) */

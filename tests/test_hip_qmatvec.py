@@ -285,6 +285,53 @@ def test_matvec_prologues_and_epilogue_chains_store_every_intermediate(hip_backe
         np.testing.assert_allclose(got, want, rtol=1e-3, atol=1e-4 * scale, err_msg=name)
 
 
+@pytest.mark.parametrize("K0,K,Ns", [(1536, 576, (576, 192, 192)), (576, 576, (1536, 1536)), (2048, 2048, (2048, 512, 512)), (4096, 4096, (4096, 4096, 4096))])
+def test_prepared_norm_hand_over_stores_every_intermediate(hip_backend, oracle, K0, K, Ns):
+    """The tail of one decoder half and the head of the next as the LLaMA lowering emits them (llama_transformer.zig:192-253):
+    projection -> residual add -> rmsnorm -> mul(gamma) -> q/k/v (or gate/up) over the result. The planner folds this into TWO
+    launches, and the first one PREPARES the second one's norm (h * gamma and the partial sums of h^2: QMV_PRO_PRENORM) so that
+    the second streams one vector and scales its finished sums — for K-on-lanes weights (K > 2048) since round 3, for the
+    x-direct n-on-lanes launches of short-K models (SmolLM-135M's 576 / 1536, and 2048) since round 4. Every buffer the
+    unfused program would have written — the projection, the residual sum, the normalised vector, its product with gamma, each
+    output — against the oracle; the plan's text says which form ran."""
+    rng = np.random.default_rng(K0 + 3 * K + len(Ns))
+    xin = rng.standard_normal(K0).astype(f32)
+    resid = rng.standard_normal(K).astype(f32)
+    gamma = (rng.random(K).astype(f32) + 0.5)
+    B = dict(xin=0, resid=1, gamma=2, y=3, h=4, normed=5, xg=6)
+    sizes = [K0, K, K, K, K, K, K] + list(Ns)
+    ops = [
+        DeviceOp.qmatmul(B["y"], B["xin"], 0, 1, K, K0),
+        DeviceOp.elementwise("add", B["h"], B["resid"], B["y"], K),
+        DeviceOp.rmsnorm(B["normed"], B["h"], 1, K, 1e-5),
+        DeviceOp.elementwise("mul", B["xg"], B["normed"], B["gamma"], K),
+    ] + [DeviceOp.qmatmul(7 + t, B["xg"], 1 + t, 1, n, K) for t, n in enumerate(Ns)]
+    prog = DeviceProgram(ops=ops, buffer_sizes=sizes,
+                         initial_uploads=[ProgramIO(B["xin"], xin), ProgramIO(B["resid"], resid), ProgramIO(B["gamma"], gamma)],
+                         qweights=[_q4_weight(rng, K0, K)] + [_q4_weight(rng, K, n) for n in Ns])
+    h = hip_backend.compileProgram(prog)
+    assert h
+    try:
+        plan = hip_backend.planText(h)
+        lines = plan.strip().splitlines()
+        assert len(lines) == 2, plan
+        import os
+        if not any(os.environ.get(v) == "0" for v in ("ZGML_HIP_PRENORM", "ZGML_HIP_PRENORM_NOL", "ZGML_QMV_XDIRECT")):
+            assert "prepares-next-norm" in lines[0] and "pro prenorm" in lines[1] and f"parts {len(Ns)}" in lines[1], plan
+        names = ["y", "h", "normed", "xg"] + [f"out{t}" for t in range(len(Ns))]
+        idx = [B["y"], B["h"], B["normed"], B["xg"]] + [7 + t for t in range(len(Ns))]
+        outs = [np.zeros(sizes[i], f32) for i in idx]
+        for _ in range(2):  # (twice: the second run replays the graph)
+            hip_backend.executeProgram(h, [], [ProgramIO(i, o) for i, o in zip(idx, outs)])
+        for name, i, got in zip(names, idx, outs):
+            want = oracle.run_program(prog, i, sizes[i])
+            scale = max(1.0, float(np.abs(want).max()))
+            # summation order only (the oracle adds K f32 products sequentially: ~1e-4 absolute at K = 4096)
+            np.testing.assert_allclose(got, want, rtol=2e-4, atol=1e-4 * scale, err_msg=name)
+    finally:
+        hip_backend.freeProgram(h)
+
+
 def test_refresh_to_a_matmul_over_a_matvec_only_weight_fails_loudly(hip_backend, oracle):
     """compile_program packs a Q4_0 weight K-on-lanes when every op that uses it has M == 1
     (K >= 2048). A later refresh_program that changes static fields is legal for the reference's CPU backend

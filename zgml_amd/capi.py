@@ -195,6 +195,7 @@ HIP_SYMBOLS = [
     "zgml_hip_qmatvec_synth", "zgml_hip_copy_bench", "zgml_hip_resident_setup", "zgml_hip_resident_decode",
     "zgml_hip_resident_prefill", "zgml_hip_shard_unique_id", "zgml_hip_shard_init", "zgml_hip_shard_destroy", "zgml_hip_shard_attach", "zgml_hip_shard_step", "zgml_hip_shard_step_mode",
     "zgml_hip_shard_profile_step", "zgml_hip_shard_init_peer", "zgml_hip_shard_peer_export", "zgml_hip_shard_peer_import",
+    "zgml_hip_program_plan_text",
 ]
 
 class ShardPointC(C.Structure):
@@ -239,6 +240,7 @@ def _bind_hip(lib: C.CDLL) -> None:
     lib.zgml_hip_free_program.restype, lib.zgml_hip_free_program.argtypes = None, [vp, vp]
     lib.zgml_hip_get_runtime_profile.restype = C.POINTER(RuntimeProfileC)
     lib.zgml_hip_get_runtime_profile.argtypes = [vp, vp]
+    lib.zgml_hip_program_plan_text.restype, lib.zgml_hip_program_plan_text.argtypes = u64, [vp, vp, C.c_char_p, u64]
     lib.zgml_hip_set_option.restype, lib.zgml_hip_set_option.argtypes = i32, [vp, i32, C.c_int64]
     lib.zgml_hip_program_buffer_ptr.restype, lib.zgml_hip_program_buffer_ptr.argtypes = vp, [vp, C.c_uint16]
     lib.zgml_hip_stage_inputs.restype, lib.zgml_hip_stage_inputs.argtypes = i32, [vp, vp, C.POINTER(ProgramIOC), u64]

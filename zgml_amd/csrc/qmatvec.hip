@@ -366,13 +366,26 @@ struct KonTail {
     // l, l + 64, l + 128, l + 192 (requested at kernel start, zero beyond n_ssq)
     bool prenorm;
     float pp[4];
+    // ... or the finished factor, when the caller folded the partials under the weight stream (n_ssq <= 256: prenorm_factor)
+    bool inv_known = false;
+    float inv_pre = 1.0f;
 };
+// PRENORM: 1 / sqrt(mean(a^2) + eps) from the producing launch's <= 256 partial sums of squares, four per lane (pp: partials
+// l, l + 64, l + 128, l + 192, zero beyond n_ssq), folded in a fixed order — the same value in every wave of every workgroup.
+// The partials are requested BEFORE the weights (loads return in order) and folded while the weights fly: in the tail, behind
+// the cross-wave barrier, the same arithmetic cost 0.45 us per launch (stamps, SmolLM-135M).
+__device__ __forceinline__ float prenorm_factor(const float (&pp)[4], uint32_t K, float eps) {
+    const float ss = rows_sum4(row16_sum((pp[0] + pp[1]) + (pp[2] + pp[3])));
+    return 1.0f / sqrtf(ss / (float)K + eps); // reference.zig:365
+}
 // wave 0 of a K-on-lanes workgroup, behind the barrier: the deferred rmsnorm factor (1 without a norm) and this workgroup's slice
 // of the prologue's side outputs
 __device__ __forceinline__ float kon_factor_and_slices(const KonTail& kt, const QMVArgs& a, const float* red, uint32_t n_waves, uint32_t lane) {
     const uint32_t col = lane & 15;
     float inv = 1.0f;
-    if (kt.prenorm) { // the producer's partials, folded in a fixed order (the same value in every workgroup of the launch)
+    if (kt.inv_known) {
+        inv = kt.inv_pre;
+    } else if (kt.prenorm) { // the producer's partials, folded in a fixed order (the same value in every workgroup of the launch)
         float s4 = (kt.pp[0] + kt.pp[1]) + (kt.pp[2] + kt.pp[3]);
         for (uint32_t j = lane + 256; j < a.pro.n_ssq; j += 64) s4 += a.pro.ssq[j];
         const float ss = rows_sum4(row16_sum(s4));
@@ -433,6 +446,7 @@ __device__ __forceinline__ void reduce_store(float acc, float* red, const QMVArg
     for (uint32_t j = 0; j < 4; j++) v += r + 4 * j < n_waves ? part[j] : 0.f;
     v = rows_sum4(v);
     if (KON) v *= kon->post * kon_factor_and_slices(*kon, a, red, n_waves, lane);
+    if (!KON && kon) v *= kon_factor_and_slices(*kon, a, red, n_waves, lane); // (the n-on-lanes body under PRENORM: the factor and the slices only)
     if (lane < 16) {
         const uint32_t n = g * 16 + threadIdx.x;
         // part 0's output pointer is a preloaded argument; further parts' come from the argument block
@@ -705,8 +719,14 @@ struct QmvWait {
     uint32_t pre_sleep = 0;   // experiments: s_sleep units before the weights are requested
 };
 
-template <typename ST, bool XVEC, int DEPTH, bool Q4, bool PRO, bool GROUPED, bool XD, bool NT, bool CONSUME = false>
+// PROM: 0 = no prologue, 1 = in-kernel prologue (second vector b, optional rmsnorm), 2 = PRENORM (x-direct launches only): xa_base
+// is the PRODUCER's a * gamma with its partial sums of a^2 right behind it (runtime.hip: arm_prenorm), xb_base the original a;
+// the finished sums are scaled by 1 / sqrt(mean(a^2) + eps) (the mat-vec is linear in x) and every workgroup stores a 16-element
+// slice of the absorbed ops' outputs — no second vector, no reduction over x and no barrier in front of the first FMA
+template <typename ST, bool XVEC, int DEPTH, bool Q4, int PROM, bool GROUPED, bool XD, bool NT, bool CONSUME = false>
 __device__ __forceinline__ void qmatvec_body(QMV_HEAD_PARAMS, const QMVArgs& a, const uint32_t bx, const QmvPublish* pub, const QmvWait* wt = nullptr) {
+    constexpr bool PRO = PROM == 1;
+    static_assert(PROM != 2 || (XD && !CONSUME), "PRENORM: x-direct launches only");
     constexpr uint32_t UNIT_X = Q4 ? 32 : 16;
     using ScaleT = typename std::conditional<Q4, Pair<ST>, ST>::type;
     using Group = typename std::conditional<Q4, Q4Group<ST, DEPTH, XD, PRO, NT>, Q8Group<ST, DEPTH, XD, PRO, NT>>::type;
@@ -768,6 +788,7 @@ __device__ __forceinline__ void qmatvec_body(QMV_HEAD_PARAMS, const QMVArgs& a, 
     // (~0.7 us on its first line) in front of the kernel's first load
     const bool norm = PRO && ((nb2_0_flags >> 29) & 1) != 0;
     const bool x_vec = ((nb2_0_flags >> 30) & 1) != 0;
+    float pn_pp[4] = {0.f, 0.f, 0.f, 0.f}, pn_inv = 1.0f; // PRENORM
     if (XD) {
         SumsqRegs sq;
         if (norm) sq = sumsq_fetch(xa_row, K, x_vec, bdim); // before the weights (in-order vmcnt)
@@ -789,10 +810,21 @@ __device__ __forceinline__ void qmatvec_body(QMV_HEAD_PARAMS, const QMVArgs& a, 
             if (threadIdx.x == 0) wt->seen[bx] = target; // (every wave read it before the barrier)
             cur.template load<2, true>(qs, sc, u, stride, u_last, xd, i);
         } else {
+            if (PROM == 2) { // the producer's partial sums of squares (K / 16 <= 256 of them, right behind its vector): BEFORE the weights
+                const uint32_t n_ssq = K >> 4;
+                const float* const ssq = xa_base + K;
+#pragma unroll
+                for (uint32_t j = 0; j < 4; j++) {
+                    const uint32_t q = lane + 64 * j;
+                    const float v = ssq[min(q, n_ssq - 1)];
+                    pn_pp[j] = q < n_ssq ? v : 0.f;
+                }
+            }
             cur.load(qs, sc, u, stride, u_last, xd, i);
         }
         QMV_STAMP(1); // loads issued
         __builtin_amdgcn_sched_barrier(0); // argument-block reads below wait while the loads above fly
+        if (PROM == 2) pn_inv = prenorm_factor(pn_pp, K, a.pro.eps); // (every wave: uniform code, folded while the weights fly)
         if (pro_owner) xd.store_x = a.pro.store_x, xd.store_mid = a.pro.store_mid;
         if (norm) { // the weights are in flight while the vector is reduced
             const float ss = block_sumsq_direct(sq, xa_row, K, red, x_vec, bdim);
@@ -832,6 +864,19 @@ __device__ __forceinline__ void qmatvec_body(QMV_HEAD_PARAMS, const QMVArgs& a, 
         for (uint32_t o = 16; o < kArgDwords; o += 16) arg_touch |= kargs[o];
     }
 #endif
+    // PRENORM: this workgroup's 16-element slice of the absorbed ops' inputs (workgroup bx: k = 16 bx ..; the planner checked
+    // that the launch has >= K / 16 workgroups), requested under the weight stream; stored by wave 0 behind the fold (reduce_store)
+    KonTail ptail{1.0f, true, 0.f, K, 0.f, 0.f, 16u * bx, 16u, true, true, {0.f, 0.f, 0.f, 0.f}};
+    if (PROM == 2) {
+        const uint32_t ks = min(ptail.k0 + i, K - 1);
+        ptail.a_s = xb_base[ks];
+        ptail.b_s = a.pro.b[ks];
+        ptail.has_pro = ptail.k0 < K && blockIdx.y == 0;
+        ptail.inv_known = !(nb2_0_flags >> 31), ptail.inv_pre = pn_inv; // (bit 31, ZGML_HIP_PRENORM_EARLY=0: the fold in the tail, for A/B runs)
+        ptail.eps = a.pro.eps;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) ptail.pp[j] = pn_pp[j];
+    }
     // single-matrix launches (O / down projection): the operand of the first epilogue step (the residual) is requested
     // now, under the weight stream, by every lane for its column (unconditional: a load under a branch would degrade
     // the counted waits); the 16 owning lanes use it behind the reduction instead of a dependent ~0.5 us load
@@ -857,7 +902,7 @@ __device__ __forceinline__ void qmatvec_body(QMV_HEAD_PARAMS, const QMVArgs& a, 
     asm volatile("" ::"s"(arg_touch)); // (keeps the touches alive; long arrived)
 #endif
     QMV_STAMP(4); // weights streamed
-    reduce_store<GROUPED>((acc0 + acc1) + (acc2 + acc3), red, a, pi, out0, g, m, pre0, have_pre0, n_waves, pub, nullptr, pre_g);
+    reduce_store<GROUPED>((acc0 + acc1) + (acc2 + acc3), red, a, pi, out0, g, m, pre0, have_pre0, n_waves, pub, PROM == 2 ? &ptail : nullptr, pre_g);
     QMV_STAMP(5);
 #undef QMV_STAMP
 }
@@ -865,6 +910,13 @@ __device__ __forceinline__ void qmatvec_body(QMV_HEAD_PARAMS, const QMVArgs& a, 
 template <typename ST, bool XVEC, int DEPTH, bool Q4, bool PRO, bool GROUPED, bool XD, bool NT>
 __global__ void __launch_bounds__(1024) qmatvec_kernel(QMV_HEAD_PARAMS, QMVArgs a) {
     qmatvec_body<ST, XVEC, DEPTH, Q4, PRO, GROUPED, XD, NT>(qs0, sc0, out0, xa_base, xb_base, in_rs, K, nb2_0_flags, nb2_12, a, blockIdx.x, nullptr);
+}
+
+// PRENORM launches of this form: Q4_0 with f16 scales, x direct, default cache policy (the short-K models whose weights stay
+// in the Infinity Cache: SmolLM-135M's 576 / 1536; the K-on-lanes kernels below carry their own PRENORM form for K > 2048)
+template <int DEPTH, bool GROUPED>
+__global__ void __launch_bounds__(1024) qmatvec_prenorm_kernel(QMV_HEAD_PARAMS, QMVArgs a) {
+    qmatvec_body<__half, false, DEPTH, true, 2, GROUPED, true, false>(qs0, sc0, out0, xa_base, xb_base, in_rs, K, nb2_0_flags, nb2_12, a, blockIdx.x, nullptr);
 }
 
 // ── K ON LANES (QW_Q4K, round 3): the M = 1 mat-vec of GGUF-Q4_0-sourced weights ───────────────────────────────────────
@@ -1091,6 +1143,7 @@ __device__ __forceinline__ void qmatvec_kon_body(QMV_HEAD_PARAMS, const QMVArgs&
     // this group has just left (no second register set, and the stream never drains inside a workgroup)
     const uint64_t pair_q = PAIR ? (uint64_t)NB2_0 * P : 0, pair_s = PAIR ? (uint64_t)(NB2_0 >> 1) * P : 0; // part 1 follows part 0 in the arenas
     KonItem<NT, PRO, XV, PAIR> it[DEPTH];
+    float pn_pp[4] = {0.f, 0.f, 0.f, 0.f}; // PRENORM
     if constexpr (CONSUME) {
         for (uint32_t z = 0; z < wt->pre_sleep; z++) __builtin_amdgcn_s_sleep(16);
 #pragma unroll
@@ -1112,6 +1165,15 @@ __device__ __forceinline__ void qmatvec_kon_body(QMV_HEAD_PARAMS, const QMVArgs&
 #pragma unroll
         for (int d = 0; d < DEPTH; d++) it[d].load_x_agent(xa_base, p + d * stride, p_last);
     } else {
+        if (PROM == 2) { // the producer's partial sums of squares: BEFORE the weights (loads return in order), folded below while those fly
+            const uint32_t n_ssq = K >> 4; // (= a.pro.n_ssq, without the argument-block load)
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) {
+                const uint32_t q = lane + 64 * j;
+                const float v = (xa_base + K)[min(q, n_ssq - 1)]; // (arm_prenorm lays the partials right behind the vector: no argument-block pointer in front of the first load)
+                pn_pp[j] = q < n_ssq ? v : 0.f;
+            }
+        }
 #pragma unroll
         for (int d = 0; d < DEPTH; d++) it[d].load(qs, sc, xa_base, xb_base, p + d * stride, p_last, K, pair_q, pair_s);
     }
@@ -1125,18 +1187,15 @@ __device__ __forceinline__ void qmatvec_kon_body(QMV_HEAD_PARAMS, const QMVArgs&
         tail.b_s = (PROM == 2 ? a.pro.b : xb_base)[ks];
     }
     if (PROM == 2) {
-        const uint32_t n_ssq = a.pro.n_ssq;
 #pragma unroll
-        for (uint32_t j = 0; j < 4; j++) {
-            const uint32_t q = lane + 64 * j;
-            const float v = a.pro.ssq[min(q, n_ssq - 1)];
-            tail.pp[j] = q < n_ssq ? v : 0.f;
-        }
+        for (uint32_t j = 0; j < 4; j++) tail.pp[j] = pn_pp[j];
     }
     QMV_STAMP(1); // loads issued
     QMV_STAMP(2); // (no separate x phases in this form: same stamp)
     QMV_STAMP(3);
     __builtin_amdgcn_sched_barrier(0);
+    if (PROM == 2 && (K >> 4) <= 256 && !(nb2_0_flags >> 31)) // all of the partials are in the registers: the factor now, while the weights fly (else, or with bit 31 — ZGML_HIP_PRENORM_EARLY=0 —, in the tail)
+        tail.inv_pre = prenorm_factor(pn_pp, K, a.pro.eps), tail.inv_known = true;
     uint32_t arg_touch = 0; // (argument-block lines into the scalar cache while the loads fly: see the form above)
 #if defined(__HIP_DEVICE_COMPILE__)
     {
@@ -1262,13 +1321,13 @@ struct QkvAttnArgs {
     QmvPublish pub;
     DecodeHandoff ho;
 };
-template <typename ST, bool Q4, int LPK, bool KVQ>
+template <typename ST, bool Q4, int LPK, bool KVQ, int PROM = 1>
 __global__ void __launch_bounds__(1024) qkv_attn_kernel(QMV_HEAD_PARAMS, QMVArgs a, QkvAttnArgs f) {
     constexpr int DEPTH = 1; // K <= 2048 with up to 16 waves: one load step
     if (blockIdx.x < f.n_mv) {
         const uint32_t n_waves = ((nb2_0_flags >> 20) & 0xFu) + 1;
         if (threadIdx.x >= n_waves * 64) return; // (whole waves: they no longer count at the barriers)
-        qmatvec_body<ST, false, DEPTH, Q4, true, true, true, false>(qs0, sc0, out0, xa_base, xb_base, in_rs, K, nb2_0_flags, nb2_12, a, blockIdx.x, &f.pub);
+        qmatvec_body<ST, false, DEPTH, Q4, PROM, true, true, false>(qs0, sc0, out0, xa_base, xb_base, in_rs, K, nb2_0_flags, nb2_12, a, blockIdx.x, &f.pub);
     } else {
         const uint32_t b = blockIdx.x - f.n_mv, n_heads = f.ho.n_heads; // head-major: the always-active split 0 of every head first
         attention_decode_body<LPK, KVQ>(f.params, f.split_buf, f.split_cnt, f.split_min_keys, b % n_heads, b / n_heads, f.n_sp, &f.ho);
@@ -2549,6 +2608,17 @@ bool qweight_packable(uint64_t K, uint64_t N, uint64_t bs) {
     return (KC * 32 + 4 + kMaxWaves * 16) * sizeof(float) <= kMaxLds;
 }
 
+// Can a mat-vec launch over `w` (K inputs, `total_cols` output columns over all its parts, M rows) take its rmsnorm -> mul(gamma)
+// prologue PREPARED by the producing launch (QMV_PRO_PRENORM)? K-on-lanes weights: always (their kernels carry the form);
+// n-on-lanes Q4_0 with f16 scales: the x-direct launches under the default cache policy, with one workgroup per 16 inputs
+// at least (every workgroup stores a 16-element slice of the absorbed ops' outputs).
+bool qmv_prenorm_ok(const QWeightDev& w, uint32_t K, uint64_t total_cols, uint32_t M) {
+    if (w.format == QW_Q4K) return true;
+    static const bool xd_enabled = !(getenv("ZGML_QMV_XDIRECT") && atoi(getenv("ZGML_QMV_XDIRECT")) == 0);
+    static const bool nol = !(getenv("ZGML_HIP_PRENORM_NOL") && atoi(getenv("ZGML_HIP_PRENORM_NOL")) == 0);
+    return nol && xd_enabled && w.format == QW_Q4 && w.scale_f16 && !w.stream_nt && M == 1 && K % 16 == 0 && K <= 4096 && total_cols >= K; // (<= 256 partial sums)
+}
+
 bool qmv_can_group(const QWeightDev& a, const QWeightDev& b) {
     return a.format != QW_RAW && a.format == b.format && a.scale_f16 == b.scale_f16 && a.K == b.K && a.KC == b.KC;
 }
@@ -2621,6 +2691,10 @@ static bool plain_head_depth1(const QMVArgs& a, const QWeightDev& w0, uint32_t b
     return true;
 }
 
+static bool prenorm_late() { // experiments: ZGML_HIP_PRENORM_EARLY=0 folds the prepared norm's partial sums in the kernel's tail (bit 31 of the head flags)
+    static const bool late = getenv("ZGML_HIP_PRENORM_EARLY") && atoi(getenv("ZGML_HIP_PRENORM_EARLY")) == 0;
+    return late;
+}
 // ── the K-on-lanes launches (QW_Q4K) ──
 // Waves: 8 for K >= 4096 (4096: one load group of 4 items per lane, every load of the workgroup in flight at once;
 // tools/exp/kon.hip sweep, round 3: 4096^2 chain 4.06 us with 8 waves against 4.9 / 4.5 with 4 / 16); short K: one wave per
@@ -2704,7 +2778,7 @@ bool launch_packed_kon(hipStream_t s, QMVArgs& a, const QWeightDev& w0, uint32_t
     const float* const head_xa = prom == 2 ? a.pro.xg : a.pro.a;
     const float* const head_xb = prom == 2 ? a.pro.a : a.pro.b;
     const uint32_t flags = a.parts[0].NB2 | ((waves_used - 1) << 20) | (a.n_parts << 24) | (contig ? 1u << 28 : 0u) | (a.pro.kind == QMV_PRO_RMSNORM_MUL ? 1u << 29 : 0u) |
-                           (a.x_vec ? 1u << 30 : 0u);
+                           (a.x_vec ? 1u << 30 : 0u) | (prenorm_late() ? 1u << 31 : 0u);
     if (fused) { // q / k / v + decode attention in one launch of 256-thread workgroups (qkv_attn_kon_kernel)
         using FusedFn = void (*)(const uint4*, const void*, float*, const float*, const float*, uint32_t, uint32_t, uint32_t, uint32_t, QMVArgs, QkvAttnArgs);
         if (!grp || !contig || !xvec || prom == 1 || (d_head != 64 && d_head != 128)) return false;
@@ -2770,6 +2844,11 @@ bool launch_packed(hipStream_t s, QMVArgs& a, const QWeightDev& w0, uint32_t tot
     // LDS round trip they replace once K is large: Llama-2-7B -5 %, SmolLM-135M +2.7 %)
     static const uint32_t xd_norm_max_k = getenv("ZGML_QMV_XDNORM_MAXK") ? (uint32_t)atoi(getenv("ZGML_QMV_XDNORM_MAXK")) : 2048u;
     const bool xd = xd_enabled && (a.pro.kind != QMV_PRO_RMSNORM_MUL || (xd_norm && a.K <= xd_norm_max_k));
+    const bool prenorm = a.pro.kind == QMV_PRO_PRENORM;
+    if (prenorm && !qmv_prenorm_ok(w0, a.K, total_blocks * 16, M)) { // (arm_prenorm asks the same question: never reached)
+        fprintf(stderr, "[zgml_hip] ERROR: a PRENORM mat-vec launch outside the shapes its kernel is built for: not launched\n");
+        return false;
+    }
     uint32_t waves = qmv_waves(w0, total_blocks);
     if (!xd && a.pro.kind != QMV_PRO_NONE) // a staged prologue keeps all of x in the register window: 16 floats per thread
         while (waves < (uint32_t)kMaxWaves && waves * 64 * 4 * kXRegs < a.K) waves++;
@@ -2787,16 +2866,21 @@ bool launch_packed(hipStream_t s, QMVArgs& a, const QWeightDev& w0, uint32_t tot
     const size_t lds = xd ? (size_t)kMaxWaves * 16 * sizeof(float) : qmv_lds_bytes(w0);
     const uint32_t n_steps = cdiv(a.U, waves * 4);
     const int depth_sel = n_steps >= 4 ? 2 : (n_steps >= 2 ? 1 : 0); // DEPTH 4 / 2 / 1 (DEPTH 8 for the staged-prologue launches of a 7B model: -9 % tok/s, round 2)
-    const bool pro = a.pro.kind != QMV_PRO_NONE, grp = a.n_parts > 1;
+    const bool pro = a.pro.kind == QMV_PRO_MUL || a.pro.kind == QMV_PRO_RMSNORM_MUL, grp = a.n_parts > 1;
     const bool nt = w0.stream_nt != 0;
-    const KernelFn fn = w0.scale_f16 ? pick_kernel<__half>(xvec, q4, pro, grp, depth_sel, xd, nt)
+    // the kernel's leading arguments: PRENORM streams the producer's vector and keeps the original one for the side outputs
+    const float* const head_xa = prenorm ? a.pro.xg : a.pro.a;
+    const float* const head_xb = prenorm ? a.pro.a : a.pro.b;
+    const KernelFn fn = prenorm ? (grp ? (depth_sel == 0 ? qmatvec_prenorm_kernel<1, true> : depth_sel == 1 ? qmatvec_prenorm_kernel<2, true> : qmatvec_prenorm_kernel<4, true>)
+                                       : (depth_sel == 0 ? qmatvec_prenorm_kernel<1, false> : depth_sel == 1 ? qmatvec_prenorm_kernel<2, false> : qmatvec_prenorm_kernel<4, false>))
+                      : w0.scale_f16 ? pick_kernel<__half>(xvec, q4, pro, grp, depth_sel, xd, nt)
                                      : pick_kernel<float>(xvec, q4, pro, grp, depth_sel, xd, nt);
     if (lds > 64 * 1024) // > 64 KiB of dynamic LDS needs an explicit opt-in per kernel (idempotent)
         hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
     if (a.n_parts > 1 && (a.parts[1].NB2 > 0xFFFFu || (a.n_parts > 2 && a.parts[2].NB2 > 0xFFFFu))) contig = false; // 16-bit fields
     const uint32_t nb2_12 = contig ? (a.parts[1].NB2 | (a.n_parts > 2 ? a.parts[2].NB2 << 16 : 0u)) : 0u;
     if (fused) {
-        if (!(xd && pro && grp && !nt && q4 && w0.scale_f16 && contig && M == 1 && a.n_parts == 3 && (d_head == 64 || d_head == 128))) return false;
+        if (!(xd && (pro || prenorm) && grp && !nt && q4 && w0.scale_f16 && contig && M == 1 && a.n_parts == 3 && (d_head == 64 || d_head == 128))) return false;
         QkvAttnArgs f = *fused;
         f.n_mv = total_blocks;
         const bool fused_kvq = f.kvq != 0;
@@ -2820,18 +2904,20 @@ bool launch_packed(hipStream_t s, QMVArgs& a, const QWeightDev& w0, uint32_t tot
         using FusedFn = void (*)(const uint4*, const void*, float*, const float*, const float*, uint32_t, uint32_t, uint32_t, uint32_t, QMVArgs, QkvAttnArgs);
         FusedFn ff = nullptr;
         if (d_head == 64)
-            ff = fused_kvq ? qkv_attn_kernel<__half, true, 16, true> : qkv_attn_kernel<__half, true, 16, false>;
+            ff = prenorm ? (fused_kvq ? qkv_attn_kernel<__half, true, 16, true, 2> : qkv_attn_kernel<__half, true, 16, false, 2>)
+                         : (fused_kvq ? qkv_attn_kernel<__half, true, 16, true> : qkv_attn_kernel<__half, true, 16, false>);
         else
-            ff = fused_kvq ? qkv_attn_kernel<__half, true, 32, true> : qkv_attn_kernel<__half, true, 32, false>;
-        hipLaunchKernelGGL(ff, dim3(total_blocks + extra_blocks), dim3(1024), lds, s, a.parts[0].qs, a.parts[0].sc, a.parts[0].out, a.pro.a, a.pro.b, a.in_rs, a.K,
+            ff = prenorm ? (fused_kvq ? qkv_attn_kernel<__half, true, 32, true, 2> : qkv_attn_kernel<__half, true, 32, false, 2>)
+                         : (fused_kvq ? qkv_attn_kernel<__half, true, 32, true> : qkv_attn_kernel<__half, true, 32, false>);
+        hipLaunchKernelGGL(ff, dim3(total_blocks + extra_blocks), dim3(1024), lds, s, a.parts[0].qs, a.parts[0].sc, a.parts[0].out, head_xa, head_xb, a.in_rs, a.K,
                            a.parts[0].NB2 | ((waves - 1) << 20) | (a.n_parts << 24) | (1u << 28) | (a.pro.kind == QMV_PRO_RMSNORM_MUL ? 1u << 29 : 0u) |
-                               (a.x_vec ? 1u << 30 : 0u),
+                               (a.x_vec ? 1u << 30 : 0u) | (prenorm_late() ? 1u << 31 : 0u),
                            nb2_12, a, f);
         return true;
     }
-    hipLaunchKernelGGL(fn, grid, dim3(waves * 64), lds, s, a.parts[0].qs, a.parts[0].sc, a.parts[0].out, a.pro.a, a.pro.b, a.in_rs, a.K,
+    hipLaunchKernelGGL(fn, grid, dim3(waves * 64), lds, s, a.parts[0].qs, a.parts[0].sc, a.parts[0].out, head_xa, head_xb, a.in_rs, a.K,
                        a.parts[0].NB2 | ((waves - 1) << 20) | (a.n_parts << 24) | (contig ? 1u << 28 : 0u) | (a.pro.kind == QMV_PRO_RMSNORM_MUL ? 1u << 29 : 0u) |
-                           (a.x_vec ? 1u << 30 : 0u),
+                           (a.x_vec ? 1u << 30 : 0u) | (prenorm_late() ? 1u << 31 : 0u),
                        nb2_12, a);
     return true;
 }

@@ -1063,7 +1063,6 @@ void fuse_qkv_attention(zgml_hip_program* p) {
         const bool kon = L.parts[0].w.format == QW_Q4K && L.K > 2048; // the 256-thread form of the launch (qkv_attn_kon_kernel)
         static const bool kon_on = !(getenv("ZGML_HIP_FUSE_QKV_ATTN_KON") && atoi(getenv("ZGML_HIP_FUSE_QKV_ATTN_KON")) == 0);
         if (L.n_parts != 3 || (L.K > 2048 && !(kon && kon_on)) || L.pro.kind == QMV_PRO_NONE || (ad->dh != 64 && ad->dh != 128) || L.trace) continue;
-        if (L.pro.kind == QMV_PRO_PRENORM && L.parts[0].w.format != QW_Q4K) continue;
         if (kon && L.pro.kind != QMV_PRO_PRENORM) continue; // (an in-kernel rmsnorm prologue runs eight waves: launch_packed_kon)
         const bool kvq = ad->kvq;
         bool ok = true;
@@ -1240,7 +1239,9 @@ void fuse_attention_o(zgml_hip_program* p) {
 // whose rmsnorm -> mul(gamma) prologue consumes h prepares that prologue (kernels.h: QmvNextNorm / QMV_PRO_PRENORM): it also
 // stores h * gamma and, per 16 columns, the sum of h^2. The consumer then streams one vector instead of two — x (16 KB at
 // K = 4096) stays in a CU's L1 across the workgroups it hosts, x and gamma together do not (tools/exp/kon.hip: +0.5 us at
-// 4096^2, +0.8 at 4096 x 11008, +1.8 at 4096 x 32000) — and needs no sum over x. Only K-on-lanes consumers (QW_Q4K).
+// 4096^2, +0.8 at 4096 x 11008, +1.8 at 4096 x 32000) — and needs no sum over x. Consumers: K-on-lanes launches (QW_Q4K) and, since
+// round 4, the x-direct n-on-lanes launches of short-K models (qmv_prenorm_ok: SmolLM-135M's q/k/v and gate/up, whose in-kernel
+// prologue — second vector, sum of squares, barrier — cost 1.1 us of a 2.6 us launch by the stamps).
 void arm_prenorm(zgml_hip_program* p) {
     static const bool on = !(getenv("ZGML_HIP_PRENORM") && atoi(getenv("ZGML_HIP_PRENORM")) == 0);
     if (!on) return;
@@ -1248,7 +1249,9 @@ void arm_prenorm(zgml_hip_program* p) {
         const auto C = p->plan[i].qmv_desc, P = p->plan[i - 1].qmv_desc;
         if (!C || !P || C->pro.kind != QMV_PRO_RMSNORM_MUL) continue;
         bool ok = true;
-        for (uint32_t t = 0; t < C->n_parts; t++) ok = ok && C->parts[t].w.format == QW_Q4K;
+        uint64_t cols = 0;
+        for (uint32_t t = 0; t < C->n_parts; t++) cols += C->parts[t].w.N;
+        for (uint32_t t = 0; t < C->n_parts; t++) ok = ok && C->parts[t].w.format == C->parts[0].w.format && qmv_prenorm_ok(C->parts[t].w, C->K, cols, 1);
         const QmvPart& pp = P->parts[0];
         ok = ok && P->n_parts == 1 && pp.w.format != QW_RAW && pp.w.N == C->K && pp.n_epi == 1 && pp.epi[0].op == ZGML_OP_ADD && pp.epi[0].operand &&
              pp.epi[0].operand != pp.dst && pp.epi[0].store == C->pro.a && C->K % 16 == 0 && !P->next.xg_out;
@@ -3193,6 +3196,37 @@ zgml_runtime_profile* zgml_hip_get_runtime_profile(zgml_hip_ctx*, zgml_hip_progr
 // ── extensions ──────────────────────────────────────────────────────────────────────────────
 
 // a caller about to touch a buffer some hoisted (run-once) repeat read or wrote: back to running every repeat in the plan
+uint64_t zgml_hip_program_plan_text(zgml_hip_ctx* ctx, zgml_hip_program* p, char* out, uint64_t cap) {
+    if (!ctx || !p) return 0;
+    if (p->plan_dirty || p->fuse_epoch != ctx->fuse_epoch) {
+        free_graph(p);
+        build_plan(p);
+    }
+    static const char* const pro_names[4] = {"none", "mul", "rmsnorm", "prenorm"};
+    std::string t;
+    for (size_t i = 0; i < p->plan.size(); i++) {
+        const Launch& L = p->plan[i];
+        char line[256];
+        snprintf(line, sizeof line, "%zu: kind %u ops %u [%u..%u]", i, L.kind, L.n_ops, L.op_lo, L.op_hi);
+        t += line;
+        if (L.qmv_desc) {
+            const QmvLaunch& q = *L.qmv_desc;
+            snprintf(line, sizeof line, " qmv parts %u K %u pro %s%s%s", q.n_parts, q.K, pro_names[q.pro.kind < 4 ? q.pro.kind : 0], q.next.xg_out ? " prepares-next-norm" : "",
+                     q.pair_out ? " pair" : "");
+            t += line;
+        }
+        if (L.adec_desc) t += L.qmv_desc ? " +decode-attention" : " decode-attention";
+        if (L.hook && L.hook->ap && *L.hook->ap) t += " writes-A-operand";
+        t += "\n";
+    }
+    if (out && cap) {
+        const uint64_t n = std::min<uint64_t>(cap - 1, t.size());
+        memcpy(out, t.data(), n);
+        out[n] = 0;
+    }
+    return t.size();
+}
+
 void unhoist_if_guarded(zgml_hip_program* p, uint16_t buf_idx) {
     if (p->hoist_ok && buf_idx < p->hoist_guard.size() && p->hoist_guard[buf_idx]) p->hoist_ok = false, p->plan_dirty = true;
 }

@@ -519,6 +519,13 @@ class Backend:
     def synchronize(self) -> None:
         self._lib.zgml_hip_synchronize(self.ctx)
 
+    def planText(self, handle) -> str:
+        """zgml_hip_program_plan_text: one line per launch of the program's plan (diagnostics, tests)."""
+        n = int(self._lib.zgml_hip_program_plan_text(self.ctx, handle, None, 0))
+        buf = C.create_string_buffer(n + 1)
+        self._lib.zgml_hip_program_plan_text(self.ctx, handle, buf, n + 1)
+        return buf.value.decode()
+
 
 def tryDenseMatMul(backend: Optional[Backend], spec: DenseMatMulSpecF32) -> bool:
     """src/backend.zig:386-390."""
