@@ -119,6 +119,44 @@ def test_matmul_shared_a_kernel_matches_oracle(hip_backend, oracle, M, K, N):
     assert np.array_equal(got, again)
 
 
+@pytest.mark.parametrize("M,K,N", [(45, 576, 12288), (64, 1100, 10240), (128, 4096, 12288), (200, 576, 12288), (100, 4096, 22016)])
+def test_matmul_wide_outputs_above_32_rows_match_oracle(hip_backend, oracle, M, K, N):
+    """33 <= M with a WIDE output: the K-split tile kernel at 4 or 8 m-tiles per workgroup (M = 45 / 64: four, 45 with padding
+    rows; 128: eight, the prefill chunk of the 7B layer's q/k/v; 200: two tile groups, the second with padding rows; 100 x 22016:
+    the gate / up width, 7 of 8 tiles live). Same bound as every other form (two-piece A operand: 2^-17 sum|x w|), bit-identical
+    across two executions (ordered fan-in)."""
+    rng = np.random.default_rng(0x7A + M + K + N)
+    x, data, scales = _q4_case(rng, M, K, N)
+    want, got = run_both(hip_backend, oracle, data, scales, x, M, N, K, in_off=4, in_rs=K + 4, dst_off=1, dst_rs=N + 5)
+    b = np.zeros_like(want, dtype=np.float64)
+    bb = bound(data, scales, x, M, N, K, 32)
+    for m in range(M):
+        b[1 + m * (N + 5):][:N] = bb[m]
+    assert np.all(np.abs(got - want) <= TOL * b + 1e-30), np.max(np.abs(got - want) / (b + 1e-30))
+    assert np.array_equal(got == -7, want == -7)
+    _, again = run_both(hip_backend, oracle, data, scales, x, M, N, K, in_off=4, in_rs=K + 4, dst_off=1, dst_rs=N + 5)
+    assert np.array_equal(got, again)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("knobs", [{}, {"ZGML_QMM_XDL7_MIN_COLS": "1", "ZGML_QMM_XDL7_MIN_RUN": "1"}, {"ZGML_QMM_XDL7_MIN_COLS": "1", "ZGML_QMM_XDL7_MIN_RUN": "1000"}])
+def test_shared_a_experiment_kernel_above_32_rows(knobs):
+    """The round-4 experiment kernel (qmatmul_xdl7_kernel: the M <= 32 form's shared-A work list at 4 / 8 m-tiles per workgroup;
+    measured slower than the K-split kernel, so it exists in the diagnostics library only, ZGML_QMM_XDL7=1) stays parity green:
+    the wide M > 32 cases above, then forced onto every M > 32 case of the tile tests and the 128-token prefill chunk (narrow and
+    ragged outputs, grouped launches) with runs of one step and with whole columns only. A process per setting (switches are read once)."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    trace_lib = Path(__file__).resolve().parent.parent / "zgml_amd" / "lib" / "libzgml_hip_trace.so"
+    assert trace_lib.exists(), "run __graft_entry__.build(): it builds the diagnostics library too"
+    env = dict(os.environ, ZGML_HIP_LIB=str(trace_lib), ZGML_QMM_XDL7="1", **knobs)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "tests/test_hip_qmatvec.py", "tests/test_hip_l7dims.py",
+                        "-k", "tile_kernel or wide_outputs_above_32 or chunk128 or worst_case"], capture_output=True, text=True, timeout=880, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 @pytest.mark.timeout(900)
 def test_shared_a_kernel_on_narrow_and_ragged_outputs():
     """The same kernel forced onto every M <= 32 case of this file and of the 7B-dimension file (ZGML_QMM_XDL5_MIN_COLS=1:

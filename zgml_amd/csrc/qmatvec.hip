@@ -2325,6 +2325,270 @@ __global__ void __launch_bounds__(WAVES * 64) qmatmul_xdl5_kernel(QMM5Args a) {
     }
 }
 
+#ifdef ZGML_TRACE
+// ── XDL tile kernel for M > 32 with the A pieces SHARED through LDS (round 4) ─────────────────────────────────────────────────────────
+// qmatmul_xdl4_kernel gives every 32-column workgroup its own pass over A (128 x 4096 rows: 2 MB of pieces per workgroup, 1.4 GB
+// per gate / up launch through L2): q/k/v and gate/up at M = 128 run at 2.4-2.8 x their MFMA time (57.6 / 87.6 us against 20.5 /
+// 36.7). This is the M <= 32 form above (qmatmul_xdl5_kernel: 8 waves = 8 block-columns = 256 columns per workgroup-column, one
+// list of (workgroup-column, K step) pairs cut into equal runs, partial tiles published and summed in run order by the last
+// arriver) at RT = 4 or 8 m-tiles per workgroup, with what the larger tile needs:
+//   * a step's A pieces (RT x 8 KB, double-buffered: 128 KB at RT = 8) come through registers in TWO halves, each fetched one
+//     stage before it is parked (a whole step's 8 uint4 per thread would not fit beside the accumulators);
+//   * the m-tiles are taken in PAIRS: the pair's A registers (2 tiles x 2 pieces) are a ring of two slots, the next pair is read
+//     from LDS while the current one multiplies (16 MFMAs over four accumulators: every accumulator is touched each fourth MFMA);
+//   * one accumulator per (column group, m-tile): 16 independent chains, no second set for the low B piece;
+//   * tile groups of RT m-tiles (M > 16 RT) are blockIdx.y: every group has its own partial tiles and counters.
+// MEASURED SLOWER than the K-split kernel it was meant to replace (profiles/r04_exp_xdl7.txt: 4096 x 22016 at M = 128 114-116 us
+// against 84-87, 4096 x 12288 89-93 against 58; M = 64: 58.6 / 43.8 against 49.5 / 34.0), parity green. The counters say why the
+// A traffic was the wrong target: 5.64 M MFMAs (90 M pipe cycles) + 18.3 M vector instructions on 1024 SIMDs are 159 k cycles per
+// SIMD when matrix and vector work serialise — which they do (tools/exp/stage_parts.hip) — i.e. 64 us at best for this
+// instruction mix, 48 us for the K-split kernel's (1.4 vector instructions per MFMA there, 3.25 here: ring copies, the staging
+// stores, address arithmetic); both kernels sit at ~57 % of that bound. Diagnostics build only (ZGML_QMM_XDL7=1).
+struct QMM7Args {
+    QMM2Part parts[kMaxQmmParts]; // NB2 = block-columns (N / 32) of the part, block_begin = its first workgroup-column
+    const uint4* ap;              // split_a_kernel output (tiles padded to a multiple of RT)
+    float* partial;               // [tile group][workgroup][segment 0 / 1][wave][2 RT 256] f32
+    uint32_t* counter;            // [tile group][workgroup-column], zero between launches
+    uint32_t n_parts, M, U, S, run, total, wg_cols;
+};
+constexpr uint32_t kX7Waves = 8;
+
+template <int RT, bool NT>
+__global__ void __launch_bounds__(kX7Waves * 64) qmatmul_xdl7_kernel(QMM7Args a) {
+    constexpr int C = 2, WAVES = kX7Waves, NP = RT / 2; // NP tile pairs
+    static_assert(RT == 4 || RT == 8, "m-tiles per workgroup");
+    constexpr uint32_t APS = 4 * kAPieces * 64;          // uint4 of one m-tile's A pieces per 128-k step: [J][piece][lane]
+    constexpr uint32_t T = WAVES * 64, STEP = RT * APS;  // uint4 of one step's A pieces: [tile][J][piece][lane]
+    constexpr uint32_t NA = STEP / T, NH = NA / 2;       // uint4 per thread and step, per half
+    static_assert(STEP % (2 * T) == 0, "two halves of whole rounds");
+    constexpr uint32_t WT = C * RT * 256;                // floats of one wave's tile
+    extern __shared__ uint4 lds_a[];                     // [2][STEP], then one flag word
+    uint32_t* const flag = (uint32_t*)(lds_a + 2 * STEP);
+    const uint32_t lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t row = lane >> 4, i = lane & 15;
+    const uint64_t tile_stride = (uint64_t)a.S * APS;
+    const uint32_t tg = blockIdx.y;
+    const uint4* const ap_g = a.ap + (uint64_t)tg * RT * tile_stride;
+    const uint32_t u_begin = blockIdx.x * a.run, u_end = min(u_begin + a.run, a.total);
+
+    for (uint32_t u0 = u_begin, seg = 0; u0 < u_end; seg++) { // at most two segments (run <= S)
+        const uint32_t wgc = u0 / a.S, s_begin = u0 - wgc * a.S, s_end = min(a.S, s_begin + (u_end - u0)), s_last = s_end - 1;
+        u0 += s_end - s_begin;
+        uint32_t pi = 0;
+#pragma unroll
+        for (uint32_t t = 1; t < (uint32_t)kMaxQmmParts; t++)
+            if (t < a.n_parts && wgc >= a.parts[t].block_begin) pi = t;
+        const QMM2Part& P = a.parts[pi];
+        const uint32_t cb_raw = (wgc - P.block_begin) * WAVES + w;
+        const bool live = cb_raw < P.NB2;
+        const uint32_t cb = live ? cb_raw : P.NB2 - 1; // idle waves shadow the last column: loads stay in bounds
+        const uint4* qs = P.qs + (uint64_t)(cb * C) * a.U * 16 + i;
+        const uint32_t* scd = (const uint32_t*)P.sc + (uint64_t)cb * a.U * 16 + i;
+
+        mfma_f4 acc[C][RT];
+#pragma unroll
+        for (int g = 0; g < C; g++)
+#pragma unroll
+            for (int t = 0; t < RT; t++) acc[g][t] = mfma_f4{0.f, 0.f, 0.f, 0.f};
+
+        struct WStep {
+            uint4 wq[C];
+            uint32_t sd;
+        };
+        struct BP {
+            uint4 b1[C], b2[C];
+        };
+        auto load_w = [&](WStep& b, uint32_t s) {
+            const uint32_t u = min(4 * s + row, a.U - 1); // units past the end: A is zero there
+#pragma unroll
+            for (int g = 0; g < C; g++) b.wq[g] = wload<NT>(qs + ((uint64_t)g * a.U + u) * 16);
+            b.sd = scd[(uint64_t)u * 16];
+        };
+        uint4 ah0 = {}, ah1 = {}, ah2 = {}, ah3 = {}; // one half of a step's A pieces (named registers: see the M <= 32 form)
+        static_assert(NH <= 4, "A pieces of half a step per thread");
+        auto a_src = [&](uint32_t s, uint32_t q) -> const uint4* {
+            const uint32_t idx = threadIdx.x + q * T;
+            return ap_g + (uint64_t)(idx / APS) * tile_stride + (uint64_t)s * APS + idx % APS;
+        };
+        auto fetch_half = [&](uint32_t s, uint32_t h) {
+            ah0 = *a_src(s, h * NH);
+            if (NH > 1) ah1 = *a_src(s, h * NH + 1);
+            if (NH > 2) ah2 = *a_src(s, h * NH + 2);
+            if (NH > 3) ah3 = *a_src(s, h * NH + 3);
+        };
+        auto park_half = [&](uint32_t buf, uint32_t h) {
+            uint4* const d = lds_a + buf * STEP + h * NH * T + threadIdx.x;
+            d[0] = ah0;
+            if (NH > 1) d[T] = ah1;
+            if (NH > 2) d[2 * T] = ah2;
+            if (NH > 3) d[3 * T] = ah3;
+        };
+        uint4 xa[2][2][kAPieces]; // ring of two tile PAIRS: [slot][tile of the pair][piece]
+        auto read_pair = [&](uint32_t buf, int J, int pr, int slot) {
+#pragma unroll
+            for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+                for (int p = 0; p < kAPieces; p++) xa[slot][tt][p] = lds_a[buf * STEP + (((2 * pr + tt) * 4 + J) * kAPieces + p) * 64 + lane];
+        };
+        auto mfma_pair = [&](const BP& o, int pr, int slot) { // 16 MFMAs over four accumulators
+#pragma unroll
+            for (int p = 0; p < kAPieces; p++) {
+#pragma unroll
+                for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+                    for (int g = 0; g < C; g++)
+                        acc[g][2 * pr + tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(xa[slot][tt][p]), as_bf16x8(o.b1[g]), acc[g][2 * pr + tt], 0, 0, 0);
+#pragma unroll
+                for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+                    for (int g = 0; g < C; g++)
+                        if (p < kXdlLoPieces)
+                            acc[g][2 * pr + tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(xa[slot][tt][p]), as_bf16x8(o.b2[g]), acc[g][2 * pr + tt], 0, 0, 0);
+            }
+        };
+        auto scale_bits = [](const WStep& b, int& lo, int& hi) {
+            const __half2 hh = __builtin_bit_cast(__half2, b.sd);
+            lo = __float_as_int(__half2float(hh.x)), hi = __float_as_int(__half2float(hh.y)); // scales of k_local i, 16 + i
+        };
+
+        WStep wa, wb, wc; // the weights of steps s, s + 1, s + 2: three names rotating
+        BP p0, p1;
+        int sl, sh;
+        // prologue: the first step's A pieces (both halves), the weights of the first two steps
+        load_w(wa, s_begin);
+        fetch_half(s_begin, 0);
+        if (seg) __syncthreads(); // the previous segment's last reads of the A buffers
+        park_half(0, 0);
+        fetch_half(s_begin, 1);
+        load_w(wb, min(s_begin + 1, s_last));
+        park_half(0, 1);
+        __syncthreads();
+        scale_bits(wa, sl, sh);
+        xdl_prep_b<0, C>(wa.wq, sl, sh, p0.b1, p0.b2);
+        read_pair(0, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // one stage = the 8-k group J of the step: the B pieces of group J + 1 are prepared (vector work beside the MFMAs), the tile
+        // pairs multiply one after the other, each one's successor (the next pair of this group, or the first pair of the next
+        // group / step) read from LDS meanwhile
+#define XDL7_STAGE(CUR, NXT, BUF, J, JN, WSRC, CHAIN)                                  \
+    do {                                                                               \
+        xdl_prep_b<JN, C>(WSRC.wq, sl, sh, NXT.b1, NXT.b2);                            \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        _Pragma("unroll") for (int pr_ = 0; pr_ < NP; pr_++) {                         \
+            if (pr_ + 1 < NP)                                                          \
+                read_pair(BUF, J, pr_ + 1, (pr_ + 1) & 1);                             \
+            else if (CHAIN)                                                            \
+                read_pair(BUF, JN, 0, NP & 1);                                         \
+            __builtin_amdgcn_sched_barrier(0); /* (hipcc otherwise sinks the reads to their first use: one LDS round trip per pair exposed) */ \
+            mfma_pair(CUR, pr_, pr_ & 1);                                              \
+            __builtin_amdgcn_sched_barrier(0);                                         \
+        }                                                                              \
+    } while (0)
+        static_assert((NP & 1) == 0, "the ring's slot of a group's first pair is 0 in every stage");
+        // one K step: the first half of A(s + 1) and the weights of step s + 2 requested first; half 0 parked and half 1 requested
+        // behind the first stage, half 1 parked behind the third. EVERY LDS read of the step (the fourth stage's pairs included) lies
+        // in front of the barrier: the next step parks into this buffer right after its first stage. The next step's first pair is
+        // read behind the barrier (a bubble of one LDS round trip per step and wave; the SIMD's other wave fills it)
+#define XDL7_STEP(S_, CUR, NXT, LD)                                                                   \
+    do {                                                                                              \
+        const uint32_t sn_ = min((S_) + 1, s_last); /* clamped: the last prefetches re-read live lines */ \
+        fetch_half(sn_, 0);                                                                           \
+        load_w(LD, min((S_) + 2, s_last));                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        XDL7_STAGE(p0, p1, buf, 0, 1, CUR, true);                                                     \
+        park_half(buf ^ 1, 0); /* every wave is past its last read of that buffer since the previous barrier */ \
+        fetch_half(sn_, 1);                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        XDL7_STAGE(p1, p0, buf, 1, 2, CUR, true);                                                     \
+        XDL7_STAGE(p0, p1, buf, 2, 3, CUR, true);                                                     \
+        park_half(buf ^ 1, 1);                                                                        \
+        scale_bits(NXT, sl, sh);                                                                      \
+        XDL7_STAGE(p1, p0, buf, 3, 0, NXT, false); /* (after the last step: a wasted preparation) */   \
+        __syncthreads();                                                                              \
+        buf ^= 1;                                                                                     \
+        read_pair(buf, 0, 0, 0);                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+    } while (0)
+        uint32_t buf = 0;
+        for (uint32_t s = s_begin;; s += 3) {
+            XDL7_STEP(s, wa, wb, wc);
+            if (s + 1 >= s_end) break;
+            XDL7_STEP(s + 1, wb, wc, wa);
+            if (s + 2 >= s_end) break;
+            XDL7_STEP(s + 2, wc, wa, wb);
+            if (s + 3 >= s_end) break;
+        }
+#undef XDL7_STEP
+#undef XDL7_STAGE
+        // D[m = 4 * row + v][n = i] in acc[g][t][v]
+        if (s_end - s_begin != a.S) { // part of a column: publish, count, the last arriver sums the column's runs in run order
+            using gf32 = __attribute__((address_space(1))) float;
+            using gu32 = __attribute__((address_space(1))) unsigned int;
+            float* const part_g = a.partial + (uint64_t)tg * gridDim.x * (2 * WAVES * WT);
+            float* const mine = part_g + (((uint64_t)blockIdx.x * 2 + seg) * WAVES + w) * WT + lane;
+#pragma unroll
+            for (int g = 0; g < C; g++)
+#pragma unroll
+                for (int t = 0; t < RT; t++)
+#pragma unroll
+                    for (int v = 0; v < 4; v++) __hip_atomic_store((gf32*)(mine + ((g * RT + t) * 4 + v) * 64), acc[g][t][v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains before the count
+            __syncthreads();
+            const uint32_t b_lo = (wgc * a.S) / a.run, b_hi = (wgc * a.S + a.S - 1) / a.run; // the workgroups whose runs touch this column
+            uint32_t* const cnt = a.counter + tg * a.wg_cols + wgc;
+            if (threadIdx.x == 0) *flag = __hip_atomic_fetch_add((gu32*)cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            const bool last = *flag == b_hi - b_lo;
+            __syncthreads(); // (the flag word is reused by the next segment)
+            if (!last) continue;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // compiler only: the loads below stay below the count
+#pragma unroll
+            for (int g = 0; g < C; g++)
+#pragma unroll
+                for (int t = 0; t < RT; t++)
+#pragma unroll
+                    for (int v = 0; v < 4; v++) acc[g][t][v] = 0.f;
+            // run order, not arrival order; the loads of kBatch runs are in flight together
+            constexpr uint32_t kBatch = RT == 8 ? 2 : 4;
+            for (uint32_t b0 = b_lo; b0 <= b_hi; b0 += kBatch) {
+                float pv[kBatch][C * RT * 4];
+#pragma unroll
+                for (uint32_t q = 0; q < kBatch; q++) {
+                    const uint32_t b = min(b0 + q, b_hi);           // (past the end: a live line again, dropped below)
+                    const uint32_t bseg = (b * a.run) / a.S != wgc; // the column is that workgroup's second one
+                    const float* const src = part_g + (((uint64_t)b * 2 + bseg) * WAVES + w) * WT + lane;
+#pragma unroll
+                    for (int e = 0; e < C * RT * 4; e++) pv[q][e] = __hip_atomic_load((gf32*)(src + e * 64), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+                for (uint32_t q = 0; q < kBatch; q++) {
+                    const bool in = b0 + q <= b_hi;
+#pragma unroll
+                    for (int g = 0; g < C; g++)
+#pragma unroll
+                        for (int t = 0; t < RT; t++)
+#pragma unroll
+                            for (int v = 0; v < 4; v++) acc[g][t][v] += in ? pv[q][(g * RT + t) * 4 + v] : 0.f;
+                }
+            }
+            if (threadIdx.x == 0) __hip_atomic_store((gu32*)cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // re-arm
+        }
+        if (live) {
+#pragma unroll
+            for (int g = 0; g < C; g++)
+#pragma unroll
+                for (int t = 0; t < RT; t++)
+#pragma unroll
+                    for (int v = 0; v < 4; v++) {
+                        const uint32_t m = (tg * RT + t) * 16 + 4 * row + v, n = (cb * C + g) * 16 + i;
+                        if (m < a.M) P.out[(uint64_t)m * P.out_rs + n] = acc[g][t][v] * 16.0f; // the tile carries q/16
+                    }
+        }
+    }
+}
+
+#endif // ZGML_TRACE (qmatmul_xdl7_kernel)
+
 // Raw layout (any block size, any N): one thread per (m, n), k sequential — exactly the
 // reference's loop order, coalesced along n. Used for odd shapes (e.g. the bs=4 conformance case).
 __global__ void __launch_bounds__(kBlock) qmatmul_raw_kernel(const int8_t* __restrict__ data,
@@ -2596,9 +2860,23 @@ static uint64_t xdl5_partial_bytes(uint32_t M) {
     if (M > 32 || !xdl5_enabled()) return 0;
     return (uint64_t)xdl5_wgs() * 2 * kX5Waves * (2 * xdl_tile_pad(M) * 256) * sizeof(float);
 }
+// M > 32 (qmatmul_xdl7_kernel, diagnostics build only, opt-in): tile groups x workgroups per group <= max(workgroups of the launch, groups)
+static bool xdl7_enabled() {
+#ifdef ZGML_TRACE
+    static const bool on = getenv("ZGML_QMM_XDL7") && atoi(getenv("ZGML_QMM_XDL7")) != 0;
+    return on;
+#else
+    return false;
+#endif
+}
+static uint64_t xdl7_partial_bytes(uint32_t M) {
+    if (M <= 32 || !xdl7_enabled()) return 0;
+    const uint64_t RT = xdl_tile_pad(M), groups = ((M + 15) / 16 + RT - 1) / RT;
+    return std::max<uint64_t>(xdl5_wgs(), groups) * 2 * 8 * (2 * RT * 256) * sizeof(float);
+}
 uint64_t qmatmul_scratch_bytes(const QWeightDev& w, uint32_t M) {
     if (!xdl2_applies(w, M)) return 0;
-    return xdl_a_bytes(w, M) + std::max((uint64_t)kMaxQmmParts * xdl4_partial_bytes(w, M), xdl5_partial_bytes(M));
+    return xdl_a_bytes(w, M) + std::max({(uint64_t)kMaxQmmParts * xdl4_partial_bytes(w, M), xdl5_partial_bytes(M), xdl7_partial_bytes(M)});
 }
 
 bool qweight_packable(uint64_t K, uint64_t N, uint64_t bs) {
@@ -3052,10 +3330,47 @@ bool launch_xdl5(hipStream_t s, const QWeightDev* w, const QMatmulParams* p, uin
     return true;
 }
 
+#ifdef ZGML_TRACE
+// M > 32: the shared-A form at RT = 4 / 8 m-tiles per workgroup. false = not applicable (narrow outputs: the K-split kernel above keeps them)
+bool launch_xdl7(hipStream_t s, const QWeightDev* w, const QMatmulParams* p, uint32_t n, float* scratch, uint32_t S, uint32_t RT, uint32_t tiles) {
+    QMM7Args a{};
+    uint32_t wg_cols = 0;
+    for (uint32_t t = 0; t < n; t++) {
+        a.parts[t] = {(const uint4*)w[t].qs, (const uint4*)w[t].sc, p[t].dst, p[t].dst_rs, p[t].N / 32, wg_cols};
+        wg_cols += cdiv(p[t].N / 32, kX7Waves);
+    }
+    const uint32_t groups = tiles / RT;
+    if ((uint64_t)groups * wg_cols * sizeof(uint32_t) > kQmmCounterBytes) return false;
+    // narrow outputs: every run of a column costs the fan-in a partial tile of 16 RT KB per wave to write and to read back; below ~40
+    // workgroup-columns (N < 10240) there are many runs per column and the K-split kernel wins (as for the M <= 32 form)
+    static const int min_cols = getenv("ZGML_QMM_XDL7_MIN_COLS") ? atoi(getenv("ZGML_QMM_XDL7_MIN_COLS")) : 40;
+    if ((int)wg_cols < min_cols) return false;
+    static const int min_run = getenv("ZGML_QMM_XDL7_MIN_RUN") ? std::max(1, atoi(getenv("ZGML_QMM_XDL7_MIN_RUN"))) : 2;
+    const uint32_t total = wg_cols * S, wgs_g = std::max(1u, xdl5_wgs() / groups);
+    const uint32_t run = std::min(S, std::max(cdiv(total, wgs_g), std::min((uint32_t)min_run, S)));
+    a.ap = (const uint4*)scratch;
+    a.partial = (float*)((char*)scratch + xdl_a_bytes(w[0], p[0].M));
+    a.counter = (uint32_t*)((char*)scratch - kQmmScratchHead);
+    a.n_parts = n, a.M = p[0].M, a.U = w[0].KC, a.S = S, a.run = run, a.total = total, a.wg_cols = wg_cols;
+    const dim3 grid(cdiv(total, run), groups); // grid.x <= wgs_g unless every run is a whole column (no partial tiles then)
+    const size_t lds = 2 * (size_t)RT * (4 * kAPieces * 64) * 16 + 64;
+    const bool nt = w[0].stream_nt != 0 && groups == 1;
+    using Fn7 = void (*)(QMM7Args);
+    const Fn7 fn = RT == 8 ? (nt ? (Fn7)qmatmul_xdl7_kernel<8, true> : (Fn7)qmatmul_xdl7_kernel<8, false>)
+                           : (nt ? (Fn7)qmatmul_xdl7_kernel<4, true> : (Fn7)qmatmul_xdl7_kernel<4, false>);
+    if (lds > 64 * 1024) hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(fn, grid, dim3(kX7Waves * 64), lds, s, a);
+    return true;
+}
+#endif
+
 void launch_xdl2(hipStream_t s, const QWeightDev* w, const QMatmulParams* p, uint32_t n, float* scratch) {
     const uint32_t U = w[0].KC, S = cdiv(U, 4), R = xdl_tile_pad(p[0].M), tiles = cdiv(cdiv(p[0].M, 16), R) * R;
     if (!p[0].reuse_split) hipLaunchKernelGGL(split_a_kernel, dim3(S, tiles), dim3(256), 0, s, p[0].input, p[0].M, p[0].K, p[0].in_rs, (uint4*)scratch, S);
     static const bool xdl4_on = !(getenv("ZGML_QMM_XDL4") && atoi(getenv("ZGML_QMM_XDL4")) == 0);
+#ifdef ZGML_TRACE
+    if (R >= 4 && xdl7_enabled() && launch_xdl7(s, w, p, n, scratch, S, R, tiles)) return;
+#endif
     if (R >= 4 && xdl4_on) {
         launch_xdl4(s, w, p, n, scratch, S, R, tiles);
         return;
