@@ -370,6 +370,52 @@ def test_prepared_norm_hand_over_stores_every_intermediate(hip_backend, oracle, 
         hip_backend.freeProgram(h)
 
 
+@pytest.mark.parametrize("K,F", [(576, 1536), (2048, 2048), (4096, 11008)])
+def test_gate_up_pair_launch_stores_every_intermediate(hip_backend, oracle, K, F):
+    """The SwiGLU half as the LLaMA lowering emits it (llama_transformer.zig:129-133, silu = nn.zig:38-44): gate and up over the
+    same input, the SiLU chain on gate, silu(gate) * up, the down projection over the product. The planner turns the first launch into
+    a PAIR launch — one workgroup computes the same 16 columns of gate AND up and stores the product itself — and the down
+    projection streams it with no prologue: K-on-lanes weights (K > 2048) since round 3, the x-direct n-on-lanes launches of short-K
+    models since round 4. Every buffer the unfused program would have written against the oracle; the plan's text says which form ran."""
+    from zgml_amd import FusedEwStep
+    rng = np.random.default_rng(K * 3 + F)
+    x = rng.standard_normal(K).astype(f32)
+    one = np.ones(F, f32)
+    B = dict(x=0, one=1, gate=2, up=3, exp_neg=4, silu=5, act=6, down=7)
+    sizes = [K, F, F, F, F, F, F, K]
+    ops = [
+        DeviceOp.qmatmul(B["gate"], B["x"], 0, 1, F, K),
+        DeviceOp.fused_elementwise([FusedEwStep("neg"), FusedEwStep("exp")], F, B["exp_neg"], B["gate"]),
+        DeviceOp.fused_elementwise([FusedEwStep("add", False, B["one"], 0), FusedEwStep("recip"), FusedEwStep("mul", True, B["gate"], 0)], F,
+                                   B["silu"], B["exp_neg"]),
+        DeviceOp.qmatmul(B["up"], B["x"], 1, 1, F, K),
+        DeviceOp.elementwise("mul", B["act"], B["silu"], B["up"], F),
+        DeviceOp.qmatmul(B["down"], B["act"], 2, 1, K, F),
+    ]
+    prog = DeviceProgram(ops=ops, buffer_sizes=sizes, initial_uploads=[ProgramIO(B["x"], x), ProgramIO(B["one"], one)],
+                         qweights=[_q4_weight(rng, K, F), _q4_weight(rng, K, F), _q4_weight(rng, F, K)])
+    h = hip_backend.compileProgram(prog)
+    assert h
+    try:
+        plan = hip_backend.planText(h)
+        lines = plan.strip().splitlines()
+        assert len(lines) == 2, plan
+        import os
+        if not any(os.environ.get(v) == "0" for v in ("ZGML_HIP_PAIR", "ZGML_HIP_PAIR_NOL", "ZGML_QMV_XDIRECT", "ZGML_QMV_EPI_SILU")):
+            assert " pair" in lines[0] and "pro none" in lines[1], plan
+        names = ["gate", "up", "exp_neg", "silu", "act", "down"]
+        outs = [np.zeros(sizes[B[n]], f32) for n in names]
+        for _ in range(2):  # (twice: the second run replays the graph)
+            hip_backend.executeProgram(h, [], [ProgramIO(B[n], o) for n, o in zip(names, outs)])
+        for name, got in zip(names, outs):
+            want = oracle.run_program(prog, B[name], sizes[B[name]])
+            scale = max(1.0, float(np.abs(want).max()))
+            # summation order only — but exp() turns the mat-vec's absolute difference into a relative one (see the chain test above)
+            np.testing.assert_allclose(got, want, rtol=1e-3, atol=1e-4 * scale, err_msg=name)
+    finally:
+        hip_backend.freeProgram(h)
+
+
 def test_refresh_to_a_matmul_over_a_matvec_only_weight_fails_loudly(hip_backend, oracle):
     """compile_program packs a Q4_0 weight K-on-lanes when every op that uses it has M == 1
     (K >= 2048). A later refresh_program that changes static fields is legal for the reference's CPU backend

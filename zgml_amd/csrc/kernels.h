@@ -404,6 +404,8 @@ uint32_t qmatmul_max_group();
 void launch_qmatmul_group(hipStream_t s, const QWeightDev* w, const QMatmulParams* p, uint32_t n, float* scratch);
 // can a mat-vec launch over `w` consume an rmsnorm -> mul(gamma) prologue prepared by its producer (QMV_PRO_PRENORM)?
 bool qmv_prenorm_ok(const QWeightDev& w, uint32_t K, uint64_t total_cols, uint32_t M);
+// can a two-matrix launch over weights like `w` compute silu(part 0) * part 1 itself (the gate / up PAIR launch)?
+bool qmv_pair_ok(const QWeightDev& w);
 // Fused M == 1 launch; all parts must be packed, share K, format and scale type (qmv_can_group).
 bool qmv_can_group(const QWeightDev& a, const QWeightDev& b);
 // Prologue kinds other than NONE keep the whole input in registers: K <= qmv_max_prologue_k(w).

@@ -723,10 +723,16 @@ struct QmvWait {
 // is the PRODUCER's a * gamma with its partial sums of a^2 right behind it (runtime.hip: arm_prenorm), xb_base the original a;
 // the finished sums are scaled by 1 / sqrt(mean(a^2) + eps) (the mat-vec is linear in x) and every workgroup stores a 16-element
 // slice of the absorbed ops' outputs — no second vector, no reduction over x and no barrier in front of the first FMA
-template <typename ST, bool XVEC, int DEPTH, bool Q4, int PROM, bool GROUPED, bool XD, bool NT, bool CONSUME = false>
+__device__ __forceinline__ void kon_pair_finish(const float* red, const QMVArgs& a, float* out0, uint32_t g, uint32_t n_waves, const KonTail& kt, float ones); // (below)
+// PAIR (x-direct launches only; the gate / up launch of a SwiGLU block whose next launch would multiply silu(gate) and up as its
+// prologue — runtime.hip: arm_pair): the workgroup computes the same 16 columns of BOTH matrices (two contiguous parts of equal
+// shape; x is loaded once) and wave 0 stores the plan's buffers and the product itself (kon_pair_finish), so the down
+// projection streams one vector with no prologue. One workgroup per column group of part 0.
+template <typename ST, bool XVEC, int DEPTH, bool Q4, int PROM, bool GROUPED, bool XD, bool NT, bool CONSUME = false, bool PAIR = false>
 __device__ __forceinline__ void qmatvec_body(QMV_HEAD_PARAMS, const QMVArgs& a, const uint32_t bx, const QmvPublish* pub, const QmvWait* wt = nullptr) {
     constexpr bool PRO = PROM == 1;
     static_assert(PROM != 2 || (XD && !CONSUME), "PRENORM: x-direct launches only");
+    static_assert(!PAIR || (XD && Q4 && GROUPED && !CONSUME && PROM != 1), "PAIR: x-direct Q4_0 gate / up launches without an in-kernel prologue");
     constexpr uint32_t UNIT_X = Q4 ? 32 : 16;
     using ScaleT = typename std::conditional<Q4, Pair<ST>, ST>::type;
     using Group = typename std::conditional<Q4, Q4Group<ST, DEPTH, XD, PRO, NT>, Q8Group<ST, DEPTH, XD, PRO, NT>>::type;
@@ -750,7 +756,7 @@ __device__ __forceinline__ void qmatvec_body(QMV_HEAD_PARAMS, const QMVArgs& a, 
     const uint32_t n_waves = ((nb2_0_flags >> 20) & 0xFu) + 1, bdim = n_waves * 64;
     const uint32_t NB2_0 = nb2_0_flags & 0xFFFFFu, n_parts = (nb2_0_flags >> 24) & 0xF, NB2_1 = nb2_12 & 0xFFFFu, NB2_2 = nb2_12 >> 16;
     uint32_t NB2 = NB2_0, block_begin = 0;
-    if (GROUPED) {
+    if (GROUPED && !PAIR) {
         if ((nb2_0_flags >> 28) & 1) { // contiguous parts: everything from preloaded scalars
             const uint32_t b1 = NB2_0, b2 = b1 + NB2_1; // (<= 3 parts: a fourth part's size would be an argument-block load in front of the first load)
             if (n_parts > 1 && bx >= b1) pi = 1, block_begin = b1, NB2 = NB2_1;
@@ -783,6 +789,10 @@ __device__ __forceinline__ void qmatvec_body(QMV_HEAD_PARAMS, const QMVArgs& a, 
     const bool pro_owner = XD && PRO && bx == 0 && blockIdx.y == 0;
     XDirect xd{xa_row, xb_base, nullptr, nullptr, K, 1.0f, false};
     Group cur;
+    // PAIR: part 1 follows part 0 in the weight arenas (same shape): its column group g sits NB2_0 groups further on
+    const uint4* const qs_b = qs + (uint64_t)NB2_0 * U * 16;
+    const ScaleT* const sc_b = sc + (uint64_t)(NB2_0 >> 1) * U * 16;
+    Group cur_b;
     // prologue kind and x alignment come with the preloaded head (bits 29 / 30), and the owner's side-output pointers are
     // read after the loads are issued: anything taken from the argument block before that is an s_load round trip
     // (~0.7 us on its first line) in front of the kernel's first load
@@ -821,6 +831,7 @@ __device__ __forceinline__ void qmatvec_body(QMV_HEAD_PARAMS, const QMVArgs& a, 
                 }
             }
             cur.load(qs, sc, u, stride, u_last, xd, i);
+            if (PAIR) cur_b.template load<1>(qs_b, sc_b, u, stride, u_last, xd, i); // (weights only: x is the other group's)
         }
         QMV_STAMP(1); // loads issued
         __builtin_amdgcn_sched_barrier(0); // argument-block reads below wait while the loads above fly
@@ -890,19 +901,46 @@ __device__ __forceinline__ void qmatvec_body(QMV_HEAD_PARAMS, const QMVArgs& a, 
         pre_g = (gp ? gp : xa_row)[gp ? g * 16 + i : 0];
     }
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+    float bcc0 = 0.f, bcc1 = 0.f, bcc2 = 0.f, bcc3 = 0.f; // PAIR: part 1's sums
+    float ones = 0.f;
+    if (PAIR) ones = a.parts[0].epi[2].operand[g * 16 + i]; // the SiLU chain's constant vector, requested under the stream
+    auto pair_x = [&](Group& b, const Group& src) { // part 1 multiplies the x values part 0's group loaded
+        if constexpr (PAIR) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; d++) b.xa[d] = src.xa[d], b.xb[d] = src.xb[d];
+        }
+    };
     for (uint32_t gi = 1; gi < n_groups; gi++) {
-        Group nxt;
+        Group nxt, nxt_b;
         nxt.template load<0, CONSUME>(qs, sc, u + DEPTH * stride, stride, u_last, xd, i);
+        if (PAIR) nxt_b.template load<1>(qs_b, sc_b, u + DEPTH * stride, stride, u_last, xd, i);
         cur.compute(xs, u, stride, U, i, acc0, acc1, acc2, acc3, xd);
+        if (PAIR) {
+            pair_x(cur_b, cur);
+            cur_b.compute(xs, u, stride, U, i, bcc0, bcc1, bcc2, bcc3, xd);
+            cur_b = nxt_b;
+        }
         cur = nxt;
         u += DEPTH * stride;
     }
     cur.compute(xs, u, stride, U, i, acc0, acc1, acc2, acc3, xd);
+    if (PAIR) {
+        pair_x(cur_b, cur);
+        cur_b.compute(xs, u, stride, U, i, bcc0, bcc1, bcc2, bcc3, xd);
+    }
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("" ::"s"(arg_touch)); // (keeps the touches alive; long arrived)
 #endif
     QMV_STAMP(4); // weights streamed
-    reduce_store<GROUPED>((acc0 + acc1) + (acc2 + acc3), red, a, pi, out0, g, m, pre0, have_pre0, n_waves, pub, PROM == 2 ? &ptail : nullptr, pre_g);
+    if constexpr (PAIR) { // both matrices' sums folded by wave 0, which stores the plan's buffers and the product (kon_pair_finish)
+        const float va = rows_sum4((acc0 + acc1) + (acc2 + acc3)), vb = rows_sum4((bcc0 + bcc1) + (bcc2 + bcc3));
+        if (lane < 16) red[w * 16 + lane] = va, red[(kMaxWaves + 1 + w) * 16 + lane] = vb;
+        if (PROM != 2) ptail.has_pro = false, ptail.norm = false, ptail.prenorm = false;
+        __syncthreads();
+        if (w == 0) kon_pair_finish(red, a, out0, g, n_waves, ptail, ones);
+    } else {
+        reduce_store<GROUPED>((acc0 + acc1) + (acc2 + acc3), red, a, pi, out0, g, m, pre0, have_pre0, n_waves, pub, PROM == 2 ? &ptail : nullptr, pre_g);
+    }
     QMV_STAMP(5);
 #undef QMV_STAMP
 }
@@ -917,6 +955,12 @@ __global__ void __launch_bounds__(1024) qmatvec_kernel(QMV_HEAD_PARAMS, QMVArgs 
 template <int DEPTH, bool GROUPED>
 __global__ void __launch_bounds__(1024) qmatvec_prenorm_kernel(QMV_HEAD_PARAMS, QMVArgs a) {
     qmatvec_body<__half, false, DEPTH, true, 2, GROUPED, true, false>(qs0, sc0, out0, xa_base, xb_base, in_rs, K, nb2_0_flags, nb2_12, a, blockIdx.x, nullptr);
+}
+
+// gate / up in pairs, n-on-lanes form (SmolLM-class models; LDS: two column sets of wave sums)
+template <int DEPTH, int PROM>
+__global__ void __launch_bounds__(1024) qmatvec_pair_kernel(QMV_HEAD_PARAMS, QMVArgs a) {
+    qmatvec_body<__half, false, DEPTH, true, PROM, true, true, false, false, true>(qs0, sc0, out0, xa_base, xb_base, in_rs, K, nb2_0_flags, nb2_12, a, blockIdx.x, nullptr);
 }
 
 // ── K ON LANES (QW_Q4K, round 3): the M = 1 mat-vec of GGUF-Q4_0-sourced weights ───────────────────────────────────────
@@ -2897,6 +2941,16 @@ bool qmv_prenorm_ok(const QWeightDev& w, uint32_t K, uint64_t total_cols, uint32
     return nol && xd_enabled && w.format == QW_Q4 && w.scale_f16 && !w.stream_nt && M == 1 && K % 16 == 0 && K <= 4096 && total_cols >= K; // (<= 256 partial sums)
 }
 
+// Can the gate / up launch over two weights shaped like `w` run as a PAIR launch (one workgroup computes the same 16 columns of both
+// and stores silu(gate) * up itself)? K-on-lanes weights: yes; n-on-lanes Q4_0 with f16 scales: the x-direct launches under the
+// default cache policy (ZGML_HIP_PAIR_NOL=0 keeps those as a grouped launch + the down projection's MUL prologue).
+bool qmv_pair_ok(const QWeightDev& w) {
+    if (w.format == QW_Q4K) return true;
+    static const bool xd_enabled = !(getenv("ZGML_QMV_XDIRECT") && atoi(getenv("ZGML_QMV_XDIRECT")) == 0);
+    static const bool nol = !(getenv("ZGML_HIP_PAIR_NOL") && atoi(getenv("ZGML_HIP_PAIR_NOL")) == 0);
+    return nol && xd_enabled && w.format == QW_Q4 && w.scale_f16 && !w.stream_nt;
+}
+
 bool qmv_can_group(const QWeightDev& a, const QWeightDev& b) {
     return a.format != QW_RAW && a.format == b.format && a.scale_f16 == b.scale_f16 && a.K == b.K && a.KC == b.KC;
 }
@@ -3157,6 +3211,19 @@ bool launch_packed(hipStream_t s, QMVArgs& a, const QWeightDev& w0, uint32_t tot
         hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
     if (a.n_parts > 1 && (a.parts[1].NB2 > 0xFFFFu || (a.n_parts > 2 && a.parts[2].NB2 > 0xFFFFu))) contig = false; // 16-bit fields
     const uint32_t nb2_12 = contig ? (a.parts[1].NB2 | (a.n_parts > 2 ? a.parts[2].NB2 << 16 : 0u)) : 0u;
+    if (a.pair_out) { // gate / up in pairs (arm_pair checked the shapes and the epilogues; the layout conditions are checked here)
+        const bool pair_ok = qmv_pair_ok(w0) && xd && !pro && !fused && a.n_parts == 2 && contig && M == 1 && a.parts[0].NB2 == a.parts[1].NB2 && a.parts[0].NB2 % 2 == 0;
+        if (!pair_ok) {
+            fprintf(stderr, "[zgml_hip] ERROR: a gate / up pair launch that does not meet the pair kernel's layout conditions: not launched\n");
+            return false;
+        }
+        const KernelFn pf = prenorm ? (depth_sel == 0 ? qmatvec_pair_kernel<1, 2> : depth_sel == 1 ? qmatvec_pair_kernel<2, 2> : qmatvec_pair_kernel<4, 2>)
+                                    : (depth_sel == 0 ? qmatvec_pair_kernel<1, 0> : depth_sel == 1 ? qmatvec_pair_kernel<2, 0> : qmatvec_pair_kernel<4, 0>);
+        const size_t lds2 = ((size_t)(2 * kMaxWaves + 1) * 16) * sizeof(float);
+        hipLaunchKernelGGL(pf, dim3(a.parts[0].NB2), dim3(waves * 64), lds2, s, a.parts[0].qs, a.parts[0].sc, a.parts[0].out, head_xa, head_xb, a.in_rs, a.K,
+                           a.parts[0].NB2 | ((waves - 1) << 20) | (a.n_parts << 24) | (1u << 28) | (a.x_vec ? 1u << 30 : 0u) | (prenorm_late() ? 1u << 31 : 0u), nb2_12, a);
+        return true;
+    }
     if (fused) {
         if (!(xd && (pro || prenorm) && grp && !nt && q4 && w0.scale_f16 && contig && M == 1 && a.n_parts == 3 && (d_head == 64 || d_head == 128))) return false;
         QkvAttnArgs f = *fused;

@@ -1283,7 +1283,8 @@ void arm_prenorm(zgml_hip_program* p) {
 // multiplies exactly silu(gate) and up becomes a PAIR launch (qmatvec.hip: qmatvec_kon_pair_kernel): one workgroup computes
 // the same 16 columns of both matrices (x is loaded once) and stores the product itself; the down projection then streams
 // one vector with no prologue (x = a * b per lane meant two 44 KB vectors per workgroup at Llama-2-7B's d_ff). K-on-lanes
-// weights only.
+// weights, and since round 4 the x-direct n-on-lanes launches of short-K models (qmv_pair_ok: SmolLM-135M, whose down projection
+// spent 0.5 us more than the O projection in front of its first load on the second vector).
 void arm_pair(zgml_hip_program* p) {
     // (ZGML_QMV_EPI_SILU=0 asks for the SiLU chain through the generic step interpreter: the pair launch IS a fused SiLU epilogue)
     static const bool on = !(getenv("ZGML_HIP_PAIR") && atoi(getenv("ZGML_HIP_PAIR")) == 0) && !(getenv("ZGML_QMV_EPI_SILU") && atoi(getenv("ZGML_QMV_EPI_SILU")) == 0);
@@ -1297,7 +1298,7 @@ void arm_pair(zgml_hip_program* p) {
         bool ok = ga.n_epi == 5 && st[0].op == ZGML_OP_NEG && !st[0].store && st[1].op == ZGML_OP_EXP && st[1].store && st[2].op == ZGML_OP_ADD &&
                   st[2].operand && st[2].operand != ga.dst && st[2].operand != st[1].store && !st[2].store && st[3].op == ZGML_OP_RECIP && !st[3].store &&
                   st[4].op == ZGML_OP_MUL && st[4].operand == ga.dst && st[4].store && up.n_epi == 0;
-        ok = ok && ga.w.format == QW_Q4K && up.w.format == QW_Q4K && ga.w.N == up.w.N && ga.w.K == up.w.K && (ga.w.N / 16) % 2 == 0 && ga.w.N == D->K &&
+        ok = ok && ga.w.format == up.w.format && qmv_pair_ok(ga.w) && qmv_pair_ok(up.w) && ga.w.N == up.w.N && ga.w.K == up.w.K && (ga.w.N / 16) % 2 == 0 && ga.w.N == D->K &&
              (G->pro.kind == QMV_PRO_NONE || G->pro.kind == QMV_PRO_PRENORM) && D->n_parts == 1;
         // the product's operands: silu(gate) and up, in either order (an f32 product does not depend on it)
         ok = ok && ((D->pro.a == st[4].store && D->pro.b == up.dst) || (D->pro.b == st[4].store && D->pro.a == up.dst));
