@@ -292,7 +292,7 @@ struct RowChainParams {
     uint32_t cols = 0;
     float eps = 0.f;
     // Optional side output for an M > 1 quantized matmul that consumes the chain's result (mul_dst, else norm_dst): the
-    // rows' exact bf16 pieces in the tile kernels' A-operand layout (qmatvec.hip: split_a_kernel), written here instead of
+    // rows' exact bf16 pieces in the tile kernels' A-operand layout (qmatmul_tiles.hip: split_a_kernel), written here instead of
     // by a launch of their own. ap_S = the matmul's K steps (cols / 128); only for rows % 16 == 0 and cols % 128 == 0.
     uint16_t* ap = nullptr;
     uint32_t ap_S = 0;
