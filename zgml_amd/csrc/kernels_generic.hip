@@ -268,6 +268,10 @@ __global__ void __launch_bounds__(kBlock) rmsnorm_kernel(float* __restrict__ dst
 // form. NPT > 0: the row fits NPT elements per thread — everything is loaded up front with independent loads
 // (a row is one dependent chain otherwise: 32 rows x 4096 columns took ~25 us) and kept in registers between
 // the two passes. NPT == 0: any width, looping.
+// gridDim.y > 1 (NPT > 0, few rows: a 32-row prefill chunk is 32 workgroups otherwise): every workgroup of a row loads the whole
+// row and forms the same sum in the same order, but stores — the add's result, the normalised row, the product, the A pieces —
+// only for its share of the thread-strided column chunks (chunk k = columns 256 k .. 256 k + 255): the stores and the
+// piece transpose are what the launch spends its time on behind the first round trip.
 template <int NPT>
 __global__ void __launch_bounds__(kBlock) row_chain_kernel(RowChainParams p) {
     __shared__ float red[8];
@@ -280,6 +284,7 @@ __global__ void __launch_bounds__(kBlock) row_chain_kernel(RowChainParams p) {
         __shared__ __attribute__((aligned(16))) uint16_t pl[kAPieces * N * kBlock]; // A pieces of the row (RowChainParams::ap)
         float v[N], mo[N];
         const uint32_t last = p.cols - 1;
+        const uint32_t k_lo = blockIdx.y * N / gridDim.y, k_hi = (blockIdx.y + 1) * N / gridDim.y; // this workgroup's column chunks
         if (p.add_dst) {
             const float *a0 = p.a0 + base, *a1 = p.a1 + base;
             float w[N];
@@ -301,7 +306,7 @@ __global__ void __launch_bounds__(kBlock) row_chain_kernel(RowChainParams p) {
         for (int k = 0; k < N; k++) {
             const uint32_t j = threadIdx.x + k * kBlock;
             if (j < p.cols) {
-                if (p.add_dst) p.add_dst[base + j] = v[k];
+                if (p.add_dst && (uint32_t)k >= k_lo && (uint32_t)k < k_hi) p.add_dst[base + j] = v[k];
                 ss += v[k] * v[k];
             }
         }
@@ -310,7 +315,7 @@ __global__ void __launch_bounds__(kBlock) row_chain_kernel(RowChainParams p) {
 #pragma unroll
         for (int k = 0; k < N; k++) {
             const uint32_t j = threadIdx.x + k * kBlock;
-            if (j < p.cols) {
+            if (j < p.cols && (uint32_t)k >= k_lo && (uint32_t)k < k_hi) {
                 const float nv = v[k] * inv;
                 nd[j] = nv;
                 const float xv = p.mul_dst ? nv * mo[k] : nv;
@@ -327,10 +332,10 @@ __global__ void __launch_bounds__(kBlock) row_chain_kernel(RowChainParams p) {
         }
         if (p.ap) { // (uniform) cols % 128 == 0 here (planner)
             __syncthreads();
-            const uint32_t groups = p.cols / 8;
+            const uint32_t c_lo = min(k_lo * kBlock, p.cols), c_hi = min(k_hi * kBlock, p.cols), groups = (c_hi - c_lo) / 8; // (cols % 128 == 0)
             const bool f16 = (p.ap_S & kApF16) != 0;
             for (uint32_t u = threadIdx.x; u < (f16 ? 1u : (uint32_t)kAPieces) * groups; u += kBlock) {
-                const uint32_t piece = u / groups, j0 = (u - piece * groups) * 8;
+                const uint32_t piece = u / groups, j0 = c_lo + (u - piece * groups) * 8;
                 const uint4 val = *(const uint4*)(pl + piece * (N * kBlock) + j0);
                 uint16_t* const d = f16 ? p.ap + a_f16_index(p.ap_S & ~kApF16, blockIdx.x, j0) : p.ap + a_piece_index(p.ap_S, blockIdx.x, j0) + piece * 512;
                 *(uint4*)d = val;
@@ -1286,14 +1291,22 @@ void launch_rmsnorm(hipStream_t s, float* dst, const float* src, uint32_t rows, 
 
 void launch_row_chain(hipStream_t s, const RowChainParams& p, uint32_t rows) {
     if (rows == 0) return;
+    // few rows: several workgroups per row share its stores (row_chain_kernel): as many as keep the grid near one workgroup per CU,
+    // at most one per 256-column chunk the row really has (ZGML_HIP_ROW_SPLIT=1 switches it off)
+    static const int split_env = getenv("ZGML_HIP_ROW_SPLIT") ? atoi(getenv("ZGML_HIP_ROW_SPLIT")) : 0;
+    const uint32_t chunks = cdiv(p.cols, kBlock);
+    uint32_t split = 1;
+    while (split * 2 <= chunks && rows * split * 2 <= 256 && chunks % (split * 2) == 0) split *= 2;
+    if (split_env > 0) split = std::min<uint32_t>((uint32_t)split_env, chunks);
+    const dim3 grid(rows, p.cols <= 32 * kBlock ? split : 1);
     if (p.cols <= 4 * kBlock)
-        row_chain_kernel<4><<<rows, kBlock, 0, s>>>(p);
+        row_chain_kernel<4><<<grid, kBlock, 0, s>>>(p);
     else if (p.cols <= 16 * kBlock)
-        row_chain_kernel<16><<<rows, kBlock, 0, s>>>(p);
+        row_chain_kernel<16><<<grid, kBlock, 0, s>>>(p);
     else if (p.cols <= 32 * kBlock)
-        row_chain_kernel<32><<<rows, kBlock, 0, s>>>(p);
+        row_chain_kernel<32><<<grid, kBlock, 0, s>>>(p);
     else
-        row_chain_kernel<0><<<rows, kBlock, 0, s>>>(p);
+        row_chain_kernel<0><<<grid, kBlock, 0, s>>>(p);
 }
 
 void launch_reduce(hipStream_t s, uint32_t op, float* dst, const float* src, uint32_t n_out, uint32_t reduce_size) {

@@ -14,221 +14,15 @@
 //     op references (the dead f32 master copies of quantized weights) are neither
 //     allocated nor uploaded.
 // There is no CPU fallback anywhere: every DeviceOp kind has a kernel.
-#include <hip/hip_runtime.h>
+#define ZGML_RUNTIME_MAIN
+#include "runtime_internal.h"
 
-#include <algorithm>
-#include <chrono>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <functional>
-#include <map>
-#include <memory>
-#include <string>
-#include <vector>
-
-#include "kernels.h"
-#include "schedule.h"
-
-using namespace zgml;
-
-namespace {
-
+namespace zgml_rt {
 std::string g_create_error;
-
-// A launch that can also emit its result rows as the A pieces of an M > 1 quantized matmul (kernels.h: RowChainParams::ap):
-// the planner arms it when the matmul that consumes exactly these rows follows with no other splitting launch in between.
-struct SplitHook {
-    const float* out = nullptr; // the rows the launch produces (dense: row stride == cols)
-    uint32_t rows = 0, cols = 0; // rows == 0: a flat launch over `n` elements, any rows x cols = n of dense rows
-    uint32_t n = 0;
-    uint16_t** ap = nullptr;    // fields of the launch's (shared) parameter block
-    uint32_t* ap_S = nullptr;
-    uint32_t* ap_cols = nullptr; // flat launches: the row length is filled in too
-};
-
-struct AdecDesc {
-    std::vector<AttnDecodeParams> host; // the records as uploaded
-    const AttnDecodeParams* dev = nullptr;
-    uint32_t nh = 0, dh = 0;
-    AttnSplit sp;
-    bool kvq = false;
-};
-
-struct Launch {
-    uint32_t kind;           // DeviceOp tag the launch is accounted to
-    uint32_t n_ops;          // DeviceOps covered (batching folds several)
-    uint32_t op_lo, op_hi;   // smallest / largest op index covered
-    std::function<void(hipStream_t)> run;
-    std::shared_ptr<SplitHook> hook; // (after `run` so the aggregate initialisers elsewhere stay valid)
-    // what a fused-launch pass needs to know about a grouped mat-vec launch / a decode-attention launch (fuse_qkv_attention)
-    std::shared_ptr<QmvLaunch> qmv_desc;
-    std::shared_ptr<struct AdecDesc> adec_desc;
-    uint64_t prof_ns = 0;    // ZGML_HIP_OPT_PROFILE: accumulated event time of this launch
-    uint32_t prof_calls = 0;
-};
-
-struct IoEntry {
-    uint16_t buf_idx;
-    uint32_t offset, size;
-    bool operator==(const IoEntry& o) const { return buf_idx == o.buf_idx && offset == o.offset && size == o.size; }
-};
-
-struct IoTableDev { // one row per transfer, consumed by scatter/gather kernels
-    float* dev;      // device address inside the program buffer
-    uint32_t stage_off_words;
-    uint32_t n_words;
-};
-
-struct IoPlan {
-    std::vector<IoEntry> entries;
-    IoTableDev* table_dev = nullptr;
-    uint32_t total_words = 0;
-    bool word_aligned = true;
-};
-
-} // namespace
-
-struct ShardState;
-struct zgml_hip_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    std::string err;
-    bool opt_fusion = true, opt_graph = true, opt_profile = false, opt_skip_dead = true, opt_f16_dense = false;
-    int64_t opt_attn_split_min_keys = -1; // -1: environment / default (attn_split_for)
-    int64_t opt_fuse_resident_wgs = -1;   // -1: one 1024-thread workgroup per CU (fuse_qkv_attention)
-    // host dense override scratch
-    float *mm_a = nullptr, *mm_b = nullptr, *mm_c = nullptr;
-    uint64_t mm_a_cap = 0, mm_b_cap = 0, mm_c_cap = 0;
-    // host dense override: device copies of B operands keyed by host pointer; opt-in
-    struct CachedB {
-        float* dev;
-        uint64_t span; // elements
-    };
-    std::map<const float*, CachedB> b_cache;
-    uint64_t b_cache_cap = 0, b_cache_bytes = 0, b_cache_hits = 0, b_cache_misses = 0;
-    void drop_b_cache() {
-        for (auto& kv : b_cache) hipFree(kv.second.dev);
-        b_cache.clear();
-        b_cache_bytes = 0;
-    }
-    // argmax scratch
-    float* arg_val = nullptr;
-    int64_t* arg_idx = nullptr;
-    int64_t* arg_out = nullptr;
-    int64_t* arg_out_host = nullptr; // pinned
-    struct ShardState* shard = nullptr; // RCCL communicator of the row-shard path (zgml_hip_shard_*), else nullptr
-    // Fused launches (q/k/v projection + decode attention): ONE host-visible word every bounded in-launch wait sets when it
-    // gives up (pinned, device-mapped: the host reads it after any synchronisation without a copy). A set word means the
-    // tokens of that run are wrong: every host sync point reports it (handoff_ok), clears it and switches the fusion off for
-    // the context — plans are rebuilt in the two-launch form (fuse_epoch).
-    uint32_t* handoff_flag = nullptr;     // host pointer
-    uint32_t* handoff_flag_dev = nullptr; // the same word as the kernels see it
-    bool fuse_qkv_off = false;
-    uint64_t fuse_epoch = 0;
-    int n_cu = 0; // compute units (residency guard of the fused launch)
-    bool handoff_ok(const char* where) {
-        if (!handoff_flag || !*(volatile uint32_t*)handoff_flag) return true;
-        *(volatile uint32_t*)handoff_flag = 0;
-        fuse_qkv_off = true, fuse_epoch++;
-        fail(std::string(where) + ": an in-launch hand-off wait of a fused q/k/v + attention launch timed out — the results of this run are wrong; "
-                                  "the fusion is now off for this context (later runs use two launches)");
-        return false;
-    }
-
-    void fail(const std::string& what) {
-        if (err.empty()) err = what;
-    }
-    bool check(hipError_t e, const char* what) {
-        if (e == hipSuccess) return true;
-        fail(std::string(what) + ": " + hipGetErrorString(e));
-        return false;
-    }
-};
-
-struct zgml_resident;
-struct zgml_hip_program {
-    zgml_hip_ctx* ctx = nullptr;
-    std::vector<zgml_device_op> ops;
-    std::vector<std::vector<zgml_fused_step>> steps; // owned copies, per op
-    std::vector<uint64_t> sizes;                      // f32 elements
-    std::vector<float*> bufs;                         // device pointers (nullptr = elided)
-    void* arena = nullptr;
-    std::vector<QWeightDev> qweights;
-    std::vector<unsigned long long*> attn_traces; // diagnostics (ZGML_HIP_ATTN_TRACE)
-    struct QmvTrace {
-        unsigned long long* t;
-        uint32_t parts, pro, K, N;
-    };
-    std::vector<QmvTrace> qmv_traces; // diagnostics (ZGML_HIP_QMV_TRACE)
-    float* zero_word = nullptr;                   // a device 0.0f: mask operand of unmasked decode attention
-    float* split_buf = nullptr;                   // long-context attention split: partials + arrival counters,
-    uint32_t* split_cnt = nullptr;                // shared by the (stream-ordered) decode-attention launches
-    uint64_t split_buf_floats = 0, split_cnt_words = 0;
-    bool f16_stream_nt = false;     // promoted weights exceed the Infinity Cache: non-temporal loads
-    std::vector<void*> f16_weights; // per buffer: MFMA-packed f16 copy of a promoted matmul B operand (else nullptr)
-    std::vector<void*> owned; // other device allocations
-    uint64_t fuse_epoch = 0;             // ctx->fuse_epoch the plan was built at (a time-out rebuilds it without the fusion)
-    std::vector<void*> fuse_owned;       // counters / seen / idx blocks of the fused launches: freed with every plan rebuild
-    // repeats of constant data (a weight broadcast to the activation shape: source never written by an op, destination written by
-    // this op only) run ONCE when the plan is built instead of in every execution; a host input that ever targets one of the
-    // buffers involved switches this off for the program (prepare_io)
-    std::vector<char> hoist_op;    // per op: executed at plan-build time, not part of the plan
-    std::vector<char> hoist_guard; // per buffer: read or written by a hoisted repeat
-    bool hoist_ok = true;
-    float* prenorm_buf = nullptr;        // arm_prenorm: [x * gamma | partial sums of squares] handed from a residual epilogue to the next prologue
-    size_t prenorm_bytes = 0;
-    float* scratch = nullptr;
-    uint64_t scratch_bytes = 0;
-    // plan building: the last quantized matmul launch that split its input into the scratch (make_single)
-    uint64_t split_pos = UINT64_MAX - 1;
-    const float* split_input = nullptr;
-    std::shared_ptr<std::vector<std::pair<QWeightDev, QMatmulParams>>> qmm_group; // parts of the launch at split_pos
-    std::shared_ptr<std::vector<DenseF16Params>> f16_group;
-    uint32_t split_M = 0, split_K = 0, split_in_rs = 0, split_kind = 0; // kind: 1 = bf16 pieces (quantized), 2 = f16 A (dense)
-    // dynamic parameter block: one word per op
-    uint32_t* dyn_dev = nullptr;
-    uint32_t* dyn_host = nullptr; // pinned
-    bool dyn_dirty = true;
-    std::vector<Launch> plan;
-    bool plan_dirty = true;
-    Schedule sched;                  // valid when plan_batched
-    bool plan_batched = false;       // plan was built from dependency levels
-    bool batching_safe = true;       // cleared when a refresh leaves the assumed dynamic bounds
-    std::vector<uint64_t> barriers;  // op indices nothing may be moved across (multi-GPU harness)
-    // per attention op: the largest seq_kv the caller ever handed over (compile time or a refresh). The schedule
-    // takes the attention's K/V read extent from here, never from the last refreshed value, so a plan rebuilt
-    // after a small-seq_kv refresh cannot put a KV store and the attention that reads it on one level.
-    std::vector<uint32_t> seq_kv_bound;
-    std::vector<void*> param_blobs;  // device parameter arrays of batched launches
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t graph_exec = nullptr;
-    // host I/O staging
-    void* stage_host = nullptr; // pinned
-    void* stage_dev = nullptr;
-    uint64_t stage_cap = 0;
-    IoPlan in_plan, out_plan;
-    uint64_t staged_bytes = 0, staged_n = 0; // zgml_hip_stage_inputs / enqueue_staged
-    zgml_runtime_profile profile{};
-    zgml_resident* resident = nullptr;
-    // row-shard path (zgml_hip_shard_attach): all-gather points in op order, the logits for the greedy token, and the
-    // captured graph of one whole step (staged inputs, op ranges, all-gathers, argmax)
-    std::vector<zgml_shard_point> shard_points;
-    uint16_t shard_logits_buf = 0;
-    uint64_t shard_vocab = 0;
-    hipGraph_t shard_graph = nullptr;
-    hipGraphExec_t shard_graph_exec = nullptr;
-    bool shard_capture_failed = false;
-    // the greedy token as a (max, index) pair per rank instead of a gather of the logits (the last gather point covers the logits
-    // buffer): device pairs [world] for the collective mode; and the peer-store gather's state (shard_peer.hip)
-    bool shard_pair_argmax = false;
-    unsigned long long* shard_pairs = nullptr;
-    struct ShardPeer* shard_peer = nullptr;
-};
+}
 
 namespace {
 
-#define CTX_CHECK(ctx, expr) (ctx)->check((expr), #expr)
 
 // ── Capabilities.hip ────────────────────────────────────────────────────────────────────────
 void fill_caps(zgml_capabilities* c) {
@@ -3306,462 +3100,6 @@ int64_t zgml_hip_argmax(zgml_hip_ctx* ctx, zgml_hip_program* p, uint16_t buf_idx
     return *ctx->arg_out_host;
 }
 
-static bool make_synth_weight(zgml_hip_ctx* ctx, uint32_t K, uint32_t N, int q4, uint32_t id, QWeightDev* w, uint32_t M = 1) {
-    static const bool kon_on = !(getenv("ZGML_HIP_QMV_KON") && atoi(getenv("ZGML_HIP_QMV_KON")) == 0);
-    w->format = q4 ? (M == 1 && kon_on ? QW_Q4K : QW_Q4) : QW_Q8; // (what compile_program picks for a weight that only feeds mat-vecs)
-    w->K = K, w->N = N, w->bs = 32;
-    w->KC = (K + 31) / 32;
-    w->scale_f16 = 1;
-    packed_bytes(w->format, 1, K, N, &w->qs_bytes, &w->sc_bytes);
-    if (!CTX_CHECK(ctx, hipMalloc(&w->qs, w->qs_bytes)) || !CTX_CHECK(ctx, hipMalloc(&w->sc, w->sc_bytes))) return false;
-    launch_synth_packed(ctx->stream, *w, id);
-    return true;
-}
-
-double zgml_hip_dense_f16_bench(zgml_hip_ctx* ctx, uint32_t M, uint32_t K, uint32_t N, uint32_t n_matrices, uint32_t warmup,
-                                uint32_t iters, uint64_t* bytes_per_launch) {
-    if (!ctx || !f16_packable(K, N) || !n_matrices || !iters || !M) return -1.0;
-    hipSetDevice(ctx->device);
-    std::vector<void*> ring(n_matrices, nullptr);
-    float *b32 = nullptr, *x = nullptr, *y = nullptr;
-    void* a_scratch = nullptr;
-    std::vector<float> bh((size_t)K * N), xh((size_t)M * K);
-    for (size_t i = 0; i < bh.size(); i++) bh[i] = ((int)((i * 7 + (i >> 5) * 3) % 31) - 15) * 0.00390625f;
-    for (size_t i = 0; i < xh.size(); i++) xh[i] = ((int)(i % 17) - 8) * 0.03125f;
-    bool ok = CTX_CHECK(ctx, hipMalloc((void**)&b32, bh.size() * 4)) && CTX_CHECK(ctx, hipMalloc((void**)&x, xh.size() * 4)) &&
-              CTX_CHECK(ctx, hipMalloc((void**)&y, (size_t)M * N * 4)) &&
-              CTX_CHECK(ctx, hipMemcpy(b32, bh.data(), bh.size() * 4, hipMemcpyHostToDevice)) &&
-              CTX_CHECK(ctx, hipMemcpy(x, xh.data(), xh.size() * 4, hipMemcpyHostToDevice));
-    for (uint32_t i = 0; ok && i < n_matrices; i++) {
-        ok = CTX_CHECK(ctx, hipMalloc(&ring[i], f16_packed_bytes(K, N)));
-        if (ok) launch_pack_f16(ctx->stream, b32, N, 1, K, N, ring[i]);
-    }
-    double us = -1.0;
-    if (ok) {
-        DenseF16Params fp{y, x, nullptr, M, N, K, K, N, f16_packed_bytes(K, N) * n_matrices >= (192ull << 20) ? 1u : 0u};
-        if (const uint64_t sb = dense_f16_scratch_bytes(M, K)) { // (kernels.h: the head in front of the block holds the K-split counters)
-            ok = CTX_CHECK(ctx, hipMalloc(&a_scratch, kQmmScratchHead + sb)) && CTX_CHECK(ctx, hipMemsetAsync(a_scratch, 0, kQmmScratchHead, ctx->stream));
-        }
-        fp.scratch = a_scratch ? (char*)a_scratch + kQmmScratchHead : nullptr;
-        for (uint32_t i = 0; ok && i < warmup; i++) {
-            fp.bp = ring[i % n_matrices];
-            launch_dense_f16(ctx->stream, fp);
-        }
-        hipGraph_t g = nullptr;
-        hipGraphExec_t ge = nullptr;
-        ok = CTX_CHECK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-        if (ok) {
-            for (uint32_t i = 0; i < n_matrices; i++) {
-                fp.bp = ring[i];
-                launch_dense_f16(ctx->stream, fp);
-            }
-            ok = CTX_CHECK(ctx, hipStreamEndCapture(ctx->stream, &g)) &&
-                 CTX_CHECK(ctx, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
-        }
-        if (ok) {
-            const uint32_t reps = (iters + n_matrices - 1) / n_matrices;
-            hipGraphLaunch(ge, ctx->stream);
-            hipEvent_t e0, e1;
-            hipEventCreate(&e0);
-            hipEventCreate(&e1);
-            hipEventRecord(e0, ctx->stream);
-            for (uint32_t r = 0; r < reps; r++) hipGraphLaunch(ge, ctx->stream);
-            hipEventRecord(e1, ctx->stream);
-            if (CTX_CHECK(ctx, hipEventSynchronize(e1))) {
-                float ms = 0;
-                hipEventElapsedTime(&ms, e0, e1);
-                us = (double)ms * 1000.0 / ((double)reps * n_matrices);
-            }
-            hipEventDestroy(e0);
-            hipEventDestroy(e1);
-        }
-        if (ge) hipGraphExecDestroy(ge);
-        if (g) hipGraphDestroy(g);
-    }
-    if (bytes_per_launch) *bytes_per_launch = 2ull * K * N + 4ull * M * K + 4ull * M * N;
-    for (void* r : ring) hipFree(r);
-    hipFree(a_scratch);
-    hipFree(b32);
-    hipFree(x);
-    hipFree(y);
-    return us;
-}
-
-double zgml_hip_qmatvec_bench(zgml_hip_ctx* ctx, uint32_t K, uint32_t N, int q4, uint32_t n_matrices, uint32_t warmup,
-                              uint32_t iters, uint64_t* bytes_per_launch) {
-    return zgml_hip_qmatmul_bench(ctx, 1, K, N, q4, n_matrices, warmup, iters, bytes_per_launch);
-}
-
-double zgml_hip_qmatmul_bench(zgml_hip_ctx* ctx, uint32_t M, uint32_t K, uint32_t N, int q4, uint32_t n_matrices,
-                              uint32_t warmup, uint32_t iters, uint64_t* bytes_per_launch) {
-    if (!ctx || N % 32 || !n_matrices || !iters || !M) return -1.0;
-    hipSetDevice(ctx->device);
-    std::vector<QWeightDev> ring(n_matrices);
-    bool ok = true;
-    for (uint32_t i = 0; ok && i < n_matrices; i++) ok = make_synth_weight(ctx, K, N, q4, i, &ring[i], M);
-    if (ok && (ring[0].qs_bytes + ring[0].sc_bytes) * n_matrices >= (192ull << 20)) // the ring stands for a model beyond the cache
-        for (auto& w : ring) w.stream_nt = 1;
-    float *x = nullptr, *y = nullptr, *scratch = nullptr;
-    char* scratch_base = nullptr;
-    std::vector<float> xh((size_t)M * K);
-    for (size_t i = 0; i < xh.size(); i++) xh[i] = ((int)(i % 17) - 8) * 0.03125f;
-    uint64_t sb = ok ? qmatmul_scratch_bytes(ring[0], M) : 0;
-    ok = ok && CTX_CHECK(ctx, hipMalloc((void**)&x, xh.size() * 4)) && CTX_CHECK(ctx, hipMalloc((void**)&y, (size_t)M * N * 4)) &&
-         (!sb || (CTX_CHECK(ctx, hipMalloc((void**)&scratch_base, kQmmScratchHead + sb)) && CTX_CHECK(ctx, hipMemsetAsync(scratch_base, 0, kQmmScratchHead, ctx->stream)))) &&
-         CTX_CHECK(ctx, hipMemcpy(x, xh.data(), xh.size() * 4, hipMemcpyHostToDevice));
-    if (scratch_base) scratch = (float*)(scratch_base + kQmmScratchHead);
-    double us = -1.0;
-    if (ok) {
-        QMatmulParams qp{y, x, M, N, K, K, N};
-        for (uint32_t i = 0; i < warmup; i++) launch_qmatmul(ctx->stream, ring[i % n_matrices], qp, scratch);
-        // One pass over the ring is captured into a hipGraph and replayed: back-to-back eager
-        // launches are host-bound below ~3 us per kernel on this platform, a graph is not.
-        hipGraph_t g = nullptr;
-        hipGraphExec_t ge = nullptr;
-        ok = CTX_CHECK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-        if (ok) {
-            for (uint32_t i = 0; i < n_matrices; i++) launch_qmatmul(ctx->stream, ring[i], qp, scratch);
-            ok = CTX_CHECK(ctx, hipStreamEndCapture(ctx->stream, &g));
-            if (ok) dump_graph(g, "ring");
-            ok = ok && CTX_CHECK(ctx, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
-        }
-        if (ok) {
-            const uint32_t reps = (iters + n_matrices - 1) / n_matrices;
-            hipGraphLaunch(ge, ctx->stream); // warm replay
-            hipEvent_t e0, e1;
-            hipEventCreate(&e0);
-            hipEventCreate(&e1);
-            hipEventRecord(e0, ctx->stream);
-            for (uint32_t r = 0; r < reps; r++) hipGraphLaunch(ge, ctx->stream);
-            hipEventRecord(e1, ctx->stream);
-            if (CTX_CHECK(ctx, hipEventSynchronize(e1))) {
-                float ms = 0;
-                hipEventElapsedTime(&ms, e0, e1);
-                us = (double)ms * 1000.0 / ((double)reps * n_matrices);
-            }
-            hipEventDestroy(e0);
-            hipEventDestroy(e1);
-        }
-        if (ge) hipGraphExecDestroy(ge);
-        if (g) hipGraphDestroy(g);
-    }
-    if (bytes_per_launch) *bytes_per_launch = (uint64_t)K * N / 32 * (q4 ? 18 : 34) + 4ull * M * K + 4ull * M * N;
-    for (auto& w : ring) {
-        hipFree(w.qs);
-        hipFree(w.sc);
-    }
-    hipFree(x);
-    hipFree(y);
-    hipFree(scratch_base);
-    return us;
-}
-
-// ── dependent CHAIN of square mat-vecs (true data dependency) ───────────────────────────────────────────────────
-// Launch i computes y_i = (x_i^T W_i) * c and launch i + 1 consumes y_i as its x (ping-pong vectors; the epilogue
-// multiply by a constant vector keeps the magnitudes bounded), so consecutive launches are ordered by DATA, not only by
-// the stream. (Round-2 experiments on top of this chain — an Infinity-Cache warmer kernel on a second graph branch,
-// per launch and as one progress-paced kernel per pass — made it slower or stalled it)
-double zgml_hip_qmatvec_chain_bench(zgml_hip_ctx* ctx, uint32_t K, int q4, uint32_t n_matrices, uint32_t warmup, uint32_t iters,
-                                    uint64_t* bytes_per_launch) {
-    const uint32_t N = K;
-    if (!ctx || N % 32 || n_matrices < 2 || n_matrices % 2 || !iters) return -1.0;
-    hipSetDevice(ctx->device);
-    std::vector<QWeightDev> ring(n_matrices);
-    bool ok = true;
-    for (uint32_t i = 0; ok && i < n_matrices; i++) ok = make_synth_weight(ctx, K, N, q4, i, &ring[i]);
-    if (ok && (ring[0].qs_bytes + ring[0].sc_bytes) * n_matrices >= (192ull << 20))
-        for (auto& w : ring) w.stream_nt = 1;
-    float *v0 = nullptr, *v1 = nullptr, *cvec = nullptr;
-    std::vector<float> xh(K), ch(N, 0.2f);
-    for (size_t i = 0; i < xh.size(); i++) xh[i] = ((int)(i % 17) - 8) * 0.03125f;
-    ok = ok && CTX_CHECK(ctx, hipMalloc((void**)&v0, K * 4)) && CTX_CHECK(ctx, hipMalloc((void**)&v1, K * 4)) &&
-         CTX_CHECK(ctx, hipMalloc((void**)&cvec, N * 4)) && CTX_CHECK(ctx, hipMemcpy(v0, xh.data(), K * 4, hipMemcpyHostToDevice)) &&
-         CTX_CHECK(ctx, hipMemcpy(cvec, ch.data(), N * 4, hipMemcpyHostToDevice));
-    double us = -1.0;
-    if (ok) {
-        // ZGML_HIP_QMV_TRACE=1 (trace build of the library): in-kernel stamps of ONE launch in the middle of the chain, printed below
-        unsigned long long* trace = nullptr;
-        if (getenv("ZGML_HIP_QMV_TRACE") && atoi(getenv("ZGML_HIP_QMV_TRACE")) &&
-            hipHostMalloc((void**)&trace, 16 * sizeof(unsigned long long), hipHostMallocMapped) == hipSuccess)
-            memset(trace, 0, 16 * sizeof(unsigned long long));
-        auto one = [&](uint32_t i) { // launch i: x = (i even ? v0 : v1), y = the other (even ring: the wrap keeps the ping-pong)
-            QmvLaunch L;
-            L.trace = i == n_matrices / 2 ? trace : nullptr;
-            L.n_parts = 1, L.K = K;
-            L.parts[0].w = ring[i];
-            L.parts[0].dst = (i & 1) ? v0 : v1;
-            L.parts[0].n_epi = 1;
-            L.parts[0].epi[0] = QmvEpiStep{ZGML_OP_MUL, 0, cvec, (i & 1) ? v0 : v1};
-            L.pro.kind = QMV_PRO_NONE, L.pro.a = (i & 1) ? v1 : v0;
-            launch_qmatvec_fused(ctx->stream, L);
-        };
-        for (uint32_t i = 0; i < warmup; i++) one(i % n_matrices);
-        hipGraph_t g = nullptr;
-        hipGraphExec_t ge = nullptr;
-        ok = CTX_CHECK(ctx, hipStreamSynchronize(ctx->stream)) && CTX_CHECK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-        if (ok) {
-            for (uint32_t i = 0; i < n_matrices; i++) one(i);
-            ok = CTX_CHECK(ctx, hipStreamEndCapture(ctx->stream, &g)) && CTX_CHECK(ctx, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
-        }
-        if (ok) {
-            const uint32_t reps = (iters + n_matrices - 1) / n_matrices;
-            hipGraphLaunch(ge, ctx->stream);
-            hipEvent_t e0, e1;
-            hipEventCreate(&e0);
-            hipEventCreate(&e1);
-            hipEventRecord(e0, ctx->stream);
-            for (uint32_t r = 0; r < reps; r++) hipGraphLaunch(ge, ctx->stream);
-            hipEventRecord(e1, ctx->stream);
-            if (CTX_CHECK(ctx, hipEventSynchronize(e1))) {
-                float ms = 0;
-                hipEventElapsedTime(&ms, e0, e1);
-                us = (double)ms * 1000.0 / ((double)reps * n_matrices);
-            }
-            hipEventDestroy(e0);
-            hipEventDestroy(e1);
-        }
-        if (ge) hipGraphExecDestroy(ge);
-        if (g) hipGraphDestroy(g);
-        if (trace) { // 100 MHz wall clock -> ns; workgroup 0, and (K-on-lanes body) the last workgroup
-            const unsigned long long* t = trace;
-            fprintf(stderr, "[zgml_hip] chain mat-vec stamps, launch %u of the ring (ns): workgroup 0: start->loads issued %lld | ->streamed %lld | ->reduced+epilogue+stored %lld",
-                    n_matrices / 2, (long long)(t[1] - t[0]) * 10, (long long)(t[4] - t[1]) * 10, (long long)(t[5] - t[4]) * 10);
-            if (t[8])
-                fprintf(stderr, " || last workgroup: starts %lld after workgroup 0 | ->loads issued %lld | ->streamed %lld | ->end %lld || first start -> last end %lld",
-                        (long long)(t[8] - t[0]) * 10, (long long)(t[9] - t[8]) * 10, (long long)(t[12] - t[9]) * 10, (long long)(t[13] - t[12]) * 10,
-                        (long long)(std::max(t[13], t[5]) - t[0]) * 10);
-            fprintf(stderr, "\n");
-            hipHostFree(trace);
-        }
-    }
-    if (bytes_per_launch) *bytes_per_launch = (uint64_t)K * N / 32 * (q4 ? 18 : 34) + 4ull * K + 4ull * N;
-    for (auto& w : ring) {
-        hipFree(w.qs);
-        hipFree(w.sc);
-    }
-    hipFree(v0);
-    hipFree(v1);
-    hipFree(cvec);
-    return us;
-}
-
-// The same ring of M = 1 mat-vecs, but as INDEPENDENT launches: the captured graph forks the ring over
-// `n_streams` branches (distinct outputs per branch), so consecutive launches may overlap on the device.
-// Not the decode path (there every mat-vec waits for its predecessor) — it separates what the kernel can
-// stream from what a dependent launch of this size costs. Returns microseconds per launch.
-double zgml_hip_qmatvec_overlap_bench(zgml_hip_ctx* ctx, uint32_t K, uint32_t N, int q4, uint32_t n_matrices, uint32_t n_streams,
-                                      uint32_t iters, uint64_t* bytes_per_launch) {
-    if (!ctx || N % 32 || !n_matrices || !iters || !n_streams || n_streams > 16) return -1.0;
-    hipSetDevice(ctx->device);
-    std::vector<QWeightDev> ring(n_matrices);
-    bool ok = true;
-    for (uint32_t i = 0; ok && i < n_matrices; i++) ok = make_synth_weight(ctx, K, N, q4, i, &ring[i]);
-    if (ok && (ring[0].qs_bytes + ring[0].sc_bytes) * n_matrices >= (192ull << 20))
-        for (auto& w : ring) w.stream_nt = 1;
-    float *x = nullptr, *y = nullptr;
-    std::vector<float> xh(K);
-    for (size_t i = 0; i < xh.size(); i++) xh[i] = ((int)(i % 17) - 8) * 0.03125f;
-    ok = ok && CTX_CHECK(ctx, hipMalloc((void**)&x, xh.size() * 4)) && CTX_CHECK(ctx, hipMalloc((void**)&y, (size_t)n_streams * N * 4)) &&
-         CTX_CHECK(ctx, hipMemcpy(x, xh.data(), xh.size() * 4, hipMemcpyHostToDevice));
-    std::vector<hipStream_t> side(n_streams, nullptr);
-    std::vector<hipEvent_t> joined(n_streams, nullptr);
-    hipEvent_t fork = nullptr;
-    for (uint32_t t = 1; ok && t < n_streams; t++)
-        ok = CTX_CHECK(ctx, hipStreamCreateWithFlags(&side[t], hipStreamNonBlocking)) && CTX_CHECK(ctx, hipEventCreateWithFlags(&joined[t], hipEventDisableTiming));
-    ok = ok && CTX_CHECK(ctx, hipEventCreateWithFlags(&fork, hipEventDisableTiming));
-    side[0] = ctx->stream;
-    double us = -1.0;
-    if (ok) {
-        for (uint32_t i = 0; i < n_matrices; i++) { // warm (and resolve the kernels) outside the capture
-            QMatmulParams qp{y + (size_t)(i % n_streams) * N, x, 1, N, K, K, N};
-            launch_qmatmul(ctx->stream, ring[i], qp, nullptr);
-        }
-        hipStreamSynchronize(ctx->stream);
-        hipGraph_t g = nullptr;
-        hipGraphExec_t ge = nullptr;
-        ok = CTX_CHECK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-        if (ok) {
-            hipEventRecord(fork, ctx->stream);
-            for (uint32_t t = 1; t < n_streams; t++) hipStreamWaitEvent(side[t], fork, 0);
-            for (uint32_t i = 0; i < n_matrices; i++) {
-                QMatmulParams qp{y + (size_t)(i % n_streams) * N, x, 1, N, K, K, N};
-                launch_qmatmul(side[i % n_streams], ring[i], qp, nullptr);
-            }
-            for (uint32_t t = 1; t < n_streams; t++) {
-                hipEventRecord(joined[t], side[t]);
-                hipStreamWaitEvent(ctx->stream, joined[t], 0);
-            }
-            ok = CTX_CHECK(ctx, hipStreamEndCapture(ctx->stream, &g)) && CTX_CHECK(ctx, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
-        }
-        if (ok) {
-            const uint32_t reps = (iters + n_matrices - 1) / n_matrices;
-            hipGraphLaunch(ge, ctx->stream);
-            hipEvent_t e0, e1;
-            hipEventCreate(&e0);
-            hipEventCreate(&e1);
-            hipEventRecord(e0, ctx->stream);
-            for (uint32_t r = 0; r < reps; r++) hipGraphLaunch(ge, ctx->stream);
-            hipEventRecord(e1, ctx->stream);
-            if (CTX_CHECK(ctx, hipEventSynchronize(e1))) {
-                float ms = 0;
-                hipEventElapsedTime(&ms, e0, e1);
-                us = (double)ms * 1000.0 / ((double)reps * n_matrices);
-            }
-            hipEventDestroy(e0);
-            hipEventDestroy(e1);
-        }
-        if (ge) hipGraphExecDestroy(ge);
-        if (g) hipGraphDestroy(g);
-    }
-    if (bytes_per_launch) *bytes_per_launch = (uint64_t)K * N / 32 * (q4 ? 18 : 34) + 4ull * K + 4ull * N;
-    for (uint32_t t = 1; t < n_streams; t++) {
-        if (side[t]) hipStreamDestroy(side[t]);
-        if (joined[t]) hipEventDestroy(joined[t]);
-    }
-    if (fork) hipEventDestroy(fork);
-    for (auto& w : ring) {
-        hipFree(w.qs);
-        hipFree(w.sc);
-    }
-    hipFree(x);
-    hipFree(y);
-    return us;
-}
-
-// The same ring as INDEPENDENT launches on EXPLICIT streams: stream t replays its own graph of the matrices i = t (mod n_streams),
-// the n_streams replays run concurrently on their own hardware queues (the fork / join form above puts the branches of ONE graph
-// wherever the runtime likes — on one queue they serialise). Throughput of overlapping launches, not the decode path's figure.
-double zgml_hip_qmatvec_streams_bench(zgml_hip_ctx* ctx, uint32_t K, uint32_t N, int q4, uint32_t n_matrices, uint32_t n_streams, uint32_t iters,
-                                      uint64_t* bytes_per_launch) {
-    if (!ctx || N % 32 || !n_matrices || !iters || !n_streams || n_streams > 16 || n_matrices % n_streams) return -1.0;
-    hipSetDevice(ctx->device);
-    std::vector<QWeightDev> ring(n_matrices);
-    bool ok = true;
-    for (uint32_t i = 0; ok && i < n_matrices; i++) ok = make_synth_weight(ctx, K, N, q4, i, &ring[i]);
-    if (ok && (ring[0].qs_bytes + ring[0].sc_bytes) * n_matrices >= (192ull << 20))
-        for (auto& w : ring) w.stream_nt = 1;
-    float *x = nullptr, *y = nullptr;
-    std::vector<float> xh(K);
-    for (size_t i = 0; i < xh.size(); i++) xh[i] = ((int)(i % 17) - 8) * 0.03125f;
-    ok = ok && CTX_CHECK(ctx, hipMalloc((void**)&x, xh.size() * 4)) && CTX_CHECK(ctx, hipMalloc((void**)&y, (size_t)n_streams * N * 4)) &&
-         CTX_CHECK(ctx, hipMemcpy(x, xh.data(), xh.size() * 4, hipMemcpyHostToDevice));
-    std::vector<hipStream_t> st(n_streams, nullptr);
-    std::vector<hipGraph_t> g(n_streams, nullptr);
-    std::vector<hipGraphExec_t> ge(n_streams, nullptr);
-    std::vector<hipEvent_t> done(n_streams, nullptr);
-    for (uint32_t t = 0; ok && t < n_streams; t++)
-        ok = CTX_CHECK(ctx, hipStreamCreateWithFlags(&st[t], hipStreamNonBlocking)) && CTX_CHECK(ctx, hipEventCreateWithFlags(&done[t], hipEventDisableTiming));
-    double us = -1.0;
-    if (ok) {
-        for (uint32_t i = 0; i < n_matrices; i++) { // warm (and resolve the kernels) outside the captures
-            QMatmulParams qp{y + (size_t)(i % n_streams) * N, x, 1, N, K, K, N};
-            launch_qmatmul(ctx->stream, ring[i], qp, nullptr);
-        }
-        hipStreamSynchronize(ctx->stream);
-        for (uint32_t t = 0; ok && t < n_streams; t++) {
-            ok = CTX_CHECK(ctx, hipStreamBeginCapture(st[t], hipStreamCaptureModeThreadLocal));
-            for (uint32_t i = t; ok && i < n_matrices; i += n_streams) {
-                QMatmulParams qp{y + (size_t)t * N, x, 1, N, K, K, N};
-                launch_qmatmul(st[t], ring[i], qp, nullptr);
-            }
-            ok = ok && CTX_CHECK(ctx, hipStreamEndCapture(st[t], &g[t])) && CTX_CHECK(ctx, hipGraphInstantiate(&ge[t], g[t], nullptr, nullptr, 0));
-        }
-    }
-    if (ok) {
-        const uint32_t reps = (iters + n_matrices - 1) / n_matrices;
-        for (uint32_t t = 0; t < n_streams; t++) hipGraphLaunch(ge[t], st[t]);
-        for (uint32_t t = 0; t < n_streams; t++) hipStreamSynchronize(st[t]);
-        hipEvent_t e0, e1;
-        hipEventCreate(&e0);
-        hipEventCreate(&e1);
-        hipEventRecord(e0, ctx->stream); // the timed region starts on the context stream; every side stream waits for it
-        for (uint32_t t = 0; t < n_streams; t++) hipStreamWaitEvent(st[t], e0, 0);
-        for (uint32_t r = 0; r < reps; r++)
-            for (uint32_t t = 0; t < n_streams; t++) hipGraphLaunch(ge[t], st[t]);
-        for (uint32_t t = 0; t < n_streams; t++) {
-            hipEventRecord(done[t], st[t]);
-            hipStreamWaitEvent(ctx->stream, done[t], 0);
-        }
-        hipEventRecord(e1, ctx->stream);
-        if (CTX_CHECK(ctx, hipEventSynchronize(e1))) {
-            float ms = 0;
-            hipEventElapsedTime(&ms, e0, e1);
-            us = (double)ms * 1000.0 / ((double)reps * n_matrices);
-        }
-        hipEventDestroy(e0);
-        hipEventDestroy(e1);
-    }
-    if (bytes_per_launch) *bytes_per_launch = (uint64_t)K * N / 32 * (q4 ? 18 : 34) + 4ull * K + 4ull * N;
-    for (uint32_t t = 0; t < n_streams; t++) {
-        if (ge[t]) hipGraphExecDestroy(ge[t]);
-        if (g[t]) hipGraphDestroy(g[t]);
-        if (st[t]) hipStreamDestroy(st[t]);
-        if (done[t]) hipEventDestroy(done[t]);
-    }
-    for (auto& w : ring) {
-        hipFree(w.qs);
-        hipFree(w.sc);
-    }
-    hipFree(x);
-    hipFree(y);
-    return us;
-}
-
-int zgml_hip_qmatvec_synth(zgml_hip_ctx* ctx, uint32_t K, uint32_t N, int q4, uint32_t matrix_id, const float* x_host,
-                           float* y_host) {
-    if (!ctx || N % 32 || !x_host || !y_host) return -1;
-    hipSetDevice(ctx->device);
-    QWeightDev w{};
-    float *x = nullptr, *y = nullptr, *scratch = nullptr;
-    char* scratch_base = nullptr;
-    bool ok = make_synth_weight(ctx, K, N, q4, matrix_id, &w);
-    uint64_t sb = ok ? qmatmul_scratch_bytes(w, 1) : 0;
-    ok = ok && CTX_CHECK(ctx, hipMalloc((void**)&x, K * 4)) && CTX_CHECK(ctx, hipMalloc((void**)&y, N * 4)) &&
-         (!sb || (CTX_CHECK(ctx, hipMalloc((void**)&scratch_base, kQmmScratchHead + sb)) && CTX_CHECK(ctx, hipMemsetAsync(scratch_base, 0, kQmmScratchHead, ctx->stream)))) &&
-         CTX_CHECK(ctx, hipMemcpyAsync(x, x_host, K * 4, hipMemcpyHostToDevice, ctx->stream));
-    if (scratch_base) scratch = (float*)(scratch_base + kQmmScratchHead);
-    if (ok) {
-        QMatmulParams qp{y, x, 1, N, K, K, N};
-        launch_qmatmul(ctx->stream, w, qp, scratch);
-        ok = CTX_CHECK(ctx, hipMemcpyAsync(y_host, y, N * 4, hipMemcpyDeviceToHost, ctx->stream)) &&
-             CTX_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    }
-    hipFree(w.qs);
-    hipFree(w.sc);
-    hipFree(x);
-    hipFree(y);
-    hipFree(scratch_base);
-    return ok ? 0 : -1;
-}
-
-double zgml_hip_copy_bench(zgml_hip_ctx* ctx, uint64_t bytes, uint32_t warmup, uint32_t iters) {
-    if (!ctx || !iters || bytes < 16) return -1.0;
-    hipSetDevice(ctx->device);
-    void *a = nullptr, *b = nullptr;
-    if (!CTX_CHECK(ctx, hipMalloc(&a, bytes)) || !CTX_CHECK(ctx, hipMalloc(&b, bytes))) {
-        hipFree(a);
-        return -1.0;
-    }
-    hipMemsetAsync(a, 1, bytes, ctx->stream);
-    for (uint32_t i = 0; i < warmup; i++) launch_copy_f4(ctx->stream, b, a, bytes);
-    hipEvent_t e0, e1;
-    hipEventCreate(&e0);
-    hipEventCreate(&e1);
-    hipEventRecord(e0, ctx->stream);
-    for (uint32_t i = 0; i < iters; i++) launch_copy_f4(ctx->stream, b, a, bytes);
-    hipEventRecord(e1, ctx->stream);
-    double us = -1.0;
-    if (CTX_CHECK(ctx, hipEventSynchronize(e1))) {
-        float ms = 0;
-        hipEventElapsedTime(&ms, e0, e1);
-        us = (double)ms * 1000.0 / iters;
-    }
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
-    hipFree(a);
-    hipFree(b);
-    return us;
-}
 
 int zgml_hip_resident_setup(zgml_hip_ctx* ctx, zgml_hip_program* p, const zgml_resident_llama* d) {
     if (!ctx || !p || !d) return -1;
@@ -3987,379 +3325,13 @@ int64_t zgml_hip_resident_prefill(zgml_hip_ctx* ctx, zgml_hip_program* p, const 
     return ok ? *ctx->arg_out_host : -1;
 }
 
-// ── row-shard (N-split) path behind the C ABI: RCCL all-gathers between op ranges ─────────────────────
-// One process per GPU (the caller's launcher decides ranks). librccl.so is opened at run time by zgml_hip_shard_*
-// only, so single-GPU users of the library carry no dependency on it. The communicator lives in the context; a step's
-// whole device side (H2D of the staged inputs, op ranges, in-place ncclAllGather of the replicated activations, argmax)
-// is recorded once into a graph on the context stream and replayed per token — the messages are 2-44 KB, so the step is
-// bound by launch and collective latency, not by xGMI bandwidth.
 } // extern "C"
-#include <dlfcn.h>
-#include <unistd.h>
-struct ShardState {
-    void* lib = nullptr;
-    void* comm = nullptr;
-    int rank = 0, world = 1;
-    bool peer = false; // gathers by peer stores (shard_peer.hip) instead of ncclAllGather: no RCCL library, no communicator
-    int (*get_unique_id)(void*) = nullptr;
-    int (*comm_init_rank)(void**, int, /* ncclUniqueId by value: 128 bytes */ struct Id128, int) = nullptr;
-    int (*all_gather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
-    int (*comm_destroy)(void*) = nullptr;
-    const char* (*get_error_string)(int) = nullptr;
-};
-struct Id128 {
-    char b[128];
-};
-namespace {
-constexpr int kNcclFloat = 7; // ncclFloat32 (rccl.h ncclDataType_t)
-bool shard_load(zgml_hip_ctx* ctx, ShardState* st) {
-    if (st->lib) return true;
-    for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-        st->lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-        if (st->lib) break;
-    }
-    if (!st->lib) {
-        if (ctx) ctx->fail(std::string("shard: cannot open librccl.so: ") + dlerror());
-        return false;
-    }
-    st->get_unique_id = (int (*)(void*))dlsym(st->lib, "ncclGetUniqueId");
-    st->comm_init_rank = (int (*)(void**, int, Id128, int))dlsym(st->lib, "ncclCommInitRank");
-    st->all_gather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(st->lib, "ncclAllGather");
-    st->comm_destroy = (int (*)(void*))dlsym(st->lib, "ncclCommDestroy");
-    st->get_error_string = (const char* (*)(int))dlsym(st->lib, "ncclGetErrorString");
-    if (!st->get_unique_id || !st->comm_init_rank || !st->all_gather || !st->comm_destroy) {
-        if (ctx) ctx->fail("shard: librccl.so lacks an expected entry point");
-        return false;
-    }
-    return true;
-}
-ShardState g_shard_loader; // for zgml_hip_shard_unique_id (no context yet)
-} // namespace
-// Peer-store gather state of one program (shard_peer.hip): ONE fine-grained block per rank —
-//   [arrival counters: (n_points + 1) x 128 B][staging of point 0: world x len_0 f32][...][pairs: world x 8 B]
-// — that every peer maps (hipIpc, or the raw pointer inside one process) and writes; this rank's private `seen` words and the
-// device table of the mapped blocks. The layout is a function of the gather points only, so it is the same on every rank.
-struct ShardPeer {
-    char* block = nullptr;
-    uint64_t bytes = 0;
-    std::vector<uint64_t> stage_off; // per point, bytes
-    uint64_t pairs_off = 0;
-    uint32_t* seen = nullptr;        // [n_points + 1] device words
-    std::vector<char*> mapped;       // per rank: its block as this process sees it (own = block)
-    std::vector<char> ipc_opened;    // per rank: mapped through hipIpcOpenMemHandle (closed on free)
-    char** table_dev = nullptr;      // device copy of `mapped`
-    bool table_ready = false;
-};
-namespace {
-void free_shard_peer(zgml_hip_program* p) {
-    ShardPeer* sp = p->shard_peer;
-    if (!sp) return;
-    for (size_t r = 0; r < sp->mapped.size(); r++)
-        if (sp->ipc_opened[r] && sp->mapped[r]) hipIpcCloseMemHandle(sp->mapped[r]);
-    hipFree(sp->block);
-    hipFree(sp->seen);
-    hipFree(sp->table_dev);
-    delete sp;
-    p->shard_peer = nullptr;
-}
-} // namespace
-extern "C" void shard_peer_release(zgml_hip_program* p) { free_shard_peer(p); }
-namespace {
-uint64_t peer_wait_ticks() { // 100 MHz ticks
-    static const uint64_t ms = getenv("ZGML_SHARD_PEER_WAIT_MS") ? (uint64_t)std::max(1, atoi(getenv("ZGML_SHARD_PEER_WAIT_MS"))) : 5000u;
-    return ms * 100000ull;
-}
 
-// the device side of one sharded step on stream order: op ranges separated by in-place all-gathers
-bool shard_segments(zgml_hip_ctx* ctx, zgml_hip_program* p, std::vector<hipEvent_t>* ev = nullptr) { // ev: 2 events per gather point (profile_step)
-    ShardState* st = ctx->shard;
-    uint64_t prev = 0;
-    size_t gi = 0;
-    ShardPeer* const sp = p->shard_peer;
-    if (st->peer && (!sp || !sp->table_ready)) {
-        ctx->fail("shard: peer gather mode, but not every rank's block has been imported (zgml_hip_shard_peer_import)");
-        return false;
-    }
-    const size_t n_pts = p->shard_points.size();
-    for (const zgml_shard_point& gp : p->shard_points) {
-        if (gp.op_end > prev) zgml_hip_enqueue_ops(ctx, p, prev, gp.op_end - prev);
-        float* full = p->bufs[gp.buf_idx] + gp.offset;
-        if (ev) hipEventRecord((*ev)[2 * gi], ctx->stream);
-        int rc = 0;
-        if (p->shard_pair_argmax && gi + 1 == n_pts) {
-            // the logits: one (max, index) pair per rank instead of the vector (every op is already enqueued: this is the last point)
-            if (p->ops.size() > gp.op_end) zgml_hip_enqueue_ops(ctx, p, gp.op_end, p->ops.size() - gp.op_end);
-            const float* const slice = full + (uint64_t)st->rank * gp.len_per_rank;
-            if (st->peer) {
-                PeerArgmaxArgs a{sp->table_dev, slice, sp->seen + gi, ctx->handoff_flag_dev, ctx->arg_out, (uint64_t)gi * 128, sp->pairs_off, peer_wait_ticks(),
-                                 gp.len_per_rank, (uint32_t)st->rank, (uint32_t)st->world};
-                launch_peer_argmax(ctx->stream, a);
-            } else {
-                launch_local_argmax_pair(ctx->stream, slice, gp.len_per_rank, (uint32_t)st->rank, p->shard_pairs);
-                rc = st->all_gather(p->shard_pairs + st->rank, p->shard_pairs, 2, kNcclFloat, st->comm, ctx->stream); // 8 bytes per rank
-                launch_reduce_pairs(ctx->stream, p->shard_pairs, (uint32_t)st->world, ctx->arg_out);
-            }
-        } else if (st->peer) {
-            PeerGatherArgs a{sp->table_dev, full, sp->seen + gi, ctx->handoff_flag_dev, (uint64_t)gi * 128, sp->stage_off[gi], peer_wait_ticks(), gp.len_per_rank,
-                             (uint32_t)st->rank, (uint32_t)st->world};
-            launch_peer_gather(ctx->stream, a);
-        } else {
-            rc = st->all_gather(full + (uint64_t)st->rank * gp.len_per_rank, full, gp.len_per_rank, kNcclFloat, st->comm, ctx->stream);
-        }
-        if (ev) hipEventRecord((*ev)[2 * gi + 1], ctx->stream);
-        gi++;
-        if (rc != 0) {
-            ctx->fail(std::string("shard: ncclAllGather: ") + (st->get_error_string ? st->get_error_string(rc) : "error"));
-            return false;
-        }
-        prev = gp.op_end;
-    }
-    if (p->ops.size() > prev && !p->shard_pair_argmax) zgml_hip_enqueue_ops(ctx, p, prev, p->ops.size() - prev);
-    if (!p->shard_pair_argmax) launch_argmax(ctx->stream, p->bufs[p->shard_logits_buf], p->shard_vocab, ctx->arg_val, ctx->arg_idx, ctx->arg_out);
-    return ctx->err.empty();
-}
-} // namespace
-extern "C" {
-
-int zgml_hip_shard_unique_id(unsigned char id_out[128]) {
-    if (!id_out || !shard_load(nullptr, &g_shard_loader)) return -1;
-    return g_shard_loader.get_unique_id(id_out) == 0 ? 0 : -1;
-}
-
-int zgml_hip_shard_init(zgml_hip_ctx* ctx, const unsigned char id[128], int rank, int world) {
-    if (!ctx || !id || world < 1 || rank < 0 || rank >= world) return -1;
-    hipSetDevice(ctx->device);
-    if (ctx->shard) return -1; // one communicator per context
-    ShardState* st = new ShardState();
-    if (!shard_load(ctx, st)) {
-        delete st;
-        return -1;
-    }
-    Id128 uid;
-    memcpy(uid.b, id, 128);
-    st->rank = rank, st->world = world;
-    const int rc = st->comm_init_rank(&st->comm, world, uid, rank);
-    if (rc != 0) {
-        ctx->fail(std::string("shard: ncclCommInitRank: ") + (st->get_error_string ? st->get_error_string(rc) : "error"));
-        delete st;
-        return -1;
-    }
-    ctx->shard = st;
-    return 0;
-}
-
-void zgml_hip_shard_destroy(zgml_hip_ctx* ctx) {
-    if (!ctx || !ctx->shard) return;
-    hipSetDevice(ctx->device);
-    hipStreamSynchronize(ctx->stream);
-    if (ctx->shard->comm && ctx->shard->comm_destroy) ctx->shard->comm_destroy(ctx->shard->comm);
-    delete ctx->shard;
-    ctx->shard = nullptr;
-}
-
-int zgml_hip_shard_attach(zgml_hip_ctx* ctx, zgml_hip_program* p, const zgml_shard_point* points, uint64_t n_points, uint16_t logits_buf,
-                          uint64_t vocab) {
-    if (!ctx || !p || (n_points && !points)) return -1;
-    const uint32_t world = ctx->shard ? (uint32_t)ctx->shard->world : 1u;
-    std::vector<uint64_t> bars;
-    uint64_t prev = 0;
-    for (uint64_t i = 0; i < n_points; i++) {
-        const zgml_shard_point& gp = points[i];
-        if (gp.op_end < prev || gp.op_end > p->ops.size() || gp.buf_idx >= p->bufs.size() || !p->bufs[gp.buf_idx] ||
-            (uint64_t)gp.offset + (uint64_t)world * gp.len_per_rank > p->sizes[gp.buf_idx]) {
-            ctx->fail("shard_attach: gather point " + std::to_string(i) + " out of range");
-            return -1;
-        }
-        prev = gp.op_end;
-        bars.push_back(gp.op_end);
-    }
-    if (logits_buf >= p->bufs.size() || !p->bufs[logits_buf] || vocab > p->sizes[logits_buf]) {
-        ctx->fail("shard_attach: bad logits buffer");
-        return -1;
-    }
-    p->shard_points.assign(points, points + n_points);
-    p->shard_logits_buf = logits_buf, p->shard_vocab = vocab;
-    p->shard_capture_failed = false;
-    hipSetDevice(ctx->device);
-    free_shard_peer(p);
-    // the last gather point covers the logits: gather one (max, index) pair per rank instead
-    p->shard_pair_argmax = false;
-    if (n_points && ctx->shard) {
-        const zgml_shard_point& last = points[n_points - 1];
-        static const bool pairs_on = !(getenv("ZGML_SHARD_PAIR_ARGMAX") && atoi(getenv("ZGML_SHARD_PAIR_ARGMAX")) == 0);
-        p->shard_pair_argmax = pairs_on && last.buf_idx == logits_buf && last.offset == 0 && (uint64_t)world * last.len_per_rank == vocab;
-    }
-    if (p->shard_pair_argmax && !p->shard_pairs) {
-        if (!CTX_CHECK(ctx, hipMalloc((void**)&p->shard_pairs, 64 * sizeof(unsigned long long)))) return -1;
-        p->owned.push_back(p->shard_pairs);
-    }
-    if (ctx->shard && ctx->shard->peer) {
-        if (n_points < 2 || world > 64) {
-            ctx->fail("shard_attach: the peer gather needs at least two gather points per step (its flow control) and at most 64 ranks");
-            return -1;
-        }
-        ShardPeer* sp = new ShardPeer();
-        uint64_t off = (n_points + 1) * 128;
-        for (uint64_t i = 0; i < n_points; i++) {
-            const zgml_shard_point& gp = points[i];
-            if (gp.len_per_rank % 2 || ((uintptr_t)(p->bufs[gp.buf_idx] + gp.offset) % 8) != 0) {
-                delete sp;
-                ctx->fail("shard_attach: peer gather: a slice that is not a whole number of aligned 8-byte units");
-                return -1;
-            }
-            sp->stage_off.push_back(off);
-            off += ((uint64_t)world * gp.len_per_rank * 4 + 255) / 256 * 256;
-        }
-        sp->pairs_off = off;
-        off += 64 * 8;
-        sp->bytes = off;
-        // fine-grained device memory: peers' stores and this rank's system-scope loads meet without a cache between them
-        if (!CTX_CHECK(ctx, hipExtMallocWithFlags((void**)&sp->block, sp->bytes, hipDeviceMallocFinegrained)) ||
-            !CTX_CHECK(ctx, hipMemset(sp->block, 0, sp->bytes)) || !CTX_CHECK(ctx, hipMalloc((void**)&sp->seen, (n_points + 1) * 4)) ||
-            !CTX_CHECK(ctx, hipMemset(sp->seen, 0, (n_points + 1) * 4)) || !CTX_CHECK(ctx, hipMalloc((void**)&sp->table_dev, (size_t)world * sizeof(char*)))) {
-            hipFree(sp->block), hipFree(sp->seen), hipFree(sp->table_dev);
-            delete sp;
-            return -1;
-        }
-        sp->mapped.assign(world, nullptr);
-        sp->ipc_opened.assign(world, 0);
-        sp->mapped[ctx->shard->rank] = sp->block;
-        p->shard_peer = sp;
-    }
-    return zgml_hip_program_set_barriers(ctx, p, bars.data(), bars.size()); // batched launches never straddle a collective
-}
-
-int zgml_hip_shard_init_peer(zgml_hip_ctx* ctx, int rank, int world) {
-    if (!ctx || world < 1 || rank < 0 || rank >= world) return -1;
-    if (ctx->shard) return -1; // one shard state per context
-    if (!ctx->handoff_flag_dev) {
-        ctx->fail("shard_init_peer: the context has no host-visible hand-off word");
-        return -1;
-    }
-    ShardState* st = new ShardState();
-    st->rank = rank, st->world = world, st->peer = true;
-    ctx->shard = st;
-    return 0;
-}
-
-int zgml_hip_shard_peer_export(zgml_hip_ctx* ctx, zgml_hip_program* p, zgml_shard_peer_handle* out) {
-    if (!ctx || !p || !out || !p->shard_peer) return -1;
-    hipSetDevice(ctx->device);
-    memset(out, 0, sizeof(*out));
-    hipIpcMemHandle_t h;
-    static_assert(sizeof(h) <= sizeof(out->ipc), "hipIpcMemHandle_t fits the handle record");
-    if (hipIpcGetMemHandle(&h, p->shard_peer->block) == hipSuccess)
-        memcpy(out->ipc, &h, sizeof(h));
-    else
-        (void)hipGetLastError(); // (same-process importers only need `raw`; a cross-process import then fails loudly)
-    out->pid = (uint64_t)getpid(), out->raw = (uint64_t)(uintptr_t)p->shard_peer->block, out->bytes = p->shard_peer->bytes;
-    return 0;
-}
-
-int zgml_hip_shard_peer_import(zgml_hip_ctx* ctx, zgml_hip_program* p, int peer_rank, const zgml_shard_peer_handle* h) {
-    if (!ctx || !p || !h || !p->shard_peer || !ctx->shard || peer_rank < 0 || peer_rank >= ctx->shard->world) return -1;
-    hipSetDevice(ctx->device);
-    ShardPeer* sp = p->shard_peer;
-    if (h->bytes != sp->bytes) {
-        ctx->fail("shard_peer_import: rank " + std::to_string(peer_rank) + "'s block has a different layout (gather points differ)");
-        return -1;
-    }
-    if (peer_rank != ctx->shard->rank) {
-        if (h->pid == (uint64_t)getpid()) {
-            sp->mapped[peer_rank] = (char*)(uintptr_t)h->raw;
-        } else {
-            hipIpcMemHandle_t ih;
-            memcpy(&ih, h->ipc, sizeof(ih));
-            void* ptr = nullptr;
-            if (!CTX_CHECK(ctx, hipIpcOpenMemHandle(&ptr, ih, hipIpcMemLazyEnablePeerAccess))) return -1;
-            sp->mapped[peer_rank] = (char*)ptr, sp->ipc_opened[peer_rank] = 1;
-        }
-    }
-    bool all = true;
-    for (char* m : sp->mapped) all = all && m != nullptr;
-    if (all) {
-        if (!CTX_CHECK(ctx, hipMemcpy(sp->table_dev, sp->mapped.data(), sp->mapped.size() * sizeof(char*), hipMemcpyHostToDevice))) return -1;
-        sp->table_ready = true;
-    }
-    return 0;
-}
-
-int64_t zgml_hip_shard_step(zgml_hip_ctx* ctx, zgml_hip_program* p, const zgml_program_io* inputs, uint64_t n_inputs) {
-    if (!ctx || !p || !ctx->shard) return -1;
-    hipSetDevice(ctx->device);
-    hipStream_t s = ctx->stream;
-    if (p->plan_dirty || p->fuse_epoch != p->ctx->fuse_epoch) {
-        free_graph(p);
-        build_plan(p);
-    }
-    if (zgml_hip_stage_inputs(ctx, p, inputs, n_inputs) != 0) return -1;
-    static const bool want_graph = !(getenv("ZGML_SHARD_GRAPH") && atoi(getenv("ZGML_SHARD_GRAPH")) == 0);
-    if (want_graph && ctx->opt_graph && !p->shard_graph_exec && !p->shard_capture_failed) {
-        // relaxed capture: RCCL may touch its own (already created) resources while it enqueues
-        hipGraph_t g = nullptr;
-        bool ok = hipStreamSynchronize(s) == hipSuccess && hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) == hipSuccess;
-        if (ok) {
-            zgml_hip_enqueue_staged(ctx, p);
-            const bool seg = shard_segments(ctx, p); // (incl. the greedy token into ctx->arg_out)
-            hipMemcpyAsync(ctx->arg_out_host, ctx->arg_out, sizeof(int64_t), hipMemcpyDeviceToHost, s);
-            ok = hipStreamEndCapture(s, &g) == hipSuccess && g && seg;
-        }
-        if (ok) ok = hipGraphInstantiate(&p->shard_graph_exec, g, nullptr, nullptr, 0) == hipSuccess;
-        if (ok) {
-            p->shard_graph = g;
-        } else {
-            if (g) hipGraphDestroy(g);
-            p->shard_graph_exec = nullptr;
-            p->shard_capture_failed = true; // eager from now on (all ranks decide alike: same program, same runtime)
-            (void)hipGetLastError();
-            if (!ctx->err.empty()) return -1;
-        }
-    }
-    if (p->shard_graph_exec) {
-        if (!CTX_CHECK(ctx, hipGraphLaunch(p->shard_graph_exec, s))) return -1;
-    } else {
-        zgml_hip_enqueue_staged(ctx, p);
-        if (!shard_segments(ctx, p)) return -1;
-        hipMemcpyAsync(ctx->arg_out_host, ctx->arg_out, sizeof(int64_t), hipMemcpyDeviceToHost, s);
-    }
-    if (!CTX_CHECK(ctx, hipStreamSynchronize(s)) || !ctx->handoff_ok("shard_step")) return -1;
-    p->profile.call_count++;
-    return *ctx->arg_out_host;
-}
-
-// One EAGER step with HIP events around every all-gather (diagnostics for bench.py's N > 1 line): the device time of the whole
-// step and the part of it spent inside the collectives. Every rank must call it (the gathers are collective). Returns the
-// greedy token, -1 on error.
-int64_t zgml_hip_shard_profile_step(zgml_hip_ctx* ctx, zgml_hip_program* p, const zgml_program_io* inputs, uint64_t n_inputs, double* step_us,
-                                    double* gather_us) {
-    if (!ctx || !p || !ctx->shard) return -1;
-    hipSetDevice(ctx->device);
-    hipStream_t s = ctx->stream;
-    if (p->plan_dirty || p->fuse_epoch != p->ctx->fuse_epoch) {
-        free_graph(p);
-        build_plan(p);
-    }
-    if (zgml_hip_stage_inputs(ctx, p, inputs, n_inputs) != 0) return -1;
-    std::vector<hipEvent_t> ev(2 * p->shard_points.size() + 2);
-    for (auto& e : ev) hipEventCreate(&e);
-    hipEventRecord(ev[ev.size() - 2], s);
-    zgml_hip_enqueue_staged(ctx, p);
-    bool ok = shard_segments(ctx, p, &ev);
-    hipMemcpyAsync(ctx->arg_out_host, ctx->arg_out, sizeof(int64_t), hipMemcpyDeviceToHost, s);
-    hipEventRecord(ev[ev.size() - 1], s);
-    ok = ok && CTX_CHECK(ctx, hipStreamSynchronize(s)) && ctx->handoff_ok("shard_profile_step");
-    if (ok) {
-        float ms = 0;
-        double g = 0;
-        for (size_t i = 0; i < p->shard_points.size(); i++)
-            if (hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]) == hipSuccess) g += ms * 1e3;
-        if (gather_us) *gather_us = g;
-        if (step_us && hipEventElapsedTime(&ms, ev[ev.size() - 2], ev[ev.size() - 1]) == hipSuccess) *step_us = ms * 1e3;
-    }
-    for (auto& e : ev) hipEventDestroy(e);
-    return ok ? *ctx->arg_out_host : -1;
-}
-
-int zgml_hip_shard_step_mode(zgml_hip_program* p) { return !p ? -1 : (p->shard_graph_exec ? 1 : 0); } // 1 = one graph per token
-
-} // extern "C"
+namespace zgml_rt { // what runtime_bench.hip / runtime_shard.hip call (runtime_internal.h)
+void rt_build_plan(zgml_hip_program* p) { build_plan(p); }
+void rt_free_graph(zgml_hip_program* p) { free_graph(p); }
+void rt_run_plan(zgml_hip_program* p, hipStream_t s, size_t first, size_t count) { run_plan(p, s, first, count); }
+bool rt_grow(zgml_hip_ctx* ctx, float** ptr, uint64_t* cap, uint64_t elems) { return grow(ctx, ptr, cap, elems); }
+uint64_t rt_now_ns() { return now_ns(); }
+void rt_dump_graph(hipGraph_t g, const char* tag) { dump_graph(g, tag); }
+} // namespace zgml_rt

@@ -1,0 +1,238 @@
+// runtime_internal.h — what the translation units of the runtime share (runtime.hip: the C ABI, planner and resident loops;
+// runtime_bench.hip: the measurement entry points; runtime_shard.hip: the row-shard path): the context and program objects and the
+// few internal functions the latter two call. Not part of the boundary (include/zgml_hip.h is).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "schedule.h"
+
+using namespace zgml;
+
+namespace zgml_rt {
+
+extern std::string g_create_error; // (defined in runtime.hip)
+
+// A launch that can also emit its result rows as the A pieces of an M > 1 quantized matmul (kernels.h: RowChainParams::ap):
+// the planner arms it when the matmul that consumes exactly these rows follows with no other splitting launch in between.
+struct SplitHook {
+    const float* out = nullptr; // the rows the launch produces (dense: row stride == cols)
+    uint32_t rows = 0, cols = 0; // rows == 0: a flat launch over `n` elements, any rows x cols = n of dense rows
+    uint32_t n = 0;
+    uint16_t** ap = nullptr;    // fields of the launch's (shared) parameter block
+    uint32_t* ap_S = nullptr;
+    uint32_t* ap_cols = nullptr; // flat launches: the row length is filled in too
+};
+
+struct AdecDesc {
+    std::vector<AttnDecodeParams> host; // the records as uploaded
+    const AttnDecodeParams* dev = nullptr;
+    uint32_t nh = 0, dh = 0;
+    AttnSplit sp;
+    bool kvq = false;
+};
+
+struct Launch {
+    uint32_t kind;           // DeviceOp tag the launch is accounted to
+    uint32_t n_ops;          // DeviceOps covered (batching folds several)
+    uint32_t op_lo, op_hi;   // smallest / largest op index covered
+    std::function<void(hipStream_t)> run;
+    std::shared_ptr<SplitHook> hook; // (after `run` so the aggregate initialisers elsewhere stay valid)
+    // what a fused-launch pass needs to know about a grouped mat-vec launch / a decode-attention launch (fuse_qkv_attention)
+    std::shared_ptr<QmvLaunch> qmv_desc;
+    std::shared_ptr<struct AdecDesc> adec_desc;
+    uint64_t prof_ns = 0;    // ZGML_HIP_OPT_PROFILE: accumulated event time of this launch
+    uint32_t prof_calls = 0;
+};
+
+struct IoEntry {
+    uint16_t buf_idx;
+    uint32_t offset, size;
+    bool operator==(const IoEntry& o) const { return buf_idx == o.buf_idx && offset == o.offset && size == o.size; }
+};
+
+struct IoTableDev { // one row per transfer, consumed by scatter/gather kernels
+    float* dev;      // device address inside the program buffer
+    uint32_t stage_off_words;
+    uint32_t n_words;
+};
+
+struct IoPlan {
+    std::vector<IoEntry> entries;
+    IoTableDev* table_dev = nullptr;
+    uint32_t total_words = 0;
+    bool word_aligned = true;
+};
+
+} // namespace zgml_rt
+using namespace zgml_rt;
+
+struct ShardState;
+struct zgml_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    bool opt_fusion = true, opt_graph = true, opt_profile = false, opt_skip_dead = true, opt_f16_dense = false;
+    int64_t opt_attn_split_min_keys = -1; // -1: environment / default (attn_split_for)
+    int64_t opt_fuse_resident_wgs = -1;   // -1: one 1024-thread workgroup per CU (fuse_qkv_attention)
+    // host dense override scratch
+    float *mm_a = nullptr, *mm_b = nullptr, *mm_c = nullptr;
+    uint64_t mm_a_cap = 0, mm_b_cap = 0, mm_c_cap = 0;
+    // host dense override: device copies of B operands keyed by host pointer; opt-in
+    struct CachedB {
+        float* dev;
+        uint64_t span; // elements
+    };
+    std::map<const float*, CachedB> b_cache;
+    uint64_t b_cache_cap = 0, b_cache_bytes = 0, b_cache_hits = 0, b_cache_misses = 0;
+    void drop_b_cache() {
+        for (auto& kv : b_cache) hipFree(kv.second.dev);
+        b_cache.clear();
+        b_cache_bytes = 0;
+    }
+    // argmax scratch
+    float* arg_val = nullptr;
+    int64_t* arg_idx = nullptr;
+    int64_t* arg_out = nullptr;
+    int64_t* arg_out_host = nullptr; // pinned
+    struct ShardState* shard = nullptr; // RCCL communicator of the row-shard path (zgml_hip_shard_*), else nullptr
+    // Fused launches (q/k/v projection + decode attention): ONE host-visible word every bounded in-launch wait sets when it
+    // gives up (pinned, device-mapped: the host reads it after any synchronisation without a copy). A set word means the
+    // tokens of that run are wrong: every host sync point reports it (handoff_ok), clears it and switches the fusion off for
+    // the context — plans are rebuilt in the two-launch form (fuse_epoch).
+    uint32_t* handoff_flag = nullptr;     // host pointer
+    uint32_t* handoff_flag_dev = nullptr; // the same word as the kernels see it
+    bool fuse_qkv_off = false;
+    uint64_t fuse_epoch = 0;
+    int n_cu = 0; // compute units (residency guard of the fused launch)
+    bool handoff_ok(const char* where) {
+        if (!handoff_flag || !*(volatile uint32_t*)handoff_flag) return true;
+        *(volatile uint32_t*)handoff_flag = 0;
+        fuse_qkv_off = true, fuse_epoch++;
+        fail(std::string(where) + ": an in-launch hand-off wait of a fused q/k/v + attention launch timed out — the results of this run are wrong; "
+                                  "the fusion is now off for this context (later runs use two launches)");
+        return false;
+    }
+
+    void fail(const std::string& what) {
+        if (err.empty()) err = what;
+    }
+    bool check(hipError_t e, const char* what) {
+        if (e == hipSuccess) return true;
+        fail(std::string(what) + ": " + hipGetErrorString(e));
+        return false;
+    }
+};
+
+struct zgml_resident;
+struct zgml_hip_program {
+    zgml_hip_ctx* ctx = nullptr;
+    std::vector<zgml_device_op> ops;
+    std::vector<std::vector<zgml_fused_step>> steps; // owned copies, per op
+    std::vector<uint64_t> sizes;                      // f32 elements
+    std::vector<float*> bufs;                         // device pointers (nullptr = elided)
+    void* arena = nullptr;
+    std::vector<QWeightDev> qweights;
+    std::vector<unsigned long long*> attn_traces; // diagnostics (ZGML_HIP_ATTN_TRACE)
+    struct QmvTrace {
+        unsigned long long* t;
+        uint32_t parts, pro, K, N;
+    };
+    std::vector<QmvTrace> qmv_traces; // diagnostics (ZGML_HIP_QMV_TRACE)
+    float* zero_word = nullptr;                   // a device 0.0f: mask operand of unmasked decode attention
+    float* split_buf = nullptr;                   // long-context attention split: partials + arrival counters,
+    uint32_t* split_cnt = nullptr;                // shared by the (stream-ordered) decode-attention launches
+    uint64_t split_buf_floats = 0, split_cnt_words = 0;
+    bool f16_stream_nt = false;     // promoted weights exceed the Infinity Cache: non-temporal loads
+    std::vector<void*> f16_weights; // per buffer: MFMA-packed f16 copy of a promoted matmul B operand (else nullptr)
+    std::vector<void*> owned; // other device allocations
+    uint64_t fuse_epoch = 0;             // ctx->fuse_epoch the plan was built at (a time-out rebuilds it without the fusion)
+    std::vector<void*> fuse_owned;       // counters / seen / idx blocks of the fused launches: freed with every plan rebuild
+    // repeats of constant data (a weight broadcast to the activation shape: source never written by an op, destination written by
+    // this op only) run ONCE when the plan is built instead of in every execution; a host input that ever targets one of the
+    // buffers involved switches this off for the program (prepare_io)
+    std::vector<char> hoist_op;    // per op: executed at plan-build time, not part of the plan
+    std::vector<char> hoist_guard; // per buffer: read or written by a hoisted repeat
+    bool hoist_ok = true;
+    float* prenorm_buf = nullptr;        // arm_prenorm: [x * gamma | partial sums of squares] handed from a residual epilogue to the next prologue
+    size_t prenorm_bytes = 0;
+    float* scratch = nullptr;
+    uint64_t scratch_bytes = 0;
+    // plan building: the last quantized matmul launch that split its input into the scratch (make_single)
+    uint64_t split_pos = UINT64_MAX - 1;
+    const float* split_input = nullptr;
+    std::shared_ptr<std::vector<std::pair<QWeightDev, QMatmulParams>>> qmm_group; // parts of the launch at split_pos
+    std::shared_ptr<std::vector<DenseF16Params>> f16_group;
+    uint32_t split_M = 0, split_K = 0, split_in_rs = 0, split_kind = 0; // kind: 1 = bf16 pieces (quantized), 2 = f16 A (dense)
+    // dynamic parameter block: one word per op
+    uint32_t* dyn_dev = nullptr;
+    uint32_t* dyn_host = nullptr; // pinned
+    bool dyn_dirty = true;
+    std::vector<Launch> plan;
+    bool plan_dirty = true;
+    Schedule sched;                  // valid when plan_batched
+    bool plan_batched = false;       // plan was built from dependency levels
+    bool batching_safe = true;       // cleared when a refresh leaves the assumed dynamic bounds
+    std::vector<uint64_t> barriers;  // op indices nothing may be moved across (multi-GPU harness)
+    // per attention op: the largest seq_kv the caller ever handed over (compile time or a refresh). The schedule
+    // takes the attention's K/V read extent from here, never from the last refreshed value, so a plan rebuilt
+    // after a small-seq_kv refresh cannot put a KV store and the attention that reads it on one level.
+    std::vector<uint32_t> seq_kv_bound;
+    std::vector<void*> param_blobs;  // device parameter arrays of batched launches
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    // host I/O staging
+    void* stage_host = nullptr; // pinned
+    void* stage_dev = nullptr;
+    uint64_t stage_cap = 0;
+    IoPlan in_plan, out_plan;
+    uint64_t staged_bytes = 0, staged_n = 0; // zgml_hip_stage_inputs / enqueue_staged
+    zgml_runtime_profile profile{};
+    zgml_resident* resident = nullptr;
+    // row-shard path (zgml_hip_shard_attach): all-gather points in op order, the logits for the greedy token, and the
+    // captured graph of one whole step (staged inputs, op ranges, all-gathers, argmax)
+    std::vector<zgml_shard_point> shard_points;
+    uint16_t shard_logits_buf = 0;
+    uint64_t shard_vocab = 0;
+    hipGraph_t shard_graph = nullptr;
+    hipGraphExec_t shard_graph_exec = nullptr;
+    bool shard_capture_failed = false;
+    // the greedy token as a (max, index) pair per rank instead of a gather of the logits (the last gather point covers the logits
+    // buffer): device pairs [world] for the collective mode; and the peer-store gather's state (shard_peer.hip)
+    bool shard_pair_argmax = false;
+    unsigned long long* shard_pairs = nullptr;
+    struct ShardPeer* shard_peer = nullptr;
+};
+
+#define CTX_CHECK(ctx, expr) (ctx)->check((expr), #expr)
+
+namespace zgml_rt {
+// defined in runtime.hip (thin exported forms of its file-local functions)
+void rt_build_plan(zgml_hip_program* p);
+void rt_free_graph(zgml_hip_program* p);
+void rt_run_plan(zgml_hip_program* p, hipStream_t s, size_t first, size_t count);
+bool rt_grow(zgml_hip_ctx* ctx, float** ptr, uint64_t* cap, uint64_t elems);
+uint64_t rt_now_ns();
+void rt_dump_graph(hipGraph_t g, const char* tag);
+} // namespace zgml_rt
+#ifndef ZGML_RUNTIME_MAIN // the other translation units call them by the names runtime.hip uses
+namespace {
+inline void build_plan(zgml_hip_program* p) { zgml_rt::rt_build_plan(p); }
+inline void free_graph(zgml_hip_program* p) { zgml_rt::rt_free_graph(p); }
+inline void run_plan(zgml_hip_program* p, hipStream_t s, size_t first, size_t count) { zgml_rt::rt_run_plan(p, s, first, count); }
+inline bool grow(zgml_hip_ctx* ctx, float** ptr, uint64_t* cap, uint64_t elems) { return zgml_rt::rt_grow(ctx, ptr, cap, elems); }
+inline uint64_t now_ns() { return zgml_rt::rt_now_ns(); }
+inline void dump_graph(hipGraph_t g, const char* tag) { zgml_rt::rt_dump_graph(g, tag); }
+} // namespace
+#endif
