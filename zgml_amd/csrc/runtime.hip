@@ -282,9 +282,7 @@ bool prepare_io(zgml_hip_program* p, IoPlan& plan, const zgml_program_io* ios, u
     }
     if (plan.word_aligned && !table.empty()) {
         if (!CTX_CHECK(ctx, hipMalloc((void**)&plan.table_dev, table.size() * sizeof(IoTableDev)))) return false;
-        if (!CTX_CHECK(ctx, hipMemcpy(plan.table_dev, table.data(), table.size() * sizeof(IoTableDev),
-                                      hipMemcpyHostToDevice)))
-            return false;
+        if (!CTX_CHECK(ctx, h2d_sync(ctx->stream, plan.table_dev, table.data(), table.size() * sizeof(IoTableDev)))) return false;
     }
     return ensure_stage(p, (uint64_t)plan.total_words * 4);
 }
@@ -303,7 +301,7 @@ const T* upload_params(zgml_hip_program* p, const std::vector<T>& v) {
         p->ctx->fail("plan: parameter array allocation failed");
         return nullptr;
     }
-    hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    if (h2d_sync(p->ctx->stream, d, v.data(), v.size() * sizeof(T)) != hipSuccess) p->ctx->fail("plan: parameter array upload failed");
     p->param_blobs.push_back(d);
     return (const T*)d;
 }
@@ -333,7 +331,7 @@ AttnSplit attn_split_for(zgml_hip_program* p, uint32_t n_heads, uint32_t d_head,
     if (n_heads > p->split_cnt_words) {
         void* d = nullptr;
         const size_t bytes = ((size_t)n_heads * 4 + 255) / 256 * 256;
-        if (hipMalloc(&d, bytes) != hipSuccess || hipMemset(d, 0, bytes) != hipSuccess) return sp;
+        if (hipMalloc(&d, bytes) != hipSuccess || memset_sync(p->ctx->stream, d, 0, bytes) != hipSuccess) return sp;
         p->param_blobs.push_back(d);
         p->split_cnt = (uint32_t*)d, p->split_cnt_words = n_heads;
     }
@@ -927,13 +925,13 @@ void fuse_qkv_attention(zgml_hip_program* p) {
         const size_t words = n_cnt + (size_t)nh * n_sp * 3 + 1 + 3 * (size_t)nh + o_blocks;
         uint32_t* block = nullptr;
         if (hipMalloc((void**)&block, words * 4) != hipSuccess) continue;
-        if (hipMemset(block, 0, words * 4) != hipSuccess) {
+        if (memset_sync(p->ctx->stream, block, 0, words * 4) != hipSuccess) {
             hipFree(block);
             continue;
         }
         p->fuse_owned.push_back(block); // (freed by the next build_plan, after its stream sync)
         uint32_t *counters = block, *seen = block + n_cnt, *timeout = p->ctx->handoff_flag_dev, *idx_dev = seen + (size_t)nh * n_sp * 3 + 1;
-        if (hipMemcpy(idx_dev, idx.data(), idx.size() * 4, hipMemcpyHostToDevice) != hipSuccess) continue;
+        if (h2d_sync(p->ctx->stream, idx_dev, idx.data(), idx.size() * 4) != hipSuccess) continue;
         const AttnDecodeParams* d = ad->dev;
         AttnSplit sp = ad->sp;
         sp.splits = n_sp; // (possibly fewer than the stand-alone launch would use: the residency guard above)
@@ -1004,7 +1002,7 @@ void fuse_attention_o(zgml_hip_program* p) {
         const size_t words = 32 + o_blocks; // the counter on a line of its own, then one `seen` word per projection workgroup
         uint32_t* block = nullptr;
         if (hipMalloc((void**)&block, words * 4) != hipSuccess) continue;
-        if (hipMemset(block, 0, words * 4) != hipSuccess) {
+        if (memset_sync(p->ctx->stream, block, 0, words * 4) != hipSuccess) {
             hipFree(block);
             continue;
         }
@@ -1059,7 +1057,7 @@ void arm_prenorm(zgml_hip_program* p) {
         const size_t need = ((size_t)C->K + C->K / 16) * sizeof(float);
         if (p->prenorm_bytes < need) { // one block for the whole program: the pairs follow each other in stream order
             float* blk = nullptr;
-            if (hipMalloc((void**)&blk, need) != hipSuccess || hipMemset(blk, 0, need) != hipSuccess) {
+            if (hipMalloc((void**)&blk, need) != hipSuccess || memset_sync(p->ctx->stream, blk, 0, need) != hipSuccess) {
                 if (blk) hipFree(blk);
                 continue;
             }
@@ -3150,13 +3148,13 @@ int zgml_hip_resident_setup(zgml_hip_ctx* ctx, zgml_hip_program* p, const zgml_r
               CTX_CHECK(ctx, hipMalloc((void**)&r->dyn_base, (n_ops + 1) * 4)) &&
               CTX_CHECK(ctx, hipMalloc((void**)&r->dyn_stride, (n_ops + 1) * 4)) &&
               CTX_CHECK(ctx, hipMalloc((void**)&r->state, 4 * 4)) && CTX_CHECK(ctx, hipMalloc((void**)&r->tok_dev, (size_t)T * 4)) &&
-              CTX_CHECK(ctx, hipMemcpy(r->embed, d->token_embed, emb, hipMemcpyHostToDevice)) &&
-              CTX_CHECK(ctx, hipMemcpy(r->cos, d->cos_table, tab, hipMemcpyHostToDevice)) &&
-              CTX_CHECK(ctx, hipMemcpy(r->sin, d->sin_table, tab, hipMemcpyHostToDevice)) &&
-              CTX_CHECK(ctx, hipMemcpy(r->rope_bufs, ropes.data(), ropes.size() * sizeof(float*), hipMemcpyHostToDevice)) &&
-              CTX_CHECK(ctx, hipMemcpy(r->dyn_kind, kind.data(), n_ops * 4, hipMemcpyHostToDevice)) &&
-              CTX_CHECK(ctx, hipMemcpy(r->dyn_base, base.data(), n_ops * 4, hipMemcpyHostToDevice)) &&
-              CTX_CHECK(ctx, hipMemcpy(r->dyn_stride, stride.data(), n_ops * 4, hipMemcpyHostToDevice));
+              CTX_CHECK(ctx, h2d_sync(ctx->stream, r->embed, d->token_embed, emb)) &&
+              CTX_CHECK(ctx, h2d_sync(ctx->stream, r->cos, d->cos_table, tab)) &&
+              CTX_CHECK(ctx, h2d_sync(ctx->stream, r->sin, d->sin_table, tab)) &&
+              CTX_CHECK(ctx, h2d_sync(ctx->stream, r->rope_bufs, ropes.data(), ropes.size() * sizeof(float*))) &&
+              CTX_CHECK(ctx, h2d_sync(ctx->stream, r->dyn_kind, kind.data(), n_ops * 4)) &&
+              CTX_CHECK(ctx, h2d_sync(ctx->stream, r->dyn_base, base.data(), n_ops * 4)) &&
+              CTX_CHECK(ctx, h2d_sync(ctx->stream, r->dyn_stride, stride.data(), n_ops * 4));
     if (!ok) {
         free_resident(p);
         return -1;

@@ -217,6 +217,22 @@ struct zgml_hip_program {
 
 #define CTX_CHECK(ctx, expr) (ctx)->check((expr), #expr)
 
+// Host -> device copies and fills of set-up data, ordered on the CONTEXT's stream and waited for there — never on the legacy
+// stream: a synchronous hipMemcpy / hipMemset synchronises with every blocking stream of the process, so with two contexts stepping
+// from two host threads (the single-GPU rehearsal of world size 2) it invalidated the other thread's stream capture ("operation
+// would make the legacy stream depend on a capturing blocking stream") or waited for the other rank's gather kernel, which in
+// turn waits for this rank (a 5 s stall ended by the bounded wait).
+namespace {
+inline hipError_t h2d_sync(hipStream_t s, void* dst, const void* src, size_t bytes) {
+    const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s);
+    return e != hipSuccess ? e : hipStreamSynchronize(s);
+}
+inline hipError_t memset_sync(hipStream_t s, void* dst, int value, size_t bytes) {
+    const hipError_t e = hipMemsetAsync(dst, value, bytes, s);
+    return e != hipSuccess ? e : hipStreamSynchronize(s);
+}
+} // namespace
+
 namespace zgml_rt {
 // defined in runtime.hip (thin exported forms of its file-local functions)
 void rt_build_plan(zgml_hip_program* p);

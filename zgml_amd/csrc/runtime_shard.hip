@@ -229,8 +229,8 @@ int zgml_hip_shard_attach(zgml_hip_ctx* ctx, zgml_hip_program* p, const zgml_sha
         sp->bytes = off;
         // fine-grained device memory: peers' stores and this rank's system-scope loads meet without a cache between them
         if (!CTX_CHECK(ctx, hipExtMallocWithFlags((void**)&sp->block, sp->bytes, hipDeviceMallocFinegrained)) ||
-            !CTX_CHECK(ctx, hipMemset(sp->block, 0, sp->bytes)) || !CTX_CHECK(ctx, hipMalloc((void**)&sp->seen, (n_points + 1) * 4)) ||
-            !CTX_CHECK(ctx, hipMemset(sp->seen, 0, (n_points + 1) * 4)) || !CTX_CHECK(ctx, hipMalloc((void**)&sp->table_dev, (size_t)world * sizeof(char*)))) {
+            !CTX_CHECK(ctx, memset_sync(ctx->stream, sp->block, 0, sp->bytes)) || !CTX_CHECK(ctx, hipMalloc((void**)&sp->seen, (n_points + 1) * 4)) ||
+            !CTX_CHECK(ctx, memset_sync(ctx->stream, sp->seen, 0, (n_points + 1) * 4)) || !CTX_CHECK(ctx, hipMalloc((void**)&sp->table_dev, (size_t)world * sizeof(char*)))) {
             hipFree(sp->block), hipFree(sp->seen), hipFree(sp->table_dev);
             delete sp;
             return -1;
@@ -292,7 +292,7 @@ int zgml_hip_shard_peer_import(zgml_hip_ctx* ctx, zgml_hip_program* p, int peer_
     bool all = true;
     for (char* m : sp->mapped) all = all && m != nullptr;
     if (all) {
-        if (!CTX_CHECK(ctx, hipMemcpy(sp->table_dev, sp->mapped.data(), sp->mapped.size() * sizeof(char*), hipMemcpyHostToDevice))) return -1;
+        if (!CTX_CHECK(ctx, h2d_sync(ctx->stream, sp->table_dev, sp->mapped.data(), sp->mapped.size() * sizeof(char*)))) return -1;
         sp->table_ready = true;
     }
     return 0;
