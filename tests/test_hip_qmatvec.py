@@ -416,6 +416,60 @@ def test_gate_up_pair_launch_stores_every_intermediate(hip_backend, oracle, K, F
         hip_backend.freeProgram(h)
 
 
+@pytest.mark.parametrize("K0,K,F", [(1536, 576, 1536), (2048, 2048, 1024), (4096, 4096, 11008)])
+def test_swiglu_half_with_prepared_norm_and_pair_stores_every_intermediate(hip_backend, oracle, K0, K, F):
+    """Both hand-overs in one chain, as a decoder layer has them: projection -> residual add -> rmsnorm -> mul(gamma) -> gate / up
+    -> SiLU chain -> silu * up -> down projection. Three launches: the first prepares the second's norm, the second is a gate / up
+    PAIR launch that consumes it (every workgroup also stores a slice of the normalised vector and of its product with gamma), the
+    third streams the product. 2048 x 1024: fewer pair workgroups than 16-element slices of the input — the n-on-lanes pair is not
+    armed there (its workgroups could not cover the slices), the prepared norm still is. Every buffer against the oracle."""
+    from zgml_amd import FusedEwStep
+    rng = np.random.default_rng(K0 + 5 * K + F)
+    xin = rng.standard_normal(K0).astype(f32)
+    resid = rng.standard_normal(K).astype(f32)
+    gamma = (rng.random(K).astype(f32) + 0.5)
+    one = np.ones(F, f32)
+    B = dict(xin=0, resid=1, gamma=2, one=3, y=4, h=5, normed=6, xg=7, gate=8, up=9, exp_neg=10, silu=11, act=12, down=13)
+    sizes = [K0, K, K, F, K, K, K, K, F, F, F, F, F, K]
+    ops = [
+        DeviceOp.qmatmul(B["y"], B["xin"], 0, 1, K, K0),
+        DeviceOp.elementwise("add", B["h"], B["resid"], B["y"], K),
+        DeviceOp.rmsnorm(B["normed"], B["h"], 1, K, 1e-5),
+        DeviceOp.elementwise("mul", B["xg"], B["normed"], B["gamma"], K),
+        DeviceOp.qmatmul(B["gate"], B["xg"], 1, 1, F, K),
+        DeviceOp.fused_elementwise([FusedEwStep("neg"), FusedEwStep("exp")], F, B["exp_neg"], B["gate"]),
+        DeviceOp.fused_elementwise([FusedEwStep("add", False, B["one"], 0), FusedEwStep("recip"), FusedEwStep("mul", True, B["gate"], 0)], F,
+                                   B["silu"], B["exp_neg"]),
+        DeviceOp.qmatmul(B["up"], B["xg"], 2, 1, F, K),
+        DeviceOp.elementwise("mul", B["act"], B["silu"], B["up"], F),
+        DeviceOp.qmatmul(B["down"], B["act"], 3, 1, K, F),
+    ]
+    prog = DeviceProgram(ops=ops, buffer_sizes=sizes,
+                         initial_uploads=[ProgramIO(B["xin"], xin), ProgramIO(B["resid"], resid), ProgramIO(B["gamma"], gamma), ProgramIO(B["one"], one)],
+                         qweights=[_q4_weight(rng, K0, K), _q4_weight(rng, K, F), _q4_weight(rng, K, F), _q4_weight(rng, F, K)])
+    h = hip_backend.compileProgram(prog)
+    assert h
+    try:
+        plan = hip_backend.planText(h)
+        lines = plan.strip().splitlines()
+        assert len(lines) == 3, plan
+        import os
+        if not any(os.environ.get(v) == "0" for v in ("ZGML_HIP_PRENORM", "ZGML_HIP_PRENORM_NOL", "ZGML_HIP_PAIR", "ZGML_HIP_PAIR_NOL", "ZGML_QMV_XDIRECT",
+                                                        "ZGML_QMV_EPI_SILU", "ZGML_HIP_QMV_KON")):
+            assert "prepares-next-norm" in lines[0] and "pro prenorm" in lines[1], plan
+            assert (" pair" in lines[1]) == (K > 2048 or F >= K), plan
+        names = ["y", "h", "normed", "xg", "gate", "up", "exp_neg", "silu", "act", "down"]
+        outs = [np.zeros(sizes[B[n]], f32) for n in names]
+        for _ in range(2):
+            hip_backend.executeProgram(h, [], [ProgramIO(B[n], o) for n, o in zip(names, outs)])
+        for name, got in zip(names, outs):
+            want = oracle.run_program(prog, B[name], sizes[B[name]])
+            scale = max(1.0, float(np.abs(want).max()))
+            np.testing.assert_allclose(got, want, rtol=2e-3, atol=2e-4 * scale, err_msg=name)
+    finally:
+        hip_backend.freeProgram(h)
+
+
 def test_refresh_to_a_matmul_over_a_matvec_only_weight_fails_loudly(hip_backend, oracle):
     """compile_program packs a Q4_0 weight K-on-lanes when every op that uses it has M == 1
     (K >= 2048). A later refresh_program that changes static fields is legal for the reference's CPU backend

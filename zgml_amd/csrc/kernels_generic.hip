@@ -284,7 +284,8 @@ __global__ void __launch_bounds__(kBlock) row_chain_kernel(RowChainParams p) {
         __shared__ __attribute__((aligned(16))) uint16_t pl[kAPieces * N * kBlock]; // A pieces of the row (RowChainParams::ap)
         float v[N], mo[N];
         const uint32_t last = p.cols - 1;
-        const uint32_t k_lo = blockIdx.y * N / gridDim.y, k_hi = (blockIdx.y + 1) * N / gridDim.y; // this workgroup's column chunks
+        const uint32_t chunks = (p.cols + kBlock - 1) / kBlock; // (<= N; the launcher's split divides it)
+        const uint32_t k_lo = blockIdx.y * chunks / gridDim.y, k_hi = (blockIdx.y + 1) * chunks / gridDim.y; // this workgroup's column chunks
         if (p.add_dst) {
             const float *a0 = p.a0 + base, *a1 = p.a1 + base;
             float w[N];

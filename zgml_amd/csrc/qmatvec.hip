@@ -1770,6 +1770,10 @@ bool launch_packed_kon(hipStream_t s, QMVArgs& a, const QWeightDev& w0, uint32_t
     const size_t lds = ((size_t)kMaxWaves * 16 + kMaxWaves) * sizeof(float);
     const bool pro = a.pro.kind != QMV_PRO_NONE, grp = a.n_parts > 1, nt = w0.stream_nt != 0;
     const int prom = a.pro.kind == QMV_PRO_PRENORM ? 2 : (pro ? 1 : 0);
+    if (prom == 2 && a.pro.ssq != a.pro.xg + a.K) { // the kernels find the partial sums right behind the producer's vector (arm_prenorm lays them out so)
+        fprintf(stderr, "[zgml_hip] ERROR: a PRENORM launch whose partial sums do not follow its vector: not launched\n");
+        return false;
+    }
     uint32_t waves_used = waves;
     // an in-kernel prologue doubles the vector loads of an item: two items per lane in flight with twice the waves
     // (four items: the compiler runs out of the 128 registers a 1024-thread launch bound leaves)
@@ -1850,7 +1854,7 @@ bool launch_packed(hipStream_t s, QMVArgs& a, const QWeightDev& w0, uint32_t tot
     static const uint32_t xd_norm_max_k = getenv("ZGML_QMV_XDNORM_MAXK") ? (uint32_t)atoi(getenv("ZGML_QMV_XDNORM_MAXK")) : 2048u;
     const bool xd = xd_enabled && (a.pro.kind != QMV_PRO_RMSNORM_MUL || (xd_norm && a.K <= xd_norm_max_k));
     const bool prenorm = a.pro.kind == QMV_PRO_PRENORM;
-    if (prenorm && !qmv_prenorm_ok(w0, a.K, total_blocks * 16, M)) { // (arm_prenorm asks the same question: never reached)
+    if (prenorm && (!qmv_prenorm_ok(w0, a.K, total_blocks * 16, M) || a.pro.ssq != a.pro.xg + a.K)) { // (arm_prenorm asks the same question and lays the partial sums right behind the vector: never reached)
         fprintf(stderr, "[zgml_hip] ERROR: a PRENORM mat-vec launch outside the shapes its kernel is built for: not launched\n");
         return false;
     }

@@ -1094,6 +1094,9 @@ void arm_pair(zgml_hip_program* p) {
              (G->pro.kind == QMV_PRO_NONE || G->pro.kind == QMV_PRO_PRENORM) && D->n_parts == 1;
         // the product's operands: silu(gate) and up, in either order (an f32 product does not depend on it)
         ok = ok && ((D->pro.a == st[4].store && D->pro.b == up.dst) || (D->pro.b == st[4].store && D->pro.a == up.dst));
+        // (n-on-lanes form under a prepared norm: every workgroup stores a 16-element slice of the absorbed ops' outputs, and a pair
+        // launch has one workgroup per column group of ONE matrix: it needs N >= K of them)
+        ok = ok && (ga.w.format == QW_Q4K || G->pro.kind != QMV_PRO_PRENORM || ga.w.N >= G->K);
         // the two weights back to back in the arenas (the pair kernel finds part 1 from part 0)
         ok = ok && (const char*)up.w.qs == (const char*)ga.w.qs + ga.w.qs_bytes && (const char*)up.w.sc == (const char*)ga.w.sc + ga.w.sc_bytes;
         ok = ok && ((uintptr_t)G->pro.a % 16 == 0) && (G->K % 4 == 0) && (G->pro.kind != QMV_PRO_PRENORM || (uintptr_t)G->pro.xg % 16 == 0);
