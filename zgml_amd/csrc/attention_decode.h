@@ -28,7 +28,6 @@ __device__ __forceinline__ void stgu(uint32_t* p, uint32_t v) { *(__attribute__(
 
 constexpr int kAttnBlock = 1024;
 constexpr int kAttnUnroll = 4;
-constexpr int kAttnUnrollKvq = 3; // int8 rows: three sets of rows rotate in the long-context loop (two steps in flight); 3 x 3 keys fit the registers 2 x 4 did
 
 // rope of 4 consecutive dims [d0, d0+4) of a head vector (reference.zig:457-478, DeviceOp
 // convention: sin at cs + pair + half_d); `own` = x[d0..], `par` = x[(d0 ^ half)..]. Same
@@ -219,7 +218,7 @@ template <int LPK, bool KVQ, int BLOCK = kAttnBlock>
 __device__ __forceinline__ void attention_decode_body(const AttnDecodeParams* __restrict__ params, float* split_buf, uint32_t* split_cnt,
                                                       uint32_t split_min_keys, const uint32_t hx, const uint32_t sp_in, const uint32_t n_sp,
                                                       const DecodeHandoff* ho) {
-    constexpr int DH = 4 * LPK, KPW = 64 / LPK, U = KVQ ? kAttnUnrollKvq : kAttnUnroll, HALF = DH / 2;
+    constexpr int DH = 4 * LPK, KPW = 64 / LPK, U = kAttnUnroll, HALF = DH / 2;
     using Row = AttnRow<KVQ>;
     // The head's parameter record in ONE scalar round trip: read through a reference, hipcc fetches it field by field where
     // the fields are used — three dependent rounds of s_load + s_waitcnt before the kernel's first vector load.
@@ -396,7 +395,7 @@ __device__ __forceinline__ void attention_decode_body(const AttnDecodeParams* __
     ATTN_STAMP(3);
     SoftState st{-INFINITY, 0.f, make_float4(0.f, 0.f, 0.f, 0.f)};
     // one step: scores of the slot's U keys, then the online-softmax update
-    auto step_on = [&](uint32_t base, const Row (&kv)[U], const Row (&vv)[U], const float (&mk)[U]) {
+    auto step = [&](uint32_t base) {
         float sc[U];
         float bm = -INFINITY;
 #pragma unroll
@@ -423,37 +422,8 @@ __device__ __forceinline__ void attention_decode_body(const AttnDecodeParams* __
             st.m = nm;
         }
     };
-    auto step = [&](uint32_t base) { step_on(base, kv, vv, mk); };
-    auto load_rows = [&](Row (&kr)[U], Row (&vr)[U], float (&mr)[U], uint32_t base) { // (clamped: steps past the end re-read live rows, L2 hits)
-#pragma unroll
-        for (int j = 0; j < U; j++) {
-            const uint32_t s = min(base + j * keys_per_iter + w * KPW + slot, last);
-            kr[j] = load_k(s);
-            vr[j] = load_v(s);
-            mr[j] = ldg1(p.mask + (uint64_t)s * p.mask_rs);
-        }
-    };
     if (n_keys <= step_keys) { // the usual decode case: everything is already in registers
         if (n_keys) step(k_begin);
-    } else if constexpr (KVQ) {
-        // Long contexts with int8 rows are paced by one memory round trip per step, not by bytes (position 1900 at 7B dimensions: + 9.8 us
-        // per layer for 17 MB; f32 rows move 62 MB in + 9.3 us, i.e. at the memory's rate). int8 rows take half the registers of f32
-        // rows, so THREE sets rotate by name — a register copy of a set whose loads are in flight would wait for them — and two steps
-        // of rows are in flight behind the one being consumed.
-        Row kb[U], vb[U], kc[U], vc[U];
-        float mb[U], mc[U];
-        load_rows(kb, vb, mb, k_begin + step_keys);
-        for (uint32_t base = k_begin;;) {
-            load_rows(kc, vc, mc, base + 2 * step_keys);
-            step_on(base, kv, vv, mk);
-            if ((base += step_keys) >= k_end) break;
-            load_rows(kv, vv, mk, base + 2 * step_keys);
-            step_on(base, kb, vb, mb);
-            if ((base += step_keys) >= k_end) break;
-            load_rows(kb, vb, mb, base + 2 * step_keys);
-            step_on(base, kc, vc, mc);
-            if ((base += step_keys) >= k_end) break;
-        }
     } else {
         for (uint32_t base = k_begin; base < k_end; base += step_keys) {
             // prefetch the next step (clamped: the last step re-reads live rows, L2 hits)
