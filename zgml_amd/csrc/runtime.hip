@@ -1800,6 +1800,15 @@ void build_fused_plan(zgml_hip_program* p) {
                     a.owner = first_head ? 1 : 0;
                     a.max_kv = t.n_cols;
                     a.kvq_block = 32, a.kvq_cols = t.n_cols;
+                    static const bool want_trace_q = getenv("ZGML_HIP_ATTN_TRACE") && atoi(getenv("ZGML_HIP_ATTN_TRACE"));
+                    if (want_trace_q && first_head) { // (diagnostics build: stamps of the int8-KV launches too)
+                        unsigned long long* tq = nullptr;
+                        if (hipHostMalloc((void**)&tq, 8 * sizeof(unsigned long long), hipHostMallocMapped) == hipSuccess) {
+                            memset(tq, 0, 8 * sizeof(unsigned long long));
+                            a.trace = tq;
+                            p->attn_traces.push_back(tq);
+                        }
+                    }
                     first_head = false;
                     adec_by_dh[t.d_head | 0x10000u].push_back(a);
                 }
