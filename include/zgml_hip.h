@@ -397,7 +397,15 @@ enum {
      * A hand-off wait that gives up is bounded and reported at the next host synchronisation (sticky error on the context): the
      * results of THAT execution are wrong, including the KV-cache column it wrote — re-run the step at the same position (the
      * context has switched the fusion off and rebuilt the plan, the re-run rewrites the column); nothing older is affected. */
-    ZGML_HIP_OPT_FUSE_RESIDENT_WGS = 8
+    ZGML_HIP_OPT_FUSE_RESIDENT_WGS = 8,
+    /* 0/1 (default 0; the environment variable ZGML_HIP_KSPLIT=1 turns it on for every context): the decoder layer of a short-K
+     * model (K <= 2048, Q4_0 weights with f16 scales, d_head 64 / 128) as launches that end at a K-split instead of an all-to-all
+     * seam — each head's attention workgroup adds its partial of the O projection, each 32-column gate / up workgroup its partial
+     * of the down projection, the next launch sums the partials in its prologue (zgml_amd/csrc/ksplit.hip). Same results within the
+     * mat-vec tolerance, two launches per layer instead of four — and MEASURED SLOWER on MI355X (DESIGN.md section 4, round 5:
+     * reading 48 partial vectors costs a consumer workgroup more than the launch boundary it replaces), hence off by default.
+     * Latched per program at compile_program. */
+    ZGML_HIP_OPT_KSPLIT = 9
 };
 int zgml_hip_set_option(zgml_hip_ctx* ctx, int option, int64_t value);
 /* Drop the cached device copy of host operand `b` (NULL: all of them). */

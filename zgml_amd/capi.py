@@ -212,6 +212,7 @@ class ShardPeerHandleC(C.Structure):
 OPT_FUSION, OPT_GRAPH, OPT_PROFILE, OPT_SKIP_DEAD_UPLOADS, OPT_F16_DENSE_WEIGHTS, OPT_DENSE_WEIGHT_CACHE = 1, 2, 3, 4, 5, 6
 OPT_ATTN_SPLIT_MIN_KEYS = 7
 OPT_FUSE_RESIDENT_WGS = 8
+OPT_KSPLIT = 9
 
 _PKG_DIR = Path(__file__).resolve().parent
 HIP_LIB_PATH = _PKG_DIR / "lib" / "libzgml_hip.so"

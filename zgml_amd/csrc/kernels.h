@@ -430,6 +430,69 @@ int qkv_attn_kon_blocks_per_cu(uint32_t d_head, bool kvq); // fused q / k / v + 
 // directly in the packed layout (SURVEY §8d generator).
 void launch_synth_packed(hipStream_t s, const QWeightDev& w, uint32_t matrix_id);
 
+// ── ksplit.hip: the decoder layer of a short-K model (K <= 2048, n-on-lanes Q4_0 weights with f16 scales: SmolLM-135M) in launches
+// that end at a K-SPLIT instead of at an all-to-all seam. The O projection is computed by the attention's
+// workgroups — head h multiplies its d_head outputs by ITS d_head rows of W_o — and the down projection by the gate / up
+// workgroups — the workgroup that holds silu(gate) * up for 32 columns multiplies them by its 32 rows of W_down; each stores a
+// PARTIAL output vector. Nothing inside the launch waits for the partials: the launch that consumes the vector next sums them
+// in a fixed order in its prologue (a "deferred vector", KsVec), where it has to read the vector anyway, and workgroup 0 of that
+// launch stores what the absorbed ops would have stored (the projection's own output and the residual sum). Op stream matched:
+// src/models/llama_transformer.zig:192-253; arithmetic of every op: src/backend/reference.zig (qmatmul :530-565, rmsnorm :349-374).
+struct KsVec { // x[k] = base[k] + sum_p parts[p][k], p ascending (n_parts == 0: x = base)
+    const float* base = nullptr;
+    const float* parts = nullptr; // [n_parts][K] dense
+    uint32_t n_parts = 0;
+    float* sum_dst = nullptr; // the absorbed mat-vec's output buffer: sum of the parts
+    float* add_dst = nullptr; // the absorbed residual add's output: base + sum
+};
+struct KsNormIn { // rmsnorm -> mul(gamma) of a (possibly deferred) vector; gamma == nullptr: no norm (materialise the vector only)
+    KsVec x;
+    const float* gamma = nullptr;
+    float eps = 0.f;
+    float* store_mid = nullptr; // x / rms(x)        (the rmsnorm op's output)
+    float* store_x = nullptr;   // ... * gamma       (the mul op's output: what the mat-vecs consume)
+    uint32_t K = 0;
+};
+struct KsProjLaunch { // up to 3 mat-vecs over the normalised vector (q / k / v), no epilogues
+    KsNormIn in;
+    uint32_t n_parts = 0;
+    QWeightDev w[3];
+    float* dst[3] = {nullptr, nullptr, nullptr};
+    unsigned long long* trace = nullptr; // diagnostics build (ZGML_HIP_KS_TRACE=1): 16 wall-clock stamps of workgroup 0
+};
+struct KsAttnOLaunch { // decode attention of n_heads heads + each head's partial O projection
+    const AttnDecodeParams* dev = nullptr;
+    uint32_t n_heads = 0, d_head = 0;
+    AttnSplit sp;
+    bool kvq = false;
+    QWeightDev wo;              // K = n_heads * d_head (head h owns rows [h * d_head, (h + 1) * d_head) — checked by the planner)
+    float* parts_out = nullptr; // [n_heads][wo.N]
+    uint8_t head_of[64] = {0};  // record -> head = its row store's static offset / d_head (the records are not in head order; n_heads <= 64)
+    unsigned long long* trace = nullptr;
+};
+struct KsMlpLaunch { // gate / up (+ SiLU chain + product) + partial down projection
+    KsNormIn in;
+    QWeightDev gate, up, down;
+    float *gate_out = nullptr, *up_out = nullptr, *exp_out = nullptr, *silu_out = nullptr, *prod_out = nullptr;
+    const float* ones = nullptr; // the SiLU chain's ADD operand (a vector of ones in the LLaMA plans)
+    float* parts_out = nullptr;  // [gate.N / 32][down.N]
+    unsigned long long* trace = nullptr;
+};
+bool ks_weight_ok(const QWeightDev& w);
+bool ks_proj_ok(const KsProjLaunch& L);
+bool ks_attn_o_ok(const KsAttnOLaunch& L);
+bool ks_mlp_ok(const KsMlpLaunch& L);
+bool ks_norm_ok(const KsNormIn& in);
+uint32_t ks_mlp_parts(const KsMlpLaunch& L); // partial vectors the launch writes (gate.N / 32)
+bool ks_layer_a_ok(const KsProjLaunch& PL, const KsAttnOLaunch& AL); // the two as ONE launch (in-launch hand-off of q / k / v)
+uint32_t ks_layer_a_proj_wgs(const KsProjLaunch& PL);
+bool launch_ks_layer_a(hipStream_t s, const KsProjLaunch& PL, const KsAttnOLaunch& AL, uint32_t n_kv, uint32_t* counters, const uint32_t* idx, uint32_t* seen,
+                       uint32_t* timeout);
+void launch_ks_proj(hipStream_t s, const KsProjLaunch& L);
+void launch_ks_attn_o(hipStream_t s, const KsAttnOLaunch& L);
+void launch_ks_mlp(hipStream_t s, const KsMlpLaunch& L);
+void launch_ks_norm(hipStream_t s, const KsNormIn& in); // one workgroup: materialises a deferred vector (and its norm, if any)
+
 // ── shard_peer.hip: the row-shard all-gather as peer stores (ZGML_SHARD_GATHER=peer) and the (max, index) gather of the greedy token ──
 struct PeerGatherArgs {
     char* const* blocks; // device array [world]: every rank's fine-grained block (own included) as THIS process maps them

@@ -47,70 +47,6 @@ namespace zgml {
 namespace {
 
 
-// ── inline-asm helpers ──────────────────────────────────────────────────────────────────────
-// The per-weight work is two VALU instructions: an SDWA convert (nibble or byte -> f32) and a
-// v_fmac_f32 whose multiplier t[k] comes from lane k of the same 16-lane row through the DPP
-// row_newbcast operand. Each 8-weight (Q4) / 4-weight (Q8) dword is ONE asm statement so hipcc
-// neither pads the statement boundaries with s_nop nor serialises convert->fmac pairs through a
-// single temporary; inside a statement producers and consumers are >= 4 instructions apart and
-// two accumulators alternate, so nothing waits on the previous instruction.
-// Hazard the assembler does not pad (guide §5.7): a VALU write of the DPP *source* VGPR (t) needs
-// 2 wait states before the DPP read — dpp_fence() below provides them once per step.
-#define ZGML_DPP(i) " row_newbcast:%" #i " row_mask:0xf bank_mask:0xf\n\t"
-
-// one dword of a Q4 item = 8 two's-complement nibbles; byte b low nibble -> t[BASE+b], high
-// nibble -> t[BASE+4+b]. v_cvt_off_f32_i4 yields q/16 (the caller folds the 16 into t).
-template <int BASE>
-__device__ __forceinline__ void q4_dword(float& accA, float& accB, uint32_t w, float t) {
-    float c0, c1, c2, c3;
-    uint32_t h;
-    asm("v_cvt_off_f32_i4_sdwa %2, %7 " ZGML_SDWA "0\n\t"
-        "v_cvt_off_f32_i4_sdwa %3, %7 " ZGML_SDWA "1\n\t"
-        "v_cvt_off_f32_i4_sdwa %4, %7 " ZGML_SDWA "2\n\t"
-        "v_cvt_off_f32_i4_sdwa %5, %7 " ZGML_SDWA "3\n\t"
-        "v_lshrrev_b32 %6, 4, %7\n\t"
-        "v_fmac_f32_dpp %0, %8, %2" ZGML_DPP(9)
-        "v_cvt_off_f32_i4_sdwa %2, %6 " ZGML_SDWA "0\n\t"
-        "v_fmac_f32_dpp %1, %8, %3" ZGML_DPP(10)
-        "v_cvt_off_f32_i4_sdwa %3, %6 " ZGML_SDWA "1\n\t"
-        "v_fmac_f32_dpp %0, %8, %4" ZGML_DPP(11)
-        "v_cvt_off_f32_i4_sdwa %4, %6 " ZGML_SDWA "2\n\t"
-        "v_fmac_f32_dpp %1, %8, %5" ZGML_DPP(12)
-        "v_cvt_off_f32_i4_sdwa %5, %6 " ZGML_SDWA "3\n\t"
-        "v_fmac_f32_dpp %0, %8, %2" ZGML_DPP(13)
-        "v_fmac_f32_dpp %1, %8, %3" ZGML_DPP(14)
-        "v_fmac_f32_dpp %0, %8, %4" ZGML_DPP(15)
-        "v_fmac_f32_dpp %1, %8, %5" ZGML_DPP(16)
-        : "+v"(accA), "+v"(accB), "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3), "=&v"(h)
-        : "v"(w), "v"(t), "i"(BASE + 0), "i"(BASE + 1), "i"(BASE + 2), "i"(BASE + 3), "i"(BASE + 4),
-          "i"(BASE + 5), "i"(BASE + 6), "i"(BASE + 7));
-}
-
-// one dword of a Q8 item = 4 signed bytes; byte b -> t[BASE+b]
-template <int BASE>
-__device__ __forceinline__ void q8_dword(float& accA, float& accB, uint32_t w, float t) {
-    float c0, c1, c2, c3;
-    asm("v_cvt_f32_i32_sdwa %2, sext(%6) " ZGML_SDWA "0\n\t"
-        "v_cvt_f32_i32_sdwa %3, sext(%6) " ZGML_SDWA "1\n\t"
-        "v_cvt_f32_i32_sdwa %4, sext(%6) " ZGML_SDWA "2\n\t"
-        "v_cvt_f32_i32_sdwa %5, sext(%6) " ZGML_SDWA "3\n\t"
-        "v_fmac_f32_dpp %0, %7, %2" ZGML_DPP(8)
-        "v_fmac_f32_dpp %1, %7, %3" ZGML_DPP(9)
-        "v_fmac_f32_dpp %0, %7, %4" ZGML_DPP(10)
-        "v_fmac_f32_dpp %1, %7, %5" ZGML_DPP(11)
-        : "+v"(accA), "+v"(accB), "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3)
-        : "v"(w), "v"(t), "i"(BASE + 0), "i"(BASE + 1), "i"(BASE + 2), "i"(BASE + 3));
-}
-
-// VALU write -> DPP read of the same VGPR needs 2 wait states; hipcc does not see inside asm.
-__device__ __forceinline__ void dpp_fence(float& a, float& b) { asm volatile("s_nop 1" : "+v"(a), "+v"(b)); }
-__device__ __forceinline__ void dpp_fence(float& a) { asm volatile("s_nop 1" : "+v"(a)); }
-
-
-template <typename ST>
-struct Pair {
-    ST a, b;
-};
 
 struct QMVPartDev {
     const uint4* qs;
@@ -213,33 +149,6 @@ __device__ __forceinline__ void run_epilogue_silu(const QMVPartDev& part, uint32
     part.epi[4].store[n] = s * raw;    // MUL by the part's own output (commutative)
 }
 
-// all 64 lanes get the sum of the wave's 4 DPP rows, (r0 + r1) + (r2 + r3), by gfx950's row swaps (no LDS round trip)
-__device__ __forceinline__ float rows_sum4(float v) {
-    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
-    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
-}
-// every lane of a DPP row gets the sum of the row's 16 lanes (quad swaps, half mirror, mirror)
-__device__ __forceinline__ float row16_sum(float v) {
-    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
-    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));
-    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xF, 0xF, true));
-    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xF, 0xF, true));
-    return v;
-}
-// workgroup total of one value per thread, the same on every thread, fixed order: lanes, rows, then the (<= 16) waves
-// with ONE LDS read per lane and a row fold (a serial loop over the waves is one dependent LDS round trip per wave)
-__device__ __forceinline__ float block_total(float v, float* red, uint32_t bdim) {
-    v = rows_sum4(row16_sum(v));
-    const uint32_t n_waves = bdim >> 6, slot = threadIdx.x & 15;
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    const float t = red[min(slot, n_waves - 1)];
-    const float total = row16_sum(slot < n_waves ? t : 0.f);
-    __syncthreads();
-    return total;
-}
 
 // sum of squares of the (zero-tailed) register window, fixed reduction order: lanes, then waves
 __device__ __forceinline__ float block_sumsq(const XRegs& r, uint32_t K, float* red, uint32_t bdim) {

@@ -1027,6 +1027,238 @@ void fuse_attention_o(zgml_hip_program* p) {
 }
 #endif
 
+// The decoder layer of a short-K model as launches that end at a K-split (ksplit.hip): in the plan built above a
+// layer is [q/k/v (rmsnorm prologue)] [decode attention] [O (+ residual)] [gate / up (rmsnorm prologue, SiLU chain)] [down (product
+// prologue, + residual)]. Here
+//   [q/k/v] [attention] [O]   ->  [ks_proj] [ks_attn_o]   (each head's workgroup adds its partial of the O projection)
+//   [gate / up] [down]        ->  [ks_mlp]                (each 32-column workgroup adds its partial of the down projection)
+// and the O / down projections' outputs and residual sums become DEFERRED vectors (kernels.h: KsVec): the next launch of the plan
+// sums the partials in its prologue and its workgroup 0 stores the absorbed ops' buffers. When that next launch is not one that can
+// (anything but a ks_proj / ks_mlp / the final rmsnorm -> mul row chain reading exactly that vector), a one-workgroup launch
+// materialises the vector at once. Conditions are checked on spans and pointers, not on a model name: n-on-lanes Q4_0 weights with
+// f16 scales (ks_weight_ok), K <= 2048, d_head 64 / 128, residual and norm outputs that do not alias their inputs.
+void fuse_ksplit(zgml_hip_program* p) {
+    p->has_deferred = false;
+    if (!p->ksplit || p->ksplit_off || !p->barriers.empty()) return;
+    auto overlap = [](const float* a, size_t na, const float* b, size_t nb) { return a && b && a < b + nb && b < a + na; };
+    auto residual_epi = [](const QmvPart& pt) {
+        return pt.n_epi == 1 && pt.epi[0].op == ZGML_OP_ADD && pt.epi[0].operand && pt.epi[0].operand != pt.dst && pt.epi[0].store && pt.epi[0].store != pt.dst;
+    };
+    // outputs the consumer's workgroup 0 stores late must not overlap anything the other workgroups still read
+    auto norm_in_safe = [&](const KsNormIn& in) {
+        const size_t K = in.K;
+        const float* outs[4] = {in.x.sum_dst, in.x.add_dst, in.store_mid, in.store_x};
+        for (const float* o : outs) {
+            if (!o) continue;
+            if (overlap(o, K, in.x.base, K) || overlap(o, K, in.gamma, K) || overlap(o, K, in.x.parts, K * in.x.n_parts)) return false;
+            for (const float* o2 : outs)
+                if (o2 && o2 != o && overlap(o, K, o2, K)) return false;
+        }
+        return true;
+    };
+    std::vector<Launch> out;
+    KsVec pend{};
+    uint32_t pend_K = 0;
+    bool have_pend = false;
+    uint32_t pend_lo = 0, pend_hi = 0;
+    auto flush = [&]() { // nobody took the deferred vector: materialise it now
+        if (!have_pend) return;
+        KsNormIn in;
+        in.x = pend, in.K = pend_K;
+        Launch M{ZGML_DOP_ELEMENTWISE, 0, pend_lo, pend_hi, [in](hipStream_t s) { launch_ks_norm(s, in); }};
+        M.tag = "ks-materialise";
+        out.push_back(std::move(M));
+        have_pend = false;
+    };
+    float *parts_o = nullptr, *parts_d = nullptr; // one block each for the whole program: producer and consumer follow each other in stream order
+    size_t parts_o_n = 0, parts_d_n = 0;
+    auto grow_parts = [&](float*& blk, size_t& have, size_t want) -> bool {
+        if (have >= want) return true;
+        float* nb = nullptr;
+        if (hipMalloc((void**)&nb, want * sizeof(float)) != hipSuccess || memset_sync(p->ctx->stream, nb, 0, want * sizeof(float)) != hipSuccess) {
+            if (nb) hipFree(nb);
+            return false;
+        }
+        p->fuse_owned.push_back(nb); // (an earlier, smaller block stays owned too: launches already emitted point into it)
+        blk = nb, have = want;
+        return true;
+    };
+    std::vector<Launch>& plan = p->plan;
+    size_t i = 0;
+    uint32_t n_fused = 0;
+    auto new_trace = [&](const char* what) -> unsigned long long* { // diagnostics build + ZGML_HIP_KS_TRACE=1
+        static const bool want = getenv("ZGML_HIP_KS_TRACE") && atoi(getenv("ZGML_HIP_KS_TRACE"));
+        unsigned long long* t = nullptr;
+        if (!want || p->ks_traces.size() >= 24 || hipHostMalloc((void**)&t, 32 * sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess) return nullptr;
+        memset(t, 0, 32 * sizeof(unsigned long long));
+        p->ks_traces.push_back({t, what});
+        return t;
+    };
+    while (i < plan.size()) {
+        // ---- [q/k/v] [attention] [O]
+        if (i + 2 < plan.size() && plan[i].qmv_desc && plan[i + 1].adec_desc && plan[i + 2].qmv_desc) {
+            const QmvLaunch &Q = *plan[i].qmv_desc, &O = *plan[i + 2].qmv_desc;
+            const AdecDesc& A = *plan[i + 1].adec_desc;
+            bool ok = Q.n_parts == 3 && Q.pro.kind == QMV_PRO_RMSNORM_MUL && !Q.trace && !O.trace && O.n_parts == 1 && O.pro.kind == QMV_PRO_NONE && residual_epi(O.parts[0]) &&
+                      !O.next.xg_out && (A.dh == 64 || A.dh == 128) && O.K == A.nh * A.dh && ks_weight_ok(O.parts[0].w);
+            for (uint32_t t = 0; ok && t < 3; t++) ok = Q.parts[t].n_epi == 0 && ks_weight_ok(Q.parts[t].w);
+            std::vector<char> seen_head(A.nh, 0);
+            uint8_t head_of[64] = {0};
+            ok = ok && A.nh <= 64;
+            for (uint32_t r = 0; ok && r < A.nh; r++) { // every head row-stores into the O projection's input at h * d_head, every h once
+                const AttnDecodeParams& a = A.host[r];
+                ok = a.att.dst2 == O.pro.a && a.att.d2_rs == 1 && a.att.dyn_dst2_off >= p->dyn_dev && a.att.dyn_dst2_off < p->dyn_dev + p->ops.size() && a.att.dst_rs == 1 &&
+                     ((uintptr_t)a.att.dst2 % 16) == 0;
+                if (!ok) break;
+                const zgml_device_op& so = p->ops[(size_t)(a.att.dyn_dst2_off - p->dyn_dev)];
+                ok = so.kind == ZGML_DOP_SLICE_ASSIGN && so.u.slice_assign.patch_stride == 0 && so.u.slice_assign.dst_offset % A.dh == 0 &&
+                     so.u.slice_assign.dst_offset / A.dh < A.nh && !seen_head[so.u.slice_assign.dst_offset / A.dh];
+                if (ok) seen_head[so.u.slice_assign.dst_offset / A.dh] = 1, head_of[r] = (uint8_t)(so.u.slice_assign.dst_offset / A.dh);
+            }
+            KsProjLaunch PL;
+            KsAttnOLaunch AL;
+            if (ok) {
+                PL.in.K = Q.K, PL.in.gamma = Q.pro.b, PL.in.eps = Q.pro.eps, PL.in.store_mid = Q.pro.store_mid, PL.in.store_x = Q.pro.store_x;
+                if (have_pend && pend.add_dst == Q.pro.a && pend_K == Q.K)
+                    PL.in.x = pend;
+                else
+                    PL.in.x.base = Q.pro.a;
+                PL.n_parts = 3;
+                for (uint32_t t = 0; t < 3; t++) PL.w[t] = Q.parts[t].w, PL.dst[t] = Q.parts[t].dst;
+                const size_t N = O.parts[0].w.N;
+                ok = ks_proj_ok(PL) && norm_in_safe(PL.in) && grow_parts(parts_o, parts_o_n, (size_t)A.nh * N);
+                PL.trace = new_trace("ks-proj"), AL.trace = new_trace("ks-attn-o");
+                memcpy(AL.head_of, head_of, sizeof head_of);
+                AL.dev = A.dev, AL.n_heads = A.nh, AL.d_head = A.dh, AL.sp = A.sp, AL.kvq = A.kvq, AL.wo = O.parts[0].w, AL.parts_out = parts_o;
+                ok = ok && ks_attn_o_ok(AL);
+            }
+            if (ok) {
+                const bool took = PL.in.x.n_parts != 0;
+                if (!took) flush();
+                have_pend = false;
+                // ... as ONE launch when the whole grid is resident (the attention's workgroups spin on the projection's: one 768-thread
+                // workgroup per CU is what is counted on; the split count shrinks to fit) and the context's hand-offs have not timed out
+                static const bool fuse_a = !(getenv("ZGML_HIP_KSPLIT_FUSE_A") && atoi(getenv("ZGML_HIP_KSPLIT_FUSE_A")) == 0);
+                bool fused = false;
+                if (fuse_a && !p->ctx->fuse_qkv_off && p->ctx->handoff_flag_dev && ks_layer_a_ok(PL, AL)) {
+                    const uint32_t nh = A.nh, dh = A.dh;
+                    const uint32_t n_kv = (uint32_t)(Q.parts[1].w.N / dh);
+                    std::vector<uint32_t> idx(3 * (size_t)nh);
+                    bool hk = n_kv != 0 && Q.parts[1].w.N % dh == 0 && Q.parts[2].w.N == Q.parts[1].w.N && (uint64_t)nh * dh == Q.parts[0].w.N && nh % n_kv == 0;
+                    for (uint32_t r = 0; hk && r < nh; r++) { // each record's q / k / v counters from its pointers into the projections' outputs
+                        const AttnDecodeParams& ar = A.host[r];
+                        const ptrdiff_t qo = ar.q_src - Q.parts[0].dst, ko = ar.k_src - Q.parts[1].dst, vo = ar.v_src - Q.parts[2].dst;
+                        hk = qo >= 0 && qo % dh == 0 && (uint64_t)qo < (uint64_t)nh * dh && ko >= 0 && ko % dh == 0 && (uint64_t)ko < (uint64_t)n_kv * dh && vo == ko;
+                        if (hk) idx[3 * r] = (uint32_t)(qo / dh), idx[3 * r + 1] = nh + (uint32_t)(ko / dh), idx[3 * r + 2] = nh + n_kv + (uint32_t)(ko / dh);
+                    }
+                    const uint64_t cap = p->ctx->opt_fuse_resident_wgs >= 0 ? (uint64_t)p->ctx->opt_fuse_resident_wgs : (uint64_t)std::max(p->ctx->n_cu, 1);
+                    const uint32_t n_pw = ks_layer_a_proj_wgs(PL);
+                    uint32_t n_sp = AL.sp.splits ? AL.sp.splits : 1;
+                    if (hk && n_pw + nh <= cap) {
+                        n_sp = (uint32_t)std::min<uint64_t>(n_sp, (cap - n_pw) / nh);
+                        const size_t n_cnt = 32 * ((size_t)nh + 2 * n_kv), words = n_cnt + (size_t)nh * n_sp * 3 + 3 * (size_t)nh;
+                        uint32_t* block = nullptr;
+                        if (hipMalloc((void**)&block, words * 4) == hipSuccess) {
+                            p->fuse_owned.push_back(block);
+                            uint32_t *counters = block, *seen = block + n_cnt, *idx_dev = seen + (size_t)nh * n_sp * 3;
+                            if (memset_sync(p->ctx->stream, block, 0, words * 4) == hipSuccess && h2d_sync(p->ctx->stream, idx_dev, idx.data(), idx.size() * 4) == hipSuccess) {
+                                KsAttnOLaunch AF = AL;
+                                AF.sp.splits = n_sp;
+                                uint32_t* const timeout = p->ctx->handoff_flag_dev;
+                                Launch LA{ZGML_DOP_QMATMUL, plan[i].n_ops + plan[i + 1].n_ops + plan[i + 2].n_ops, std::min({plan[i].op_lo, plan[i + 1].op_lo, plan[i + 2].op_lo}),
+                                          std::max({plan[i].op_hi, plan[i + 1].op_hi, plan[i + 2].op_hi}), [PL, AF, AL, n_kv, counters, idx_dev, seen, timeout](hipStream_t s) {
+                                              if (!launch_ks_layer_a(s, PL, AF, n_kv, counters, idx_dev, seen, timeout)) {
+                                                  launch_ks_proj(s, PL);
+                                                  launch_ks_attn_o(s, AL);
+                                              }
+                                          }};
+                                LA.tag = took ? "ks-layer-a (sums the deferred vector): q / k / v + attention + partial O projection"
+                                              : "ks-layer-a: q / k / v + attention + partial O projection";
+                                out.push_back(std::move(LA));
+                                fused = true;
+                            }
+                        }
+                    }
+                }
+                if (!fused) {
+                    Launch L1{ZGML_DOP_QMATMUL, plan[i].n_ops, plan[i].op_lo, plan[i].op_hi, [PL](hipStream_t s) { launch_ks_proj(s, PL); }};
+                    L1.tag = took ? "ks-proj (sums the deferred vector)" : "ks-proj";
+                    Launch L2{ZGML_DOP_ATTENTION, plan[i + 1].n_ops + plan[i + 2].n_ops, std::min(plan[i + 1].op_lo, plan[i + 2].op_lo), std::max(plan[i + 1].op_hi, plan[i + 2].op_hi),
+                              [AL](hipStream_t s) { launch_ks_attn_o(s, AL); }};
+                    L2.tag = "ks-attention + partial O projection";
+                    out.push_back(std::move(L1));
+                    out.push_back(std::move(L2));
+                }
+                pend = KsVec{O.parts[0].epi[0].operand, parts_o, A.nh, O.parts[0].dst, O.parts[0].epi[0].store};
+                pend_K = (uint32_t)O.parts[0].w.N, have_pend = true, pend_lo = plan[i + 2].op_lo, pend_hi = plan[i + 2].op_hi;
+                i += 3, n_fused++;
+                continue;
+            }
+        }
+        // ---- [gate / up] [down]
+        if (i + 1 < plan.size() && plan[i].qmv_desc && plan[i + 1].qmv_desc) {
+            const QmvLaunch &G = *plan[i].qmv_desc, &D = *plan[i + 1].qmv_desc;
+            const QmvPart &ga = G.parts[0], &up = G.parts[1];
+            const QmvEpiStep* st = ga.epi;
+            bool ok = G.n_parts == 2 && G.pro.kind == QMV_PRO_RMSNORM_MUL && !G.pair_out && !G.trace && !D.trace && D.n_parts == 1 && D.pro.kind == QMV_PRO_MUL && D.pro.store_x &&
+                      residual_epi(D.parts[0]) && !D.next.xg_out;
+            // the SiLU chain exactly as build_qmv_args recognises it (NEG, EXP [store], ADD vector, RECIP, MUL by the gate [store])
+            ok = ok && ga.n_epi == 5 && st[0].op == ZGML_OP_NEG && !st[0].store && st[1].op == ZGML_OP_EXP && st[1].store && st[2].op == ZGML_OP_ADD && st[2].operand &&
+                 st[2].operand != ga.dst && st[2].operand != st[1].store && !st[2].store && st[3].op == ZGML_OP_RECIP && !st[3].store && st[4].op == ZGML_OP_MUL &&
+                 st[4].operand == ga.dst && st[4].store && up.n_epi == 0;
+            ok = ok && ((D.pro.a == st[4].store && D.pro.b == up.dst) || (D.pro.b == st[4].store && D.pro.a == up.dst)) && D.K == ga.w.N;
+            KsMlpLaunch ML;
+            if (ok) {
+                ML.in.K = G.K, ML.in.gamma = G.pro.b, ML.in.eps = G.pro.eps, ML.in.store_mid = G.pro.store_mid, ML.in.store_x = G.pro.store_x;
+                if (have_pend && pend.add_dst == G.pro.a && pend_K == G.K)
+                    ML.in.x = pend;
+                else
+                    ML.in.x.base = G.pro.a;
+                ML.gate = ga.w, ML.up = up.w, ML.down = D.parts[0].w;
+                ML.gate_out = ga.dst, ML.up_out = up.dst, ML.exp_out = st[1].store, ML.silu_out = st[4].store, ML.prod_out = D.pro.store_x, ML.ones = st[2].operand;
+                ok = grow_parts(parts_d, parts_d_n, (size_t)ks_mlp_parts(ML) * ML.down.N);
+                ML.parts_out = parts_d, ML.trace = new_trace("ks-mlp");
+                ok = ok && ks_mlp_ok(ML) && norm_in_safe(ML.in);
+            }
+            if (ok) {
+                const bool took = ML.in.x.n_parts != 0;
+                if (!took) flush();
+                have_pend = false;
+                Launch L{ZGML_DOP_QMATMUL, plan[i].n_ops + plan[i + 1].n_ops, std::min(plan[i].op_lo, plan[i + 1].op_lo), std::max(plan[i].op_hi, plan[i + 1].op_hi),
+                         [ML](hipStream_t s) { launch_ks_mlp(s, ML); }};
+                L.tag = took ? "ks-mlp (sums the deferred vector): gate / up + partial down projection" : "ks-mlp: gate / up + partial down projection";
+                out.push_back(std::move(L));
+                pend = KsVec{D.parts[0].epi[0].operand, parts_d, ks_mlp_parts(ML), D.parts[0].dst, D.parts[0].epi[0].store};
+                pend_K = (uint32_t)ML.down.N, have_pend = true, pend_lo = plan[i + 1].op_lo, pend_hi = plan[i + 1].op_hi;
+                i += 2, n_fused++;
+                continue;
+            }
+        }
+        // ---- the deferred vector's rmsnorm -> mul row chain (the final norm in front of the LM head): one workgroup does both
+        if (have_pend && plan[i].rc_desc && plan[i].rc_rows == 1) {
+            const RowChainParams& rc = *plan[i].rc_desc;
+            KsNormIn in;
+            in.x = pend, in.K = pend_K, in.gamma = rc.mul_other, in.eps = rc.eps, in.store_mid = rc.norm_dst, in.store_x = rc.mul_dst;
+            if (!rc.a0 && !rc.ap && rc.src == pend.add_dst && rc.mul_other && rc.mul_dst && rc.cols == pend_K && ks_norm_ok(in) && norm_in_safe(in)) {
+                Launch L{ZGML_DOP_RMSNORM, plan[i].n_ops, std::min(plan[i].op_lo, pend_lo), std::max(plan[i].op_hi, pend_hi), [in](hipStream_t s) { launch_ks_norm(s, in); }};
+                L.tag = "ks-norm (sums the deferred vector): rmsnorm -> mul";
+                out.push_back(std::move(L));
+                have_pend = false;
+                i++;
+                continue;
+            }
+        }
+        flush();
+        out.push_back(std::move(plan[i]));
+        i++;
+    }
+    flush();
+    if (n_fused) {
+        plan = std::move(out);
+        p->has_deferred = true;
+    }
+}
+
 // A mat-vec launch with a residual-add epilogue (h = y + r: the O / down projections) that is DIRECTLY followed by the launch
 // whose rmsnorm -> mul(gamma) prologue consumes h prepares that prologue (kernels.h: QmvNextNorm / QMV_PRO_PRENORM): it also
 // stores h * gamma and, per 16 columns, the sum of h^2. The consumer then streams one vector instead of two — x (16 KB at
@@ -1882,6 +2114,7 @@ void build_fused_plan(zgml_hip_program* p) {
                 Launch L{ZGML_DOP_RMSNORM, (uint32_t)m.members.size(), m.members.front(), m.members.back(),
                          [=](hipStream_t s) { launch_row_chain(s, *rcp, rows); }};
                 L.hook = std::make_shared<SplitHook>(SplitHook{rcp->mul_dst ? rcp->mul_dst : rcp->norm_dst, rows, rcp->cols, 0, &rcp->ap, &rcp->ap_S, nullptr});
+                L.rc_desc = rcp, L.rc_rows = rows;
                 chains.push_back(std::move(L));
                 continue;
             }
@@ -1965,6 +2198,7 @@ void build_fused_plan(zgml_hip_program* p) {
             p->plan.push_back(std::move(QL));
         }
     }
+    fuse_ksplit(p);
     arm_prenorm(p);
     arm_pair(p);
     fuse_qkv_attention(p);
@@ -2335,6 +2569,7 @@ zgml_hip_ctx* zgml_hip_create(int device_ordinal) {
     // environment overrides of the option defaults (profilers: ZGML_HIP_GRAPH=0 traces eager launches)
     if (const char* e = getenv("ZGML_HIP_GRAPH")) ctx->opt_graph = atoi(e) != 0;
     if (const char* e = getenv("ZGML_HIP_FUSION")) ctx->opt_fusion = atoi(e) != 0;
+    if (const char* e = getenv("ZGML_HIP_KSPLIT")) ctx->opt_ksplit = atoi(e) != 0;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         g_create_error = "hipStreamCreate failed";
         delete ctx;
@@ -2397,6 +2632,7 @@ int zgml_hip_set_option(zgml_hip_ctx* ctx, int option, int64_t value) {
             ctx->opt_fuse_resident_wgs = value < 0 ? -1 : value;
             ctx->fuse_epoch++; // existing programs rebuild their plans under the new capacity
             return 0;
+        case ZGML_HIP_OPT_KSPLIT: ctx->opt_ksplit = value != 0; return 0; // (latched per program at compile_program)
         case ZGML_HIP_OPT_DENSE_WEIGHT_CACHE:
             ctx->b_cache_cap = value > 0 ? (uint64_t)value : 0;
             if (!ctx->b_cache_cap) ctx->drop_b_cache();
@@ -2497,6 +2733,7 @@ zgml_hip_program* zgml_hip_compile_program(zgml_hip_ctx* ctx, const zgml_device_
     hipSetDevice(ctx->device);
     zgml_hip_program* p = new zgml_hip_program();
     p->ctx = ctx;
+    p->ksplit = ctx->opt_ksplit;
     own_ops(p, prog->ops, prog->n_ops);
     const size_t nb = prog->n_buffers;
     p->sizes.resize(nb);
@@ -2957,6 +3194,26 @@ void zgml_hip_free_program(zgml_hip_ctx* ctx, zgml_hip_program* p) {
         }
         for (auto* t : p->attn_traces) hipHostFree(t);
     }
+    if (!p->ks_traces.empty()) {
+        fprintf(stderr, "[zgml_hip] K-split launches, workgroup 0, ns between stamps (gap = since the previous launch's last stamp); ks-proj / ks-mlp: start | loads issued | "
+                        "parts summed | vector whole | x staged | FMAs | barrier | folded (mlp: + SiLU) | (mlp: barrier | down partial); ks-attn-o: start | record | loads issued | attention | merged | partial O\n");
+        unsigned long long prev_end = 0;
+        for (const auto& k : p->ks_traces) {
+            int last = 0;
+            for (int j = 0; j < 16; j++)
+                if (k.t[j]) last = j;
+            fprintf(stderr, "  %-10s gap %6lld |", k.what, prev_end ? (long long)(k.t[0] - prev_end) * 10 : -1);
+            for (int j = 1; j <= last; j++) fprintf(stderr, " %5lld", k.t[j] ? (long long)(k.t[j] - k.t[j - 1]) * 10 : -1);
+            fprintf(stderr, " | span %5lld\n", (long long)(k.t[last] - k.t[0]) * 10);
+            if (k.t[16]) { // lane 0 of the workgroup's last wave: its stamps relative to thread 0's start
+                fprintf(stderr, "      last wave: start %+5lld |", (long long)(k.t[16] - k.t[0]) * 10);
+                for (int j = 1; j <= last && j < 12; j++) fprintf(stderr, " %5lld", k.t[16 + j] ? (long long)(k.t[16 + j] - k.t[16 + j - 1]) * 10 : -1);
+                fprintf(stderr, "\n");
+            }
+            prev_end = k.t[last];
+        }
+        for (auto& k : p->ks_traces) hipHostFree(k.t);
+    }
     if (!p->qmv_traces.empty()) {
         fprintf(stderr, "[zgml_hip] mat-vec trace, workgroup 0 (ns: gap since previous mat-vec end | ->loads issued | ->x arrived(+sumsq) | ->x staged | ->streamed | ->reduced+epilogue)"
                         " || K-on-lanes launches also: LAST workgroup, start after workgroup 0's start | ->loads issued | ->streamed | ->end; launch span = first start -> last end\n");
@@ -3021,6 +3278,7 @@ uint64_t zgml_hip_program_plan_text(zgml_hip_ctx* ctx, zgml_hip_program* p, char
             t += line;
         }
         if (L.adec_desc) t += L.qmv_desc ? " +decode-attention" : " decode-attention";
+        if (L.tag) t += std::string(" ") + L.tag;
         if (L.hook && L.hook->ap && *L.hook->ap) t += " writes-A-operand";
         t += "\n";
     }
@@ -3071,6 +3329,8 @@ int zgml_hip_copy_program_buffer(zgml_hip_ctx* ctx, zgml_hip_program* dst, uint1
 void zgml_hip_enqueue_ops(zgml_hip_ctx* ctx, zgml_hip_program* p, uint64_t first, uint64_t count) {
     if (!ctx || !p) return;
     hipSetDevice(ctx->device);
+    if (!p->ksplit_off && !(first == 0 && count >= p->ops.size())) // an op range must leave every buffer written: no deferred vectors in this program's plans
+        p->ksplit_off = true, p->plan_dirty = p->plan_dirty || p->has_deferred;
     if (p->plan_dirty || p->fuse_epoch != p->ctx->fuse_epoch) {
         free_graph(p);
         build_plan(p);

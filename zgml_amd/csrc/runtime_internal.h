@@ -52,6 +52,9 @@ struct Launch {
     // what a fused-launch pass needs to know about a grouped mat-vec launch / a decode-attention launch (fuse_qkv_attention)
     std::shared_ptr<QmvLaunch> qmv_desc;
     std::shared_ptr<struct AdecDesc> adec_desc;
+    std::shared_ptr<RowChainParams> rc_desc; // a row-chain launch ([add ->] rmsnorm [-> mul]) and its row count (fuse_ksplit)
+    uint32_t rc_rows = 0;
+    const char* tag = nullptr; // plan text: what a fused launch is
     uint64_t prof_ns = 0;    // ZGML_HIP_OPT_PROFILE: accumulated event time of this launch
     uint32_t prof_calls = 0;
 };
@@ -84,6 +87,7 @@ struct zgml_hip_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     bool opt_fusion = true, opt_graph = true, opt_profile = false, opt_skip_dead = true, opt_f16_dense = false;
+    bool opt_ksplit = false; // ZGML_HIP_OPT_KSPLIT (zgml_hip_create takes the default from ZGML_HIP_KSPLIT)
     int64_t opt_attn_split_min_keys = -1; // -1: environment / default (attn_split_for)
     int64_t opt_fuse_resident_wgs = -1;   // -1: one 1024-thread workgroup per CU (fuse_qkv_attention)
     // host dense override scratch
@@ -150,6 +154,11 @@ struct zgml_hip_program {
         uint32_t parts, pro, K, N;
     };
     std::vector<QmvTrace> qmv_traces; // diagnostics (ZGML_HIP_QMV_TRACE)
+    struct KsTrace {
+        unsigned long long* t;
+        const char* what;
+    };
+    std::vector<KsTrace> ks_traces;   // diagnostics (ZGML_HIP_KS_TRACE): stamps of the K-split launches' workgroup 0
     float* zero_word = nullptr;                   // a device 0.0f: mask operand of unmasked decode attention
     float* split_buf = nullptr;                   // long-context attention split: partials + arrival counters,
     uint32_t* split_cnt = nullptr;                // shared by the (stream-ordered) decode-attention launches
@@ -165,6 +174,9 @@ struct zgml_hip_program {
     std::vector<char> hoist_op;    // per op: executed at plan-build time, not part of the plan
     std::vector<char> hoist_guard; // per buffer: read or written by a hoisted repeat
     bool hoist_ok = true;
+    bool ksplit = false;                 // ZGML_HIP_OPT_KSPLIT as it stood at compile_program
+    bool ksplit_off = false;             // fuse_ksplit: off for this program (a caller enqueues op ranges: a deferred vector must not outlive a range)
+    bool has_deferred = false;           // the plan holds launches that leave a vector deferred to their successor
     float* prenorm_buf = nullptr;        // arm_prenorm: [x * gamma | partial sums of squares] handed from a residual epilogue to the next prologue
     size_t prenorm_bytes = 0;
     float* scratch = nullptr;
