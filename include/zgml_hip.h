@@ -353,6 +353,13 @@ zgml_hip_program* zgml_hip_compile_program(zgml_hip_ctx* ctx, const zgml_device_
  * (slice_assign.dst_offset, attention.seq_kv). Other fields must be unchanged. */
 void zgml_hip_refresh_program(zgml_hip_ctx* ctx, zgml_hip_program* handle,
                               const zgml_device_op* ops, uint64_t n_ops);
+/* The per-token refresh reduced to its two numbers (src/backend/program.zig:7452-7490 StepDynamicParams, what the reference's wgpu
+ * backend uploads per step, src/backend/wgpu.zig:1162-1169): every dynamic KV store goes to column `slice_pos` (dst_offset =
+ * dst_base_offset + slice_pos * patch_stride), every attention reads `seq_kv` keys. O(#dynamic ops) instead of a compare of the
+ * whole op list; static fields are not examined — an adapter derives (slice_pos, seq_kv) with stepDynamicStateFromOps and calls
+ * this when `needsUpload()`, and calls zgml_hip_refresh_program (which detects static changes and rebuilds) otherwise.
+ * Returns 0, -1 on a null argument. */
+int zgml_hip_refresh_dynamic(zgml_hip_ctx* ctx, zgml_hip_program* handle, uint32_t slice_pos, uint32_t seq_kv);
 
 /* VTable.execute_program: upload inputs, run all ops in order, download outputs; blocking. */
 void zgml_hip_execute_program(zgml_hip_ctx* ctx, zgml_hip_program* handle,

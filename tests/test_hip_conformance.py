@@ -117,6 +117,29 @@ def test_rowwise_large(hip_backend, oracle):
         np.testing.assert_allclose(got, want, atol=1e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize("inplace", ["add", "norm", "add+norm", "mul"])
+def test_row_chain_in_place_forms_at_few_rows(hip_backend, oracle, inplace):
+    """at few rows the [add ->] rmsnorm [-> mul] launch puts several workgroups on one row (each re-reads the whole
+    row, stores its own column chunks), which is only legal when nothing it stores is something a sibling still reads. The
+    reference API has in-place forms (x.addInplace(y) — src/tensor/api.zig:132 — then rmsNorm; a norm or a gain written over its
+    input): the launcher must fall back to one workgroup per row for them. rows = 32, cols = 4096 (the shape that splits)."""
+    rng = np.random.default_rng(11)
+    rows, cols = 32, 4096
+    n = rows * cols
+    x, y, g = (rng.standard_normal(n).astype(f32) for _ in range(3))
+    X, Y, G, H, NRM, OUT = 0, 1, 2, 3, 4, 5
+    h = X if "add" in inplace else H               # x.addInplace(y): the sum lands in x
+    nrm = h if "norm" in inplace else NRM          # the norm written over its input
+    out = nrm if inplace == "mul" else OUT         # the gain written over the normalised rows
+    ops = [DeviceOp.elementwise("add", h, X, Y, n), DeviceOp.rmsnorm(nrm, h, rows, cols, 1e-5), DeviceOp.elementwise("mul", out, nrm, G, n)]
+    prog = DeviceProgram(ops=ops, buffer_sizes=[n] * 6, initial_uploads=[ProgramIO(X, x), ProgramIO(Y, y), ProgramIO(G, g)])
+    for b in sorted({h, nrm, out}):
+        want = oracle.run_program(prog, b, n)
+        got = oracle.run_program(prog, b, n, backend=hip_backend)
+        assert not hip_backend.last_error(), hip_backend.last_error()
+        np.testing.assert_allclose(got, want, atol=1e-5, rtol=1e-5, err_msg=f"{inplace}: buffer {b}")
+
+
 def test_repeat_generic_and_rope_strided_bit_exact(hip_backend, oracle):
     rng = np.random.default_rng(3)
     # generic repeat: src [3,2] (strided view, row stride 4) -> dst [6,4]

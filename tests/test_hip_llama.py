@@ -90,6 +90,54 @@ def test_resident_decode_equals_vtable_stepping(hip_backend, name, kind):
     m.close()
 
 
+@pytest.mark.parametrize("kvq", [0, 32])
+def test_dynamic_refresh_equals_full_refresh(hip_backend, kvq):
+    """The adapter's per-token refresh — (slice_pos, seq_kv) through zgml_hip_refresh_dynamic, as the reference's wgpu backend
+    reduces refresh_program (src/backend/program.zig:7452-7490, src/backend/wgpu.zig:1162-1169) — against the whole op list through
+    zgml_hip_refresh_program: the same logits, bit for bit, at every position, also after jumping back in the context (the KV
+    store offsets and seq_kv of ALL dynamic ops move) and with the quantised-KV extension ops (kvq_store.col)."""
+    cfg = llama.preset("tiny", 128)
+    cfg.kv_quant_block = kvq
+    m = llama.Model(cfg, llama.Q4_0, threads=8)
+    s_full = llama.Session(m, llama.hip_backend_fns(hip_backend))
+    s_dyn = llama.Session(m, llama.hip_backend_fns(hip_backend))
+    s_dyn.use_dynamic_refresh()
+    toks = [3, 17, 200, 5, 9, 11, 400, 2, 77, 31]
+    for rep in range(2):  # the second pass restarts at position 0 over a warm cache
+        for pos, t in enumerate(toks):
+            t_f, l_f = s_full.step(t, pos)
+            t_d, l_d = s_dyn.step(t, pos)
+            assert not hip_backend.last_error(), hip_backend.last_error()
+            assert t_f == t_d and np.array_equal(l_f, l_d), (rep, pos)
+    s_full.close(), s_dyn.close(), m.close()
+
+
+def test_full_refresh_still_detects_a_static_change(hip_backend, oracle):
+    """zgml_hip_refresh_program compares the static part of every op (without copying them: ~4 us per 1654-op SmolLM token) and
+    rebuilds the launch list when one changed — legal for the reference's cpu backend, which re-reads the ops on every execute
+    (src/backend/cpu.zig:128-131). Here the rmsnorm eps of a two-op program changes between executes."""
+    from zgml_amd import DeviceOp, DeviceProgram, ProgramIO
+    rng = np.random.default_rng(5)
+    rows, cols = 2, 320
+    x = rng.standard_normal(rows * cols).astype(np.float32)
+    g = rng.standard_normal(rows * cols).astype(np.float32)
+
+    def ops(eps):
+        return [DeviceOp.rmsnorm(1, 0, rows, cols, eps), DeviceOp.elementwise("mul", 2, 1, 3, rows * cols)]
+    prog = DeviceProgram(ops=ops(1e-5), buffer_sizes=[rows * cols] * 4, initial_uploads=[ProgramIO(0, x), ProgramIO(3, g)])
+    h = hip_backend.compileProgram(prog)
+    out = np.zeros(rows * cols, np.float32)
+    try:
+        for eps in (1e-5, 0.5, 1e-5):
+            hip_backend.refreshProgram(h, ops(eps))
+            hip_backend.executeProgram(h, [], [ProgramIO(2, out)])
+            assert not hip_backend.last_error(), hip_backend.last_error()
+            want = oracle.run_program(DeviceProgram(ops=ops(eps), buffer_sizes=[rows * cols] * 4, initial_uploads=[ProgramIO(0, x), ProgramIO(3, g)]), 2, rows * cols)
+            np.testing.assert_allclose(out, want, atol=1e-5, rtol=1e-5, err_msg=f"eps {eps}")
+    finally:
+        hip_backend.freeProgram(h)
+
+
 def test_resident_decode_survives_a_plan_rebuild(hip_backend):
     """The resident graph bakes the plan's kernel nodes and parameter arrays: a plan rebuild (here forced by
     set_barriers, and by a small-seq_kv refresh in between) must re-capture it, and the rebuilt plan must keep the

@@ -16,7 +16,7 @@ import csv, glob, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob("$OUT/p*_counters.csv")):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0][-60:]
+        k = r["Kernel_Name"].replace("zgml::(anonymous namespace)::", "").replace("void ", "").split("(")[0][-60:]
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in agg.items():
     if not any(s in k for s in ("dense_f16_tile", "qmatvec_kon", "qmatmul_xdl")): continue

@@ -186,7 +186,7 @@ class RuntimeProfileC(C.Structure):
 HIP_SYMBOLS = [
     "zgml_hip_create", "zgml_hip_destroy", "zgml_hip_last_error", "zgml_hip_clear_error",
     "zgml_hip_capabilities", "zgml_hip_program_supported", "zgml_hip_dense_matmul_f32",
-    "zgml_hip_compile_program", "zgml_hip_refresh_program", "zgml_hip_execute_program",
+    "zgml_hip_compile_program", "zgml_hip_refresh_program", "zgml_hip_refresh_dynamic", "zgml_hip_execute_program",
     "zgml_hip_free_program", "zgml_hip_get_runtime_profile", "zgml_hip_set_option",
     "zgml_hip_program_buffer_ptr", "zgml_hip_copy_program_buffer", "zgml_hip_stage_inputs", "zgml_hip_enqueue_staged",
     "zgml_hip_enqueue_argmax", "zgml_hip_argmax_result", "zgml_hip_stream", "zgml_hip_enqueue_program",
@@ -235,6 +235,8 @@ def _bind_hip(lib: C.CDLL) -> None:
     lib.zgml_hip_compile_program.restype = vp
     lib.zgml_hip_compile_program.argtypes = [vp, C.POINTER(DeviceProgramC)]
     lib.zgml_hip_refresh_program.restype = None
+    lib.zgml_hip_refresh_dynamic.restype = C.c_int
+    lib.zgml_hip_refresh_dynamic.argtypes = [vp, vp, C.c_uint32, C.c_uint32]
     lib.zgml_hip_refresh_program.argtypes = [vp, vp, C.POINTER(DeviceOpC), u64]
     lib.zgml_hip_execute_program.restype = None
     lib.zgml_hip_execute_program.argtypes = [vp, vp, C.POINTER(ProgramIOC), u64, C.POINTER(ProgramIOC), u64]

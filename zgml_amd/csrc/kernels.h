@@ -372,6 +372,26 @@ struct ArgmaxAdvance {
 };
 void launch_argmax(hipStream_t s, const float* v, uint64_t n, float* scratch_val, int64_t* scratch_idx, int64_t* out,
                    const ArgmaxAdvance& adv = ArgmaxAdvance{});
+// Everything LlamaInferencePlan.execute patches on the host per execution (src/llama_inference.zig:405-446; for T > 1
+// patch_tokens of zgml_amd/host/llama_decode.cpp), produced on the device as one flat index space: T embedding rows, T
+// causal-mask columns, T RoPE rows per layer leaf, the dynamic words (KV store offsets at `pos`, seq_kv = pos + T).
+struct ResidentPrepArgs {
+    const float *embed, *cos, *sin;
+    float *tok_in, *mask;
+    float* const* rope_bufs;
+    const uint32_t *dyn_kind, *dyn_base, *dyn_stride;
+    uint32_t* dyn;
+    const uint32_t* state;  // [0] token, [1] position, [2] produced count
+    const uint32_t* tokens; // T token ids (decode: &state[0])
+    uint32_t d, max_seq, dh, n_rope, n_ops, T;
+};
+void launch_resident_prep(hipStream_t s, const ResidentPrepArgs& a, uint32_t total); // total = T d + T max_seq + n_rope T 2 dh + n_ops
+// The token tail of the device-resident decode loop in ONE launch: the first maximum of v[0, n) (the two stages of launch_argmax:
+// the workgroup whose arrival is the last one on `cnt` — one zeroed word, re-armed here — does the second), the advance of the
+// device state (`adv`) and, by that same workgroup, the NEXT token's patches (`prep`, T = 1, at the advanced position; skipped once
+// the position has reached max_seq). Same (value, index) ordering as launch_argmax: results are identical.
+void launch_argmax_tail(hipStream_t s, const float* v, uint64_t n, float* scratch_val, int64_t* scratch_idx, uint32_t* cnt, int64_t* out,
+                        const ArgmaxAdvance& adv, const ResidentPrepArgs* prep, uint32_t prep_total);
 void launch_copy_f4(hipStream_t s, void* dst, const void* src, uint64_t bytes);
 void launch_f32_to_f16(hipStream_t s, void* dst, const float* src, uint64_t n);
 

@@ -1299,6 +1299,20 @@ void launch_row_chain(hipStream_t s, const RowChainParams& p, uint32_t rows) {
     uint32_t split = 1;
     while (split * 2 <= chunks && rows * split * 2 <= 256 && chunks % (split * 2) == 0) split *= 2;
     if (split_env > 0) split = std::min<uint32_t>((uint32_t)split_env, chunks);
+    { // The workgroups of a row each re-read the WHOLE row (a0, a1, src, mul_other) and store only their own column chunks (add_dst,
+      // norm_dst, mul_dst). One workgroup per row is safe in place (a thread reads its elements before it writes them); several
+      // are not: a sibling may already have overwritten what this one still has to read — x.addInplace(y) followed by rmsNorm is
+      // a legal op stream (src/tensor/api.zig:132) and would get a double add and a wrong sum of squares. So: any
+      // written span overlapping any span the siblings read -> one workgroup per row.
+        const size_t n = (size_t)rows * p.cols;
+        auto overlap = [n](const float* a, const float* b) { return a && b && a < b + n && b < a + n; };
+        const float* const reads[4] = {p.a0, p.a1, p.src, p.mul_other};
+        const float* const writes[3] = {p.add_dst, p.norm_dst, p.mul_dst};
+        for (const float* w : writes)
+            for (const float* r : reads)
+                if (overlap(w, r) && !(w == p.add_dst && r == p.src && p.a0)) // (src == add_dst behind a pre-add is the chain itself: every workgroup recomputes the add from a0 / a1 and never reads add_dst back)
+                    split = 1;
+    }
     const dim3 grid(rows, p.cols <= 32 * kBlock ? split : 1);
     if (p.cols <= 4 * kBlock)
         row_chain_kernel<4><<<grid, kBlock, 0, s>>>(p);
@@ -1450,6 +1464,124 @@ void launch_dense_matmul(hipStream_t s, const DenseMatmulParams& p) {
         else
             dense_strided_kernel<float><<<grid, kBlock, 0, s>>>(p);
     }
+}
+
+namespace {
+// one element of the flat prep index space (kernels.h: ResidentPrepArgs) at position `pos` with the chunk's tokens `tokens`
+__device__ __forceinline__ void resident_prep_element(const ResidentPrepArgs& a, uint32_t i, uint32_t pos, const uint32_t* tokens, uint32_t token0, bool use_token0) {
+    if (i < a.T * a.d) {
+        const uint32_t j = i / a.d, e = i - j * a.d;
+        a.tok_in[i] = a.embed[(uint64_t)(use_token0 ? token0 : tokens[j]) * a.d + e];
+        return;
+    }
+    i -= a.T * a.d;
+    if (i < a.T * a.max_seq) {
+        const uint32_t j = i / a.max_seq, sidx = i - j * a.max_seq;
+        a.mask[i] = sidx <= pos + j ? 0.0f : -INFINITY;
+        return;
+    }
+    i -= a.T * a.max_seq;
+    if (i < a.n_rope * a.T * 2 * a.dh) {
+        const uint32_t l = i / (a.T * 2 * a.dh), rem = i - l * (a.T * 2 * a.dh), j = rem / (2 * a.dh), e = rem - j * 2 * a.dh;
+        a.rope_bufs[l][rem] = e < a.dh ? a.cos[(uint64_t)(pos + j) * a.dh + e] : a.sin[(uint64_t)(pos + j) * a.dh + e - a.dh];
+        return;
+    }
+    i -= a.n_rope * a.T * 2 * a.dh;
+    if (i < a.n_ops) {
+        if (a.dyn_kind[i] == 1) a.dyn[i] = a.dyn_base[i] + pos * a.dyn_stride[i];
+        if (a.dyn_kind[i] == 2) a.dyn[i] = pos + a.T;
+    }
+}
+__global__ void __launch_bounds__(256) resident_prep_kernel(ResidentPrepArgs a) {
+    resident_prep_element(a, blockIdx.x * 256 + threadIdx.x, a.state[1], a.tokens, 0, false);
+}
+
+// argmax_stage1 + (last arriver) argmax_stage2 + advance + the next token's prep (kernels.h: launch_argmax_tail)
+__global__ void __launch_bounds__(kBlock) argmax_tail_kernel(const float* __restrict__ v, uint64_t n, float* vals, int64_t* idxs, uint32_t* cnt, int64_t* out,
+                                                             ArgmaxAdvance adv, ResidentPrepArgs prep, uint32_t prep_total, uint32_t has_prep) {
+    __shared__ float sv[kBlock];
+    __shared__ int64_t si[kBlock];
+    __shared__ uint32_t bc[2];
+    using gu32 = __attribute__((address_space(1))) uint32_t;
+    using gu64 = __attribute__((address_space(1))) unsigned long long;
+    float bv = -INFINITY;
+    int64_t bi = INT64_MAX;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) { // (as argmax_stage1)
+        const float x = v[i];
+        if (x > bv || bi == INT64_MAX) {
+            bv = x;
+            bi = (int64_t)i;
+        }
+    }
+    sv[threadIdx.x] = bv, si[threadIdx.x] = bi;
+    __syncthreads();
+    for (int off = kBlock / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) arg_combine(sv[threadIdx.x], si[threadIdx.x], sv[threadIdx.x + off], si[threadIdx.x + off]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { // publish this workgroup's pair write-through, drain, count (the guide's fan-in form: sc1 payload + vmcnt(0) + agent atomic)
+        __hip_atomic_store((gu32*)vals + blockIdx.x, __float_as_uint(sv[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store((gu64*)idxs + blockIdx.x, (unsigned long long)si[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        bc[0] = __hip_atomic_fetch_add((gu32*)cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!bc[0]) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // compiler only: the agent-scope loads below stay below the count
+    bv = -INFINITY, bi = INT64_MAX; // ---- stage 2 (as argmax_stage2), every pair read with agent-scope loads
+    for (uint32_t i = threadIdx.x; i < gridDim.x; i += kBlock) {
+        const int64_t ix = (int64_t)__hip_atomic_load((gu64*)idxs + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float vx = __uint_as_float(__hip_atomic_load((gu32*)vals + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (ix != INT64_MAX) {
+            if (bi == INT64_MAX)
+                bv = vx, bi = ix;
+            else
+                arg_combine(bv, bi, vx, ix);
+        }
+    }
+    sv[threadIdx.x] = bv, si[threadIdx.x] = bi;
+    __syncthreads();
+    for (int off = kBlock / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off && si[threadIdx.x + off] != INT64_MAX) {
+            if (si[threadIdx.x] == INT64_MAX)
+                sv[threadIdx.x] = sv[threadIdx.x + off], si[threadIdx.x] = si[threadIdx.x + off];
+            else
+                arg_combine(sv[threadIdx.x], si[threadIdx.x], sv[threadIdx.x + off], si[threadIdx.x + off]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const int64_t next = si[0] == INT64_MAX ? -1 : si[0];
+        *out = next;
+        uint32_t pos_next = 0;
+        if (adv.state) { // the resident loop's advance step
+            const uint32_t k = adv.state[2];
+            if (k < adv.cap) adv.tokens[k] = next;
+            adv.state[0] = (uint32_t)next;
+            pos_next = adv.state[1] + 1;
+            adv.state[1] = pos_next;
+            adv.state[2] = k + 1;
+        }
+        __hip_atomic_store((gu32*)cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // re-arm
+        bc[0] = (uint32_t)next, bc[1] = pos_next;
+    }
+    __syncthreads();
+    if (!has_prep) return;
+    const uint32_t token = bc[0], pos = bc[1];
+    if (pos >= prep.max_seq || token >= 0x7FFFFFFFu) return; // (the context is full, or no finite logit: nothing to prepare)
+    for (uint32_t i = threadIdx.x; i < prep_total; i += kBlock) resident_prep_element(prep, i, pos, nullptr, token, true);
+}
+} // namespace
+
+void launch_resident_prep(hipStream_t s, const ResidentPrepArgs& a, uint32_t total) {
+    if (total) resident_prep_kernel<<<(total + 255) / 256, 256, 0, s>>>(a);
+}
+
+void launch_argmax_tail(hipStream_t s, const float* v, uint64_t n, float* scratch_val, int64_t* scratch_idx, uint32_t* cnt, int64_t* out,
+                        const ArgmaxAdvance& adv, const ResidentPrepArgs* prep, uint32_t prep_total) {
+    int nblk = (int)(n / (kBlock * 4) + 1);
+    if (nblk > kArgBlocks) nblk = kArgBlocks;
+    argmax_tail_kernel<<<nblk, kBlock, 0, s>>>(v, n, scratch_val, scratch_idx, cnt, out, adv, prep ? *prep : ResidentPrepArgs{}, prep_total, prep ? 1u : 0u);
 }
 
 void launch_argmax(hipStream_t s, const float* v, uint64_t n, float* scratch_val, int64_t* scratch_idx, int64_t* out, const ArgmaxAdvance& adv) {

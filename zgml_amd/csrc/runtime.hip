@@ -217,6 +217,9 @@ void free_graph(zgml_hip_program* p) {
     if (p->graph) hipGraphDestroy(p->graph);
     p->graph_exec = nullptr;
     p->graph = nullptr;
+    if (p->graph_tail_exec) hipGraphExecDestroy(p->graph_tail_exec);
+    if (p->graph_tail) hipGraphDestroy(p->graph_tail);
+    p->graph_tail_exec = nullptr, p->graph_tail = nullptr;
     if (p->shard_graph_exec) hipGraphExecDestroy(p->shard_graph_exec);
     if (p->shard_graph) hipGraphDestroy(p->shard_graph);
     p->shard_graph_exec = nullptr, p->shard_graph = nullptr;
@@ -280,11 +283,16 @@ bool prepare_io(zgml_hip_program* p, IoPlan& plan, const zgml_program_io* ios, u
         table.push_back({(float*)((char*)p->bufs[io.buf_idx] + io.offset), plan.total_words, io.size / 4});
         plan.total_words += (io.size + 3) / 4;
     }
+    // the input table carries one more row: the program's dynamic words (one per op), so that a refresh's changes ride in the same
+    // staging copy and scatter launch as the inputs instead of a transfer of their own (upload_inputs)
+    const bool with_dyn = &plan == &p->in_plan && plan.word_aligned && !table.empty() && p->dyn_dev && !p->ops.empty();
+    if (with_dyn) table.push_back({(float*)p->dyn_dev, plan.total_words, (uint32_t)p->ops.size()});
     if (plan.word_aligned && !table.empty()) {
         if (!CTX_CHECK(ctx, hipMalloc((void**)&plan.table_dev, table.size() * sizeof(IoTableDev)))) return false;
         if (!CTX_CHECK(ctx, h2d_sync(ctx->stream, plan.table_dev, table.data(), table.size() * sizeof(IoTableDev)))) return false;
     }
-    return ensure_stage(p, (uint64_t)plan.total_words * 4);
+    plan.dyn_row = with_dyn;
+    return ensure_stage(p, ((uint64_t)plan.total_words + (with_dyn ? p->ops.size() : 0)) * 4);
 }
 
 // ── plan building ───────────────────────────────────────────────────────────────────────────
@@ -2284,6 +2292,11 @@ void own_ops(zgml_hip_program* p, const zgml_device_op* ops, uint64_t n_ops) {
         for (uint64_t i = 0; i < n_ops; i++)
             if (p->ops[i].kind != ops[i].kind) p->seq_kv_bound[i] = 0;
     p->ops.assign(ops, ops + n_ops);
+    p->dyn_ops.clear(); // the ops with a dynamic field (what a per-token refresh touches: zgml_hip_refresh_dynamic)
+    for (uint64_t i = 0; i < n_ops; i++)
+        if ((ops[i].kind == ZGML_DOP_SLICE_ASSIGN && ops[i].u.slice_assign.patch_stride != 0) || ops[i].kind == ZGML_DOP_ATTENTION ||
+            (ops[i].kind == ZGML_DOP_KVQ_STORE && ops[i].u.kvq_store.patch_stride != 0) || ops[i].kind == ZGML_DOP_ATTENTION_KVQ)
+            p->dyn_ops.push_back((uint32_t)i);
     p->steps.assign(n_ops, {});
     for (uint64_t i = 0; i < n_ops; i++) {
         if (ops[i].kind == ZGML_DOP_FUSED_ELEMENTWISE) {
@@ -2295,52 +2308,42 @@ void own_ops(zgml_hip_program* p, const zgml_device_op* ops, uint64_t n_ops) {
     note_seq_kv_bounds(p);
 }
 
-// true when the static part of two ops is identical (dynamic fields and step pointers ignored)
+// true when the static part of two ops is identical (dynamic fields and step pointers ignored). No copies: the bytes of the
+// ACTIVE union member (the rest may be uninitialised padding) are compared around the member's dynamic field — this runs once per
+// op per token on the drop-in path (refresh_program is called before every execute: src/device_inference.zig:260-263).
 bool same_static(const zgml_device_op& a, const zgml_device_op& b) {
     if (a.kind != b.kind) return false;
-    zgml_device_op x = a, y = b;
-    if (a.kind == ZGML_DOP_SLICE_ASSIGN) x.u.slice_assign.dst_offset = y.u.slice_assign.dst_offset = 0;
-    if (a.kind == ZGML_DOP_ATTENTION) x.u.attention.seq_kv = y.u.attention.seq_kv = 0;
-    if (a.kind == ZGML_DOP_KVQ_STORE) x.u.kvq_store.col = y.u.kvq_store.col = 0;
-    if (a.kind == ZGML_DOP_ATTENTION_KVQ) x.u.attention_kvq.seq_kv = y.u.attention_kvq.seq_kv = 0;
-    if (a.kind == ZGML_DOP_FUSED_ELEMENTWISE) {
-        const auto &fa = a.u.fused_elementwise, &fb = b.u.fused_elementwise;
-        if (fa.n_steps != fb.n_steps) return false;
-        for (uint32_t s = 0; s < fa.n_steps; s++)
-            if (fa.steps[s].op != fb.steps[s].op || fa.steps[s].is_swapped != fb.steps[s].is_swapped ||
-                fa.steps[s].secondary_buf != fb.steps[s].secondary_buf ||
-                fa.steps[s].secondary_offset != fb.steps[s].secondary_offset)
-                return false;
-        x.u.fused_elementwise.steps = y.u.fused_elementwise.steps = nullptr;
-    }
-    // compare only the bytes of the active union member (the rest may be uninitialised padding)
-    size_t len = 0;
-    const void *pa = nullptr, *pb = nullptr;
-#define ARM(tag, member)                \
-    case tag:                           \
-        pa = &x.u.member;               \
-        pb = &y.u.member;               \
-        len = sizeof(x.u.member);       \
-        break;
+    auto except = [](const void* pa, const void* pb, size_t len, size_t off, size_t flen) { // equal but for [off, off + flen)
+        const char *x = (const char*)pa, *y = (const char*)pb;
+        return memcmp(x, y, off) == 0 && memcmp(x + off + flen, y + off + flen, len - off - flen) == 0;
+    };
     switch (a.kind) {
-        ARM(ZGML_DOP_ELEMENTWISE, elementwise)
-        ARM(ZGML_DOP_MATMUL, matmul)
-        ARM(ZGML_DOP_QMATMUL, qmatmul)
-        ARM(ZGML_DOP_SOFTMAX, softmax)
-        ARM(ZGML_DOP_LAYERNORM, layernorm)
-        ARM(ZGML_DOP_RMSNORM, rmsnorm)
-        ARM(ZGML_DOP_REDUCE, reduce)
-        ARM(ZGML_DOP_REPEAT, repeat)
-        ARM(ZGML_DOP_SLICE_ASSIGN, slice_assign)
-        ARM(ZGML_DOP_ROPE, rope)
-        ARM(ZGML_DOP_ATTENTION, attention)
-        ARM(ZGML_DOP_FUSED_ELEMENTWISE, fused_elementwise)
-        ARM(ZGML_DOP_KVQ_STORE, kvq_store)
-        ARM(ZGML_DOP_ATTENTION_KVQ, attention_kvq)
+        case ZGML_DOP_SLICE_ASSIGN:
+            return except(&a.u.slice_assign, &b.u.slice_assign, sizeof(a.u.slice_assign), offsetof(zgml_op_slice_assign, dst_offset), sizeof(uint32_t));
+        case ZGML_DOP_ATTENTION: return except(&a.u.attention, &b.u.attention, sizeof(a.u.attention), offsetof(zgml_op_attention, seq_kv), sizeof(uint32_t));
+        case ZGML_DOP_KVQ_STORE: return except(&a.u.kvq_store, &b.u.kvq_store, sizeof(a.u.kvq_store), offsetof(zgml_op_kvq_store, col), sizeof(uint32_t));
+        case ZGML_DOP_ATTENTION_KVQ:
+            return except(&a.u.attention_kvq, &b.u.attention_kvq, sizeof(a.u.attention_kvq), offsetof(zgml_op_attention_kvq, seq_kv), sizeof(uint32_t));
+        case ZGML_DOP_FUSED_ELEMENTWISE: {
+            const auto &fa = a.u.fused_elementwise, &fb = b.u.fused_elementwise;
+            if (fa.n_steps != fb.n_steps) return false;
+            for (uint32_t s = 0; s < fa.n_steps; s++)
+                if (fa.steps[s].op != fb.steps[s].op || fa.steps[s].is_swapped != fb.steps[s].is_swapped ||
+                    fa.steps[s].secondary_buf != fb.steps[s].secondary_buf || fa.steps[s].secondary_offset != fb.steps[s].secondary_offset)
+                    return false;
+            return except(&fa, &fb, sizeof(fa), offsetof(zgml_op_fused_elementwise, steps), sizeof(fa.steps));
+        }
+        case ZGML_DOP_ELEMENTWISE: return memcmp(&a.u.elementwise, &b.u.elementwise, sizeof(a.u.elementwise)) == 0;
+        case ZGML_DOP_MATMUL: return memcmp(&a.u.matmul, &b.u.matmul, sizeof(a.u.matmul)) == 0;
+        case ZGML_DOP_QMATMUL: return memcmp(&a.u.qmatmul, &b.u.qmatmul, sizeof(a.u.qmatmul)) == 0;
+        case ZGML_DOP_SOFTMAX: return memcmp(&a.u.softmax, &b.u.softmax, sizeof(a.u.softmax)) == 0;
+        case ZGML_DOP_LAYERNORM: return memcmp(&a.u.layernorm, &b.u.layernorm, sizeof(a.u.layernorm)) == 0;
+        case ZGML_DOP_RMSNORM: return memcmp(&a.u.rmsnorm, &b.u.rmsnorm, sizeof(a.u.rmsnorm)) == 0;
+        case ZGML_DOP_REDUCE: return memcmp(&a.u.reduce, &b.u.reduce, sizeof(a.u.reduce)) == 0;
+        case ZGML_DOP_REPEAT: return memcmp(&a.u.repeat, &b.u.repeat, sizeof(a.u.repeat)) == 0;
+        case ZGML_DOP_ROPE: return memcmp(&a.u.rope, &b.u.rope, sizeof(a.u.rope)) == 0;
         default: return false;
     }
-#undef ARM
-    return memcmp(pa, pb, len) == 0;
 }
 
 void run_plan(zgml_hip_program* p, hipStream_t s, size_t first, size_t count) {
@@ -2406,23 +2409,35 @@ void enqueue(zgml_hip_program* p) {
     }
     if (ctx->opt_graph && !p->plan.empty()) {
         if (!p->graph_exec) {
-            hipGraph_t g = nullptr;
-            if (CTX_CHECK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal))) {
-                run_plan(p, ctx->stream, 0, p->plan.size());
-                if (CTX_CHECK(ctx, hipStreamEndCapture(ctx->stream, &g)) && g) {
-                    dump_graph(g, "program");
-                    hipGraphExec_t ge = nullptr;
-                    if (CTX_CHECK(ctx, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0))) {
-                        p->graph = g;
-                        p->graph_exec = ge;
-                    } else {
-                        hipGraphDestroy(g);
-                    }
+            // two graphs (zgml_hip_program::graph_tail): the head holds the first sixth of the launches (at least 8: its device
+            // time has to cover the host's submission of the tail), short plans stay one graph
+            static const int split_env = getenv("ZGML_HIP_GRAPH_SPLIT") ? atoi(getenv("ZGML_HIP_GRAPH_SPLIT")) : -1;
+            size_t head = p->plan.size() >= 48 ? std::max<size_t>(8, p->plan.size() / 6) : p->plan.size();
+            if (split_env == 0) head = p->plan.size();
+            if (split_env > 0) head = std::min<size_t>((size_t)split_env, p->plan.size());
+            auto capture = [&](size_t first, size_t count, hipGraph_t* g_out, hipGraphExec_t* e_out, const char* tag) {
+                hipGraph_t g = nullptr;
+                if (!CTX_CHECK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal))) return false;
+                run_plan(p, ctx->stream, first, count);
+                if (!CTX_CHECK(ctx, hipStreamEndCapture(ctx->stream, &g)) || !g) return false;
+                dump_graph(g, tag);
+                hipGraphExec_t ge = nullptr;
+                if (!CTX_CHECK(ctx, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0))) {
+                    hipGraphDestroy(g);
+                    return false;
                 }
+                *g_out = g, *e_out = ge;
+                return true;
+            };
+            if (capture(0, head, &p->graph, &p->graph_exec, "program") && head < p->plan.size() &&
+                !capture(head, p->plan.size() - head, &p->graph_tail, &p->graph_tail_exec, "program-tail")) {
+                hipGraphExecDestroy(p->graph_exec), hipGraphDestroy(p->graph); // (all or nothing: eager below)
+                p->graph_exec = nullptr, p->graph = nullptr;
             }
         }
         if (p->graph_exec) {
             CTX_CHECK(ctx, hipGraphLaunch(p->graph_exec, ctx->stream));
+            if (p->graph_tail_exec) CTX_CHECK(ctx, hipGraphLaunch(p->graph_tail_exec, ctx->stream));
             return;
         }
     }
@@ -2492,47 +2507,6 @@ void free_resident(zgml_hip_program* p) {
     p->resident = nullptr;
 }
 
-struct ResidentPrepArgs {
-    const float *embed, *cos, *sin;
-    float *tok_in, *mask;
-    float* const* rope_bufs;
-    const uint32_t *dyn_kind, *dyn_base, *dyn_stride;
-    uint32_t* dyn;
-    const uint32_t* state;
-    const uint32_t* tokens; // T token ids (decode: &state[0])
-    uint32_t d, max_seq, dh, n_rope, n_ops, T;
-};
-
-// Everything LlamaInferencePlan.execute patches on the host per execution (src/llama_inference.zig:405-446; for T > 1
-// patch_tokens of zgml_amd/host/llama_decode.cpp), as one flat index space: T embedding rows, T causal-mask columns,
-// T RoPE rows per layer leaf, the dynamic words (KV store offsets at `pos`, seq_kv = pos + T).
-__global__ void __launch_bounds__(256) resident_prep_kernel(ResidentPrepArgs a) {
-    const uint32_t pos = a.state[1];
-    uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i < a.T * a.d) {
-        const uint32_t j = i / a.d, e = i - j * a.d;
-        a.tok_in[i] = a.embed[(uint64_t)a.tokens[j] * a.d + e];
-        return;
-    }
-    i -= a.T * a.d;
-    if (i < a.T * a.max_seq) {
-        const uint32_t j = i / a.max_seq, sidx = i - j * a.max_seq;
-        a.mask[i] = sidx <= pos + j ? 0.0f : -INFINITY;
-        return;
-    }
-    i -= a.T * a.max_seq;
-    if (i < a.n_rope * a.T * 2 * a.dh) {
-        const uint32_t l = i / (a.T * 2 * a.dh), rem = i - l * (a.T * 2 * a.dh), j = rem / (2 * a.dh), e = rem - j * 2 * a.dh;
-        a.rope_bufs[l][rem] = e < a.dh ? a.cos[(uint64_t)(pos + j) * a.dh + e] : a.sin[(uint64_t)(pos + j) * a.dh + e - a.dh];
-        return;
-    }
-    i -= a.n_rope * a.T * 2 * a.dh;
-    if (i < a.n_ops) {
-        if (a.dyn_kind[i] == 1) a.dyn[i] = a.dyn_base[i] + pos * a.dyn_stride[i];
-        if (a.dyn_kind[i] == 2) a.dyn[i] = pos + a.T;
-    }
-}
-
 } // namespace
 
 // ════════════════════════════════ C ABI ════════════════════════════════
@@ -2570,6 +2544,7 @@ zgml_hip_ctx* zgml_hip_create(int device_ordinal) {
     if (const char* e = getenv("ZGML_HIP_GRAPH")) ctx->opt_graph = atoi(e) != 0;
     if (const char* e = getenv("ZGML_HIP_FUSION")) ctx->opt_fusion = atoi(e) != 0;
     if (const char* e = getenv("ZGML_HIP_KSPLIT")) ctx->opt_ksplit = atoi(e) != 0;
+    if (const char* e = getenv("ZGML_HIP_HOST_PROF")) ctx->host_prof = atoi(e) != 0;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         g_create_error = "hipStreamCreate failed";
         delete ctx;
@@ -2577,6 +2552,8 @@ zgml_hip_ctx* zgml_hip_create(int device_ordinal) {
     }
     hipMalloc((void**)&ctx->arg_val, 256 * sizeof(float));
     hipMalloc((void**)&ctx->arg_idx, 256 * sizeof(int64_t));
+    hipMalloc((void**)&ctx->arg_cnt, 128);
+    hipMemset(ctx->arg_cnt, 0, 128);
     hipMalloc((void**)&ctx->arg_out, sizeof(int64_t));
     hipHostMalloc((void**)&ctx->arg_out_host, sizeof(int64_t), hipHostMallocDefault);
     ctx->n_cu = prop.multiProcessorCount;
@@ -2590,6 +2567,12 @@ zgml_hip_ctx* zgml_hip_create(int device_ordinal) {
 
 void zgml_hip_shard_destroy(zgml_hip_ctx* ctx);
 void zgml_hip_destroy(zgml_hip_ctx* ctx) {
+    if (ctx && ctx->host_prof && ctx->prof_calls[1]) {
+        static const char* const names[4] = {"refresh", "upload (pack + H2D + scatter)", "enqueue (dynamic words + graph launch)", "download (gather + D2H + wait + unpack)"};
+        fprintf(stderr, "[zgml_hip] host time per call of the vtable path's phases:\n");
+        for (int k = 0; k < 4; k++)
+            if (ctx->prof_calls[k]) fprintf(stderr, "  %-44s %8.2f us x %llu\n", names[k], ctx->prof_ns[k] / 1e3 / ctx->prof_calls[k], (unsigned long long)ctx->prof_calls[k]);
+    }
     if (!ctx) return;
     zgml_hip_shard_destroy(ctx);
     hipSetDevice(ctx->device);
@@ -2600,6 +2583,7 @@ void zgml_hip_destroy(zgml_hip_ctx* ctx) {
     hipFree(ctx->mm_c);
     hipFree(ctx->arg_val);
     hipFree(ctx->arg_idx);
+    hipFree(ctx->arg_cnt);
     hipFree(ctx->arg_out);
     hipHostFree(ctx->arg_out_host);
     if (ctx->handoff_flag) hipHostFree(ctx->handoff_flag);
@@ -3001,26 +2985,81 @@ zgml_hip_program* zgml_hip_compile_program(zgml_hip_ctx* ctx, const zgml_device_
     return p;
 }
 
+// one op's dynamic field taken over from `src` (same kind, same static part): the program's copy, the device word, the attention's
+// compile-time bound; false when the value leaves the span the level schedule assumed (dynamic_fields_in_bounds for this op)
+static bool apply_dynamic(zgml_hip_program* p, uint32_t i, const zgml_device_op& src) {
+    auto ext2 = [](uint64_t n0, uint64_t s0, uint64_t n1, uint64_t s1) -> uint64_t { return n0 && n1 ? (n0 - 1) * s0 + (n1 - 1) * s1 + 1 : 0; }; // (schedule.hip's extent of a strided 2-D view)
+    zgml_device_op& op = p->ops[i];
+    uint32_t v = 0;
+    bool ok = true;
+    const DynBound* const b = p->plan_batched && i < p->sched.bounds.size() ? &p->sched.bounds[i] : nullptr;
+    switch (op.kind) {
+        case ZGML_DOP_SLICE_ASSIGN: {
+            auto& sa = op.u.slice_assign;
+            v = sa.dst_offset = src.u.slice_assign.dst_offset;
+            if (b && b->kind == 1) {
+                const uint64_t lo = sa.dst_offset, hi = lo + ext2(sa.rows, sa.dst_row_stride, sa.cols, sa.dst_col_stride);
+                ok = !(lo < b->lo || hi > b->hi);
+            }
+            break;
+        }
+        case ZGML_DOP_ATTENTION:
+            v = op.u.attention.seq_kv = src.u.attention.seq_kv;
+            if (b && b->kind == 2) ok = v <= b->max_seq_kv;
+            if (i < p->seq_kv_bound.size()) p->seq_kv_bound[i] = std::max(p->seq_kv_bound[i], v);
+            break;
+        case ZGML_DOP_KVQ_STORE: v = op.u.kvq_store.col = src.u.kvq_store.col; break;
+        case ZGML_DOP_ATTENTION_KVQ:
+            v = op.u.attention_kvq.seq_kv = src.u.attention_kvq.seq_kv;
+            if (b && b->kind == 3) ok = v <= b->max_seq_kv;
+            if (i < p->seq_kv_bound.size()) p->seq_kv_bound[i] = std::max(p->seq_kv_bound[i], v);
+            break;
+        default: return true;
+    }
+    if (p->dyn_host[i] != v) p->dyn_host[i] = v, p->dyn_dirty = true;
+    return ok;
+}
+
+// The per-token refresh reduced to what it is (src/backend/program.zig:7452-7490 StepDynamicParams, as the reference's wgpu backend
+// applies it — src/backend/wgpu.zig:1162-1169): every KV store goes to column `slice_pos` (dst_offset = dst_base_offset +
+// slice_pos * patch_stride; quantised caches: col = col_base + slice_pos * patch_stride) and every attention reads `seq_kv` keys.
+// O(#dynamic ops); static fields are NOT looked at — a caller that may have changed them calls zgml_hip_refresh_program.
+int zgml_hip_refresh_dynamic(zgml_hip_ctx* ctx, zgml_hip_program* p, uint32_t slice_pos, uint32_t seq_kv) {
+    if (!ctx || !p) return -1;
+    const uint64_t t_prof = ctx->host_prof ? now_ns() : 0;
+    bool in_bounds = true;
+    for (const uint32_t i : p->dyn_ops) {
+        zgml_device_op src = p->ops[i];
+        switch (src.kind) {
+            case ZGML_DOP_SLICE_ASSIGN: src.u.slice_assign.dst_offset = src.u.slice_assign.dst_base_offset + slice_pos * src.u.slice_assign.patch_stride; break;
+            case ZGML_DOP_ATTENTION: src.u.attention.seq_kv = seq_kv; break;
+            case ZGML_DOP_KVQ_STORE: src.u.kvq_store.col = src.u.kvq_store.col_base + slice_pos * src.u.kvq_store.patch_stride; break;
+            case ZGML_DOP_ATTENTION_KVQ: src.u.attention_kvq.seq_kv = seq_kv; break;
+            default: break;
+        }
+        in_bounds = apply_dynamic(p, i, src) && in_bounds;
+    }
+    if (p->plan_batched && !in_bounds) p->batching_safe = false, p->plan_dirty = true;
+    if (ctx->host_prof) ctx->prof_ns[0] += now_ns() - t_prof, ctx->prof_calls[0]++;
+    return 0;
+}
+
 void zgml_hip_refresh_program(zgml_hip_ctx* ctx, zgml_hip_program* p, const zgml_device_op* ops, uint64_t n_ops) {
     if (!ctx || !p || !ops) return;
+    const uint64_t t_prof = ctx->host_prof ? now_ns() : 0;
     bool static_same = n_ops == p->ops.size();
     for (uint64_t i = 0; static_same && i < n_ops; i++) static_same = same_static(p->ops[i], ops[i]);
     if (static_same) {
-        // the common per-token case: only dynamic fields moved
-        for (uint64_t i = 0; i < n_ops; i++) {
-            if (ops[i].kind == ZGML_DOP_SLICE_ASSIGN) p->ops[i].u.slice_assign.dst_offset = ops[i].u.slice_assign.dst_offset;
-            if (ops[i].kind == ZGML_DOP_ATTENTION) p->ops[i].u.attention.seq_kv = ops[i].u.attention.seq_kv;
-            if (ops[i].kind == ZGML_DOP_KVQ_STORE) p->ops[i].u.kvq_store.col = ops[i].u.kvq_store.col;
-            if (ops[i].kind == ZGML_DOP_ATTENTION_KVQ) p->ops[i].u.attention_kvq.seq_kv = ops[i].u.attention_kvq.seq_kv;
-        }
-        set_dyn_from_ops(p);
-        note_seq_kv_bounds(p);
-        if (p->plan_batched && !dynamic_fields_in_bounds(p->sched, p->ops)) {
+        // the common per-token case: only dynamic fields moved — of the ops that have one (p->dyn_ops)
+        bool in_bounds = true;
+        for (const uint32_t i : p->dyn_ops) in_bounds = apply_dynamic(p, i, ops[i]) && in_bounds;
+        if (p->plan_batched && !in_bounds) {
             // a dynamic field left the span the level schedule assumed: the reordered plan is no
             // longer provably equivalent, fall back to program order for good
             p->batching_safe = false;
             p->plan_dirty = true;
         }
+        if (ctx->host_prof) ctx->prof_ns[0] += now_ns() - t_prof, ctx->prof_calls[0]++;
         return;
     }
     if (n_ops != p->ops.size()) {
@@ -3060,8 +3099,15 @@ static bool upload_inputs(zgml_hip_ctx* ctx, zgml_hip_program* p, const zgml_pro
             memcpy(st + off, inputs[i].host_ptr, inputs[i].size);
             off += (inputs[i].size + 3) / 4 * 4;
         }
+        uint32_t rows = (uint32_t)n_inputs;
+        if (p->in_plan.dyn_row && p->dyn_dirty) { // the refreshed dynamic words ride along (prepare_io: the table's last row)
+            memcpy(st + off, p->dyn_host, p->ops.size() * sizeof(uint32_t));
+            off += p->ops.size() * sizeof(uint32_t);
+            rows++;
+            p->dyn_dirty = false;
+        }
         hipMemcpyAsync(p->stage_dev, p->stage_host, off, hipMemcpyHostToDevice, s);
-        scatter_words_kernel<<<(uint32_t)n_inputs, 256, 0, s>>>(p->in_plan.table_dev, (const uint32_t*)p->stage_dev);
+        scatter_words_kernel<<<rows, 256, 0, s>>>(p->in_plan.table_dev, (const uint32_t*)p->stage_dev);
     } else {
         for (uint64_t i = 0; i < n_inputs; i++)
             hipMemcpyAsync((char*)p->bufs[inputs[i].buf_idx] + inputs[i].offset, inputs[i].host_ptr, inputs[i].size,
@@ -3075,7 +3121,9 @@ static bool download_outputs(zgml_hip_ctx* ctx, zgml_hip_program* p, const zgml_
     hipStream_t s = ctx->stream;
     if (!prepare_io(p, p->out_plan, outputs, n_outputs)) return false;
     if (n_outputs) {
-        if (p->out_plan.word_aligned) {
+        if (p->out_plan.word_aligned && n_outputs == 1) { // (the decode step: the logits) straight from the buffer, no gather launch in front
+            hipMemcpyAsync(p->stage_host, (char*)p->bufs[outputs[0].buf_idx] + outputs[0].offset, outputs[0].size, hipMemcpyDeviceToHost, s);
+        } else if (p->out_plan.word_aligned) {
             gather_words_kernel<<<(uint32_t)n_outputs, 256, 0, s>>>(p->out_plan.table_dev, (uint32_t*)p->stage_dev);
             hipMemcpyAsync(p->stage_host, p->stage_dev, (uint64_t)p->out_plan.total_words * 4, hipMemcpyDeviceToHost, s);
         } else {
@@ -3105,9 +3153,17 @@ void zgml_hip_execute_program(zgml_hip_ctx* ctx, zgml_hip_program* p, const zgml
     hipSetDevice(ctx->device);
     // both transfer tables are validated before anything is enqueued
     if (!prepare_io(p, p->in_plan, inputs, n_inputs) || !prepare_io(p, p->out_plan, outputs, n_outputs)) return;
+    const uint64_t t0 = ctx->host_prof ? now_ns() : 0;
     if (!upload_inputs(ctx, p, inputs, n_inputs)) return;
+    const uint64_t t1 = ctx->host_prof ? now_ns() : 0;
     enqueue(p);
+    const uint64_t t2 = ctx->host_prof ? now_ns() : 0;
     download_outputs(ctx, p, outputs, n_outputs);
+    if (ctx->host_prof) {
+        const uint64_t t3 = now_ns();
+        ctx->prof_ns[1] += t1 - t0, ctx->prof_ns[2] += t2 - t1, ctx->prof_ns[3] += t3 - t2;
+        ctx->prof_calls[1]++, ctx->prof_calls[2]++, ctx->prof_calls[3]++;
+    }
     p->profile.call_count++;
     p->profile.backend_op_count += p->ops.size();
     p->profile.backend_dispatch_count += p->plan.size();
@@ -3490,10 +3546,20 @@ int zgml_hip_resident_decode(zgml_hip_ctx* ctx, zgml_hip_program* p, uint32_t fi
     ResidentPrepArgs a{r->embed, r->cos, r->sin, r->tok_in, r->mask, r->rope_bufs, r->dyn_kind, r->dyn_base, r->dyn_stride,
                        p->dyn_dev, r->state, r->state /* the token is state[0] */, r->d, r->max_seq, r->dh, r->n_rope, (uint32_t)p->ops.size(), 1};
     const uint32_t total = r->d + r->max_seq + r->n_rope * 2 * r->dh + (uint32_t)p->ops.size();
+    // (measured SLOWER, off unless ZGML_HIP_TAIL_FUSED=1 — SmolLM-135M 1756 against 1773 tok/s, Llama-2-7B 790 against 817 over 128-512
+    // positions, gpurun_out/r5/vtable_prof4.txt: the one workgroup that finishes the argmax walks the ~8-16 K elements of the next
+    // token's patches alone, a latency chain longer than the two small launches it replaces)
+    static const bool tail_fused = getenv("ZGML_HIP_TAIL_FUSED") && atoi(getenv("ZGML_HIP_TAIL_FUSED")) != 0;
     auto one_token = [&](hipStream_t st) {
-        resident_prep_kernel<<<(total + 255) / 256, 256, 0, st>>>(a);
+        if (!tail_fused) launch_resident_prep(st, a, total);
+        // [prep] [plan] [argmax stage 1] [stage 2 + advance]; or, opt-in, [plan] [token tail]: the argmax of the logits, the advance
+        // of the device state AND the next token's patches in ONE launch (launch_argmax_tail; the first token's patches then
+        // come from a stand-alone prep launch in front of the loop) — two launches fewer per token.
         run_plan(p, st, 0, p->plan.size());
-        launch_argmax(st, r->logits, r->vocab, ctx->arg_val, ctx->arg_idx, ctx->arg_out, ArgmaxAdvance{r->state, r->tokens, r->tokens_cap});
+        if (tail_fused)
+            launch_argmax_tail(st, r->logits, r->vocab, ctx->arg_val, ctx->arg_idx, ctx->arg_cnt, ctx->arg_out, ArgmaxAdvance{r->state, r->tokens, r->tokens_cap}, &a, total);
+        else
+            launch_argmax(st, r->logits, r->vocab, ctx->arg_val, ctx->arg_idx, ctx->arg_out, ArgmaxAdvance{r->state, r->tokens, r->tokens_cap});
     };
     // static dyn words (row stores with patch_stride 0) come from the host mirror; the prep kernel
     // only rewrites the position-dependent ones
@@ -3502,6 +3568,7 @@ int zgml_hip_resident_decode(zgml_hip_ctx* ctx, zgml_hip_program* p, uint32_t fi
     flush_dyn(p);
     const uint32_t st0[4] = {first_token, start_pos, 0, 0};
     if (!CTX_CHECK(ctx, hipMemcpyAsync(r->state, st0, sizeof(st0), hipMemcpyHostToDevice, s))) return -1;
+    if (tail_fused) launch_resident_prep(s, a, total); // the first token's patches (every later token's come from its predecessor's tail)
     if (ctx->opt_graph && !r->graph_exec) {
         hipGraph_t g = nullptr;
         if (CTX_CHECK(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal))) {
@@ -3530,7 +3597,7 @@ int zgml_hip_resident_decode(zgml_hip_ctx* ctx, zgml_hip_program* p, uint32_t fi
     p->dyn_dirty = true;
     p->profile.call_count += n_steps;
     p->profile.backend_op_count += (uint64_t)n_steps * p->ops.size();
-    p->profile.backend_dispatch_count += (uint64_t)n_steps * (p->plan.size() + 3);
+    p->profile.backend_dispatch_count += (uint64_t)n_steps * (p->plan.size() + (tail_fused ? 1 : 3));
     return ok ? 0 : -1;
 }
 
@@ -3578,7 +3645,7 @@ int64_t zgml_hip_resident_prefill(zgml_hip_ctx* ctx, zgml_hip_program* p, const 
     ResidentPrepArgs a{r->embed, r->cos, r->sin, r->tok_in, r->mask, r->rope_bufs, r->dyn_kind, r->dyn_base, r->dyn_stride,
                        p->dyn_dev, r->state, r->tok_dev, r->d, r->max_seq, r->dh, r->n_rope, (uint32_t)p->ops.size(), n_tokens};
     const uint64_t total = (uint64_t)n_tokens * r->d + (uint64_t)n_tokens * r->max_seq + (uint64_t)r->n_rope * n_tokens * 2 * r->dh + p->ops.size();
-    resident_prep_kernel<<<(uint32_t)((total + 255) / 256), 256, 0, s>>>(a);
+    launch_resident_prep(s, a, (uint32_t)total);
     p->dyn_dirty = false;
     enqueue(p); // the plan (graph replay when enabled); flush_dyn is a no-op: the device words are current
     // the logits buffer holds one row per token: the greedy token comes from the LAST position's row

@@ -76,6 +76,7 @@ struct IoPlan {
     IoTableDev* table_dev = nullptr;
     uint32_t total_words = 0;
     bool word_aligned = true;
+    bool dyn_row = false; // (input plan) the table's last row scatters the program's dynamic words (prepare_io)
 };
 
 } // namespace zgml_rt
@@ -87,6 +88,10 @@ struct zgml_hip_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     bool opt_fusion = true, opt_graph = true, opt_profile = false, opt_skip_dead = true, opt_f16_dense = false;
+    // ZGML_HIP_HOST_PROF=1: host time of the drop-in path's phases — [0] refresh, [1] upload (pack + H2D + scatter), [2] enqueue
+    // (dynamic words + graph launch), [3] download (gather + D2H + wait + unpack) — printed by zgml_hip_destroy
+    bool host_prof = false;
+    uint64_t prof_ns[4] = {0, 0, 0, 0}, prof_calls[4] = {0, 0, 0, 0};
     bool opt_ksplit = false; // ZGML_HIP_OPT_KSPLIT (zgml_hip_create takes the default from ZGML_HIP_KSPLIT)
     int64_t opt_attn_split_min_keys = -1; // -1: environment / default (attn_split_for)
     int64_t opt_fuse_resident_wgs = -1;   // -1: one 1024-thread workgroup per CU (fuse_qkv_attention)
@@ -108,6 +113,7 @@ struct zgml_hip_ctx {
     // argmax scratch
     float* arg_val = nullptr;
     int64_t* arg_idx = nullptr;
+    uint32_t* arg_cnt = nullptr; // arrival counter of the fused token tail (launch_argmax_tail), re-armed by its last workgroup
     int64_t* arg_out = nullptr;
     int64_t* arg_out_host = nullptr; // pinned
     struct ShardState* shard = nullptr; // RCCL communicator of the row-shard path (zgml_hip_shard_*), else nullptr
@@ -143,6 +149,7 @@ struct zgml_resident;
 struct zgml_hip_program {
     zgml_hip_ctx* ctx = nullptr;
     std::vector<zgml_device_op> ops;
+    std::vector<uint32_t> dyn_ops;                    // indices of the ops with a dynamic field (own_ops)
     std::vector<std::vector<zgml_fused_step>> steps; // owned copies, per op
     std::vector<uint64_t> sizes;                      // f32 elements
     std::vector<float*> bufs;                         // device pointers (nullptr = elided)
@@ -204,6 +211,11 @@ struct zgml_hip_program {
     std::vector<void*> param_blobs;  // device parameter arrays of batched launches
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
+    // ... in two pieces: hipGraphLaunch costs the host ~0.36 us per kernel node BEFORE the device sees the first one (45-50 us for a
+    // 124-launch SmolLM token, all of it on the critical path of a blocking execute_program); the head piece is short, so the device
+    // starts after ~10 us and runs it while the host submits the tail
+    hipGraph_t graph_tail = nullptr;
+    hipGraphExec_t graph_tail_exec = nullptr;
     // host I/O staging
     void* stage_host = nullptr; // pinned
     void* stage_dev = nullptr;

@@ -16,6 +16,7 @@ struct HipBackend::Api {
                             const zgml_matmul_geom*);
     zgml_hip_program* (*compile_program)(zgml_hip_ctx*, const zgml_device_program*);
     void (*refresh_program)(zgml_hip_ctx*, zgml_hip_program*, const zgml_device_op*, uint64_t);
+    int (*refresh_dynamic)(zgml_hip_ctx*, zgml_hip_program*, uint32_t, uint32_t);
     void (*execute_program)(zgml_hip_ctx*, zgml_hip_program*, const zgml_program_io*, uint64_t, const zgml_program_io*,
                             uint64_t);
     void (*free_program)(zgml_hip_ctx*, zgml_hip_program*);
@@ -41,6 +42,17 @@ Backend::CompiledHandle vt_compile(void* c, const DeviceProgram& p) {
 }
 void vt_refresh(void* c, Backend::CompiledHandle hd, const DeviceOp* ops, size_t n) {
     auto* h = (HipCtx*)c;
+    // the per-token case as two numbers (zig/backend_hip.zig: refreshProgram; stepDynamicStateFromOps, src/backend/program.zig:7466-7490)
+    uint32_t slice_pos = 0, seq_kv = 0;
+    bool has_sa = false, has_att = false;
+    for (size_t i = 0; i < n && !(has_sa && has_att); i++) {
+        const DeviceOp& op = ops[i];
+        if (op.kind == ZGML_DOP_SLICE_ASSIGN && !has_sa && op.u.slice_assign.patch_stride != 0 && op.u.slice_assign.dst_offset >= op.u.slice_assign.dst_base_offset)
+            slice_pos = (op.u.slice_assign.dst_offset - op.u.slice_assign.dst_base_offset) / op.u.slice_assign.patch_stride, has_sa = true;
+        else if (op.kind == ZGML_DOP_ATTENTION && !has_att)
+            seq_kv = op.u.attention.seq_kv, has_att = true;
+    }
+    if ((has_sa || has_att) && h->api->refresh_dynamic && h->api->refresh_dynamic(h->ctx, (zgml_hip_program*)hd, slice_pos, seq_kv) == 0) return;
     h->api->refresh_program(h->ctx, (zgml_hip_program*)hd, ops, n);
 }
 void vt_execute(void* c, Backend::CompiledHandle hd, const ProgramIO* in, size_t n_in, const ProgramIO* out, size_t n_out) {
@@ -79,6 +91,7 @@ bool HipBackend::init(const char* lib_path, int device_ordinal) {
     SYM(dense_matmul_f32, "zgml_hip_dense_matmul_f32")
     SYM(compile_program, "zgml_hip_compile_program")
     SYM(refresh_program, "zgml_hip_refresh_program")
+    SYM(refresh_dynamic, "zgml_hip_refresh_dynamic")
     SYM(execute_program, "zgml_hip_execute_program")
     SYM(free_program, "zgml_hip_free_program")
     SYM(get_runtime_profile, "zgml_hip_get_runtime_profile")

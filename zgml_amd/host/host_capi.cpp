@@ -48,6 +48,10 @@ struct zh_session {
     zh_model* m;
     zh_backend_fns fns;
     void* handle;
+    // the adapter's per-token refresh (zig/backend_hip.zig: refreshProgram): when set, a step derives (slice_pos, seq_kv) from the
+    // patched ops exactly as the reference does for its wgpu backend (stepDynamicStateFromOps, src/backend/program.zig:7466-7490)
+    // and hands over those two numbers instead of the whole op list
+    int (*refresh_dynamic)(void* ctx, void* handle, uint32_t slice_pos, uint32_t seq_kv) = nullptr;
 };
 
 void zh_preset(const char* name, uint32_t max_seq, zh_config* out) {
@@ -98,6 +102,7 @@ uint32_t zh_model_token_len(zh_model* m) { return m->dp->token_len; }
 // One execution of a token_len = N plan (prefill chunk): patch, refresh, execute; logits of the
 // last position are left in the model's host buffer. Returns its greedy token.
 int64_t zh_session_prefill(struct zh_session* s, const uint32_t* tokens, uint32_t pos, float* logits_out);
+void zh_session_set_refresh_dynamic(struct zh_session* s, int (*fn)(void*, void*, uint32_t, uint32_t));
 
 const zgml_program_io* zh_model_step_inputs(zh_model* m, uint64_t* n) {
     *n = m->dp->step_inputs.size();
@@ -156,11 +161,39 @@ void zh_session_free(zh_session* s) {
 
 void* zh_session_handle(zh_session* s) { return s->handle; }
 
+void zh_session_set_refresh_dynamic(zh_session* s, int (*fn)(void*, void*, uint32_t, uint32_t)) { s->refresh_dynamic = fn; }
+
+// stepDynamicStateFromOps (src/backend/program.zig:7466-7490): the first dynamic slice_assign gives slice_pos, the first attention
+// seq_kv; false when the op list has neither (then the whole list is refreshed)
+static bool step_dynamic_state(const std::vector<zgml::backend::DeviceOp>& ops, uint32_t& slice_pos, uint32_t& seq_kv) {
+    bool has_sa = false, has_att = false;
+    for (const zgml::backend::DeviceOp& op : ops) {
+        if (op.kind == ZGML_DOP_SLICE_ASSIGN && !has_sa && op.u.slice_assign.patch_stride != 0 && op.u.slice_assign.dst_offset >= op.u.slice_assign.dst_base_offset) {
+            slice_pos = (op.u.slice_assign.dst_offset - op.u.slice_assign.dst_base_offset) / op.u.slice_assign.patch_stride;
+            has_sa = true;
+        } else if (op.kind == ZGML_DOP_KVQ_STORE && !has_sa && op.u.kvq_store.patch_stride != 0 && op.u.kvq_store.col >= op.u.kvq_store.col_base) { // (extension op: same role)
+            slice_pos = (op.u.kvq_store.col - op.u.kvq_store.col_base) / op.u.kvq_store.patch_stride;
+            has_sa = true;
+        } else if (op.kind == ZGML_DOP_ATTENTION && !has_att) {
+            seq_kv = op.u.attention.seq_kv, has_att = true;
+        } else if (op.kind == ZGML_DOP_ATTENTION_KVQ && !has_att) {
+            seq_kv = op.u.attention_kvq.seq_kv, has_att = true;
+        }
+        if (has_sa && has_att) break;
+    }
+    return has_sa || has_att;
+}
+static void session_refresh(zh_session* s, DecodeProgram& dp) {
+    uint32_t slice_pos = 0, seq_kv = 0;
+    if (s->refresh_dynamic && step_dynamic_state(dp.program.ops, slice_pos, seq_kv) && s->refresh_dynamic(s->fns.ctx, s->handle, slice_pos, seq_kv) == 0) return;
+    s->fns.refresh_program(s->fns.ctx, s->handle, dp.program.ops.data(), dp.program.ops.size());
+}
+
 // doStep (llama_smollm_bench.zig:290-314): patch, refresh, execute. Returns the greedy token.
 int64_t zh_session_step(zh_session* s, uint32_t token, uint32_t pos, float* logits_out) {
     DecodeProgram& dp = *s->m->dp;
     patch_step(*s->m->model, dp, token, pos);
-    s->fns.refresh_program(s->fns.ctx, s->handle, dp.program.ops.data(), dp.program.ops.size());
+    session_refresh(s, dp);
     s->fns.execute_program(s->fns.ctx, s->handle, dp.step_inputs.data(), dp.step_inputs.size(), dp.step_outputs.data(),
                            dp.step_outputs.size());
     if (logits_out) std::memcpy(logits_out, dp.logits_host.data(), dp.logits_host.size() * sizeof(float));
@@ -170,7 +203,7 @@ int64_t zh_session_step(zh_session* s, uint32_t token, uint32_t pos, float* logi
 int64_t zh_session_prefill(zh_session* s, const uint32_t* tokens, uint32_t pos, float* logits_out) {
     DecodeProgram& dp = *s->m->dp;
     patch_tokens(*s->m->model, dp, tokens, pos);
-    s->fns.refresh_program(s->fns.ctx, s->handle, dp.program.ops.data(), dp.program.ops.size());
+    session_refresh(s, dp);
     s->fns.execute_program(s->fns.ctx, s->handle, dp.step_inputs.data(), dp.step_inputs.size(), dp.step_outputs.data(),
                            dp.step_outputs.size());
     if (logits_out) std::memcpy(logits_out, dp.logits_host.data(), dp.logits_host.size() * sizeof(float));

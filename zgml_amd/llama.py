@@ -70,6 +70,7 @@ def load_host() -> C.CDLL:
         lib.zh_session_handle.argtypes, lib.zh_session_handle.restype = [vp], vp
         lib.zh_session_step.argtypes, lib.zh_session_step.restype = [vp, u32, u32, vp], C.c_int64
         lib.zh_session_decode.argtypes, lib.zh_session_decode.restype = [vp, u32, u32, u32, vp], C.c_double
+        lib.zh_session_set_refresh_dynamic.argtypes, lib.zh_session_set_refresh_dynamic.restype = [vp, vp], None
         _lib = lib
     return _lib
 
@@ -161,6 +162,11 @@ class Session:
     @property
     def handle(self):
         return self.lib.zh_session_handle(self.ptr)
+
+    def use_dynamic_refresh(self, on: bool = True) -> None:
+        """The adapter's per-token refresh (zig/backend_hip.zig: refreshProgram): (slice_pos, seq_kv) through
+        zgml_hip_refresh_dynamic instead of the whole op list through zgml_hip_refresh_program. HIP sessions only."""
+        self.lib.zh_session_set_refresh_dynamic(self.ptr, _fn_addr(capi.load_hip(), "zgml_hip_refresh_dynamic") if on else None)
 
     def step(self, token: int, pos: int, want_logits: bool = True):
         logits = np.zeros(self.model.cfg.vocab_size, np.float32) if want_logits else None

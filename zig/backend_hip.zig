@@ -15,6 +15,7 @@
 const std = @import("std");
 const backend_mod = @import("../backend.zig");
 const profile = @import("../profile.zig");
+const backend_program = @import("program.zig"); // src/backend/program.zig: stepDynamicStateFromOps
 const c = @cImport(@cInclude("zgml_hip.h"));
 
 comptime {
@@ -43,6 +44,9 @@ comptime {
 pub const HipBackend = struct {
     ctx: *c.zgml_hip_ctx,
     profile_storage: profile.RuntimeProfile = .{},
+    /// refresh_program re-sends the whole op list (the cpu backend's contract: a changed static field is honoured) instead of the
+    /// two dynamic numbers (the wgpu backend's, the default here: see refreshProgram)
+    strict_refresh: bool = false,
 
     /// null device / not a gfx950 / library missing: error.HipNotAvailable; `lastError(null)` says why.
     pub fn init(device_ordinal: c_int) !HipBackend {
@@ -215,10 +219,19 @@ fn compileProgram(ctx: *anyopaque, program: backend_mod.DeviceProgram) ?backend_
 }
 
 fn refreshProgram(ctx: *anyopaque, handle: backend_mod.Backend.CompiledHandle, ops: []const backend_mod.DeviceOp) void {
+    const self = selfOf(ctx);
+    // The per-token case, as the wgpu backend handles it (src/backend/wgpu.zig:1162-1169): the refresh IS two numbers — the KV
+    // stores' column and the attentions' seq_kv (src/backend/program.zig:7466-7490) — so derive them from the first dynamic ops and
+    // hand those over: O(#dynamic ops) in the library, no flattening of 1654 ops here. `strict_refresh` (off by default) keeps
+    // the cpu backend's semantics instead: every field of every op is re-read, a changed static field rebuilds the launch list.
+    if (!self.strict_refresh) {
+        const st = backend_program.stepDynamicStateFromOps(ops);
+        if (st.needsUpload() and c.zgml_hip_refresh_dynamic(self.ctx, @ptrCast(handle), st.params.slice_pos, st.params.seq_kv) == 0) return;
+    }
     var arena = std.heap.ArenaAllocator.init(std.heap.page_allocator);
     defer arena.deinit();
     const flat = flattenOps(arena.allocator(), ops) catch return;
-    c.zgml_hip_refresh_program(selfOf(ctx).ctx, @ptrCast(handle), flat.ptr, flat.len);
+    c.zgml_hip_refresh_program(self.ctx, @ptrCast(handle), flat.ptr, flat.len);
 }
 
 fn executeProgram(ctx: *anyopaque, handle: backend_mod.Backend.CompiledHandle, inputs: []const backend_mod.ProgramIO, outputs: []const backend_mod.ProgramIO) void {
