@@ -729,6 +729,12 @@ def bench_sharded(args):
         os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29533"
     dist.init_process_group("gloo", rank=rank, world_size=ws)
     be = Backend(local)
+    # one diagnosable log for the first real multi-device run: per rank, the device it sits on and which peers it can
+    # address (hipDeviceCanAccessPeer: what the peer-store gather needs); gather mode and microseconds per gather point follow below
+    n_dev = be._lib.zgml_hip_device_count()
+    peer_row = [be._lib.zgml_hip_device_can_access_peer(local, d) for d in range(n_dev)]
+    log(f"[bench] rank {rank}/{ws}: device ordinal {local} of {n_dev} visible; can access peers {peer_row}; "
+        f"HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}; ZGML_SHARD_GATHER={os.environ.get('ZGML_SHARD_GATHER', 'auto')}")
 
     def exchange_id(mine: bytes) -> bytes:
         t = torch.tensor(list(mine), dtype=torch.uint8)
@@ -825,6 +831,10 @@ def bench_sharded(args):
         if i:  # (the first eager step after graph replays pays one-off costs)
             prof["step_us"].append(su)
             prof["gather_us"].append(gu)
+    point_us = dec.last_point_us()
+    log(f"[bench] rank {rank}: gather mode {gather_mode}; step mode {dec.mode}; eager step {prof['step_us'][-1] if prof['step_us'] else None} us, "
+        f"of which gathers {prof['gather_us'][-1] if prof['gather_us'] else None} us; per gather point (first layer's four, then the last two): "
+        f"{point_us[:4]} ... {point_us[-2:]}")
     n_gather = max(1, dec.n_points)
     gather_us = sum(prof["gather_us"]) / max(1, len(prof["gather_us"]))
     eager_us = sum(prof["step_us"]) / max(1, len(prof["step_us"]))
@@ -861,6 +871,7 @@ def bench_sharded(args):
                 "traffic": None, "kernel": "per-rank weight stream of one sharded decode token (all quantized mat-vecs of the rank)",
                 "bytes_per_token_per_rank": qb, "all_gathers_per_token": dec.n_points if ws > 1 else 0,
                 "us_per_all_gather": round(gather_us / n_gather, 2), "gather_us_per_token": round(gather_us, 1),
+                "us_per_gather_point_first_layer": point_us[:4], "peer_access_row_rank0": peer_row, "device_ordinal_rank0": local,
                 "eager_step_us": round(eager_us, 1), "gather_share_of_eager_step": round(gather_us / eager_us, 3) if eager_us else None,
                 "timing": "value: host clock around K graph-replayed steps, max over ranks; gather figures: HIP events around every gather point "
                           "of 3 eager steps on rank 0 (zgml_hip_shard_profile_step)"}

@@ -510,6 +510,12 @@ int zgml_hip_shard_peer_import(zgml_hip_ctx* ctx, zgml_hip_program* program, int
  * collectives inside it (launch-bound: eager steps are slower than graph replays; the ratio is what it is for). */
 int64_t zgml_hip_shard_profile_step(zgml_hip_ctx* ctx, zgml_hip_program* program, const zgml_program_io* inputs, uint64_t n_inputs,
                                     double* step_us, double* gather_us);
+/* ... and, gather point by gather point, the microseconds of the last profiled step (writes min(cap, points) values; returns the
+ * number of points). With the device ordinal and the peer-access row below, the first multi-device run can be read from one log. */
+uint64_t zgml_hip_shard_last_point_us(zgml_hip_program* program, double* out, uint64_t cap);
+/* hipDeviceCanAccessPeer(device, peer) as 0 / 1 (-1: the query failed); touches no context. */
+int zgml_hip_device_can_access_peer(int device, int peer);
+int zgml_hip_device_count(void);
 
 /* Device-resident greedy decode for LLaMA-shaped programs (measurement protocol: inputs already
  * in HBM when the timed region starts). The reference's per-token host work — embedding-row

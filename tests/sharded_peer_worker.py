@@ -110,11 +110,21 @@ def run_lonely():
     for d in decs:
         for r, h in enumerate(handles):
             d.import_handle(r, h)
+    import time
     try:
         decs[0].step(3, 0)
         raise SystemExit("a lonely rank's step succeeded")
     except RuntimeError as e:
-        assert "hand-off" in str(e) or "timed out" in str(e), str(e)
+        assert "peer gather" in str(e) and "timed out" in str(e), str(e)  # (the PEER cause: the q/k/v + attention fusion of the context stays on)
+    # ... and the rank that was merely late must not get a token out of the failed rank's stale slices: rank 0's
+    # give-up poisoned every block, so rank 1's step fails too — at once, not after its own bound
+    t0 = time.perf_counter()
+    try:
+        tok = decs[1].step(3, 0)
+        raise SystemExit(f"the late rank's step returned token {tok} although its peer had failed the step")
+    except RuntimeError as e:
+        assert "peer gather" in str(e), str(e)
+    assert time.perf_counter() - t0 < 0.15, "the late rank waited its own bound instead of seeing the poison"
     print("PEER_LONELY_OK")
 
 

@@ -194,7 +194,7 @@ HIP_SYMBOLS = [
     "zgml_hip_qmatmul_bench", "zgml_hip_qmatvec_overlap_bench", "zgml_hip_qmatvec_streams_bench", "zgml_hip_qmatvec_chain_bench", "zgml_hip_dense_f16_bench", "zgml_hip_dense_cache_invalidate", "zgml_hip_dense_cache_stats",
     "zgml_hip_qmatvec_synth", "zgml_hip_copy_bench", "zgml_hip_resident_setup", "zgml_hip_resident_decode",
     "zgml_hip_resident_prefill", "zgml_hip_shard_unique_id", "zgml_hip_shard_init", "zgml_hip_shard_destroy", "zgml_hip_shard_attach", "zgml_hip_shard_step", "zgml_hip_shard_step_mode",
-    "zgml_hip_shard_profile_step", "zgml_hip_shard_init_peer", "zgml_hip_shard_peer_export", "zgml_hip_shard_peer_import",
+    "zgml_hip_shard_profile_step", "zgml_hip_shard_last_point_us", "zgml_hip_device_can_access_peer", "zgml_hip_device_count", "zgml_hip_shard_init_peer", "zgml_hip_shard_peer_export", "zgml_hip_shard_peer_import",
     "zgml_hip_program_plan_text",
 ]
 
@@ -293,6 +293,13 @@ def _bind_hip(lib: C.CDLL) -> None:
         lib.zgml_hip_shard_init_peer.restype, lib.zgml_hip_shard_init_peer.argtypes = i32, [vp, i32, i32]
         lib.zgml_hip_shard_peer_export.restype, lib.zgml_hip_shard_peer_export.argtypes = i32, [vp, vp, C.POINTER(ShardPeerHandleC)]
         lib.zgml_hip_shard_peer_import.restype, lib.zgml_hip_shard_peer_import.argtypes = i32, [vp, vp, i32, C.POINTER(ShardPeerHandleC)]
+    if hasattr(lib, "zgml_hip_shard_last_point_us"):
+        lib.zgml_hip_shard_last_point_us.restype = u64
+        lib.zgml_hip_shard_last_point_us.argtypes = [vp, C.POINTER(C.c_double), u64]
+        lib.zgml_hip_device_can_access_peer.restype = C.c_int
+        lib.zgml_hip_device_can_access_peer.argtypes = [C.c_int, C.c_int]
+        lib.zgml_hip_device_count.restype = C.c_int
+        lib.zgml_hip_device_count.argtypes = []
     if hasattr(lib, "zgml_hip_shard_profile_step"):
         lib.zgml_hip_shard_profile_step.restype = C.c_int64
         lib.zgml_hip_shard_profile_step.argtypes = [vp, vp, C.POINTER(ProgramIOC), u64, C.POINTER(C.c_double), C.POINTER(C.c_double)]

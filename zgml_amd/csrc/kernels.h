@@ -443,6 +443,7 @@ bool launch_qkv_attention(hipStream_t s, const QmvLaunch& L, const AttnDecodePar
 bool launch_attention_o(hipStream_t s, const AttnDecodeParams* dev_params, uint32_t n_heads, uint32_t d_head, const AttnSplit& sp, const QmvLaunch& o_proj,
                         uint32_t* out_cnt, uint32_t* o_seen, uint32_t* timeout);
 int attn_o_blocks_per_cu(uint32_t d_head);
+int qkv_attn_kon_census(hipStream_t s, uint32_t d_head, bool kvq, uint32_t grid); // 1 = the whole grid of that launch is co-resident (run once, plan-build time), 0 = not, -1 = unknown
 int qkv_attn_kon_blocks_per_cu(uint32_t d_head, bool kvq); // fused q / k / v + attention launch of K-on-lanes weights (256-thread workgroups) // occupancy query of that kernel
 // (o_proj: the single-matrix projection that reads the heads' row stores rides in the same launch; out_cnt: one zeroed
 // word, o_seen: one zeroed word per workgroup of that projection)
@@ -522,6 +523,7 @@ struct PeerGatherArgs {
     uint64_t ctr_off, stage_off; // byte offsets of the point's arrival counter / staging area inside a block
     uint64_t wait_ticks;         // give-up bound of the wait, 100 MHz ticks
     uint32_t len, rank, world;
+    uint64_t poison_off;         // byte offset of the block's poison word (set in EVERY rank's block by a rank whose wait gave up)
 };
 struct PeerArgmaxArgs {
     char* const* blocks;
@@ -531,6 +533,7 @@ struct PeerArgmaxArgs {
     int64_t* out;       // the greedy token (-1 after a give-up)
     uint64_t ctr_off, pairs_off, wait_ticks;
     uint32_t len, rank, world;
+    uint64_t poison_off;
 };
 void launch_peer_gather(hipStream_t s, const PeerGatherArgs& a);
 void launch_peer_argmax(hipStream_t s, const PeerArgmaxArgs& a);

@@ -1234,6 +1234,7 @@ struct QkvAttnArgs {
     uint32_t kvq; // int8 KV caches (the attention half's template variant)
     QmvPublish pub;
     DecodeHandoff ho;
+    uint32_t* census; // (the CENSUS instantiation of qkv_attn_kon_kernel only) [0] arrivals, [1] set when a workgroup gave up waiting for the grid
 };
 template <typename ST, bool Q4, int LPK, bool KVQ, int PROM = 1>
 __global__ void __launch_bounds__(1024) qkv_attn_kernel(QMV_HEAD_PARAMS, QMVArgs a, QkvAttnArgs f) {
@@ -1254,8 +1255,28 @@ __global__ void __launch_bounds__(1024) qkv_attn_kernel(QMV_HEAD_PARAMS, QMVArgs
 // four per CU at <= 128 registers and 96-100 SGPRs, which both the register file and the guide's SGPR admission rule confirm — NO
 // margin: the 7B grid is exactly 1024 = 4 x 256; the projection's workgroups carry the lower ids, so should fewer be resident than
 // counted the attention's workgroups queue behind them instead of spinning beside them; a wait that gives up is bounded and loud).
-template <int LPK, int DEPTH, int PROM, bool NT, bool KVQ>
+// CENSUS = true: the SAME kernel (both bodies compiled in: same registers, same LDS, same launch bounds — the launcher checks the
+// register counts agree) whose workgroups, handed a census block, only count themselves and wait (bounded: 200 us) until the
+// whole grid has arrived. The planner runs it once per grid size before it builds the fused launch (qkv_attn_kon_census): the
+// attention's workgroups spin on workgroups of the same grid, the occupancy query can read one workgroup per CU high near a
+// register-file edge (guide: residency and cooperative launch), and the 7B grid is exactly 4 x 256 with no margin.
+template <int LPK, int DEPTH, int PROM, bool NT, bool KVQ, bool CENSUS = false>
 __global__ void __launch_bounds__(256, 4) qkv_attn_kon_kernel(QMV_HEAD_PARAMS, QMVArgs a, QkvAttnArgs f) {
+    if (CENSUS && f.census) {
+        if (threadIdx.x == 0) {
+            using gu32c = __attribute__((address_space(1))) uint32_t;
+            __hip_atomic_fetch_add((gu32c*)f.census, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+            while (__hip_atomic_load((gu32c*)f.census, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 20000u) { // 200 us of the 100 MHz clock: somebody is not resident
+                    __hip_atomic_store((gu32c*)f.census + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+        return;
+    }
     if (blockIdx.x < f.n_mv) {
         qmatvec_kon_body<DEPTH, PROM, true, true, NT>(qs0, sc0, out0, xa_base, xb_base, in_rs, K, nb2_0_flags, nb2_12, a, blockIdx.x, f.n_mv, &f.pub);
     } else {
@@ -1970,6 +1991,36 @@ bool launch_qkv_attention(hipStream_t s, const QmvLaunch& L, const AttnDecodePar
 // the decode attention of `n_heads` heads + the single-matrix K-on-lanes projection that reads their row stores, one launch
 // (attn_o_kon_kernel). `out_cnt`: one zeroed word, `o_seen`: one zeroed word per workgroup of the projection. false: not a shape the
 // kernel is built for (nothing launched). attn_o_blocks_per_cu(): what the occupancy query admits per CU (for the planner's guard).
+// Is a grid of `grid` 256-thread workgroups of the fused K-on-lanes launch co-resident on this device? Runs the kernel's CENSUS
+// instantiation once (synchronises the stream: plan-build time only). 1 = every workgroup saw the whole grid arrive, 0 = some
+// workgroup waited in vain (the launch must not be fused), -1 = the census could not run (the caller falls back to the occupancy query).
+int qkv_attn_kon_census(hipStream_t s, uint32_t d_head, bool kvq, uint32_t grid) {
+    using Fn = void (*)(const uint4*, const void*, float*, const float*, const float*, uint32_t, uint32_t, uint32_t, uint32_t, QMVArgs, QkvAttnArgs);
+    const Fn census = d_head == 64 ? (kvq ? (Fn)qkv_attn_kon_kernel<16, 4, 2, true, true, true> : (Fn)qkv_attn_kon_kernel<16, 4, 2, true, false, true>)
+                                   : (kvq ? (Fn)qkv_attn_kon_kernel<32, 4, 2, true, true, true> : (Fn)qkv_attn_kon_kernel<32, 4, 2, true, false, true>);
+    const Fn product = d_head == 64 ? (kvq ? (Fn)qkv_attn_kon_kernel<16, 4, 2, true, true> : (Fn)qkv_attn_kon_kernel<16, 4, 2, true, false>)
+                                    : (kvq ? (Fn)qkv_attn_kon_kernel<32, 4, 2, true, true> : (Fn)qkv_attn_kon_kernel<32, 4, 2, true, false>);
+    hipFuncAttributes fa{}, fb{};
+    if (hipFuncGetAttributes(&fa, (const void*)census) != hipSuccess || hipFuncGetAttributes(&fb, (const void*)product) != hipSuccess) return -1;
+    if (fa.numRegs < fb.numRegs || fa.sharedSizeBytes != fb.sharedSizeBytes) return -1; // (the census must be at least as heavy as what it stands for)
+    uint32_t* blk = nullptr;
+    if (hipMalloc((void**)&blk, 8) != hipSuccess) return -1;
+    int result = -1;
+    uint32_t host[2] = {0, 1};
+    if (hipMemsetAsync(blk, 0, 8, s) == hipSuccess) {
+        QMVArgs a{};
+        QkvAttnArgs f{};
+        f.census = blk;
+        const size_t lds = ((size_t)kMaxWaves * 16 + kMaxWaves) * sizeof(float);
+        hipLaunchKernelGGL(census, dim3(grid), dim3(256), lds, s, (const uint4*)nullptr, (const void*)nullptr, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0u, 0u, 0u,
+                           0u, a, f);
+        if (hipMemcpyAsync(host, blk, 8, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess)
+            result = host[0] == grid && host[1] == 0 ? 1 : 0;
+    }
+    hipFree(blk);
+    return result;
+}
+
 int qkv_attn_kon_blocks_per_cu(uint32_t d_head, bool kvq) { // what the occupancy query admits per CU for the fused K-on-lanes launch (the deepest variant)
     int nb = 0;
     const void* fn = d_head == 64 ? (kvq ? (const void*)qkv_attn_kon_kernel<16, 4, 2, true, true> : (const void*)qkv_attn_kon_kernel<16, 4, 2, true, false>)

@@ -906,6 +906,20 @@ void fuse_qkv_attention(zgml_hip_program* p) {
         n_sp = (uint32_t)std::min<uint64_t>(n_sp, (cap - n_mv) / nh);
         for (uint32_t t = 0; kon && t < 3; t++) ok = ok && L.parts[t].w.format == QW_Q4K;
         if (!ok) continue;
+        if (kon && p->ctx->opt_fuse_resident_wgs < 0) {
+            // ... and the grid it comes to is CENSUSED once per context and size: the kernel's own census instantiation counts its
+            // workgroups and each waits (bounded) for all of them — co-residency measured, not inferred
+            const uint32_t grid = (uint32_t)(n_mv + (uint64_t)nh * n_sp);
+            const uint64_t key = ((uint64_t)ad->dh << 40) | ((uint64_t)(kvq ? 1 : 0) << 32) | grid;
+            auto it = p->ctx->census.find(key);
+            if (it == p->ctx->census.end()) {
+                static const bool census_on = !(getenv("ZGML_HIP_FUSE_CENSUS") && atoi(getenv("ZGML_HIP_FUSE_CENSUS")) == 0);
+                const int r = census_on ? qkv_attn_kon_census(p->ctx->stream, ad->dh, kvq, grid) : -1;
+                it = p->ctx->census.emplace(key, r).first;
+                if (r == 0) fprintf(stderr, "[zgml_hip] the fused q/k/v + attention launch of %u workgroups is NOT co-resident on this device (census): two launches instead\n", grid);
+            }
+            if (it->second == 0) continue;
+        }
         // ... and the single-matrix projection that reads exactly the heads' row stores (the O projection) rides along:
         // no prologue, K = n_heads * d_head, every head's rows stored at its static offset h * d_head of that input
         std::shared_ptr<QmvLaunch> od = i + 2 < p->plan.size() ? p->plan[i + 2].qmv_desc : nullptr;

@@ -126,9 +126,16 @@ struct zgml_hip_ctx {
     bool fuse_qkv_off = false;
     uint64_t fuse_epoch = 0;
     int n_cu = 0; // compute units (residency guard of the fused launch)
+    std::map<uint64_t, int> census; // (d_head, kvq, grid) -> qkv_attn_kon_census result: measured co-residency of the fused K-on-lanes launch
     bool handoff_ok(const char* where) {
         if (!handoff_flag || !*(volatile uint32_t*)handoff_flag) return true;
+        const uint32_t cause = *(volatile uint32_t*)handoff_flag; // 1: a fused launch's in-launch hand-off; 2: a peer gather's wait (shard_peer.hip kHandoffPeer)
         *(volatile uint32_t*)handoff_flag = 0;
+        if (cause == 2) { // a slow or failed PEER says nothing about the fusion: leave it on, no plan rebuild
+            fail(std::string(where) + ": a peer gather's wait at a gather point timed out (or a peer had already failed the step) — the results of "
+                                      "this step are wrong on every rank; all ranks must re-attach (zgml_hip_shard_attach + peer export / import) before stepping again");
+            return false;
+        }
         fuse_qkv_off = true, fuse_epoch++;
         fail(std::string(where) + ": an in-launch hand-off wait of a fused q/k/v + attention launch timed out — the results of this run are wrong; "
                                   "the fusion is now off for this context (later runs use two launches)");
@@ -232,6 +239,7 @@ struct zgml_hip_program {
     hipGraph_t shard_graph = nullptr;
     hipGraphExec_t shard_graph_exec = nullptr;
     bool shard_capture_failed = false;
+    std::vector<double> shard_point_us; // per gather point: microseconds in the last zgml_hip_shard_profile_step
     // the greedy token as a (max, index) pair per rank instead of a gather of the logits (the last gather point covers the logits
     // buffer): device pairs [world] for the collective mode; and the peer-store gather's state (shard_peer.hip)
     bool shard_pair_argmax = false;

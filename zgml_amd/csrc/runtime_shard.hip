@@ -50,7 +50,7 @@ bool shard_load(zgml_hip_ctx* ctx, ShardState* st) {
 ShardState g_shard_loader; // for zgml_hip_shard_unique_id (no context yet)
 } // namespace
 // Peer-store gather state of one program (shard_peer.hip): ONE fine-grained block per rank —
-//   [arrival counters: (n_points + 1) x 128 B][staging of point 0: world x len_0 f32][...][pairs: world x 8 B]
+//   [arrival counters: (n_points + 1) x 128 B][poison word: 128 B][staging of point 0: world x len_0 f32][...][pairs: world x 8 B]
 // — that every peer maps (hipIpc, or the raw pointer inside one process) and writes; this rank's private `seen` words and the
 // device table of the mapped blocks. The layout is a function of the gather points only, so it is the same on every rank.
 struct ShardPeer {
@@ -58,6 +58,7 @@ struct ShardPeer {
     uint64_t bytes = 0;
     std::vector<uint64_t> stage_off; // per point, bytes
     uint64_t pairs_off = 0;
+    uint64_t poison_off = 0;         // one word every rank's give-up sets in every block (shard_peer.hip: peer_poison)
     uint32_t* seen = nullptr;        // [n_points + 1] device words
     std::vector<char*> mapped;       // per rank: its block as this process sees it (own = block)
     std::vector<char> ipc_opened;    // per rank: mapped through hipIpcOpenMemHandle (closed on free)
@@ -106,7 +107,7 @@ bool shard_segments(zgml_hip_ctx* ctx, zgml_hip_program* p, std::vector<hipEvent
             const float* const slice = full + (uint64_t)st->rank * gp.len_per_rank;
             if (st->peer) {
                 PeerArgmaxArgs a{sp->table_dev, slice, sp->seen + gi, ctx->handoff_flag_dev, ctx->arg_out, (uint64_t)gi * 128, sp->pairs_off, peer_wait_ticks(),
-                                 gp.len_per_rank, (uint32_t)st->rank, (uint32_t)st->world};
+                                 gp.len_per_rank, (uint32_t)st->rank, (uint32_t)st->world, sp->poison_off};
                 launch_peer_argmax(ctx->stream, a);
             } else {
                 launch_local_argmax_pair(ctx->stream, slice, gp.len_per_rank, (uint32_t)st->rank, p->shard_pairs);
@@ -115,7 +116,7 @@ bool shard_segments(zgml_hip_ctx* ctx, zgml_hip_program* p, std::vector<hipEvent
             }
         } else if (st->peer) {
             PeerGatherArgs a{sp->table_dev, full, sp->seen + gi, ctx->handoff_flag_dev, (uint64_t)gi * 128, sp->stage_off[gi], peer_wait_ticks(), gp.len_per_rank,
-                             (uint32_t)st->rank, (uint32_t)st->world};
+                             (uint32_t)st->rank, (uint32_t)st->world, sp->poison_off};
             launch_peer_gather(ctx->stream, a);
         } else {
             rc = st->all_gather(full + (uint64_t)st->rank * gp.len_per_rank, full, gp.len_per_rank, kNcclFloat, st->comm, ctx->stream);
@@ -203,6 +204,10 @@ int zgml_hip_shard_attach(zgml_hip_ctx* ctx, zgml_hip_program* p, const zgml_sha
         static const bool pairs_on = !(getenv("ZGML_SHARD_PAIR_ARGMAX") && atoi(getenv("ZGML_SHARD_PAIR_ARGMAX")) == 0);
         p->shard_pair_argmax = pairs_on && last.buf_idx == logits_buf && last.offset == 0 && (uint64_t)world * last.len_per_rank == vocab;
     }
+    if (p->shard_pair_argmax && world > 64) { // (the pair block — device array or the peer block's slots — holds 64 entries, in BOTH gather modes)
+        ctx->fail("shard_attach: the (max, index) pair gather of the greedy token holds at most 64 ranks");
+        return -1;
+    }
     if (p->shard_pair_argmax && !p->shard_pairs) {
         if (!CTX_CHECK(ctx, hipMalloc((void**)&p->shard_pairs, 64 * sizeof(unsigned long long)))) return -1;
         p->owned.push_back(p->shard_pairs);
@@ -213,7 +218,8 @@ int zgml_hip_shard_attach(zgml_hip_ctx* ctx, zgml_hip_program* p, const zgml_sha
             return -1;
         }
         ShardPeer* sp = new ShardPeer();
-        uint64_t off = (n_points + 1) * 128;
+        sp->poison_off = (n_points + 1) * 128;
+        uint64_t off = (n_points + 2) * 128;
         for (uint64_t i = 0; i < n_points; i++) {
             const zgml_shard_point& gp = points[i];
             if (gp.len_per_rank % 2 || ((uintptr_t)(p->bufs[gp.buf_idx] + gp.offset) % 8) != 0) {
@@ -365,13 +371,37 @@ int64_t zgml_hip_shard_profile_step(zgml_hip_ctx* ctx, zgml_hip_program* p, cons
     if (ok) {
         float ms = 0;
         double g = 0;
+        p->shard_point_us.assign(p->shard_points.size(), 0.0);
         for (size_t i = 0; i < p->shard_points.size(); i++)
-            if (hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]) == hipSuccess) g += ms * 1e3;
+            if (hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]) == hipSuccess) g += ms * 1e3, p->shard_point_us[i] = ms * 1e3;
         if (gather_us) *gather_us = g;
         if (step_us && hipEventElapsedTime(&ms, ev[ev.size() - 2], ev[ev.size() - 1]) == hipSuccess) *step_us = ms * 1e3;
     }
     for (auto& e : ev) hipEventDestroy(e);
     return ok ? *ctx->arg_out_host : -1;
+}
+
+uint64_t zgml_hip_shard_last_point_us(zgml_hip_program* p, double* out, uint64_t cap) {
+    if (!p) return 0;
+    for (uint64_t i = 0; out && i < cap && i < p->shard_point_us.size(); i++) out[i] = p->shard_point_us[i];
+    return p->shard_point_us.size();
+}
+int zgml_hip_device_can_access_peer(int device, int peer) {
+    int can = 0;
+    if (device == peer) return 1;
+    if (hipDeviceCanAccessPeer(&can, device, peer) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    return can ? 1 : 0;
+}
+int zgml_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
 }
 
 int zgml_hip_shard_step_mode(zgml_hip_program* p) { return !p ? -1 : (p->shard_graph_exec ? 1 : 0); } // 1 = one graph per token

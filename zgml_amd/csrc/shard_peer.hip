@@ -35,17 +35,30 @@ using gu64 = __attribute__((address_space(1))) unsigned long long;
 
 constexpr int kPeerBlock = 512;
 
-// bounded wait of ONE lane for `cnt` to reach `target` (wrap-safe); returns false after `ticks` of the 100 MHz wall clock
-__device__ __forceinline__ bool peer_wait(const uint32_t* cnt, uint32_t target, uint64_t ticks, const uint32_t* timeout) {
+// The value a peer wait leaves in the context's host-visible hand-off word when it gives up (1 = an in-launch hand-off of a fused
+// q / k / v + attention launch: runtime_internal.h handoff_ok tells the two apart — a slow peer must not switch that fusion off)
+constexpr uint32_t kHandoffPeer = 2;
+
+// bounded wait of ONE lane for `cnt` to reach `target` (wrap-safe); returns false after `ticks` of the 100 MHz wall clock, or at once
+// when the block's POISON word is set: a rank whose wait gave up poisons EVERY rank's block (peer_poison), because its later
+// pushes of that step carry slices computed from data that never landed — without the poison a peer that is merely late would find
+// all its arrivals present and return a token built from them with no error. The poison is sticky: after any rank
+// returned -1 all ranks re-attach (fresh blocks) before they step again.
+__device__ __forceinline__ bool peer_wait(const uint32_t* cnt, const uint32_t* poison, uint32_t target, uint64_t ticks, const uint32_t* timeout) {
     // a wait of this step has already given up (the word is host-visible and cleared by the host when it reports the failure): the
     // step is lost, do not wait the bound again at each of its remaining ~130 points
     if (__hip_atomic_load((const gu32*)timeout, __ATOMIC_RELAXED, ZGML_SYS) != 0) return false;
     const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
     for (;;) {
+        if (__hip_atomic_load((const gu32*)poison, __ATOMIC_RELAXED, ZGML_SYS) != 0) return false;
         if ((int32_t)(__hip_atomic_load((const gu32*)cnt, __ATOMIC_RELAXED, ZGML_SYS) - target) >= 0) return true;
         if (__builtin_amdgcn_s_memrealtime() - t0 > ticks) return false;
         __builtin_amdgcn_s_sleep(8);
     }
+}
+// one lane per rank: the poison word of every rank's block (own included)
+__device__ __forceinline__ void peer_poison(char* const* blocks, uint64_t poison_off, uint32_t world) {
+    if (threadIdx.x < world) __hip_atomic_store((gu32*)(blocks[threadIdx.x] + poison_off), 1u, __ATOMIC_RELAXED, ZGML_SYS);
 }
 
 __global__ void __launch_bounds__(kPeerBlock) peer_gather_kernel(PeerGatherArgs a) {
@@ -64,14 +77,17 @@ __global__ void __launch_bounds__(kPeerBlock) peer_gather_kernel(PeerGatherArgs 
     // ---- wait: world - 1 new arrivals on the own counter
     if (tid == 0) {
         const uint32_t target = *a.seen + (a.world - 1);
-        const bool ok = peer_wait((const uint32_t*)(a.blocks[a.rank] + a.ctr_off), target, a.wait_ticks, a.timeout);
-        if (!ok) __hip_atomic_store((gu32*)a.timeout, 1u, __ATOMIC_RELAXED, ZGML_SYS);
+        const bool ok = peer_wait((const uint32_t*)(a.blocks[a.rank] + a.ctr_off), (const uint32_t*)(a.blocks[a.rank] + a.poison_off), target, a.wait_ticks, a.timeout);
+        if (!ok) __hip_atomic_store((gu32*)a.timeout, kHandoffPeer, __ATOMIC_RELAXED, ZGML_SYS);
         *a.seen = target; // (also after a give-up: the step is reported failed, the counters stay in step)
         ok_s = ok ? 1u : 0u;
     }
     __syncthreads();
     __threadfence_system(); // acquire side: the staging loads below are issued after the count was observed
-    if (!ok_s) return;
+    if (!ok_s) {
+        peer_poison(a.blocks, a.poison_off, a.world); // every rank fails this step (and stays failed until all re-attach)
+        return;
+    }
     // ---- land: the peers' slices, staging -> program buffer
     const unsigned long long* const stage = (const unsigned long long*)(a.blocks[a.rank] + a.stage_off);
     unsigned long long* const full = (unsigned long long*)a.local;
@@ -131,14 +147,18 @@ __global__ void __launch_bounds__(kPeerBlock) peer_argmax_kernel(PeerArgmaxArgs 
         if (threadIdx.x != a.rank) __hip_atomic_fetch_add((gu32*)(a.blocks[threadIdx.x] + a.ctr_off), 1u, __ATOMIC_RELEASE, ZGML_SYS);
     }
     __syncthreads();
+    __shared__ uint32_t ok_a;
     if (threadIdx.x == 0) {
         const uint32_t target = *a.seen + (a.world - 1);
-        const bool ok = peer_wait((const uint32_t*)(a.blocks[a.rank] + a.ctr_off), target, a.wait_ticks, a.timeout);
-        if (!ok) __hip_atomic_store((gu32*)a.timeout, 1u, __ATOMIC_RELAXED, ZGML_SYS);
+        const bool ok = peer_wait((const uint32_t*)(a.blocks[a.rank] + a.ctr_off), (const uint32_t*)(a.blocks[a.rank] + a.poison_off), target, a.wait_ticks, a.timeout);
+        if (!ok) __hip_atomic_store((gu32*)a.timeout, kHandoffPeer, __ATOMIC_RELAXED, ZGML_SYS);
         *a.seen = target;
         __threadfence_system();
         *a.out = ok ? reduce_pairs((const unsigned long long*)(a.blocks[a.rank] + a.pairs_off), a.world, true) : (int64_t)-1;
+        ok_a = ok ? 1u : 0u;
     }
+    __syncthreads();
+    if (!ok_a) peer_poison(a.blocks, a.poison_off, a.world);
 }
 
 // collective (RCCL) mode: the local pair into slot `rank` of a device array that is then all-gathered, and the reduction behind it

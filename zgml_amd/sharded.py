@@ -96,6 +96,13 @@ class NativeShardedDecoder:
             raise RuntimeError("shard_profile_step: " + self.be.last_error())
         return tok, step_us.value, gather_us.value
 
+    def last_point_us(self):
+        """Microseconds of every gather point in the last profile_step (diagnostics)."""
+        n = int(self.lib.zgml_hip_shard_last_point_us(self.handle, None, 0))
+        buf = (C.c_double * max(1, n))()
+        self.lib.zgml_hip_shard_last_point_us(self.handle, buf, n)
+        return [round(buf[i], 2) for i in range(n)]
+
     @property
     def mode(self) -> str:
         return "graph" if self.lib.zgml_hip_shard_step_mode(self.handle) == 1 else "eager"
