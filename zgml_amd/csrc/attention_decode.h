@@ -194,6 +194,77 @@ __device__ __forceinline__ AttnRow<true> quantise_block32(float4 v) {
     return AttnRow<true>{q8(v.x) | (q8(v.y) << 8) | (q8(v.z) << 16) | (q8(v.w) << 24), scale};
 }
 
+// ── quantised KV, 16 dims per lane (round 5) ────────────────────────────────────────────────
+// The int8 caches keep a key's d_head bytes contiguous (QuantizedKVCache, src/quant.zig:925-1091: [col][d] int8, then
+// [col][d / 32] f32 scales), so a lane can take 16 dims of a key with ONE 16-byte load: a key then occupies d_head / 16 lanes
+// instead of d_head / 4, a wave streams 4x the keys per load instruction, and the number of dependent memory round trips of a
+// long context drops with it (at Llama-2-7B dimensions a 4-wave workgroup covers 128 keys per round instead of 32). The
+// ropes, the storeColumn quantisation and the cache stores stay in the 4-dims-per-lane form above (same bytes in the caches);
+// q and the new column are re-laid-out once by lane shuffles, the result goes back through the merge's LDS arrays.
+#ifndef ZGML_ATTN_KVQ16
+#define ZGML_ATTN_KVQ16 1
+#endif
+constexpr int kAttnUnrollQ16 = 4;
+typedef uint32_t u4v_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u4v_t ldgu4(const void* p) { return *(const __attribute__((address_space(1))) u4v_t*)p; }
+// (float)(int8) of byte B of a dword: one SDWA convert (sign-extended byte select)
+template <int B>
+__device__ __forceinline__ float s8_to_f32(uint32_t w) {
+    float r;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (B == 0) asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0" : "=v"(r) : "v"(w));
+    if constexpr (B == 1) asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1" : "=v"(r) : "v"(w));
+    if constexpr (B == 2) asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2" : "=v"(r) : "v"(w));
+    if constexpr (B == 3) asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3" : "=v"(r) : "v"(w));
+#else
+    r = (float)(int8_t)(w >> (8 * B));
+#endif
+    return r;
+}
+// The attention workgroups of a fused launch run ONE wave per SIMD, where every instruction costs its 4-5 cycles of issue
+// whatever its class: the products go through v_pk_fma_f32 (two per instruction: 6 instructions per 4 int8 instead of 8). One
+// dword at a time behind a scheduling barrier — left alone, hipcc converts every row of a step up front and spills.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+// sum_e q[e] * k8[e] over the lane's 16 dims: two running sums (even / odd dims), added at the end
+__device__ __forceinline__ float dot16(const f32x2_t (&q)[8], const u4v_t& w) {
+    f32x2_t s = {0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const f32x2_t lo = {s8_to_f32<0>(w[c]), s8_to_f32<1>(w[c])}, hi = {s8_to_f32<2>(w[c]), s8_to_f32<3>(w[c])};
+        s = __builtin_elementwise_fma(lo, q[2 * c], s);
+        s = __builtin_elementwise_fma(hi, q[2 * c + 1], s);
+#if defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+    return s.x + s.y;
+}
+__device__ __forceinline__ void axpy16(f32x2_t (&acc)[8], float ws, const u4v_t& w) {
+    const f32x2_t ws2 = {ws, ws};
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const f32x2_t lo = {s8_to_f32<0>(w[c]), s8_to_f32<1>(w[c])}, hi = {s8_to_f32<2>(w[c]), s8_to_f32<3>(w[c])};
+        acc[2 * c] = __builtin_elementwise_fma(lo, ws2, acc[2 * c]);
+        acc[2 * c + 1] = __builtin_elementwise_fma(hi, ws2, acc[2 * c + 1]);
+#if defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+}
+// all lanes with the same (lane % L) — the same dims of different key slots — get the sum / max over the wave's 64 / L slots:
+// rotations inside a 16-lane row (DPP), row swaps above
+template <int L, bool MAX>
+__device__ __forceinline__ float slots_all(float v) {
+    auto op = [](float a, float b) { return MAX ? fmaxf(a, b) : a + b; };
+    if (L <= 1) v = op(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x121, 0xF, 0xF, true))); // row_ror:1
+    if (L <= 2) v = op(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x122, 0xF, 0xF, true))); // row_ror:2
+    if (L <= 4) v = op(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x124, 0xF, 0xF, true))); // row_ror:4
+    if (L <= 8) v = op(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x128, 0xF, 0xF, true))); // row_ror:8
+    if (L <= 16) v = MAX ? xor16_max(v) : xor16_sum(v);
+    if (L <= 32) v = MAX ? xor32_max(v) : xor32_sum(v);
+    return v;
+}
+
 // A launch that also holds the workgroups of the q / k / v projection (qmatvec.hip: fused launch) hands the projections
 // over through agent-scope counters instead of a kernel boundary: one counter per 64-column... per head slice of each
 // projection, bumped once by every column group (16 columns) that has stored its outputs with write-through stores. The
@@ -218,7 +289,13 @@ template <int LPK, bool KVQ, int BLOCK = kAttnBlock>
 __device__ __forceinline__ void attention_decode_body(const AttnDecodeParams* __restrict__ params, float* split_buf, uint32_t* split_cnt,
                                                       uint32_t split_min_keys, const uint32_t hx, const uint32_t sp_in, const uint32_t n_sp,
                                                       const DecodeHandoff* ho) {
-    constexpr int DH = 4 * LPK, KPW = 64 / LPK, U = kAttnUnroll, HALF = DH / 2;
+    constexpr int DH = 4 * LPK, HALF = DH / 2;
+    // Q16: quantised KV with 16 dims per lane in the key loop (LPKM lanes per key there); KPW4 / LPK stay the mapping of the
+    // ropes, the stores, the wave merge and the split merge
+    // (d_head >= 128 only: measured on MI355X at position 1900 / short contexts, Llama-2-7B dims 724-738 against 686 tok/s / 868
+    // against 843; SmolLM's d_head 64 — 16 waves per workgroup, the whole chunk in one round already — loses 1 % either way)
+    constexpr bool Q16 = KVQ && ZGML_ATTN_KVQ16 != 0 && LPK >= 32;
+    constexpr int LPKM = Q16 ? DH / 16 : LPK, KPW = 64 / LPKM, KPW4 = 64 / LPK, U = Q16 ? kAttnUnrollQ16 : kAttnUnroll;
     using Row = AttnRow<KVQ>;
     // The head's parameter record in ONE scalar round trip: read through a reference, hipcc fetches it field by field where
     // the fields are used — three dependent rounds of s_load + s_waitcnt before the kernel's first vector load.
@@ -257,6 +334,9 @@ __device__ __forceinline__ void attention_decode_body(const AttnDecodeParams* __
     ATTN_STAMP(0);
     __shared__ __attribute__((aligned(8))) float part_ml[2 * (BLOCK / 64)];
     __shared__ float4 part_acc[(BLOCK / 64) * LPK];
+    constexpr int COLV = DH / 4 + DH / 32; // Q16: the new K column's words and block scales, then the V column's
+    __shared__ __attribute__((aligned(16))) float q16_lds[Q16 ? DH : 4];
+    __shared__ __attribute__((aligned(16))) uint32_t col_lds[Q16 ? 2 * COLV : 4];
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t slot = lane / LPK, li = lane % LPK, d0 = 4 * li, pair = d0 & (HALF - 1);
     const bool is_hi = d0 >= (uint32_t)HALF;
@@ -296,7 +376,10 @@ __device__ __forceinline__ void attention_decode_body(const AttnDecodeParams* __
     }
     const uint32_t n_keys = k_end - k_begin;
     // waves the chunk needs: one step of a wave covers KPW * U keys
-    uint32_t NW = (n_keys + KPW * U - 1) / (KPW * U);
+    // (Q16: one key per slot and wave while waves are left — a slot's key costs 4x the instructions of the 4-dims form, and the
+    // rows a wave does not need are skipped by a scalar branch)
+    constexpr int KEYS_PER_WAVE = Q16 ? KPW : KPW * U;
+    uint32_t NW = (n_keys + KEYS_PER_WAVE - 1) / KEYS_PER_WAVE;
     NW = NW < 1 ? 1 : (NW > (uint32_t)(BLOCK / 64) ? (uint32_t)(BLOCK / 64) : NW);
     if (w >= NW) return;
     const uint32_t keys_per_iter = KPW * NW, step_keys = keys_per_iter * U, last = k_end ? k_end - 1 : 0;
@@ -318,14 +401,46 @@ __device__ __forceinline__ void attention_decode_body(const AttnDecodeParams* __
         else
             return Row{ldg4(p.v + (uint64_t)s * p.v_cs + d0)};
     };
-    Row kv[U], vv[U];
+    Row kv[Q16 ? 1 : U], vv[Q16 ? 1 : U];
     float mk[U];
+    // Q16: the key loop's own lane mapping (slotm, lim) and ONE set of rows — K rows are re-issued as soon as the scores are
+    // formed, V rows as soon as they are accumulated (no second register set: 16-byte rows would not fit twice)
+    const uint32_t slotm = lane / LPKM, lim = lane % LPKM;
+    // (addresses: wave-uniform base in scalar registers + a 32-bit byte offset per lane, formed from the key index where the load
+    // is issued — U rows x 5 arrays of 64-bit pointers carried through the loop are 40 vector registers)
+    const char* const kb16 = (const char*)P.k_cache;
+    const char* const vb16 = (const char*)P.v_cache;
+    const uint32_t sc_base16 = P.kvq_cols * (uint32_t)DH + 4 * (lim / 2); // bytes: the scales start behind the int8 rows
+    u4v_t kw[Q16 ? U : 1], vw[Q16 ? U : 1];
+    float ks[Q16 ? U : 1], vs[Q16 ? U : 1];
+    auto issue_k16 = [&](uint32_t base) { // (clamped to live rows, unconditional: the waits stay counted)
 #pragma unroll
-    for (int j = 0; j < U; j++) {
-        const uint32_t s = min(k_begin + j * keys_per_iter + w * KPW + slot, last);
-        kv[j] = load_k(s);
-        vv[j] = load_v(s);
-        mk[j] = ldg1(p.mask + (uint64_t)s * p.mask_rs); // host passes a zero word with stride 0 when there is no mask
+        for (int j = 0; j < U; j++) {
+            const uint32_t s = min(base + j * keys_per_iter + w * KPW + slotm, last);
+            kw[j] = ldgu4(kb16 + (s * (uint32_t)DH + 16 * lim));
+            ks[j] = ldg1((const float*)(kb16 + (sc_base16 + s * (4 * BPC))));
+            mk[j] = ldg1((const float*)((const char*)p.mask + s * (4 * p.mask_rs))); // (< 4 GB: checked where the launch is planned)
+        }
+    };
+    auto issue_v16 = [&](uint32_t base) {
+#pragma unroll
+        for (int j = 0; j < U; j++) {
+            const uint32_t s = min(base + j * keys_per_iter + w * KPW + slotm, last);
+            vw[j] = ldgu4(vb16 + (s * (uint32_t)DH + 16 * lim));
+            vs[j] = ldg1((const float*)(vb16 + (sc_base16 + s * (4 * BPC))));
+        }
+    };
+    if constexpr (Q16) {
+        issue_k16(k_begin);
+        issue_v16(k_begin);
+    } else {
+#pragma unroll
+        for (int j = 0; j < U; j++) {
+            const uint32_t s = min(k_begin + j * keys_per_iter + w * KPW + slot, last);
+            kv[j] = load_k(s);
+            vv[j] = load_v(s);
+            mk[j] = ldg1(p.mask + (uint64_t)s * p.mask_rs); // host passes a zero word with stride 0 when there is no mask
+        }
     }
     uint32_t target[3] = {0, 0, 0}; // fused launch: the counter values this execution waits for (written back at the end)
     if (wait_qkv) { // ---- hand-off: the q / k / v column groups of this head have been stored (DecodeHandoff)
@@ -394,6 +509,103 @@ __device__ __forceinline__ void attention_decode_body(const AttnDecodeParams* __
     }
     ATTN_STAMP(3);
     SoftState st{-INFINITY, 0.f, make_float4(0.f, 0.f, 0.f, 0.f)};
+    if constexpr (Q16) {
+        // q and the new column in the key loop's mapping, through LDS: the first 4-dims-per-lane group of every wave writes the
+        // same values to the same words (every group and every wave hold identical q / columns), each wave reads back behind its
+        // own writes (the DS operations of a wave complete in order). The new column stays in LDS: exactly one key slot of one
+        // step meets it, behind a wave-uniform branch
+        if (slot == 0) {
+            *(float4*)&q16_lds[d0] = qv;
+            col_lds[li] = k_col.w, col_lds[COLV + li] = v_col.w;
+            if ((li & 7) == 0) col_lds[DH / 4 + li / 8] = __float_as_uint(k_col.sc), col_lds[COLV + DH / 4 + li / 8] = __float_as_uint(v_col.sc);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        f32x2_t q16[8], acc16[8];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const float4 t4 = *(const float4*)&q16_lds[16 * lim + 4 * c];
+            q16[2 * c] = f32x2_t{t4.x, t4.y}, q16[2 * c + 1] = f32x2_t{t4.z, t4.w};
+        }
+        float m16 = -INFINITY, l16 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; e++) acc16[e] = f32x2_t{0.f, 0.f};
+        const uint32_t wu = __builtin_amdgcn_readfirstlane(w); // (scalar: rows wholly behind the chunk's end are skipped by a scalar branch)
+        float sc[U], bm;
+        auto scores = [&](uint32_t base) {
+            bm = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < U; j++) {
+                sc[j] = -INFINITY;
+                if (base + j * keys_per_iter + wu * KPW >= k_end) continue;
+                const uint32_t t = base + j * keys_per_iter + w * KPW + slotm;
+                u4v_t kk = kw[j];
+                float kss = ks[j];
+                if (__builtin_amdgcn_ballot_w64(t == col_k) != 0 && t == col_k)
+                    kk = *(const u4v_t*)&col_lds[4 * lim], kss = __uint_as_float(col_lds[DH / 4 + lim / 2]);
+                const float dot = group_sum<LPKM>(dot16(q16, kk) * kss);
+                sc[j] = t < k_end ? score_of(dot, mk[j], p.scale) : -INFINITY;
+                bm = fmaxf(bm, sc[j]);
+            }
+        };
+        auto update = [&](uint32_t base) {
+            const float nm = fmaxf(m16, bm);
+            if (nm > -INFINITY) { // per key slot; lanes of a slot agree
+                // (__expf = v_exp_f32 of x * log2(e): relative error ~ |x| * 1e-7, three instructions instead of a dozen; the int8
+                // caches are compared at 1e-3 of the logit range)
+                const float alpha = m16 > -INFINITY ? __expf(m16 - nm) : 0.0f;
+                l16 *= alpha;
+#pragma unroll
+                for (int e = 0; e < 8; e++) acc16[e] *= alpha;
+#pragma unroll
+                for (int j = 0; j < U; j++) {
+                    if (base + j * keys_per_iter + wu * KPW >= k_end) continue;
+                    const uint32_t t = base + j * keys_per_iter + w * KPW + slotm;
+                    const float wgt = sc[j] > -INFINITY ? __expf(sc[j] - nm) : 0.0f;
+                    u4v_t xx = vw[j];
+                    float vss = vs[j];
+                    if (__builtin_amdgcn_ballot_w64(t == col_v) != 0 && t == col_v)
+                        xx = *(const u4v_t*)&col_lds[COLV + 4 * lim], vss = __uint_as_float(col_lds[COLV + DH / 4 + lim / 2]);
+                    l16 += wgt;
+                    // (no branch on the slot: a dead slot's row contributes 0 * int8 — its bytes are numbers whatever they are, and
+                    // its scale, which may be anything, is selected away, not multiplied)
+                    axpy16(acc16, sc[j] > -INFINITY ? wgt * vss : 0.0f, xx);
+                }
+                m16 = nm;
+            }
+        };
+        if (n_keys <= step_keys) { // the usual decode case: everything is already in registers
+            if (n_keys) scores(k_begin), update(k_begin);
+        } else {
+            for (uint32_t base = k_begin; base < k_end; base += step_keys) {
+                scores(base);
+                issue_k16(base + step_keys); // (the last round re-reads live rows: L2 hits nobody waits for)
+                update(base);
+                issue_v16(base + step_keys);
+            }
+        }
+        ATTN_STAMP(4);
+        // slots of the wave: common max, one rescale, sums over the lanes that hold the same dims; then into the merge's LDS
+        // arrays in the 4-dims-per-lane form (lane lim of slot 0 holds four float4 of it)
+        const float M = slots_all<LPKM, true>(m16);
+        const float f = m16 > -INFINITY ? expf(m16 - M) : 0.0f;
+        l16 = slots_all<LPKM, false>(l16 * f);
+#pragma unroll
+        for (int e = 0; e < 8; e++) acc16[e] = f32x2_t{slots_all<LPKM, false>(acc16[e].x * f), slots_all<LPKM, false>(acc16[e].y * f)};
+        if (lane < LPKM) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) part_acc[w * LPK + 4 * lane + c] = make_float4(acc16[2 * c].x, acc16[2 * c].y, acc16[2 * c + 1].x, acc16[2 * c + 1].y);
+            if (lane == 0) part_ml[2 * w] = M, part_ml[2 * w + 1] = l16;
+        }
+        st.m = M, st.l = l16;
+        if (NW == 1) { // a single wave: its own LDS writes, read back in the other mapping (DS operations of a wave complete in order)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            st.acc = part_acc[w * LPK + li];
+        }
+    } else {
     // one step: scores of the slot's U keys, then the online-softmax update
     auto step = [&](uint32_t base) {
         float sc[U];
@@ -445,9 +657,10 @@ __device__ __forceinline__ void attention_decode_body(const AttnDecodeParams* __
     // ---- merge the key slots of the wave, then the waves. Every merge is two-pass (common max first,
     // then ONE rescale per stream and plain sums): no chain of dependent exponentials.
     slots_merge<LPK>(st);
+    }
     SoftState r = st;
     if (NW > 1) { // (uniform) a single wave has the workgroup's result already
-        if (lane < LPK) {
+        if (!Q16 && lane < LPK) {
             part_acc[w * LPK + lane] = st.acc;
             if (lane == 0) part_ml[2 * w] = st.m, part_ml[2 * w + 1] = st.l;
         }
@@ -457,14 +670,14 @@ __device__ __forceinline__ void attention_decode_body(const AttnDecodeParams* __
         if (w != 0) return;
         // wave 0, all 64 lanes: lane ww < 16 fetches wave ww's max for the common max (DPP row reduction);
         // slot g folds waves g, g + KPW, ... — every LDS read is issued up front, the exponentials are independent
-        constexpr int MAXW = BLOCK / 64, NPS = MAXW / KPW > 0 ? MAXW / KPW : 1;
+        constexpr int MAXW = BLOCK / 64, NPS = MAXW / KPW4 > 0 ? MAXW / KPW4 : 1;
         static_assert(MAXW <= 16, "lanes 0..15 (one DPP row) hold the waves' maxima");
         float M = lane < NW ? part_ml[2 * lane] : -INFINITY;
         float2 ml[NPS];
         float4 pa[NPS];
 #pragma unroll
         for (int i = 0; i < NPS; i++) {
-            const uint32_t ww = slot + i * KPW, wc = ww < NW ? ww : 0;
+            const uint32_t ww = slot + i * KPW4, wc = ww < NW ? ww : 0;
             ml[i] = *(const float2*)&part_ml[2 * wc];
             pa[i] = part_acc[wc * LPK + li];
         }
@@ -476,7 +689,7 @@ __device__ __forceinline__ void attention_decode_body(const AttnDecodeParams* __
         r = SoftState{M, 0.f, make_float4(0.f, 0.f, 0.f, 0.f)};
 #pragma unroll
         for (int i = 0; i < NPS; i++) {
-            const bool live = slot + i * KPW < NW && ml[i].x > -INFINITY;
+            const bool live = slot + i * KPW4 < NW && ml[i].x > -INFINITY;
             const float f = live ? expf(ml[i].x - M) : 0.0f;
             r.l += ml[i].y * f;
             r.acc.x += pa[i].x * f, r.acc.y += pa[i].y * f, r.acc.z += pa[i].z * f, r.acc.w += pa[i].w * f;
@@ -508,7 +721,7 @@ __device__ __forceinline__ void attention_decode_body(const AttnDecodeParams* __
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // compiler only: the loads below stay below the count
             // slot g folds chunks g, g + KPW, ... in chunk order (not arrival order), then the slots merge
             r = SoftState{-INFINITY, 0.f, make_float4(0.f, 0.f, 0.f, 0.f)};
-            for (uint32_t c = slot; c < n_active; c += KPW) {
+            for (uint32_t c = slot; c < n_active; c += KPW4) {
                 const float* rec = head_buf + (uint64_t)c * REC;
                 float om, ol;
                 float4 oa;

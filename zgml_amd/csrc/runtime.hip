@@ -1773,6 +1773,8 @@ void build_fused_plan(zgml_hip_program* p) {
                 continue;
             const uint64_t cache_elems = (uint64_t)t.n_cols * dh / 4 + (uint64_t)t.n_cols * (dh / 32);
             if (cache_elems > p->sizes[t.k] || cache_elems > p->sizes[t.v]) continue;
+            // (the key loop addresses cache rows, scales and mask words as a uniform base + a 32-bit byte offset: attention_decode.h)
+            if (cache_elems * 4 >= (1ull << 32) || (t.has_mask && (uint64_t)t.n_cols * t.mask_rs * 4 >= (1ull << 32))) continue;
             const int rq = last_writer(ExactSpan{t.q, t.q_off, dh}, i);
             if (rq < 0 || in_macro[rq] || ops[rq].kind != ZGML_DOP_ROPE) continue;
             const auto& q = ops[rq].u.rope;
