@@ -269,6 +269,7 @@ def bench_single(args):
     sess.decode(1, 0, 4)
     _, secs_full = sess.decode(1, 0, n_vt)
     sess.use_dynamic_refresh()
+    sess.pin_outputs(be)  # (the adapter's: DeviceInference's logits slice is session-owned — zgml_hip_program_pin_outputs)
     sess.decode(1, 0, 4)
     _, secs = sess.decode(1, 0, n_vt)
     extra["vtable_path_tok_s"] = round(n_vt / secs, 1)

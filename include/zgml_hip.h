@@ -353,6 +353,15 @@ zgml_hip_program* zgml_hip_compile_program(zgml_hip_ctx* ctx, const zgml_device_
  * (slice_assign.dst_offset, attention.seq_kv). Other fields must be unchanged. */
 void zgml_hip_refresh_program(zgml_hip_ctx* ctx, zgml_hip_program* handle,
                               const zgml_device_op* ops, uint64_t n_ops);
+/* (extension, round 5) Outputs written straight into the caller's buffer. By default execute_program lands outputs in the
+ * library's pinned staging buffer and copies them to `host_ptr` (197 KB of logits per SmolLM-135M token). With on = 1 a program
+ * whose execute_program calls name ONE output at the SAME host address three times in a row registers that buffer with the
+ * driver (hipHostRegister) and the step's last kernel writes into it. THE CALLER PROMISES that such a buffer stays allocated
+ * and mapped until it passes a different address, switches this off, or frees the program: pages are pinned at registration,
+ * so a buffer that is freed and re-allocated at the same address would silently stop receiving data. DeviceInference's
+ * session-owned logits slice (src/device_inference.zig:262) qualifies. Returns 0. */
+int zgml_hip_program_pin_outputs(zgml_hip_ctx* ctx, zgml_hip_program* program, int on);
+
 /* The per-token refresh reduced to its two numbers (src/backend/program.zig:7452-7490 StepDynamicParams, what the reference's wgpu
  * backend uploads per step, src/backend/wgpu.zig:1162-1169): every dynamic KV store goes to column `slice_pos` (dst_offset =
  * dst_base_offset + slice_pos * patch_stride), every attention reads `seq_kv` keys. O(#dynamic ops) instead of a compare of the

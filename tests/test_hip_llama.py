@@ -4,6 +4,8 @@ forwardCachedMasked) stepped through the HIP C ABI and through the oracle.
 Tolerance: logits within 2e-4 of the logit range (f32 reassociation across ~50 ops per layer; the
 reference's own integration tests use 1e-4..1e-5 on much smaller models,
 src/llama_inference.zig:854-1034); greedy tokens must be identical."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -457,3 +459,45 @@ def test_resident_prefill_equals_vtable_prefill(hip_backend, name, T):
     toks = [(3 * i + 1) % cfg.vocab_size for i in range(T)]  # the resident program through the vtable again (position 0)
     assert b.prefill(toks, 0)[0] == a.prefill(toks, 0)[0]
     a.close(), b.close(), m.close()
+
+
+def test_pinned_outputs_equal_the_staged_path(hip_backend):
+    """zgml_hip_program_pin_outputs: after three steps into the same host buffer the logits are written straight into it by the
+    step's own graph; the numbers are those of the staging path, a different buffer falls back (and still gets its data), and
+    switching the promise off returns to staging."""
+    hip = capi.load_hip()
+    m = llama.Model(llama.preset("tiny", 64), llama.Q4_0, threads=4)
+    s_a = llama.Session(m, llama.hip_backend_fns(hip_backend))
+    s_b = llama.Session(m, llama.hip_backend_fns(hip_backend))
+    s_a.use_dynamic_refresh(), s_b.use_dynamic_refresh()
+    s_b.pin_outputs(hip_backend)
+    tok = 3
+    for pos in range(10):  # (zh_session_step copies the session's own logits buffer out: same host address every step)
+        t_a, l_a = s_a.step(tok, pos)
+        t_b, l_b = s_b.step(tok, pos)
+        assert not hip_backend.last_error(), hip_backend.last_error()
+        assert t_a == t_b and np.array_equal(l_a, l_b), pos
+        tok = t_a
+    # the raw entry point with caller buffers: the same address three times, then another one, then the promise withdrawn
+    n_in, n_out = C.c_uint64(), C.c_uint64()
+    ins = s_b.lib.zh_model_step_inputs(m.ptr, C.byref(n_in))
+    outs = s_b.lib.zh_model_step_outputs(m.ptr, C.byref(n_out))
+    assert n_out.value == 1
+    vocab = m.cfg.vocab_size
+    want = l_a.copy()  # position 9's logits: re-executing the same step gives them again
+    buf1, buf2 = np.zeros(vocab, np.float32), np.zeros(vocab, np.float32)
+
+    def run(buf):
+        buf[:] = -7.0
+        io = (capi.ProgramIOC * 1)(capi.ProgramIOC(outs[0].buf_idx, 0, outs[0].offset, buf.ctypes.data, outs[0].size, 0))
+        hip.zgml_hip_execute_program(hip_backend.ctx, s_b.handle, ins, n_in.value, io, 1)
+        assert not hip_backend.last_error(), hip_backend.last_error()
+        return buf
+
+    for _ in range(5):
+        assert np.array_equal(run(buf1), want)
+    assert np.array_equal(run(buf2), want)  # moved: unregistered, staged
+    assert np.array_equal(run(buf1), want)
+    hip.zgml_hip_program_pin_outputs(hip_backend.ctx, s_b.handle, 0)
+    assert np.array_equal(run(buf1), want)
+    s_a.close(), s_b.close(), m.close()

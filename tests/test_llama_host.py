@@ -210,3 +210,38 @@ def test_quantised_kv_program_tracks_the_f32_cache_program():
         assert np.abs(l_q - l_f).max() <= 0.05 * np.abs(l_f).max(), pos
         tok = t_f
     s_f.close(), s_q.close(), m_f.close(), m_q.close()
+
+
+def test_greedy_pick_is_the_reference_loops_index():
+    """The session's argmax (two vector passes where the host has AVX2) against the reference's compare-and-keep loop
+    (src/nn.zig:122-138: first maximum wins, a NaN never wins, a NaN in front keeps index 0): ties, maxima in every lane and in
+    the scalar tail, -inf rows, NaNs, +inf, short vectors."""
+    lib = llama.load_host()
+    rng = np.random.default_rng(5)
+
+    def both(v):
+        v = np.ascontiguousarray(v, np.float32)
+        return lib.zh_argmax(v.ctypes.data, v.size), lib.zh_argmax_reference(v.ctypes.data, v.size)
+
+    for n in (1, 7, 63, 64, 65, 127, 1000, 49152, 32000):
+        for _ in range(6):
+            v = rng.standard_normal(n).astype(np.float32)
+            a, b = both(v)
+            assert a == b == int(np.argmax(v)), n
+            k = int(rng.integers(0, n))
+            v[k] = v.max()  # a tie: the first one wins
+            a, b = both(v)
+            assert a == b, n
+        for pos in {0, n // 2, n - 1, max(0, n - 3)}:  # the maximum in the head, the body and the scalar tail
+            v = np.full(n, -1.0, np.float32)
+            v[pos] = 2.0
+            assert both(v) == (pos, pos)
+        assert both(np.full(n, -np.inf, np.float32)) == (0, 0)
+        v = rng.standard_normal(n).astype(np.float32)
+        v[n // 3] = np.inf
+        assert both(v) == (n // 3, n // 3)
+        for pos in {0, n // 2, n - 1}:  # NaNs: never the winner; in front they freeze index 0 (every later compare is false)
+            v = rng.standard_normal(n).astype(np.float32)
+            v[pos] = np.nan
+            a, b = both(v)
+            assert a == b, (n, pos)

@@ -195,7 +195,7 @@ HIP_SYMBOLS = [
     "zgml_hip_qmatvec_synth", "zgml_hip_copy_bench", "zgml_hip_resident_setup", "zgml_hip_resident_decode",
     "zgml_hip_resident_prefill", "zgml_hip_shard_unique_id", "zgml_hip_shard_init", "zgml_hip_shard_destroy", "zgml_hip_shard_attach", "zgml_hip_shard_step", "zgml_hip_shard_step_mode",
     "zgml_hip_shard_profile_step", "zgml_hip_shard_last_point_us", "zgml_hip_device_can_access_peer", "zgml_hip_device_count", "zgml_hip_shard_init_peer", "zgml_hip_shard_peer_export", "zgml_hip_shard_peer_import",
-    "zgml_hip_program_plan_text",
+    "zgml_hip_program_plan_text", "zgml_hip_program_pin_outputs",
 ]
 
 class ShardPointC(C.Structure):
@@ -237,6 +237,8 @@ def _bind_hip(lib: C.CDLL) -> None:
     lib.zgml_hip_refresh_program.restype = None
     lib.zgml_hip_refresh_dynamic.restype = C.c_int
     lib.zgml_hip_refresh_dynamic.argtypes = [vp, vp, C.c_uint32, C.c_uint32]
+    lib.zgml_hip_program_pin_outputs.restype = C.c_int
+    lib.zgml_hip_program_pin_outputs.argtypes = [vp, vp, C.c_int]
     lib.zgml_hip_refresh_program.argtypes = [vp, vp, C.POINTER(DeviceOpC), u64]
     lib.zgml_hip_execute_program.restype = None
     lib.zgml_hip_execute_program.argtypes = [vp, vp, C.POINTER(ProgramIOC), u64, C.POINTER(ProgramIOC), u64]

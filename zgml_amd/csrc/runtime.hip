@@ -171,6 +171,13 @@ __global__ void scatter_words_kernel(const IoTableDev* table, const uint32_t* st
     const uint32_t* src = stage + e.stage_off_words;
     for (uint32_t i = threadIdx.x; i < e.n_words; i += blockDim.x) dst[i] = src[i];
 }
+// (blockIdx.y strides over a row: the logits of a decode step are one row of ~50k words)
+__global__ void gather_words_wide_kernel(const IoTableDev* table, uint32_t* stage) {
+    const IoTableDev e = table[blockIdx.x];
+    const uint32_t* src = (const uint32_t*)e.dev;
+    uint32_t* dst = stage + e.stage_off_words;
+    for (uint32_t i = blockIdx.y * blockDim.x + threadIdx.x; i < e.n_words; i += blockDim.x * gridDim.y) dst[i] = src[i];
+}
 __global__ void gather_words_kernel(const IoTableDev* table, uint32_t* stage) {
     const IoTableDev e = table[blockIdx.x];
     const uint32_t* src = (const uint32_t*)e.dev;
@@ -212,7 +219,14 @@ void dump_graph(hipGraph_t g, const char* tag) {
 
 // Drop every captured graph of the program: both bake the plan's kernel nodes and the device parameter arrays
 // build_plan() is about to free, so a plan rebuild must never leave one behind (the resident graph included).
+void free_io_graph(zgml_hip_program* p) {
+    if (p->io_graph_exec) hipGraphExecDestroy(p->io_graph_exec);
+    if (p->io_graph) hipGraphDestroy(p->io_graph);
+    p->io_graph_exec = nullptr, p->io_graph = nullptr;
+}
+
 void free_graph(zgml_hip_program* p) {
+    free_io_graph(p);
     if (p->graph_exec) hipGraphExecDestroy(p->graph_exec);
     if (p->graph) hipGraphDestroy(p->graph);
     p->graph_exec = nullptr;
@@ -230,12 +244,15 @@ bool ensure_stage(zgml_hip_program* p, uint64_t bytes) {
     if (bytes <= p->stage_cap) return true;
     zgml_hip_ctx* ctx = p->ctx;
     hipStreamSynchronize(ctx->stream);
+    free_io_graph(p); // (its kernels hold the buffers' addresses)
     if (p->stage_host) hipHostFree(p->stage_host);
+    if (p->stage_out_host) hipHostFree(p->stage_out_host);
     if (p->stage_dev) hipFree(p->stage_dev);
-    p->stage_host = p->stage_dev = nullptr;
+    p->stage_host = p->stage_out_host = p->stage_dev = nullptr;
     uint64_t cap = 1 << 16;
     while (cap < bytes) cap <<= 1;
-    if (!CTX_CHECK(ctx, hipHostMalloc(&p->stage_host, cap, hipHostMallocDefault))) return false;
+    if (!CTX_CHECK(ctx, hipHostMalloc(&p->stage_host, cap, hipHostMallocMapped))) return false;
+    if (!CTX_CHECK(ctx, hipHostMalloc(&p->stage_out_host, cap, hipHostMallocMapped))) return false;
     if (!CTX_CHECK(ctx, hipMalloc(&p->stage_dev, cap))) return false;
     p->stage_cap = cap;
     return true;
@@ -256,6 +273,7 @@ bool prepare_io(zgml_hip_program* p, IoPlan& plan, const zgml_program_io* ios, u
     if (same) return true;
     zgml_hip_ctx* ctx = p->ctx;
     hipStreamSynchronize(ctx->stream);
+    free_io_graph(p); // (captured for the tables that are about to change)
     plan.entries.clear();
     plan.word_aligned = true;
     plan.total_words = 0;
@@ -3163,6 +3181,134 @@ static bool download_outputs(zgml_hip_ctx* ctx, zgml_hip_program* p, const zgml_
     return ok;
 }
 
+// The decode step's fast path (round 5): inputs, dynamic words, the plan and the outputs as ONE graph launch (zgml_hip_program::
+// io_graph). The GPU-side timeline of the copy-command form (profiles/r05_vtable_timeline.txt) shows what the commands around the
+// plan's graph cost per token: H2D + wait for the scatter kernel + the kernel, then ~18 us from the last kernel to the D2H's start
+// + the copy. Here the scatter kernel reads the pinned staging buffer through its device mapping, the gather kernel writes the
+// outputs into a second pinned buffer, and both are nodes of the graph. false: not applicable (no graph, odd alignment, no
+// inputs or outputs, profiling) — the caller takes the general path.
+static bool execute_io_graph(zgml_hip_ctx* ctx, zgml_hip_program* p, const zgml_program_io* inputs, uint64_t n_inputs,
+                             const zgml_program_io* outputs, uint64_t n_outputs, uint64_t t0) {
+    static const bool enabled = !(getenv("ZGML_HIP_IO_GRAPH") && atoi(getenv("ZGML_HIP_IO_GRAPH")) == 0);
+    if (!enabled || !ctx->opt_graph || ctx->opt_profile || !n_inputs || !n_outputs || !p->in_plan.word_aligned || !p->out_plan.word_aligned ||
+        !p->in_plan.dyn_row || !p->in_plan.table_dev || !p->out_plan.table_dev)
+        return false;
+    if (p->plan_dirty || p->fuse_epoch != ctx->fuse_epoch) {
+        free_graph(p);
+        build_plan(p);
+    }
+    if (p->plan.empty()) return false;
+    hipStream_t s = ctx->stream;
+    { // pack: the inputs, then the dynamic words (always: the graph's scatter launch has a fixed number of rows)
+        char* st = (char*)p->stage_host;
+        uint64_t off = 0;
+        for (uint64_t i = 0; i < n_inputs; i++) {
+            memcpy(st + off, inputs[i].host_ptr, inputs[i].size);
+            off += (inputs[i].size + 3) / 4 * 4;
+        }
+        memcpy(st + off, p->dyn_host, p->ops.size() * sizeof(uint32_t));
+        p->dyn_dirty = false;
+    }
+    const uint64_t t1 = ctx->host_prof ? now_ns() : 0;
+    const uint32_t in_rows = (uint32_t)n_inputs + 1, out_rows = (uint32_t)n_outputs;
+    // where the outputs land: the caller's own buffer once it has proved stable (zgml_hip_program::pin_host), else the staging buffer
+    if (p->pin_allowed && !p->pin_off && n_outputs == 1) {
+        const zgml_program_io& o = outputs[0];
+        if (p->pin_host && (p->pin_host != o.host_ptr || p->pin_size != o.size)) { // moved: give the registration up for good
+            hipStreamSynchronize(s);
+            free_io_graph(p);
+            (void)hipHostUnregister(p->pin_host);
+            p->pin_host = p->pin_dev = nullptr, p->pin_off = true;
+        } else if (!p->pin_host) {
+            p->pin_seen = p->pin_cand == o.host_ptr ? p->pin_seen + 1 : 1;
+            p->pin_cand = o.host_ptr;
+            if (p->pin_seen >= 3 && o.size >= 4096) {
+                void* dev = nullptr;
+                if (hipHostRegister(o.host_ptr, o.size, hipHostRegisterMapped) == hipSuccess && hipHostGetDevicePointer(&dev, o.host_ptr, 0) == hipSuccess && dev) {
+                    p->pin_host = o.host_ptr, p->pin_dev = dev, p->pin_size = o.size;
+                } else {
+                    (void)hipGetLastError();
+                    (void)hipHostUnregister(o.host_ptr);
+                    (void)hipGetLastError();
+                    p->pin_off = true;
+                }
+            }
+        }
+    } else if (p->pin_host) {
+        hipStreamSynchronize(s);
+        free_io_graph(p);
+        (void)hipHostUnregister(p->pin_host);
+        p->pin_host = p->pin_dev = nullptr, p->pin_off = true;
+    }
+    void* out_dev = p->pin_host ? p->pin_dev : nullptr;
+    if (!out_dev && hipHostGetDevicePointer(&out_dev, p->stage_out_host, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    if (p->io_graph_exec && (p->io_in_rows != in_rows || p->io_out_rows != out_rows || p->io_out_dev != out_dev)) free_io_graph(p);
+    if (!p->io_graph_exec) {
+        void* in_dev = nullptr;
+        if (hipHostGetDevicePointer(&in_dev, p->stage_host, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        uint32_t max_words = 0;
+        for (uint64_t i = 0; i < n_outputs; i++) max_words = std::max<uint32_t>(max_words, outputs[i].size / 4);
+        const uint32_t gy = std::max<uint32_t>(1, std::min<uint32_t>(64, max_words / 1024));
+        hipGraph_t g = nullptr;
+        if (!CTX_CHECK(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal))) return false;
+        scatter_words_kernel<<<in_rows, 256, 0, s>>>(p->in_plan.table_dev, (const uint32_t*)in_dev);
+        run_plan(p, s, 0, p->plan.size());
+        gather_words_wide_kernel<<<dim3(out_rows, gy), 256, 0, s>>>(p->out_plan.table_dev, (uint32_t*)out_dev);
+        if (!CTX_CHECK(ctx, hipStreamEndCapture(s, &g)) || !g) return false;
+        dump_graph(g, "program-io");
+        hipGraphExec_t ge = nullptr;
+        if (!CTX_CHECK(ctx, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0))) {
+            hipGraphDestroy(g);
+            return false;
+        }
+        p->io_graph = g, p->io_graph_exec = ge, p->io_in_rows = in_rows, p->io_out_rows = out_rows, p->io_out_dev = out_dev;
+    }
+    CTX_CHECK(ctx, hipGraphLaunch(p->io_graph_exec, s));
+    const uint64_t t2 = ctx->host_prof ? now_ns() : 0;
+    const uint64_t ts = now_ns();
+    const bool ok = CTX_CHECK(ctx, hipStreamSynchronize(s)) && ctx->handoff_ok("execute_program");
+    p->profile.sync_time_ns += now_ns() - ts;
+    p->profile.sync_count++;
+    if (ok && !p->pin_host) {
+        const char* st = (const char*)p->stage_out_host;
+        uint64_t off = 0;
+        for (uint64_t i = 0; i < n_outputs; i++) {
+            memcpy(outputs[i].host_ptr, st + off, outputs[i].size);
+            off += (outputs[i].size + 3) / 4 * 4;
+        }
+    }
+    if (ctx->host_prof) {
+        const uint64_t t3 = now_ns();
+        ctx->prof_ns[1] += t1 - t0, ctx->prof_ns[2] += t2 - t1, ctx->prof_ns[3] += t3 - t2;
+        ctx->prof_calls[1]++, ctx->prof_calls[2]++, ctx->prof_calls[3]++;
+    }
+    p->profile.call_count++;
+    p->profile.backend_op_count += p->ops.size();
+    p->profile.backend_dispatch_count += p->plan.size();
+    CTX_CHECK(ctx, hipGetLastError());
+    return true;
+}
+
+int zgml_hip_program_pin_outputs(zgml_hip_ctx* ctx, zgml_hip_program* p, int on) {
+    if (!ctx || !p) return -1;
+    hipSetDevice(ctx->device);
+    if (!on && p->pin_host) {
+        hipStreamSynchronize(ctx->stream);
+        free_io_graph(p);
+        (void)hipHostUnregister(p->pin_host);
+        (void)hipGetLastError();
+        p->pin_host = p->pin_dev = nullptr;
+    }
+    p->pin_allowed = on != 0, p->pin_off = false, p->pin_seen = 0, p->pin_cand = nullptr;
+    return 0;
+}
+
 void zgml_hip_execute_program(zgml_hip_ctx* ctx, zgml_hip_program* p, const zgml_program_io* inputs, uint64_t n_inputs,
                               const zgml_program_io* outputs, uint64_t n_outputs) {
     if (!ctx || !p) return;
@@ -3170,6 +3316,7 @@ void zgml_hip_execute_program(zgml_hip_ctx* ctx, zgml_hip_program* p, const zgml
     // both transfer tables are validated before anything is enqueued
     if (!prepare_io(p, p->in_plan, inputs, n_inputs) || !prepare_io(p, p->out_plan, outputs, n_outputs)) return;
     const uint64_t t0 = ctx->host_prof ? now_ns() : 0;
+    if (execute_io_graph(ctx, p, inputs, n_inputs, outputs, n_outputs, t0)) return;
     if (!upload_inputs(ctx, p, inputs, n_inputs)) return;
     const uint64_t t1 = ctx->host_prof ? now_ns() : 0;
     enqueue(p);
@@ -3316,7 +3463,9 @@ void zgml_hip_free_program(zgml_hip_ctx* ctx, zgml_hip_program* p) {
     if (p->scratch) hipFree((char*)p->scratch - kQmmScratchHead);
     if (p->dyn_dev) hipFree(p->dyn_dev);
     if (p->dyn_host) hipHostFree(p->dyn_host);
+    if (p->pin_host) (void)hipHostUnregister(p->pin_host), (void)hipGetLastError();
     if (p->stage_host) hipHostFree(p->stage_host);
+    if (p->stage_out_host) hipHostFree(p->stage_out_host);
     if (p->stage_dev) hipFree(p->stage_dev);
     if (p->in_plan.table_dev) hipFree(p->in_plan.table_dev);
     if (p->out_plan.table_dev) hipFree(p->out_plan.table_dev);

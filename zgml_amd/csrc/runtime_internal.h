@@ -227,6 +227,26 @@ struct zgml_hip_program {
     void* stage_host = nullptr; // pinned
     void* stage_dev = nullptr;
     uint64_t stage_cap = 0;
+    // execute_program's own graph (round 5): [scatter the packed inputs + dynamic words straight from the pinned staging buffer]
+    // [the plan] [gather the outputs into a second pinned buffer] — no copy commands, one hipGraphLaunch per token. The kernels
+    // read / write host memory through its device mapping; captured for one (input table, output table) pair, dropped with the
+    // plan's graphs, with either table and with the staging buffers.
+    void* stage_out_host = nullptr; // pinned, outputs
+    hipGraph_t io_graph = nullptr;
+    hipGraphExec_t io_graph_exec = nullptr;
+    uint32_t io_in_rows = 0, io_out_rows = 0;
+    // zgml_hip_program_pin_outputs (opt-in: the caller promises its output buffer stays allocated): a single output handed over at
+    // the same address call after call (DeviceInference's logits slice) is registered with the driver after three such calls and
+    // the gather kernel then writes INTO it — no staging copy, no unpack (197 KB per SmolLM token). A different address later:
+    // unregistered, staging from then on.
+    bool pin_allowed = false;
+    void* pin_host = nullptr;
+    void* pin_dev = nullptr;
+    uint64_t pin_size = 0;
+    const void* pin_cand = nullptr;
+    uint32_t pin_seen = 0;
+    bool pin_off = false;
+    void* io_out_dev = nullptr; // the address the captured gather kernel writes to
     IoPlan in_plan, out_plan;
     uint64_t staged_bytes = 0, staged_n = 0; // zgml_hip_stage_inputs / enqueue_staged
     zgml_runtime_profile profile{};

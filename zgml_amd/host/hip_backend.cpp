@@ -17,6 +17,7 @@ struct HipBackend::Api {
     zgml_hip_program* (*compile_program)(zgml_hip_ctx*, const zgml_device_program*);
     void (*refresh_program)(zgml_hip_ctx*, zgml_hip_program*, const zgml_device_op*, uint64_t);
     int (*refresh_dynamic)(zgml_hip_ctx*, zgml_hip_program*, uint32_t, uint32_t);
+    int (*pin_outputs)(zgml_hip_ctx*, zgml_hip_program*, int);
     void (*execute_program)(zgml_hip_ctx*, zgml_hip_program*, const zgml_program_io*, uint64_t, const zgml_program_io*,
                             uint64_t);
     void (*free_program)(zgml_hip_ctx*, zgml_hip_program*);
@@ -38,7 +39,11 @@ Backend::CompiledHandle vt_compile(void* c, const DeviceProgram& p) {
     auto* h = (HipCtx*)c;
     std::vector<zgml_qweight_upload> qw;
     zgml_device_program flat = p.view(qw);
-    return h->api->compile_program(h->ctx, &flat);
+    zgml_hip_program* prog = h->api->compile_program(h->ctx, &flat);
+    // DeviceInference hands execute_program the same session-owned output slice every step (src/device_inference.zig:170-262):
+    // let the step's last kernel write into it (zig/backend_hip.zig does the same)
+    if (prog && h->api->pin_outputs) h->api->pin_outputs(h->ctx, prog, 1);
+    return prog;
 }
 void vt_refresh(void* c, Backend::CompiledHandle hd, const DeviceOp* ops, size_t n) {
     auto* h = (HipCtx*)c;
@@ -92,6 +97,7 @@ bool HipBackend::init(const char* lib_path, int device_ordinal) {
     SYM(compile_program, "zgml_hip_compile_program")
     SYM(refresh_program, "zgml_hip_refresh_program")
     SYM(refresh_dynamic, "zgml_hip_refresh_dynamic")
+    SYM(pin_outputs, "zgml_hip_program_pin_outputs")
     SYM(execute_program, "zgml_hip_execute_program")
     SYM(free_program, "zgml_hip_free_program")
     SYM(get_runtime_profile, "zgml_hip_get_runtime_profile")

@@ -210,6 +210,10 @@ int64_t zh_session_prefill(zh_session* s, const uint32_t* tokens, uint32_t pos, 
     return LlamaDeviceSession::argmax(dp.logits_host.data(), (uint32_t)dp.logits_host.size());
 }
 
+// the session's greedy pick and the reference's own loop (tests compare them; first maximum wins, src/nn.zig:122-138)
+uint32_t zh_argmax(const float* logits, uint32_t n) { return LlamaDeviceSession::argmax(logits, n); }
+uint32_t zh_argmax_reference(const float* logits, uint32_t n) { return LlamaDeviceSession::argmax_reference(logits, n); }
+
 // Greedy decode through the vtable contract (host logits every step): feeds `first_token` at
 // `start_pos`, then its own argmax, for n_steps; writes the produced tokens; returns seconds.
 double zh_session_decode(zh_session* s, uint32_t first_token, uint32_t start_pos, uint32_t n_steps, int64_t* tokens_out) {

@@ -129,7 +129,8 @@ struct LlamaDeviceSession {
     void deinit();
     // One decode step through the vtable (refresh + execute); returns the logits slice.
     const float* step(uint32_t token, uint32_t pos);
-    static uint32_t argmax(const float* logits, uint32_t n); // first max wins, src/nn.zig:122-138
+    static uint32_t argmax(const float* logits, uint32_t n); // first max wins, src/nn.zig:122-138 (two vector passes where AVX2 is there)
+    static uint32_t argmax_reference(const float* logits, uint32_t n); // the reference's loop itself (tests)
 };
 
 } // namespace zgml::llama

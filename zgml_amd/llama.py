@@ -71,6 +71,8 @@ def load_host() -> C.CDLL:
         lib.zh_session_step.argtypes, lib.zh_session_step.restype = [vp, u32, u32, vp], C.c_int64
         lib.zh_session_decode.argtypes, lib.zh_session_decode.restype = [vp, u32, u32, u32, vp], C.c_double
         lib.zh_session_set_refresh_dynamic.argtypes, lib.zh_session_set_refresh_dynamic.restype = [vp, vp], None
+        lib.zh_argmax.argtypes, lib.zh_argmax.restype = [vp, u32], u32
+        lib.zh_argmax_reference.argtypes, lib.zh_argmax_reference.restype = [vp, u32], u32
         _lib = lib
     return _lib
 
@@ -167,6 +169,11 @@ class Session:
         """The adapter's per-token refresh (zig/backend_hip.zig: refreshProgram): (slice_pos, seq_kv) through
         zgml_hip_refresh_dynamic instead of the whole op list through zgml_hip_refresh_program. HIP sessions only."""
         self.lib.zh_session_set_refresh_dynamic(self.ptr, _fn_addr(capi.load_hip(), "zgml_hip_refresh_dynamic") if on else None)
+
+    def pin_outputs(self, backend, on: bool = True) -> None:
+        """The adapter's promise that the session's logits buffer outlives the program (zgml_hip_program_pin_outputs): the step's
+        last kernel then writes the logits straight into it. HIP sessions only."""
+        capi.load_hip().zgml_hip_program_pin_outputs(backend.ctx, self.handle, 1 if on else 0)
 
     def step(self, token: int, pos: int, want_logits: bool = True):
         logits = np.zeros(self.model.cfg.vocab_size, np.float32) if want_logits else None

@@ -47,6 +47,9 @@ pub const HipBackend = struct {
     /// refresh_program re-sends the whole op list (the cpu backend's contract: a changed static field is honoured) instead of the
     /// two dynamic numbers (the wgpu backend's, the default here: see refreshProgram)
     strict_refresh: bool = false,
+    /// compiled programs may register the caller's output slice with the driver and write results straight into it
+    /// (zgml_hip_program_pin_outputs: the slice must outlive the program, as DeviceInference's does)
+    pin_outputs: bool = true,
 
     /// null device / not a gfx950 / library missing: error.HipNotAvailable; `lastError(null)` says why.
     pub fn init(device_ordinal: c_int) !HipBackend {
@@ -214,7 +217,12 @@ fn compileProgram(ctx: *anyopaque, program: backend_mod.DeviceProgram) ?backend_
     var arena = std.heap.ArenaAllocator.init(std.heap.page_allocator);
     defer arena.deinit();
     const flat = flattenProgram(arena.allocator(), program) catch return null;
-    const h = c.zgml_hip_compile_program(selfOf(ctx).ctx, &flat) orelse return null;
+    const self = selfOf(ctx);
+    const h = c.zgml_hip_compile_program(self.ctx, &flat) orelse return null;
+    // DeviceInference passes the same caller-owned output slice to every executeProgram (src/device_inference.zig:170-262) and
+    // requires it to outlive the session: let the step's last kernel write the logits straight into it (no staging copy of
+    // 197 KB per SmolLM token). `pin_outputs = false` on the backend struct keeps the copying path.
+    if (self.pin_outputs) _ = c.zgml_hip_program_pin_outputs(self.ctx, h, 1);
     return @ptrCast(h);
 }
 
