@@ -222,6 +222,76 @@ def cpu_config1_q8_matvec(iters=200):
             "max_abs_diff_vs_exact_dequant": float(np.abs(dst - exact).max()), "out_abs_max": float(np.abs(exact).max())}
 
 
+def w8a8_device_leg(be, llama, cpu_us=None, ring=16, chain=64, reps=6):
+    """BASELINE configs[0]'s workload on the device through the reference's own W8A8 arithmetic (ZGML_HIP_OPT_W8A8, w8a8.hip): a
+    data-dependent chain of 4096 x 4096 Q8_0 mat-vecs (y_i is x_{i+1}) over a ring of `ring` distinct weights (300 MB: beyond
+    the Infinity Cache), one program of `chain` qmatmul ops replayed as a graph; checked BIT-EXACT against the oracle's
+    prepareTransposed + quantizeInput + gemvRange on the first link. Then SmolLM-135M decode with every M = 1 qmatmul on that arm
+    (unfused launches: the arm is there for like-for-like arithmetic with the CPU baseline's variant B3, not for speed)."""
+    import numpy as np
+    from oracle import oracle as O
+    from zgml_amd import DeviceOp, DeviceProgram, ProgramIO, QuantizedWeightUpload, capi
+    K = N = 4096
+    out = {"workload": "4096x4096 Q8_0 mat-vec through the W8A8 arm (quantizeInput + prepareTransposed'd weight + gemvRange) ON THE DEVICE, data-dependent chain"}
+    rng = np.random.default_rng(11)
+    ws = []
+    for r in range(ring):
+        data = rng.integers(-127, 128, K * N, dtype=np.int8)
+        scales = np.full(K * N // 32, 1.0 / (127.0 * np.sqrt(K / 3.0)), np.float32) * (1.0 + (np.arange(K * N // 32) % 5) / 16.0).astype(np.float32)
+        ws.append((data, scales))
+    x = (((np.arange(K) % 17) - 8) * 0.03125).astype(np.float32)
+    bufs = [K] * (chain + 1)
+    ops = [DeviceOp.qmatmul(i + 1, i, i % ring, 1, N, K, 0, 0, 0, 0) for i in range(chain)]
+    prog = DeviceProgram(ops=ops, buffer_sizes=bufs, initial_uploads=[ProgramIO(0, x)],
+                         qweights=[QuantizedWeightUpload(d, sc, K, N, 32) for d, sc in ws])
+    be.set_option(capi.OPT_W8A8, 1)
+    try:
+        h = be.compileProgram(prog)
+        if not h:
+            raise RuntimeError(be.last_error())
+        y1 = np.zeros(N, np.float32)
+        ylast = np.zeros(N, np.float32)
+        ios_in = [ProgramIO(0, x)]
+        ios_out = [ProgramIO(1, y1), ProgramIO(chain, ylast)]
+        be.executeProgram(h, ios_in, ios_out)
+        t_d, t_s = O.prepare_transposed(ws[0][0], ws[0][1], K, N, 32)
+        want = O.gemv(t_d, t_s, x, N, K, 32)
+        if not np.array_equal(y1.view(np.uint32), want.view(np.uint32)):
+            raise ParityError(f"W8A8 device mat-vec differs from the oracle's gemvRange (max {np.abs(y1 - want).max()})")
+        out["verified_bit_exact_against_oracle"] = True
+        for _ in range(2):
+            be.executeProgram(h, ios_in, ios_out)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            be.executeProgram(h, ios_in, ios_out)
+        us = (time.perf_counter() - t0) / (reps * chain) * 1e6
+        nbytes = K * N // 32 * 36 + 4 * K + 4 * N
+        out.update({"us_per_matvec": round(us, 3), "GBps": round(nbytes / us / 1e3, 1), "frac_of_hbm_peak": round(nbytes / us / 1e3 / HBM_PEAK_GBPS, 4),
+                    "bytes_per_matvec": nbytes, "timing": f"wall clock around {reps} executions of a {chain}-op program (graph replay; includes the step's input / output kernels)",
+                    "out_finite": bool(np.isfinite(ylast).all())})
+        if cpu_us:
+            out["x_cpu_config1"] = round(cpu_us / us, 1)
+        be.freeProgram(h)
+        # SmolLM-135M decode on the arm
+        cfg = llama.preset("smollm-135m")
+        m = llama.Model(cfg, llama.Q4_0, include_dead_f32=False, threads=16)
+        s = llama.Session(m, llama.hip_backend_fns(be))
+        s.resident_setup(be)
+        w = s.resident_decode(1, 0, 8)
+        be.synchronize()
+        t0 = time.perf_counter()
+        s.resident_decode(int(w[-1]), 8, 64)
+        be.synchronize()
+        out["smollm135m_decode_tok_s"] = round(64 / (time.perf_counter() - t0), 1)
+        prof = be.getRuntimeProfile(s.handle)
+        out["smollm135m_note"] = "every M = 1 qmatmul on the W8A8 arm, launched unfused (no norm prologue / residual epilogue / grouping)"
+        s.close()
+        m.close()
+    finally:
+        be.set_option(capi.OPT_W8A8, 0)
+    return out
+
+
 def bench_single(args):
     from zgml_amd import Backend, llama
     be = Backend(0)
@@ -366,6 +436,15 @@ def bench_single(args):
             extra["cpu_config1_q8_0_matvec"] = cpu_config1_q8_matvec()
         except Exception as e:
             extra["cpu_config1_q8_0_matvec"] = {"error": str(e)[:200]}
+    try:  # the same workload (and SmolLM decode) through the W8A8 arm on the device: like-for-like with the CPU's arithmetic
+        extra["w8a8_device"] = w8a8_device_leg(be, llama, (extra.get("cpu_config1_q8_0_matvec") or {}).get("us_per_matvec"))
+        log(f"[bench] W8A8 arm on the device: {extra['w8a8_device'].get('us_per_matvec')} us per 4096x4096 mat-vec, SmolLM {extra['w8a8_device'].get('smollm135m_decode_tok_s')} tok/s")
+    except ParityError as e:
+        extra["w8a8_device"] = {"error": "PARITY FAILURE: " + str(e)[:300]}
+        parity_failed = True
+        log("[bench] " + extra["w8a8_device"]["error"])
+    except Exception as e:
+        extra["w8a8_device"] = {"error": str(e)[:200]}
     be.close()
 
     def stream_roofline(bytes_per_token, tok_s, what):  # a decode step as a weight stream: bytes every token must read / token time / HBM peak

@@ -421,7 +421,16 @@ enum {
      * mat-vec tolerance, two launches per layer instead of four — and MEASURED SLOWER on MI355X (DESIGN.md section 4, round 5:
      * reading 48 partial vectors costs a consumer workgroup more than the launch boundary it replaces), hence off by default.
      * Latched per program at compile_program. */
-    ZGML_HIP_OPT_KSPLIT = 9
+    ZGML_HIP_OPT_KSPLIT = 9,
+    /* 0/1 (default 0; ZGML_HIP_W8A8 in the environment): M = 1 qmatmuls take the reference's W8A8 arm — what its CPU executor does
+     * when a weight carries a transposed image (src/backend/reference.zig:512-528): quantizeInput on the input row (int8 + one f32
+     * scale per 32 values, src/quant.zig:604-640), the weight re-quantised per (column, 32 k) as prepareTransposed does
+     * (src/quant.zig:560-603; done on the device at compile_program from the int8 + f32-scale upload) and gemvRange's block-ordered
+     * f32 combine of int32 dots (src/quant.zig:320-440). BIT-IDENTICAL to that arm (zgml_amd/csrc/w8a8.hip); it is NOT the exact
+     * dequantise-then-dot arithmetic the default path (and the reference's x86 / GPU backends) computes: results differ by the
+     * activations' int8 rounding. Applies to weights of block size 32 with K % 64 == 0, K <= 16384, N % 16 == 0 every use of which
+     * is a dense M = 1 row; such ops run unfused. Read at compile_program. */
+    ZGML_HIP_OPT_W8A8 = 10
 };
 int zgml_hip_set_option(zgml_hip_ctx* ctx, int option, int64_t value);
 /* Drop the cached device copy of host operand `b` (NULL: all of them). */

@@ -213,6 +213,7 @@ OPT_FUSION, OPT_GRAPH, OPT_PROFILE, OPT_SKIP_DEAD_UPLOADS, OPT_F16_DENSE_WEIGHTS
 OPT_ATTN_SPLIT_MIN_KEYS = 7
 OPT_FUSE_RESIDENT_WGS = 8
 OPT_KSPLIT = 9
+OPT_W8A8 = 10
 
 _PKG_DIR = Path(__file__).resolve().parent
 HIP_LIB_PATH = _PKG_DIR / "lib" / "libzgml_hip.so"

@@ -186,6 +186,7 @@ enum QWFormat : uint32_t {
     QW_Q4 = 1,  // packed nibbles, lane-tiled (see qmatvec.hip)
     QW_Q8 = 2,  // packed int8, lane-tiled
     QW_Q4K = 3, // packed offset-binary nibbles, K ON LANES (qmatvec.hip: qmatvec_kon_body): M = 1 mat-vecs only, f16 scales
+    QW_W8A8 = 4, // the reference's W8A8 arm (w8a8.hip): re-quantised transposed int8 + f32 scale per (column, 32 k); M = 1 only, opt-in
 };
 
 struct QWeightDev {
@@ -407,6 +408,12 @@ uint32_t classify_qweight(hipStream_t s, const int8_t* raw_data, uint64_t n_elem
 void launch_pack_gguf(hipStream_t s, const uint8_t* raw_blocks, const QWeightDev& out);
 // True when (K, N, block size) can use the packed fast path (else QW_RAW).
 bool qweight_packable(uint64_t K, uint64_t N, uint64_t bs);
+// W8A8 arm (w8a8.hip; src/backend/reference.zig:512-528): shapes it takes, sizes of its packed image, the pack (prepareTransposed on
+// the device, from the raw int8 + f32-scale upload) and the mat-vec (quantizeInput + gemvRange, bit-identical to the reference's)
+bool w8a8_applies(uint64_t K, uint64_t N, uint64_t bs);
+void w8a8_packed_bytes(uint64_t K, uint64_t N, uint64_t* qs_bytes, uint64_t* sc_bytes);
+void launch_pack_w8a8(hipStream_t s, const int8_t* raw_data, const float* raw_scales, const QWeightDev& out);
+void launch_w8a8_matvec(hipStream_t s, const QWeightDev& w, const float* x, float* dst);
 void packed_bytes(QWFormat format, uint32_t scale_f16, uint64_t K, uint64_t N, uint64_t* qs_bytes,
                   uint64_t* sc_bytes);
 void launch_pack_qweight(hipStream_t s, const int8_t* raw_data, const float* raw_scales, const QWeightDev& out);

@@ -1564,6 +1564,14 @@ void launch_qmatmul(hipStream_t s, const QWeightDev& w, const QMatmulParams& p, 
         qmatmul_raw_kernel<<<grid, kBlock, 0, s>>>((const int8_t*)w.qs, (const float*)w.sc, w.bs, p);
         return;
     }
+    if (w.format == QW_W8A8) { // (opt-in) the reference's W8A8 arm: compile_program only gives it to weights every use of which is a dense M = 1 row
+        if (p.M != 1) {
+            fprintf(stderr, "[zgml_hip] ERROR: an M = %u matmul over a W8A8 (mat-vec only) weight: not launched\n", p.M);
+            return;
+        }
+        launch_w8a8_matvec(s, w, p.input, p.dst);
+        return;
+    }
     if (w.format == QW_Q4K && p.M != 1) { // compile_program only gives this layout to weights every use of which has M = 1
         fprintf(stderr, "[zgml_hip] ERROR: an M = %u matmul over a K-on-lanes (mat-vec only) weight: not launched\n", p.M);
         return;

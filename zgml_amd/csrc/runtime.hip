@@ -850,7 +850,7 @@ bool anchor_ok(zgml_hip_program* p, uint32_t i) {
     const zgml_device_op& op = p->ops[i];
     if (op.kind != ZGML_DOP_QMATMUL || op.u.qmatmul.M != 1) return false;
     const QWeightDev& w = p->qweights[op.u.qmatmul.weight_idx];
-    return w.format != QW_RAW && (op.u.qmatmul.input_offset % 4) == 0;
+    return w.format != QW_RAW && w.format != QW_W8A8 && (op.u.qmatmul.input_offset % 4) == 0; // (W8A8: the reference's arm, launched as it is — no prologue / epilogue fusion)
 }
 
 // A grouped q / k / v projection launch directly followed by the decode-attention launch of exactly its heads becomes ONE
@@ -2578,6 +2578,7 @@ zgml_hip_ctx* zgml_hip_create(int device_ordinal) {
     if (const char* e = getenv("ZGML_HIP_GRAPH")) ctx->opt_graph = atoi(e) != 0;
     if (const char* e = getenv("ZGML_HIP_FUSION")) ctx->opt_fusion = atoi(e) != 0;
     if (const char* e = getenv("ZGML_HIP_KSPLIT")) ctx->opt_ksplit = atoi(e) != 0;
+    if (const char* e = getenv("ZGML_HIP_W8A8")) ctx->opt_w8a8 = atoi(e) != 0;
     if (const char* e = getenv("ZGML_HIP_HOST_PROF")) ctx->host_prof = atoi(e) != 0;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         g_create_error = "hipStreamCreate failed";
@@ -2651,6 +2652,7 @@ int zgml_hip_set_option(zgml_hip_ctx* ctx, int option, int64_t value) {
             ctx->fuse_epoch++; // existing programs rebuild their plans under the new capacity
             return 0;
         case ZGML_HIP_OPT_KSPLIT: ctx->opt_ksplit = value != 0; return 0; // (latched per program at compile_program)
+        case ZGML_HIP_OPT_W8A8: ctx->opt_w8a8 = value != 0; return 0;     // (decides the weights' device format at compile_program)
         case ZGML_HIP_OPT_DENSE_WEIGHT_CACHE:
             ctx->b_cache_cap = value > 0 ? (uint64_t)value : 0;
             if (!ctx->b_cache_cap) ctx->drop_b_cache();
@@ -2901,8 +2903,13 @@ zgml_hip_program* zgml_hip_compile_program(zgml_hip_ctx* ctx, const zgml_device_
     // a weight an M > 1 matmul reads keeps the n-on-lanes layout the tile kernels are built for
     static const bool kon_on = !(getenv("ZGML_HIP_QMV_KON") && atoi(getenv("ZGML_HIP_QMV_KON")) == 0);
     std::vector<char> qw_m1(prog->n_qweights, kon_on ? 1 : 0);
+    std::vector<char> qw_m1_all(prog->n_qweights, 1); // every use is a dense M = 1 row (the W8A8 arm's condition, reference.zig:512-516)
     for (const auto& op : p->ops)
-        if (op.kind == ZGML_DOP_QMATMUL && op.u.qmatmul.M != 1 && op.u.qmatmul.weight_idx < prog->n_qweights) qw_m1[op.u.qmatmul.weight_idx] = 0;
+        if (op.kind == ZGML_DOP_QMATMUL && op.u.qmatmul.weight_idx < prog->n_qweights) {
+            const auto& q = op.u.qmatmul;
+            if (q.M != 1) qw_m1[q.weight_idx] = 0;
+            if (q.M != 1 || (q.input_row_stride != 0 && q.input_row_stride != q.K) || (q.dst_row_stride != 0 && q.dst_row_stride != q.N)) qw_m1_all[q.weight_idx] = 0;
+        }
     for (uint64_t i = 0; ok && i < prog->n_qweights; i++) {
         if (!qw_live[i]) continue;
         const zgml_qweight_upload& qw = prog->qweights[i];
@@ -2922,6 +2929,13 @@ zgml_hip_program* zgml_hip_compile_program(zgml_hip_ctx* ctx, const zgml_device_
                  CTX_CHECK(ctx, hipMemcpyAsync(pending[i].raw_a, qw.data, n_elems, hipMemcpyHostToDevice, ctx->stream)) &&
                  CTX_CHECK(ctx, hipMemcpyAsync(pending[i].raw_s, qw.scales, n_blocks * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
             if (!ok) break;
+            if (ctx->opt_w8a8 && qw_m1_all[i] && w8a8_applies(qw.rows, qw.cols, qw.block_size)) { // the reference's W8A8 arm (w8a8.hip)
+                w.format = QW_W8A8;
+                w.KC = (uint32_t)(qw.rows / 32);
+                w8a8_packed_bytes(qw.rows, qw.cols, &w.qs_bytes, &w.sc_bytes);
+                qs_total += w.qs_bytes, sc_total += w.sc_bytes;
+                continue;
+            }
             if (!qweight_packable(qw.rows, qw.cols, qw.block_size)) { // odd shapes keep the raw form
                 w.format = QW_RAW;
                 w.qs = pending[i].raw_a, w.sc = pending[i].raw_s;
@@ -2967,6 +2981,8 @@ zgml_hip_program* zgml_hip_compile_program(zgml_hip_ctx* ctx, const zgml_device_
             }
             if (pending[i].gguf)
                 launch_pack_gguf(ctx->stream, (const uint8_t*)pending[i].raw_a, w);
+            else if (w.format == QW_W8A8)
+                launch_pack_w8a8(ctx->stream, (const int8_t*)pending[i].raw_a, pending[i].raw_s, w);
             else
                 launch_pack_qweight(ctx->stream, (const int8_t*)pending[i].raw_a, pending[i].raw_s, w);
         }
@@ -3108,7 +3124,7 @@ void zgml_hip_refresh_program(zgml_hip_ctx* ctx, zgml_hip_program* p, const zgml
         // program keeps its previous ops) instead of skipping the launch later: a stale destination must never look like success.
         const zgml_device_op& op = ops[i];
         if (op.kind == ZGML_DOP_QMATMUL && op.u.qmatmul.M != 1 && op.u.qmatmul.weight_idx < p->qweights.size() &&
-            p->qweights[op.u.qmatmul.weight_idx].format == QW_Q4K) {
+            (p->qweights[op.u.qmatmul.weight_idx].format == QW_Q4K || p->qweights[op.u.qmatmul.weight_idx].format == QW_W8A8)) {
             ctx->fail("refresh_program: op " + std::to_string(i) + " turns weight " + std::to_string(op.u.qmatmul.weight_idx) +
                       " into the operand of an M = " + std::to_string(op.u.qmatmul.M) +
                       " qmatmul, but the weight was packed for M = 1 mat-vecs at compile time (K-on-lanes layout): recompile the program");

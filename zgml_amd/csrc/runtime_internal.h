@@ -93,6 +93,7 @@ struct zgml_hip_ctx {
     bool host_prof = false;
     uint64_t prof_ns[4] = {0, 0, 0, 0}, prof_calls[4] = {0, 0, 0, 0};
     bool opt_ksplit = false; // ZGML_HIP_OPT_KSPLIT (zgml_hip_create takes the default from ZGML_HIP_KSPLIT)
+    bool opt_w8a8 = false;   // ZGML_HIP_OPT_W8A8: M = 1 qmatmuls through the reference's W8A8 arm (w8a8.hip); read at compile_program
     int64_t opt_attn_split_min_keys = -1; // -1: environment / default (attn_split_for)
     int64_t opt_fuse_resident_wgs = -1;   // -1: one 1024-thread workgroup per CU (fuse_qkv_attention)
     // host dense override scratch
