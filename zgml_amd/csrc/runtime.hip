@@ -2511,6 +2511,9 @@ struct zgml_resident {
     uint32_t tokens_cap = 0;
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
+    hipGraph_t graph_multi = nullptr; // `multi_n` consecutive tokens as one graph (ZGML_HIP_RESIDENT_TOKENS_PER_GRAPH)
+    hipGraphExec_t graph_multi_exec = nullptr;
+    uint32_t multi_n = 0;
 };
 using Resident = zgml_resident;
 namespace {
@@ -2521,6 +2524,9 @@ void free_resident_graph(zgml_hip_program* p) {
     if (r->graph_exec) hipGraphExecDestroy(r->graph_exec);
     if (r->graph) hipGraphDestroy(r->graph);
     r->graph_exec = nullptr, r->graph = nullptr;
+    if (r->graph_multi_exec) hipGraphExecDestroy(r->graph_multi_exec);
+    if (r->graph_multi) hipGraphDestroy(r->graph_multi);
+    r->graph_multi_exec = nullptr, r->graph_multi = nullptr, r->multi_n = 0;
 }
 
 void free_resident(zgml_hip_program* p) {
@@ -3763,11 +3769,32 @@ int zgml_hip_resident_decode(zgml_hip_ctx* ctx, zgml_hip_program* p, uint32_t fi
             }
         }
     }
-    for (uint32_t i = 0; i < n_steps; i++) {
-        if (r->graph_exec)
+    // several tokens per graph launch: everything a token needs is produced on the device from the state words, so a graph may
+    // simply hold the launches of G consecutive tokens (experiment: is there a per-graph gap on the device?)
+    static const uint32_t per_graph = getenv("ZGML_HIP_RESIDENT_TOKENS_PER_GRAPH") ? (uint32_t)atoi(getenv("ZGML_HIP_RESIDENT_TOKENS_PER_GRAPH")) : 1u;
+    if (ctx->opt_graph && r->graph_exec && per_graph > 1 && n_steps >= per_graph && !r->graph_multi_exec) {
+        hipGraph_t g = nullptr;
+        if (CTX_CHECK(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal))) {
+            for (uint32_t t = 0; t < per_graph; t++) one_token(s);
+            if (CTX_CHECK(ctx, hipStreamEndCapture(s, &g)) && g) {
+                if (CTX_CHECK(ctx, hipGraphInstantiate(&r->graph_multi_exec, g, nullptr, nullptr, 0)))
+                    r->graph_multi = g, r->multi_n = per_graph;
+                else
+                    hipGraphDestroy(g);
+            }
+        }
+    }
+    for (uint32_t i = 0; i < n_steps;) {
+        if (r->graph_multi_exec && n_steps - i >= r->multi_n) {
+            hipGraphLaunch(r->graph_multi_exec, s);
+            i += r->multi_n;
+        } else if (r->graph_exec) {
             hipGraphLaunch(r->graph_exec, s);
-        else
+            i++;
+        } else {
             one_token(s);
+            i++;
+        }
     }
     hipMemcpyAsync(tokens_out, r->tokens, (size_t)n_steps * 8, hipMemcpyDeviceToHost, s);
     bool ok = CTX_CHECK(ctx, hipStreamSynchronize(s));
