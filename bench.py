@@ -48,7 +48,7 @@ def _pmc_traffic(K, N, q4):
     the 1 GiB copy kernel of the same run), newest round first; stamped with the commit the pass was collected at."""
     if (K, N, q4) != (4096, 4096, 1):
         return None, None
-    for name in ("r04_qmatvec_pmc.json", "r03_qmatvec_pmc.json", "r02_qmatvec_pmc.json", "r01_qmatvec_pmc.json"):
+    for name in ("r05_qmatvec_pmc.json", "r04_qmatvec_pmc.json", "r03_qmatvec_pmc.json", "r02_qmatvec_pmc.json", "r01_qmatvec_pmc.json"):
         f = ROOT / "profiles" / name
         if f.exists():
             d = json.loads(f.read_text())
