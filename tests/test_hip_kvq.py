@@ -98,3 +98,36 @@ def test_kvq_dynamic_column_refresh_and_bounds(hip_backend, oracle):
     for a, b in zip(outs[0][:-1], outs[1][:-1]):
         np.testing.assert_allclose(b, a, atol=1e-5, rtol=0)
     assert np.array_equal(outs[0][-1].view(np.uint32), outs[1][-1].view(np.uint32))
+
+
+@pytest.mark.parametrize("dh,n_pos", [(128, 560), (256, 300)])
+def test_int8_kv_decode_attention_wide_heads_many_rounds(hip_backend, oracle, dh, n_pos):
+    """The 16-dims-per-lane key loop of the fused decode attention (attention_decode.h, d_head >= 128) with ONE workgroup per head
+    (split off): beyond 8 x 16 x 4 = 512 keys at d_head 128 (4 x 16 x 4 = 256 at d_head 256) the loop runs a second round on rows
+    re-issued into the same registers. Against the oracle over a cache that fills from position 0 (1e-3 of the logit range, the int8
+    caches' bound), the new column met in every position's last slot; then the same with the split on (several workgroups per head)."""
+    from zgml_amd import capi, llama
+    cfg = llama.preset("tiny", n_pos + 8)
+    cfg.d_model, cfg.n_heads, cfg.n_kv_heads, cfg.d_ff, cfg.n_layers, cfg.vocab_size = 2 * dh, 2, 1, 256, 1, 256
+    cfg.kv_quant_block = 32
+    m = llama.Model(cfg, llama.Q4_0, threads=8)
+    s_ref = llama.Session(m, oracle.backend_fns())
+    hip_backend.set_option(capi.OPT_ATTN_SPLIT_MIN_KEYS, 0)
+    try:
+        s_one = llama.Session(m, llama.hip_backend_fns(hip_backend))
+        hip_backend.set_option(capi.OPT_ATTN_SPLIT_MIN_KEYS, 64)
+        s_split = llama.Session(m, llama.hip_backend_fns(hip_backend))
+        tok = 3
+        for pos in range(n_pos):
+            t_ref, l_ref = s_ref.step(tok, pos)
+            t_a, l_a = s_one.step(tok, pos)
+            t_b, l_b = s_split.step(tok, pos)
+            assert not hip_backend.last_error(), hip_backend.last_error()
+            scale = np.abs(l_ref).max()
+            assert np.abs(l_a - l_ref).max() <= 1e-3 * scale, pos
+            assert np.abs(l_b - l_ref).max() <= 1e-3 * scale, pos
+            tok = t_ref
+        s_one.close(), s_split.close()
+    finally:
+        hip_backend.set_option(capi.OPT_ATTN_SPLIT_MIN_KEYS, -1)
+    s_ref.close(), m.close()
