@@ -336,11 +336,15 @@ const T* upload_params(zgml_hip_program* p, const std::vector<T>& v) {
 // per `min_keys` keys of the longest context the plan allows, the whole launch within ~256 workgroups.
 // ZGML_HIP_OPT_ATTN_SPLIT_MIN_KEYS (or the ZGML_HIP_ATTN_SPLIT_MIN_KEYS environment variable) moves the
 // threshold (>= 32, 0 = off); ZGML_HIP_ATTN_SPLIT caps the workgroups per head (<= 1 = off).
-AttnSplit attn_split_for(zgml_hip_program* p, uint32_t n_heads, uint32_t d_head, uint32_t max_kv) {
+// `default_min_keys`: 128 — except where a workgroup covers few keys per memory round trip: the 4-wave form of the f32-KV decode
+// attention at d_head 128 (stand-alone and inside the K-on-lanes fused launch) streams 32 keys per round, so a head waits four
+// dependent rounds per 128 keys; splitting from 64 keys on gave Llama-2-7B +4 % over positions 200..328 (760 -> 791 tok/s) at no
+// cost at positions 4..132 and 1900 (profiles/r05_split_sweep_7b.txt; 32 is worse again: the merge costs more than a round).
+AttnSplit attn_split_for(zgml_hip_program* p, uint32_t n_heads, uint32_t d_head, uint32_t max_kv, int default_min_keys = 128) {
     static const int want = getenv("ZGML_HIP_ATTN_SPLIT") ? atoi(getenv("ZGML_HIP_ATTN_SPLIT")) : 16;
-    static const int min_keys_env = getenv("ZGML_HIP_ATTN_SPLIT_MIN_KEYS") ? atoi(getenv("ZGML_HIP_ATTN_SPLIT_MIN_KEYS")) : 128;
+    static const int min_keys_env = getenv("ZGML_HIP_ATTN_SPLIT_MIN_KEYS") ? atoi(getenv("ZGML_HIP_ATTN_SPLIT_MIN_KEYS")) : -1;
     AttnSplit sp;
-    const int64_t min_keys = p->ctx->opt_attn_split_min_keys >= 0 ? p->ctx->opt_attn_split_min_keys : min_keys_env;
+    const int64_t min_keys = p->ctx->opt_attn_split_min_keys >= 0 ? p->ctx->opt_attn_split_min_keys : (min_keys_env >= 0 ? min_keys_env : default_min_keys);
     if (min_keys == 0 || want <= 1) return sp;
     sp.min_keys = (uint32_t)std::min<int64_t>(std::max<int64_t>(32, min_keys), 1 << 30);
     uint32_t S = std::min<uint32_t>((uint32_t)std::max(want, 1), max_kv / sp.min_keys);
@@ -2185,7 +2189,7 @@ void build_fused_plan(zgml_hip_program* p) {
             const bool kvq = (kv.first & 0x10000u) != 0; // quantised-KV heads launch on their own
             uint32_t max_kv = 0;
             for (const auto& a : kv.second) max_kv = std::max(max_kv, a.max_kv);
-            const AttnSplit sp = attn_split_for(p, nh, dh, max_kv);
+            const AttnSplit sp = attn_split_for(p, nh, dh, max_kv, dh == 128 && !kvq ? 64 : 128);
             Launch AL{ZGML_DOP_ATTENTION, adec_ops, adec_lo, adec_hi, [=](hipStream_t s) { launch_attention_decode_batch(s, d, nh, dh, sp, kvq); }};
             AL.adec_desc = std::make_shared<AdecDesc>(AdecDesc{kv.second, d, nh, dh, sp, kvq});
             p->plan.push_back(std::move(AL));
