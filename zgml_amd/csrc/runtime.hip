@@ -165,11 +165,13 @@ bool program_supported(const zgml_device_program* pr) {
 }
 
 // ── small device helpers ────────────────────────────────────────────────────────────────────
+// (blockIdx.y strides over a row: a prefill chunk's token rows are one transfer of 512 KB — one workgroup walking that alone took
+// 200 us from device memory and 680 us from mapped host memory)
 __global__ void scatter_words_kernel(const IoTableDev* table, const uint32_t* stage) {
     const IoTableDev e = table[blockIdx.x];
     uint32_t* dst = (uint32_t*)e.dev;
     const uint32_t* src = stage + e.stage_off_words;
-    for (uint32_t i = threadIdx.x; i < e.n_words; i += blockDim.x) dst[i] = src[i];
+    for (uint32_t i = blockIdx.y * blockDim.x + threadIdx.x; i < e.n_words; i += blockDim.x * gridDim.y) dst[i] = src[i];
 }
 // (blockIdx.y strides over a row: the logits of a decode step are one row of ~50k words)
 __global__ void gather_words_wide_kernel(const IoTableDev* table, uint32_t* stage) {
@@ -178,12 +180,8 @@ __global__ void gather_words_wide_kernel(const IoTableDev* table, uint32_t* stag
     uint32_t* dst = stage + e.stage_off_words;
     for (uint32_t i = blockIdx.y * blockDim.x + threadIdx.x; i < e.n_words; i += blockDim.x * gridDim.y) dst[i] = src[i];
 }
-__global__ void gather_words_kernel(const IoTableDev* table, uint32_t* stage) {
-    const IoTableDev e = table[blockIdx.x];
-    const uint32_t* src = (const uint32_t*)e.dev;
-    uint32_t* dst = stage + e.stage_off_words;
-    for (uint32_t i = threadIdx.x; i < e.n_words; i += blockDim.x) dst[i] = src[i];
-}
+
+uint32_t io_grid_y(uint32_t max_row_words) { return std::max<uint32_t>(1, std::min<uint32_t>(64, max_row_words / 1024)); } // workgroups per transfer row
 
 void free_resident_graph(zgml_hip_program* p); // below (zgml_resident is defined there)
 
@@ -276,7 +274,7 @@ bool prepare_io(zgml_hip_program* p, IoPlan& plan, const zgml_program_io* ios, u
     free_io_graph(p); // (captured for the tables that are about to change)
     plan.entries.clear();
     plan.word_aligned = true;
-    plan.total_words = 0;
+    plan.total_words = 0, plan.max_row_words = 0;
     if (plan.table_dev) hipFree(plan.table_dev);
     plan.table_dev = nullptr;
     std::vector<IoTableDev> table;
@@ -299,12 +297,13 @@ bool prepare_io(zgml_hip_program* p, IoPlan& plan, const zgml_program_io* ios, u
         plan.entries.push_back({io.buf_idx, io.offset, io.size});
         if ((io.offset & 3) || (io.size & 3)) plan.word_aligned = false;
         table.push_back({(float*)((char*)p->bufs[io.buf_idx] + io.offset), plan.total_words, io.size / 4});
+        plan.max_row_words = std::max<uint32_t>(plan.max_row_words, io.size / 4);
         plan.total_words += (io.size + 3) / 4;
     }
     // the input table carries one more row: the program's dynamic words (one per op), so that a refresh's changes ride in the same
     // staging copy and scatter launch as the inputs instead of a transfer of their own (upload_inputs)
     const bool with_dyn = &plan == &p->in_plan && plan.word_aligned && !table.empty() && p->dyn_dev && !p->ops.empty();
-    if (with_dyn) table.push_back({(float*)p->dyn_dev, plan.total_words, (uint32_t)p->ops.size()});
+    if (with_dyn) table.push_back({(float*)p->dyn_dev, plan.total_words, (uint32_t)p->ops.size()}), plan.max_row_words = std::max<uint32_t>(plan.max_row_words, (uint32_t)p->ops.size());
     if (plan.word_aligned && !table.empty()) {
         if (!CTX_CHECK(ctx, hipMalloc((void**)&plan.table_dev, table.size() * sizeof(IoTableDev)))) return false;
         if (!CTX_CHECK(ctx, h2d_sync(ctx->stream, plan.table_dev, table.data(), table.size() * sizeof(IoTableDev)))) return false;
@@ -3167,7 +3166,7 @@ static bool upload_inputs(zgml_hip_ctx* ctx, zgml_hip_program* p, const zgml_pro
             p->dyn_dirty = false;
         }
         hipMemcpyAsync(p->stage_dev, p->stage_host, off, hipMemcpyHostToDevice, s);
-        scatter_words_kernel<<<rows, 256, 0, s>>>(p->in_plan.table_dev, (const uint32_t*)p->stage_dev);
+        scatter_words_kernel<<<dim3(rows, io_grid_y(p->in_plan.max_row_words)), 256, 0, s>>>(p->in_plan.table_dev, (const uint32_t*)p->stage_dev);
     } else {
         for (uint64_t i = 0; i < n_inputs; i++)
             hipMemcpyAsync((char*)p->bufs[inputs[i].buf_idx] + inputs[i].offset, inputs[i].host_ptr, inputs[i].size,
@@ -3184,7 +3183,7 @@ static bool download_outputs(zgml_hip_ctx* ctx, zgml_hip_program* p, const zgml_
         if (p->out_plan.word_aligned && n_outputs == 1) { // (the decode step: the logits) straight from the buffer, no gather launch in front
             hipMemcpyAsync(p->stage_host, (char*)p->bufs[outputs[0].buf_idx] + outputs[0].offset, outputs[0].size, hipMemcpyDeviceToHost, s);
         } else if (p->out_plan.word_aligned) {
-            gather_words_kernel<<<(uint32_t)n_outputs, 256, 0, s>>>(p->out_plan.table_dev, (uint32_t*)p->stage_dev);
+            gather_words_wide_kernel<<<dim3((uint32_t)n_outputs, io_grid_y(p->out_plan.max_row_words)), 256, 0, s>>>(p->out_plan.table_dev, (uint32_t*)p->stage_dev);
             hipMemcpyAsync(p->stage_host, p->stage_dev, (uint64_t)p->out_plan.total_words * 4, hipMemcpyDeviceToHost, s);
         } else {
             for (uint64_t i = 0; i < n_outputs; i++)
@@ -3278,12 +3277,10 @@ static bool execute_io_graph(zgml_hip_ctx* ctx, zgml_hip_program* p, const zgml_
             (void)hipGetLastError();
             return false;
         }
-        uint32_t max_words = 0;
-        for (uint64_t i = 0; i < n_outputs; i++) max_words = std::max<uint32_t>(max_words, outputs[i].size / 4);
-        const uint32_t gy = std::max<uint32_t>(1, std::min<uint32_t>(64, max_words / 1024));
+        const uint32_t gy = io_grid_y(p->out_plan.max_row_words);
         hipGraph_t g = nullptr;
         if (!CTX_CHECK(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal))) return false;
-        scatter_words_kernel<<<in_rows, 256, 0, s>>>(p->in_plan.table_dev, (const uint32_t*)in_dev);
+        scatter_words_kernel<<<dim3(in_rows, io_grid_y(p->in_plan.max_row_words)), 256, 0, s>>>(p->in_plan.table_dev, (const uint32_t*)in_dev);
         run_plan(p, s, 0, p->plan.size());
         gather_words_wide_kernel<<<dim3(out_rows, gy), 256, 0, s>>>(p->out_plan.table_dev, (uint32_t*)out_dev);
         if (!CTX_CHECK(ctx, hipStreamEndCapture(s, &g)) || !g) return false;
@@ -3389,7 +3386,7 @@ void zgml_hip_enqueue_staged(zgml_hip_ctx* ctx, zgml_hip_program* p) {
     hipStream_t s = ctx->stream;
     if (p->staged_n) {
         hipMemcpyAsync(p->stage_dev, p->stage_host, p->staged_bytes, hipMemcpyHostToDevice, s);
-        scatter_words_kernel<<<(uint32_t)p->staged_n, 256, 0, s>>>(p->in_plan.table_dev, (const uint32_t*)p->stage_dev);
+        scatter_words_kernel<<<dim3((uint32_t)p->staged_n, io_grid_y(p->in_plan.max_row_words)), 256, 0, s>>>(p->in_plan.table_dev, (const uint32_t*)p->stage_dev);
     }
     if (!p->ops.empty()) hipMemcpyAsync(p->dyn_dev, p->dyn_host, p->ops.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s);
     p->dyn_dirty = false;

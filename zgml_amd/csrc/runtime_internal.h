@@ -74,7 +74,7 @@ struct IoTableDev { // one row per transfer, consumed by scatter/gather kernels
 struct IoPlan {
     std::vector<IoEntry> entries;
     IoTableDev* table_dev = nullptr;
-    uint32_t total_words = 0;
+    uint32_t total_words = 0, max_row_words = 0;
     bool word_aligned = true;
     bool dyn_row = false; // (input plan) the table's last row scatters the program's dynamic words (prepare_io)
 };
