@@ -3232,7 +3232,7 @@ static bool execute_io_graph(zgml_hip_ctx* ctx, zgml_hip_program* p, const zgml_
             off += (inputs[i].size + 3) / 4 * 4;
         }
         memcpy(st + off, p->dyn_host, p->ops.size() * sizeof(uint32_t));
-        p->dyn_dirty = false;
+        p->dyn_dirty = true; // (until the graph that carries them has been launched: a fall-back to the general path must still send them)
     }
     const uint64_t t1 = ctx->host_prof ? now_ns() : 0;
     const uint32_t in_rows = (uint32_t)n_inputs + 1, out_rows = (uint32_t)n_outputs;
@@ -3249,11 +3249,14 @@ static bool execute_io_graph(zgml_hip_ctx* ctx, zgml_hip_program* p, const zgml_
             p->pin_cand = o.host_ptr;
             if (p->pin_seen >= 3 && o.size >= 4096) {
                 void* dev = nullptr;
-                if (hipHostRegister(o.host_ptr, o.size, hipHostRegisterMapped) == hipSuccess && hipHostGetDevicePointer(&dev, o.host_ptr, 0) == hipSuccess && dev) {
+                if (hipHostRegister(o.host_ptr, o.size, hipHostRegisterMapped) != hipSuccess) { // (e.g. memory the caller has pinned itself: left alone)
+                    (void)hipGetLastError();
+                    p->pin_off = true;
+                } else if (hipHostGetDevicePointer(&dev, o.host_ptr, 0) == hipSuccess && dev) {
                     p->pin_host = o.host_ptr, p->pin_dev = dev, p->pin_size = o.size;
                 } else {
                     (void)hipGetLastError();
-                    (void)hipHostUnregister(o.host_ptr);
+                    (void)hipHostUnregister(o.host_ptr); // (our own registration)
                     (void)hipGetLastError();
                     p->pin_off = true;
                 }
@@ -3292,7 +3295,8 @@ static bool execute_io_graph(zgml_hip_ctx* ctx, zgml_hip_program* p, const zgml_
         }
         p->io_graph = g, p->io_graph_exec = ge, p->io_in_rows = in_rows, p->io_out_rows = out_rows, p->io_out_dev = out_dev;
     }
-    CTX_CHECK(ctx, hipGraphLaunch(p->io_graph_exec, s));
+    if (!CTX_CHECK(ctx, hipGraphLaunch(p->io_graph_exec, s))) return true; // (reported; nothing ran)
+    p->dyn_dirty = false;
     const uint64_t t2 = ctx->host_prof ? now_ns() : 0;
     const uint64_t ts = now_ns();
     const bool ok = CTX_CHECK(ctx, hipStreamSynchronize(s)) && ctx->handoff_ok("execute_program");
