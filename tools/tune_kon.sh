@@ -1,4 +1,4 @@
-mkdir -p gpurun_out/r3
+mkdir -p gpurun_out/r5
 run() { echo "TUNE=$1"; ZGML_QMV_KON_TUNE="$1" python tools/decode_run.py llama2-7b 128; }
 base="1376x4096:4:2,768x4096:4:4,256x4096:4:4,256x11008:8:4,2000x4096:4:4"
 run "$base"

@@ -1504,6 +1504,17 @@ __global__ void __launch_bounds__(kBlock) argmax_tail_kernel(const float* __rest
     __shared__ uint32_t bc[2];
     using gu32 = __attribute__((address_space(1))) uint32_t;
     using gu64 = __attribute__((address_space(1))) unsigned long long;
+    // The next token's patches that depend on its POSITION only — mask column, RoPE rows, dynamic words: everything but the
+    // embedding row — are written here by ALL workgroups (the position is known: state[1] + 1, read before this workgroup's
+    // arrival is counted, i.e. before the last arriver advances it; the plan that read the current token's patches has finished).
+    // Round 5's first form left the whole prep to the last arriver: one workgroup walking 8-16 K elements alone was a longer chain
+    // than the two launches it replaced. What is left for the last arriver is the embedding row of the token it has just found.
+    const uint32_t prep_tok = has_prep ? prep.T * prep.d : 0;
+    if (has_prep && adv.state) {
+        const uint32_t pos_next = adv.state[1] + 1;
+        if (pos_next < prep.max_seq)
+            for (uint32_t i = prep_tok + blockIdx.x * kBlock + threadIdx.x; i < prep_total; i += gridDim.x * kBlock) resident_prep_element(prep, i, pos_next, nullptr, 0, true);
+    }
     float bv = -INFINITY;
     int64_t bi = INT64_MAX;
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) { // (as argmax_stage1)
@@ -1569,7 +1580,7 @@ __global__ void __launch_bounds__(kBlock) argmax_tail_kernel(const float* __rest
     if (!has_prep) return;
     const uint32_t token = bc[0], pos = bc[1];
     if (pos >= prep.max_seq || token >= 0x7FFFFFFFu) return; // (the context is full, or no finite logit: nothing to prepare)
-    for (uint32_t i = threadIdx.x; i < prep_total; i += kBlock) resident_prep_element(prep, i, pos, nullptr, token, true);
+    for (uint32_t i = threadIdx.x; i < prep_tok; i += kBlock) resident_prep_element(prep, i, pos, nullptr, token, true); // the embedding row(s)
 }
 } // namespace
 

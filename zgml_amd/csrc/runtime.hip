@@ -3738,9 +3738,10 @@ int zgml_hip_resident_decode(zgml_hip_ctx* ctx, zgml_hip_program* p, uint32_t fi
     ResidentPrepArgs a{r->embed, r->cos, r->sin, r->tok_in, r->mask, r->rope_bufs, r->dyn_kind, r->dyn_base, r->dyn_stride,
                        p->dyn_dev, r->state, r->state /* the token is state[0] */, r->d, r->max_seq, r->dh, r->n_rope, (uint32_t)p->ops.size(), 1};
     const uint32_t total = r->d + r->max_seq + r->n_rope * 2 * r->dh + (uint32_t)p->ops.size();
-    // (measured SLOWER, off unless ZGML_HIP_TAIL_FUSED=1 — SmolLM-135M 1756 against 1773 tok/s, Llama-2-7B 790 against 817 over 128-512
-    // positions, gpurun_out/r5/vtable_prof4.txt: the one workgroup that finishes the argmax walks the ~8-16 K elements of the next
-    // token's patches alone, a latency chain longer than the two small launches it replaces)
+    // (off unless ZGML_HIP_TAIL_FUSED=1. First form — the last arriver walks all 8-16 K elements of the next token's patches alone —
+    // measured SLOWER: SmolLM-135M 1756 against 1773 tok/s, Llama-2-7B 790 against 817. Second form — every workgroup writes the
+    // position-only patches, the last arriver the embedding row — a wash: 1777-1782 against 1768-1780, 838 against 842;
+    // profiles/r05_token_tail_ab.txt)
     static const bool tail_fused = getenv("ZGML_HIP_TAIL_FUSED") && atoi(getenv("ZGML_HIP_TAIL_FUSED")) != 0;
     auto one_token = [&](hipStream_t st) {
         if (!tail_fused) launch_resident_prep(st, a, total);
