@@ -518,7 +518,7 @@ struct F16Args4 {
     uint32_t* counter;            // one word per column group, zero between launches
     uint32_t n_parts, M, KC, SK, chunks_per_slice, n_cwg, total_groups;
 };
-template <bool NT>
+template <bool NT, int kT4Depth = 4>
 __global__ void __launch_bounds__(kT4Waves * 64) dense_f16_tile4_kernel(F16Args4 a) {
     constexpr int R = 2;
     extern __shared__ uint4 lds_a4[]; // [chunk of the slice][R][64]
@@ -786,9 +786,15 @@ static bool launch_dense_f16_tile4(hipStream_t s, const DenseF16Params* p, uint3
     const bool nt = p[0].stream_nt != 0;
     const size_t lds = std::max<size_t>((size_t)cps * 2 * 1024, 96 * 1024); // >= 96 KiB: never two workgroups on one CU
     using Fn4 = void (*)(F16Args4);
-    const Fn4 fn = nt ? (Fn4)dense_f16_tile4_kernel<true> : (Fn4)dense_f16_tile4_kernel<false>;
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[nt]) attr_set[nt] = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+    // (round 5) weight loads in flight per wave: a wave walks its task's 64 chunks one after the other, so with 4 in flight and
+    // ~1.6 us of loaded latency a chunk costs >= 0.4 us whatever else happens: ZGML_F16_TILE4_DEPTH=8 doubles the ring
+    static const int env_depth = getenv("ZGML_F16_TILE4_DEPTH") ? atoi(getenv("ZGML_F16_TILE4_DEPTH")) : 4;
+    const bool deep = env_depth >= 8 && cps % 8 == 0;
+    const Fn4 fn = deep ? (nt ? (Fn4)dense_f16_tile4_kernel<true, 8> : (Fn4)dense_f16_tile4_kernel<false, 8>)
+                        : (nt ? (Fn4)dense_f16_tile4_kernel<true, 4> : (Fn4)dense_f16_tile4_kernel<false, 4>);
+    static bool attr_set[4] = {false, false, false, false};
+    const int ai = (deep ? 2 : 0) + (nt ? 1 : 0);
+    if (!attr_set[ai]) attr_set[ai] = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
     hipLaunchKernelGGL(fn, dim3(a.n_cwg * SK), dim3(kT4Waves * 64), lds, s, a);
     return true;
 #endif
